@@ -1,0 +1,170 @@
+/*
+ * occnet_amd.h — C ABI of the MI355X (gfx950) OccNet / BEVFormer-occ forward hot path.
+ *
+ * Every entry point takes plain device pointers + sizes (no torch types) and a
+ * hipStream_t passed as void*.  All tensors are device-resident, contiguous, row-major.
+ * Work is enqueued on `stream`; no call synchronises the device.  Every function returns
+ * 0 on success and a negative OCC_E_* code on failure; occ_last_error() returns a
+ * thread-local human readable message (the Python mirror turns it into RuntimeError, the
+ * analogue of the TORCH_CHECK exceptions the reference's extension raises).
+ *
+ * Reference interfaces replaced (paths relative to the OccNet tree,
+ *   P/ = projects/mmdet3d_plugin/):
+ *   occ_ms_deform_attn_forward_f32   <- mmcv._ext.ms_deform_attn_forward, bound at
+ *        P/bevformer/modules/multi_scale_deformable_attn_function.py:10-12, called :42-48,:118-124
+ *   occ_ms_deform_attn_backward_f32  <- mmcv._ext.ms_deform_attn_backward, same file :74-84,:150-160
+ *   occ_point_sampling_f32           <- BEVFormerEncoder.point_sampling, P/bevformer/modules/encoder.py:92-151
+ *   occ_sca_fused_forward_f32        <- SpatialCrossAttention.forward :136-173 (rebatch, scatter-add,
+ *        visible-camera mean) fused with MSDeformableAttention3D.forward :338-396 (softmax,
+ *        offset normalisation, z-anchor add, deformable gather), P/bevformer/modules/spatial_cross_attention.py
+ *   occ_tsa_fused_forward_f32        <- TemporalSelfAttention.forward :206-262 (softmax, locations,
+ *        gather, mean over the 2-deep BEV queue), P/bevformer/modules/temporal_self_attention.py
+ *   occ_linear_f32                   <- nn.Linear call sites on the path (value_proj
+ *        spatial_cross_attention.py:334, temporal_self_attention.py:198; query Linears :338-341)
+ *   occ_feat_flatten_f32             <- TransformerOcc.get_bev_features feature flatten + cams/level
+ *        embeds, P/bevformer/modules/transformer_occ.py:207-227
+ *   occ_conv3d_bn_relu_f32, occ_occ_heads_f32 <- TransformerOcc.forward lifter + decoder + heads,
+ *        transformer_occ.py:304-321 (modules :106-141)
+ */
+#ifndef OCCNET_AMD_H_
+#define OCCNET_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCC_OK 0
+#define OCC_E_INVALID (-1)     /* bad argument / unsupported shape                */
+#define OCC_E_LAUNCH (-2)      /* hipLaunch / runtime error                       */
+#define OCC_E_UNSUPPORTED (-3) /* shape is valid but has no fused kernel: caller  */
+                               /* must use the unfused HIP path (never a CPU one) */
+
+/* ABI version: bumped whenever a signature below changes. */
+int occ_abi_version(void);
+/* Thread-local message describing the last failure in this thread ("" if none). */
+const char* occ_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention, forward (mmcv op semantics).
+ *   value            (B, S, M, D)        f32   S = sum_l H_l*W_l
+ *   spatial_shapes   (L, 2)              i64   (H_l, W_l), device memory
+ *   level_start_index(L)                 i64   device memory
+ *   sampling_loc     (B, Lq, M, L, P, 2) f32   (x, y) in [0,1] image-normalised
+ *   attn_weight      (B, Lq, M, L, P)    f32
+ *   out              (B, Lq, M*D)        f32   fully overwritten
+ * out[b,q,m,:] = sum_l sum_p attn[b,q,m,l,p] * bilinear(value_l[b,:,m,:], loc*(W,H)-0.5),
+ * zero padding, align_corners=False.  im2col_step keeps mmcv's contract:
+ * step = min(B, im2col_step) must divide B (otherwise OCC_E_INVALID).
+ */
+int occ_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
+                                   const int64_t* level_start_index, const float* sampling_loc,
+                                   const float* attn_weight, float* out, int B, int S, int M, int D,
+                                   int L, int Lq, int P, int im2col_step, void* stream);
+
+/* Backward of the op above.  The three grad outputs must be pre-zeroed by the caller
+ * (the reference allocates them with zeros_like); grad_value is accumulated with atomics.
+ *   grad_output (B, Lq, M*D); grad_value like value; grad_sampling_loc like sampling_loc;
+ *   grad_attn_weight like attn_weight.
+ */
+int occ_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start_index, const float* sampling_loc,
+                                    const float* attn_weight, const float* grad_output,
+                                    float* grad_value, float* grad_sampling_loc,
+                                    float* grad_attn_weight, int B, int S, int M, int D, int L,
+                                    int Lq, int P, int im2col_step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pillar reference points -> per-camera image coordinates + visibility.
+ *   ref_3d     (B, Z, Nq, 3) f32  normalised (x, y, z) in [0,1]
+ *   lidar2img  (B, NC, 4, 4) f32 ; ego2lidar (4, 4) f32 ; pc_range[6] host floats
+ *   ref_cam    (NC, B, Nq, Z, 2) f32 out ; bev_mask (NC, B, Nq, Z) u8 out (0/1)
+ *   vis_bits   (B, Nq) u32 out: bit c set iff any z-anchor of query q is visible in camera c
+ *              (may be NULL).  NC <= 32.
+ */
+int occ_point_sampling_f32(const float* ref_3d, const float* lidar2img, const float* ego2lidar,
+                           const float* pc_range, float img_h, float img_w, float* ref_cam,
+                           uint8_t* bev_mask, uint32_t* vis_bits, int B, int NC, int Nq, int Z,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused spatial cross-attention gather (one encoder layer, all cameras):
+ *   slots[b,q,:] = (1/max(1,count[b,q])) * sum_{c : query q visible in camera c (batch 0's mask)}
+ *                  MSDA( value[b*NC+c], softmax(logits[b,q]), ref_cam[c,b,q,z(p)] + offs[b,q]/(W_l,H_l) )
+ *   value     (B*NC, S, M, D) f32 ; spatial_shapes (L,2) i64 ; level_start_index (L) i64
+ *   offs      (B, Nq, M*L*P*2) f32 raw sampling_offsets Linear output, row stride offs_stride floats
+ *   logits    (B, Nq, M*L*P)   f32 raw attention_weights Linear output, row stride logits_stride
+ *   ref_cam   (NC, B, Nq, Z, 2) f32 ; vis_bits (B, Nq) u32 (see occ_point_sampling_f32)
+ *   order     (Nq) i32 processing order of the queries (permutation; NULL = identity); only
+ *             affects cache locality, never results
+ *   slots     (B, Nq, M*D) f32 out, fully overwritten
+ *   stats     NULL, or 2 x u64 device counters (pre-zeroed): [0] += visible (camera,query) rows,
+ *             [1] += bilinear corners that fall inside their map (the N_in of the roofline formula)
+ * Fused kernels exist for M=8, D=32, (L,P) in {(4,8),(4,4),(2,8),(1,8)}, Z | P; other shapes
+ * return OCC_E_UNSUPPORTED.
+ */
+int occ_sca_fused_forward_f32(const float* value, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const float* offs,
+                              int64_t offs_stride, const float* logits, int64_t logits_stride,
+                              const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
+                              float* slots, uint64_t* stats, int B, int NC, int S, int M, int D,
+                              int L, int P, int Z, int Nq, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused temporal self-attention gather over the 2-deep BEV queue (single level):
+ *   out[b,q,:] = 0.5 * sum_{t in {0,1}} MSDA( value[b*2+t], softmax_p(logits[b,q,m,t,:]),
+ *                                            ref_2d[b*2+t,q] + offs[b,q,m,t,p]/(W,H) )
+ *   value    f32, queue entry t of batch b at value + (b*2+t)*value_bt_stride floats, each (Nq_v, M, D)
+ *            with Nq_v = bev_h*bev_w (pass value_bt_stride such that both entries alias one buffer
+ *            when there is no history BEV: the reference stacks the same tensor twice)
+ *   offs     (B, Nq, M*2*P*2) f32, row stride offs_stride ; logits (B, Nq, M*2*P), stride logits_stride
+ *   ref_2d   (B*2, Nq, 1, 2) f32
+ *   out      (B, Nq, M*D) f32
+ * Fused kernel exists for M=8, D=32, P=4, one level; otherwise OCC_E_UNSUPPORTED.
+ */
+int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_stride, const float* offs,
+                              int64_t offs_stride, const float* logits, int64_t logits_stride,
+                              const float* ref_2d, const int32_t* order, float* out, int B, int Nq,
+                              int bev_h, int bev_w, int M, int D, int P, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * y = x @ W^T + bias on the f32 MFMA path (v_mfma_f32_32x32x2_f32: exact f32 products).
+ *   x (Mrows, K) row stride ldx ; W (N, K) row-major (nn.Linear layout) ; bias (N) or NULL ;
+ *   y (Mrows, N) row stride ldy ; residual (Mrows, N) row stride ldr or NULL (added after bias) ;
+ *   relu != 0 applies max(.,0) last.  K % 4 == 0.
+ */
+int occ_linear_f32(const float* x, int64_t ldx, const float* W, const float* bias,
+                   const float* residual, int64_t ldr, float* y, int64_t ldy, int64_t Mrows, int N,
+                   int K, int relu, void* stream);
+
+/* Flatten the FPN maps into the (B*NC, S, C) key/value tensor and add camera/level embeddings.
+ *   feats[l] (B, NC, C, H_l, W_l) f32, l < L (array of L device pointers, host array)
+ *   cams_embeds (NC, C) or NULL ; level_embeds (L, C) ; out (B*NC, S, C)
+ */
+int occ_feat_flatten_f32(const float* const* feats, const int* hs, const int* ws, int L,
+                         const float* cams_embeds, const float* level_embeds, float* out, int B,
+                         int NC, int C, void* stream);
+
+/* Conv3d k=3, stride 1, pad 1, no bias, fused with eval-mode BatchNorm3d (scale/shift) and ReLU.
+ *   x (B, Cin, Z, H, W) f32 (the lifter view of the BEV embedding) -> y (B, Cout, Z, H, W)
+ *   weight (Cout, Cin, 3, 3, 3) ; scale, shift (Cout): y = relu(conv*scale + shift)
+ */
+int occ_conv3d_bn_relu_f32(const float* x, const float* weight, const float* scale,
+                           const float* shift, float* y, int B, int Cin, int Cout, int Z, int H,
+                           int W, void* stream);
+
+/* Occupancy + flow heads on the decoder output, written in the reference's (B, W, H, Z, C) order.
+ *   feat (B, C, Z, H, W) f32 ; occ MLP: w1 (Hd, C), b1 (Hd), Softplus, w2 (NCLS, Hd), b2 (NCLS)
+ *   flow MLP: fw1 (Hd, C), fb1 (Hd), ReLU, fw2 (2, Hd), fb2 (2)
+ *   occ (B, W, H, Z, NCLS) ; flow (B, W, H, Z, 2)
+ */
+int occ_occ_heads_f32(const float* feat, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* fw1, const float* fb1, const float* fw2,
+                      const float* fb2, float* occ, float* flow, int B, int C, int Hd, int NCLS,
+                      int Z, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCCNET_AMD_H_ */

@@ -1,0 +1,125 @@
+// Shared device helpers for the gfx950 deformable-gather kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/occnet_amd.h"
+
+namespace occ {
+
+// Error plumbing for the C ABI (thread-local message, negative return codes).
+void set_error(const char* fmt, ...);
+#define OCC_CHECK_ARG(cond, ...)              \
+  do {                                        \
+    if (!(cond)) {                            \
+      ::occ::set_error(__VA_ARGS__);          \
+      return OCC_E_INVALID;                   \
+    }                                         \
+  } while (0)
+#define OCC_CHECK_LAUNCH(what)                                                  \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      ::occ::set_error("%s: launch failed: %s", what, hipGetErrorString(e__));  \
+      return OCC_E_LAUNCH;                                                      \
+    }                                                                           \
+  } while (0)
+
+// One bilinear sample, pre-resolved: four corner weights (already multiplied by the attention
+// weight; 0 for corners outside the map) and four element offsets into the value tensor of one
+// batch entry (0 for corners outside the map, so the load stays legal and contributes 0*v).
+struct __attribute__((aligned(16))) SampleParam {
+  float w[4];
+  int o[4];
+};
+
+// Arithmetic of mmcv's ms_deformable_im2col:
+//   h_im = loc_y*H - 0.5, w_im = loc_x*W - 0.5, admitted iff -1 < h_im < H and -1 < w_im < W,
+//   corners (h_low,w_low) (h_low,w_high) (h_high,w_low) (h_high,w_high) each read only if inside.
+// row_stride = floats between two consecutive keys (= M*D).  Returns #corners inside the map.
+__device__ __forceinline__ int bilinear_setup(float loc_x, float loc_y, float attn, int H, int W,
+                                              int lvl_start, int row_stride, SampleParam& sp) {
+  sp.w[0] = sp.w[1] = sp.w[2] = sp.w[3] = 0.f;
+  sp.o[0] = sp.o[1] = sp.o[2] = sp.o[3] = 0;
+  const float h_im = loc_y * (float)H - 0.5f;
+  const float w_im = loc_x * (float)W - 0.5f;
+  int n_in = 0;
+  if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h_low = (int)hf, w_low = (int)wf;
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = h_im - hf, lw = w_im - wf;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const bool t = h_low >= 0, b = h_high <= H - 1, l = w_low >= 0, r = w_high <= W - 1;
+    const int base = lvl_start + h_low * W + w_low;
+    if (t && l) { sp.w[0] = hh * hw * attn; sp.o[0] = base * row_stride; ++n_in; }
+    if (t && r) { sp.w[1] = hh * lw * attn; sp.o[1] = (base + 1) * row_stride; ++n_in; }
+    if (b && l) { sp.w[2] = lh * hw * attn; sp.o[2] = (base + W) * row_stride; ++n_in; }
+    if (b && r) { sp.w[3] = lh * lw * attn; sp.o[3] = (base + W + 1) * row_stride; ++n_in; }
+  }
+  return n_in;
+}
+
+// Orders this wave's LDS writes before its later LDS reads (cross-lane hand-off inside ONE wave:
+// the hardware executes a wave's DS instructions in order, the fences only pin the compiler).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// acc += sum over NS samples of sum_k w[k] * value[o[k] .. o[k]+3]; vb already points at this
+// lane's 4 channels (batch base + head*D + 4*(lane&7)).  UNROLL samples (= 4*UNROLL independent
+// 16-byte loads) are kept in flight per lane.
+template <int UNROLL>
+__device__ __forceinline__ float4 gather_samples(const float* __restrict__ vb,
+                                                 const SampleParam* sp, int ns, float4 acc) {
+  int s = 0;
+  for (; s + UNROLL <= ns; s += UNROLL) {
+    float4 w[UNROLL];
+    int4 o[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      w[u] = *reinterpret_cast<const float4*>(sp[s + u].w);
+      o[u] = *reinterpret_cast<const int4*>(sp[s + u].o);
+    }
+    float4 v[UNROLL][4];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      v[u][0] = *reinterpret_cast<const float4*>(vb + o[u].x);
+      v[u][1] = *reinterpret_cast<const float4*>(vb + o[u].y);
+      v[u][2] = *reinterpret_cast<const float4*>(vb + o[u].z);
+      v[u][3] = *reinterpret_cast<const float4*>(vb + o[u].w);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const float ww[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc.x = fmaf(ww[k], v[u][k].x, acc.x);
+        acc.y = fmaf(ww[k], v[u][k].y, acc.y);
+        acc.z = fmaf(ww[k], v[u][k].z, acc.z);
+        acc.w = fmaf(ww[k], v[u][k].w, acc.w);
+      }
+    }
+  }
+  for (; s < ns; ++s) {
+    const float4 w = *reinterpret_cast<const float4*>(sp[s].w);
+    const int4 o = *reinterpret_cast<const int4*>(sp[s].o);
+    const float4 v0 = *reinterpret_cast<const float4*>(vb + o.x);
+    const float4 v1 = *reinterpret_cast<const float4*>(vb + o.y);
+    const float4 v2 = *reinterpret_cast<const float4*>(vb + o.z);
+    const float4 v3 = *reinterpret_cast<const float4*>(vb + o.w);
+    acc.x = fmaf(w.x, v0.x, acc.x); acc.y = fmaf(w.x, v0.y, acc.y);
+    acc.z = fmaf(w.x, v0.z, acc.z); acc.w = fmaf(w.x, v0.w, acc.w);
+    acc.x = fmaf(w.y, v1.x, acc.x); acc.y = fmaf(w.y, v1.y, acc.y);
+    acc.z = fmaf(w.y, v1.z, acc.z); acc.w = fmaf(w.y, v1.w, acc.w);
+    acc.x = fmaf(w.z, v2.x, acc.x); acc.y = fmaf(w.z, v2.y, acc.y);
+    acc.z = fmaf(w.z, v2.z, acc.z); acc.w = fmaf(w.z, v2.w, acc.w);
+    acc.x = fmaf(w.w, v3.x, acc.x); acc.y = fmaf(w.w, v3.y, acc.y);
+    acc.z = fmaf(w.w, v3.z, acc.z); acc.w = fmaf(w.w, v3.w, acc.w);
+  }
+  return acc;
+}
+
+}  // namespace occ

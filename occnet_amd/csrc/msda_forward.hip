@@ -1,0 +1,147 @@
+// Multi-scale deformable attention forward for gfx950 — the drop-in for mmcv's
+// `ms_deform_attn_forward` (call sites: projects/mmdet3d_plugin/bevformer/modules/
+// multi_scale_deformable_attn_function.py:42-48,118-124).
+//
+// Layout: value (B, S, M, D) keeps one pixel's M*D floats contiguous, so a bilinear corner of one
+// head is one 4*D-byte row (128 B at D=32).  Fast kernel (D == 32): a 64-lane wave owns 8
+// consecutive (b,q,m) items; the 8 lanes of a group hold 4 channels each (one 16-byte load per
+// lane = one full 128-byte corner row per group, 8 rows = 1 KiB per wave instruction).
+//   phase 1: the wave resolves all 8*L*P samples of its items once (4 corner weights * attention
+//            weight, 4 element offsets) and parks them in LDS (32 B per sample);
+//   phase 2: each group walks its item's samples: 2 ds_read_b128 + 4 global_load_dwordx4 + 16 FMA
+//            per sample, 4 samples (16 loads) in flight per lane; no cross-lane reduction, the
+//            wave writes 8 x 128 B of output.
+// Any other D uses the scalar kernel (one thread per output element, mmcv's own decomposition).
+#include "common.h"
+
+namespace occ {
+
+constexpr int kWavesPerBlock = 4;
+
+__global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lstart, const float* __restrict__ loc,
+    const float* __restrict__ attn, float* __restrict__ out, int S, int M, int L, int Lq, int P,
+    long n_items) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = 32;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int LP = L * P;
+  const int LPp = LP + 1;  // +32 B per item: neighbouring groups land on different LDS banks
+  SampleParam* sp = reinterpret_cast<SampleParam*>(smem) + (size_t)wave * 8 * LPp;
+  const long item0 = ((long)blockIdx.x * kWavesPerBlock + wave) * 8;
+  if (item0 >= n_items) return;
+  const int row_stride = M * D;
+
+  for (int i = lane; i < 8 * LP; i += 64) {
+    const int g = i / LP, s = i - g * LP;
+    const long item = item0 + g;
+    SampleParam p;
+    p.w[0] = p.w[1] = p.w[2] = p.w[3] = 0.f;
+    p.o[0] = p.o[1] = p.o[2] = p.o[3] = 0;
+    if (item < n_items) {
+      const int l = s / P;
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const int st = (int)lstart[l];
+      const long si = item * LP + s;
+      const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
+      bilinear_setup(xy.x, xy.y, attn[si], H, W, st, row_stride, p);
+    }
+    sp[g * LPp + s] = p;
+  }
+  wave_lds_sync();
+
+  const int g = lane >> 3, c4 = lane & 7;
+  const long item = item0 + g;
+  if (item < n_items) {
+    const long m = item % M;
+    const long b = item / ((long)M * Lq);
+    const float* vb = value + b * (long)S * row_stride + m * D + c4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = gather_samples<4>(vb, sp + g * LPp, LP, acc);
+    *reinterpret_cast<float4*>(out + item * D + c4 * 4) = acc;
+  }
+}
+
+// Scalar fallback: one thread per output element (b, q, m, c); any D / L / P.
+__global__ __launch_bounds__(256) void msda_fwd_scalar_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lstart, const float* __restrict__ loc,
+    const float* __restrict__ attn, float* __restrict__ out, int S, int M, int D, int L, int Lq,
+    int P, long n_out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_out) return;
+  const int c = (int)(idx % D);
+  const long item = idx / D;  // (b*Lq + q)*M + m
+  const int m = (int)(item % M);
+  const long b = item / ((long)M * Lq);
+  const long row_stride = (long)M * D;
+  const float* vb = value + b * S * row_stride + (long)m * D + c;
+  float col = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const long st = lstart[l];
+    for (int p = 0; p < P; ++p) {
+      const long si = (item * L + l) * P + p;
+      const float loc_w = loc[si * 2], loc_h = loc[si * 2 + 1];
+      const float weight = attn[si];
+      const float h_im = loc_h * (float)H - 0.5f;
+      const float w_im = loc_w * (float)W - 0.5f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
+        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+        float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        if (h_low >= 0 && w_low >= 0) v1 = vb[(st + (long)h_low * W + w_low) * row_stride];
+        if (h_low >= 0 && w_high <= W - 1) v2 = vb[(st + (long)h_low * W + w_high) * row_stride];
+        if (h_high <= H - 1 && w_low >= 0) v3 = vb[(st + (long)h_high * W + w_low) * row_stride];
+        if (h_high <= H - 1 && w_high <= W - 1)
+          v4 = vb[(st + (long)h_high * W + w_high) * row_stride];
+        const float val = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+        col += val * weight;
+      }
+    }
+  }
+  out[idx] = col;
+}
+
+}  // namespace occ
+
+extern "C" int occ_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_shapes,
+                                              const int64_t* level_start_index,
+                                              const float* sampling_loc, const float* attn_weight,
+                                              float* out, int B, int S, int M, int D, int L, int Lq,
+                                              int P, int im2col_step, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
+                "ms_deform_attn_forward: null pointer argument");
+  OCC_CHECK_ARG(B > 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq > 0 && P > 0,
+                "ms_deform_attn_forward: non-positive dimension (B=%d S=%d M=%d D=%d L=%d Lq=%d P=%d)",
+                B, S, M, D, L, Lq, P);
+  OCC_CHECK_ARG(im2col_step > 0, "ms_deform_attn_forward: im2col_step must be positive");
+  const int step = B < im2col_step ? B : im2col_step;
+  OCC_CHECK_ARG(B % step == 0, "ms_deform_attn_forward: batch(%d) must divide im2col_step(%d)", B,
+                step);
+  OCC_CHECK_ARG((long)S * M * D < (1L << 31),
+                "ms_deform_attn_forward: one batch entry of value exceeds 2^31 elements");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long n_items = (long)B * Lq * M;
+  const int LP = L * P;
+  const size_t lds = (size_t)kWavesPerBlock * 8 * (LP + 1) * sizeof(SampleParam);
+  if (D == 32 && lds <= 64 * 1024) {
+    const long waves = (n_items + 7) / 8;
+    const long blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(msda_fwd_d32_kernel, dim3((unsigned)blocks), dim3(256), lds, st, value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, out, S, M, L,
+                       Lq, P, n_items);
+  } else {
+    const long n_out = n_items * D;
+    const long blocks = (n_out + 255) / 256;
+    hipLaunchKernelGGL(msda_fwd_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, st, value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, out, S, M, D,
+                       L, Lq, P, n_out);
+  }
+  OCC_CHECK_LAUNCH("ms_deform_attn_forward");
+  return OCC_OK;
+}

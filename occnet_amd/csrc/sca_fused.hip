@@ -1,0 +1,167 @@
+// Fused spatial cross-attention gather for gfx950.
+//
+// Replaces, in one launch per encoder layer (reference: projects/mmdet3d_plugin/bevformer/modules/
+// spatial_cross_attention.py):
+//   :136-153  per-camera visible-query index lists + rebatch gather (nonzero() host sync, padding)
+//   :338-373  softmax over L*P logits, offsets/(W_l,H_l), + z-anchor reference point (anchor p % Z)
+//   :386-396  ms_deform_attn_forward on (bs*6, max_len) padded rows
+//   :165-173  scatter-add into slots, count of visible cameras, divide
+// Query-major instead of camera-major: one 64-lane wave owns one BEV query (all 8 heads, 8 lanes x 4
+// channels per head) and loops over the cameras that see it (batch 0's mask decides, as the
+// reference does), so nothing is padded, nothing is scattered and the camera mean is a register
+// reduction in the reference's camera order.  The softmax and the normalised offsets do not depend on
+// the camera and are computed once per query.  Per (query, camera): 256 samples are resolved by the
+// wave (4 per lane) into LDS, then every 8-lane group gathers its head's 32 samples:
+// 128 x 16-byte loads per lane, 16 in flight.
+#include "common.h"
+
+namespace occ {
+
+constexpr int kScaWaves = 4;
+
+template <int L, int P>
+__global__ __launch_bounds__(256) void sca_fused_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lstart, const float* __restrict__ offs, long offs_stride,
+    const float* __restrict__ logits, long logits_stride, const float* __restrict__ ref_cam,
+    const uint32_t* __restrict__ vis_bits, const int32_t* __restrict__ order,
+    float* __restrict__ slots, unsigned long long* __restrict__ stats, int B, int NC, int S, int Z,
+    int Nq) {
+  constexpr int M = 8, D = 32, LP = L * P;
+  constexpr int K = M * LP / 64;  // samples resolved per lane
+  static_assert(LP >= 8 && LP <= 32 && (LP & (LP - 1)) == 0, "L*P must be a power of two in [8,32]");
+  constexpr int LPp = LP + 1;
+  __shared__ __attribute__((aligned(16))) SampleParam smem[kScaWaves * M * LPp];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long wg = (long)blockIdx.x * kScaWaves + wave;
+  if (wg >= (long)B * Nq) return;
+  const int b = (int)(wg / Nq);
+  const int r = (int)(wg - (long)b * Nq);
+  const int q = order ? order[r] : r;
+  SampleParam* sp = smem + wave * M * LPp;
+
+  constexpr int row_stride = M * D;
+  const uint32_t vis = vis_bits[q];                       // batch 0's mask picks the cameras
+  const uint32_t own = vis_bits[(long)b * Nq + q];        // this batch's mask gives the divisor
+  const int count = __builtin_popcount(own);
+
+  // ---- camera-independent part: softmax(logits) and offsets / (W_l, H_l) ------------------
+  float aw[K], ox[K], oy[K];
+  int lvH[K], lvW[K], lvS[K];
+  const float* lrow = logits + ((long)b * Nq + q) * logits_stride;
+  const float* orow = offs + ((long)b * Nq + q) * offs_stride;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int idx = lane + 64 * k;  // = m*LP + s
+    const int s = idx % LP;
+    const int l = s / P;
+    float x = lrow[idx];
+    float mx = x;
+#pragma unroll
+    for (int d = LP / 2; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    const float e = expf(x - mx);
+    float sum = e;
+#pragma unroll
+    for (int d = LP / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    aw[k] = e / sum;
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    lvH[k] = H; lvW[k] = W; lvS[k] = (int)lstart[l];
+    const float2 o = *reinterpret_cast<const float2*>(orow + 2 * idx);
+    ox[k] = o.x / (float)W;
+    oy[k] = o.y / (float)H;
+  }
+
+  const int g = lane >> 3, c4 = lane & 7;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned n_in = 0, n_rows = 0;
+
+  for (int c = 0; c < NC; ++c) {
+    if (!((vis >> c) & 1u)) continue;  // wave-uniform
+    const float* rp = ref_cam + (((long)c * B + b) * Nq + q) * Z * 2;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int idx = lane + 64 * k;
+      const int m = idx / LP, s = idx % LP;
+      const int z = (s % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
+      const float2 rxy = *reinterpret_cast<const float2*>(rp + 2 * z);
+      SampleParam p;
+      n_in += bilinear_setup(rxy.x + ox[k], rxy.y + oy[k], aw[k], lvH[k], lvW[k], lvS[k],
+                             row_stride, p);
+      sp[m * LPp + s] = p;
+    }
+    wave_lds_sync();
+    const float* vb = value + ((long)b * NC + c) * S * row_stride + g * D + c4 * 4;
+    acc = gather_samples<4>(vb, sp + g * LPp, LP, acc);
+    wave_lds_sync();  // WAR: next camera rewrites the LDS slab
+    ++n_rows;
+  }
+
+  const float inv = (float)(count > 0 ? count : 1);
+  float4 o4 = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
+  *reinterpret_cast<float4*>(slots + ((long)b * Nq + q) * row_stride + g * D + c4 * 4) = o4;
+
+  if (stats) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_in += __shfl_xor(n_in, d);
+    if (lane == 0) {
+      atomicAdd(&stats[0], (unsigned long long)n_rows);
+      atomicAdd(&stats[1], (unsigned long long)n_in);
+    }
+  }
+}
+
+template <int L, int P>
+static int launch_sca(const float* value, const int64_t* shapes, const int64_t* lstart,
+                      const float* offs, long offs_stride, const float* logits, long logits_stride,
+                      const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
+                      float* slots, uint64_t* stats, int B, int NC, int S, int Z, int Nq,
+                      hipStream_t st) {
+  const long waves = (long)B * Nq;
+  const long blocks = (waves + kScaWaves - 1) / kScaWaves;
+  hipLaunchKernelGGL((sca_fused_kernel<L, P>), dim3((unsigned)blocks), dim3(256), 0, st, value,
+                     shapes, lstart, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits,
+                     order, slots, reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq);
+  OCC_CHECK_LAUNCH("sca_fused_forward");
+  return OCC_OK;
+}
+
+}  // namespace occ
+
+extern "C" int occ_sca_fused_forward_f32(const float* value, const int64_t* spatial_shapes,
+                                         const int64_t* level_start_index, const float* offs,
+                                         int64_t offs_stride, const float* logits,
+                                         int64_t logits_stride, const float* ref_cam,
+                                         const uint32_t* vis_bits, const int32_t* order,
+                                         float* slots, uint64_t* stats, int B, int NC, int S, int M,
+                                         int D, int L, int P, int Z, int Nq, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(value && spatial_shapes && level_start_index && offs && logits && ref_cam &&
+                    vis_bits && slots,
+                "sca_fused_forward: null pointer argument");
+  OCC_CHECK_ARG(B > 0 && NC > 0 && NC <= 32 && S > 0 && Nq > 0 && Z > 0 && L > 0 && P > 0,
+                "sca_fused_forward: bad dimension (B=%d NC=%d S=%d Nq=%d Z=%d L=%d P=%d)", B, NC, S,
+                Nq, Z, L, P);
+  OCC_CHECK_ARG(P % Z == 0, "sca_fused_forward: num_points(%d) must be a multiple of Z(%d)", P, Z);
+  OCC_CHECK_ARG(offs_stride >= (int64_t)M * L * P * 2 && logits_stride >= (int64_t)M * L * P,
+                "sca_fused_forward: row strides smaller than a row");
+  OCC_CHECK_ARG((long)S * M * D < (1L << 31), "sca_fused_forward: value batch entry too large");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (M != 8 || D != 32) {
+    set_error("sca_fused_forward: no fused kernel for M=%d D=%d", M, D);
+    return OCC_E_UNSUPPORTED;
+  }
+#define OCC_SCA_CASE(LL, PP)                                                                      \
+  if (L == LL && P == PP)                                                                         \
+    return launch_sca<LL, PP>(value, spatial_shapes, level_start_index, offs, (long)offs_stride,  \
+                              logits, (long)logits_stride, ref_cam, vis_bits, order, slots, stats, \
+                              B, NC, S, Z, Nq, st);
+  OCC_SCA_CASE(4, 8)
+  OCC_SCA_CASE(4, 4)
+  OCC_SCA_CASE(2, 8)
+  OCC_SCA_CASE(1, 8)
+#undef OCC_SCA_CASE
+  set_error("sca_fused_forward: no fused kernel for L=%d P=%d", L, P);
+  return OCC_E_UNSUPPORTED;
+}

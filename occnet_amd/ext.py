@@ -1,0 +1,183 @@
+"""The operator module: mirror of the reference's `mmcv._ext` surface for this path.
+
+`ms_deform_attn_forward` / `ms_deform_attn_backward` keep mmcv's exact Python signatures
+(reference call sites: projects/mmdet3d_plugin/bevformer/modules/
+multi_scale_deformable_attn_function.py:42-48, 74-84, 118-124, 150-160): tensors are torch-owned and
+device resident, `im2col_step` is passed as a keyword, the op runs on the current stream without
+synchronising, failures raise Python exceptions.  Underneath, each call hands raw device pointers to
+the C ABI (include/occnet_amd.h) of libocc_amd.so.
+
+The remaining functions expose the fused MI355X kernels (no counterpart in mmcv._ext).
+"""
+import torch
+
+from . import _lib
+from ._lib import OccAmdError, f32, i32, i64, ptr, stream_ptr
+
+
+def _need_cuda_f32(name, t, contiguous=True):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise OccAmdError(f"{name} must be a device (HIP) tensor: the MI355X path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise OccAmdError(f"{name} must be float32, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise OccAmdError(f"{name} must be contiguous")
+
+
+def _need_cuda_i64(name, t):
+    if not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
+        raise OccAmdError(f"{name} must be a contiguous int64 device tensor")
+
+
+def ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                           sampling_locations, attention_weights, im2col_step=64):
+    """-> Tensor (B, Lq, M*D).  Same contract as mmcv._ext.ms_deform_attn_forward."""
+    for n, t in (("value", value), ("sampling_locations", sampling_locations),
+                 ("attention_weights", attention_weights)):
+        _need_cuda_f32(n, t)
+    _need_cuda_i64("value_spatial_shapes", value_spatial_shapes)
+    _need_cuda_i64("value_level_start_index", value_level_start_index)
+    if value.dim() != 4 or sampling_locations.dim() != 6 or attention_weights.dim() != 5:
+        raise OccAmdError("ms_deform_attn_forward: expected value (B,S,M,D), sampling_locations "
+                          "(B,Lq,M,L,P,2), attention_weights (B,Lq,M,L,P)")
+    B, S, M, D = value.shape
+    _, Lq, M2, L, P, two = sampling_locations.shape
+    if (M2 != M or two != 2 or sampling_locations.shape[0] != B or
+            tuple(attention_weights.shape) != (B, Lq, M, L, P) or
+            tuple(value_spatial_shapes.shape) != (L, 2) or value_level_start_index.numel() != L):
+        raise OccAmdError("ms_deform_attn_forward: inconsistent shapes")
+    out = torch.empty((B, Lq, M * D), dtype=torch.float32, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = _lib.lib().occ_ms_deform_attn_forward_f32(
+            ptr(value), ptr(value_spatial_shapes), ptr(value_level_start_index),
+            ptr(sampling_locations), ptr(attention_weights), ptr(out), i32(B), i32(S), i32(M),
+            i32(D), i32(L), i32(Lq), i32(P), i32(int(im2col_step)), stream_ptr(value.device))
+    _lib.check(rc, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, value_spatial_shapes, value_level_start_index,
+                            sampling_locations, attention_weights, grad_output, grad_value,
+                            grad_sampling_loc, grad_attn_weight, im2col_step=64):
+    """Writes into the three pre-zeroed grad tensors; returns None (mmcv contract)."""
+    for n, t in (("value", value), ("sampling_locations", sampling_locations),
+                 ("attention_weights", attention_weights), ("grad_output", grad_output),
+                 ("grad_value", grad_value), ("grad_sampling_loc", grad_sampling_loc),
+                 ("grad_attn_weight", grad_attn_weight)):
+        _need_cuda_f32(n, t)
+    _need_cuda_i64("value_spatial_shapes", value_spatial_shapes)
+    _need_cuda_i64("value_level_start_index", value_level_start_index)
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    if (grad_value.shape != value.shape or grad_sampling_loc.shape != sampling_locations.shape or
+            grad_attn_weight.shape != attention_weights.shape or
+            grad_output.numel() != B * Lq * M * D):
+        raise OccAmdError("ms_deform_attn_backward: inconsistent shapes")
+    with torch.cuda.device(value.device):
+        rc = _lib.lib().occ_ms_deform_attn_backward_f32(
+            ptr(value), ptr(value_spatial_shapes), ptr(value_level_start_index),
+            ptr(sampling_locations), ptr(attention_weights), ptr(grad_output), ptr(grad_value),
+            ptr(grad_sampling_loc), ptr(grad_attn_weight), i32(B), i32(S), i32(M), i32(D), i32(L),
+            i32(Lq), i32(P), i32(int(im2col_step)), stream_ptr(value.device))
+    _lib.check(rc, "ms_deform_attn_backward")
+
+
+def point_sampling(ref_3d, lidar2img, ego2lidar, pc_range, img_h, img_w):
+    """ref_3d (B,Z,Nq,3), lidar2img (B,NC,4,4), ego2lidar (4,4) ->
+    ref_cam (NC,B,Nq,Z,2) f32, bev_mask (NC,B,Nq,Z) bool, vis_bits (B,Nq) int32 bit field."""
+    for n, t in (("ref_3d", ref_3d), ("lidar2img", lidar2img), ("ego2lidar", ego2lidar)):
+        _need_cuda_f32(n, t)
+    B, Z, Nq, three = ref_3d.shape
+    NC = lidar2img.shape[1]
+    if three != 3 or tuple(lidar2img.shape) != (B, NC, 4, 4) or tuple(ego2lidar.shape) != (4, 4):
+        raise OccAmdError("point_sampling: inconsistent shapes")
+    dev = ref_3d.device
+    ref_cam = torch.empty((NC, B, Nq, Z, 2), dtype=torch.float32, device=dev)
+    mask = torch.empty((NC, B, Nq, Z), dtype=torch.uint8, device=dev)
+    vis = torch.empty((B, Nq), dtype=torch.int32, device=dev)
+    pcr = (f32 * 6)(*[float(v) for v in pc_range])
+    with torch.cuda.device(dev):
+        rc = _lib.lib().occ_point_sampling_f32(
+            ptr(ref_3d), ptr(lidar2img), ptr(ego2lidar), pcr, f32(float(img_h)), f32(float(img_w)),
+            ptr(ref_cam), ptr(mask), ptr(vis), i32(B), i32(NC), i32(Nq), i32(Z), stream_ptr(dev))
+    _lib.check(rc, "point_sampling")
+    return ref_cam, mask.view(torch.bool), vis
+
+
+def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, ref_cam, vis_bits,
+                      num_heads, num_levels, num_points, order=None, stats=None):
+    """Fused SCA gather.  value (B*NC, S, M, D); offs (B, Nq, M*L*P*2) / logits (B, Nq, M*L*P) may
+    be column slices of one wider Linear output (last dim contiguous); ref_cam (NC,B,Nq,Z,2);
+    vis_bits (B,Nq) int32.  -> slots (B, Nq, M*D)."""
+    _need_cuda_f32("value", value)
+    _need_cuda_f32("ref_cam", ref_cam)
+    _need_cuda_f32("offs", offs, contiguous=False)
+    _need_cuda_f32("logits", logits, contiguous=False)
+    _need_cuda_i64("spatial_shapes", spatial_shapes)
+    _need_cuda_i64("level_start_index", level_start_index)
+    NC, B, Nq, Z, _ = ref_cam.shape
+    BN, S, M, D = value.shape
+    L, P = int(num_levels), int(num_points)
+    if BN != B * NC or M != num_heads:
+        raise OccAmdError("sca_fused_forward: value batch must equal B*num_cams")
+    for n, t, w in (("offs", offs, M * L * P * 2), ("logits", logits, M * L * P)):
+        if tuple(t.shape[:2]) != (B, Nq) or t.shape[-1] != w or t.stride(-1) != 1 \
+                or t.stride(0) != Nq * t.stride(1):
+            raise OccAmdError(f"sca_fused_forward: {n} must be (B,Nq,{w}) with unit inner stride")
+    if vis_bits.dtype != torch.int32 or tuple(vis_bits.shape) != (B, Nq) or not vis_bits.is_contiguous():
+        raise OccAmdError("sca_fused_forward: vis_bits must be contiguous int32 (B,Nq)")
+    if order is not None and (order.dtype != torch.int32 or order.numel() != Nq):
+        raise OccAmdError("sca_fused_forward: order must be int32 (Nq)")
+    slots = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = _lib.lib().occ_sca_fused_forward_f32(
+            ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
+            i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
+            ptr(order), ptr(slots), ptr(stats), i32(B), i32(NC), i32(S), i32(M), i32(D), i32(L),
+            i32(P), i32(Z), i32(Nq), stream_ptr(value.device))
+    _lib.check(rc, "sca_fused_forward")
+    return slots
+
+
+def tsa_fused_forward(value, offs, logits, ref_2d, bev_h, bev_w, num_heads, num_points,
+                      shared_queue=False, order=None):
+    """Fused TSA gather.  value: (B*2, Nq, M, D), or (B, Nq, M, D) with shared_queue=True when both
+    queue entries are the same projected BEV (no history).  offs (B,Nq,M*2*P*2), logits
+    (B,Nq,M*2*P), ref_2d (B*2,Nq,1,2).  -> (B, Nq, M*D)."""
+    _need_cuda_f32("value", value)
+    _need_cuda_f32("ref_2d", ref_2d)
+    _need_cuda_f32("offs", offs, contiguous=False)
+    _need_cuda_f32("logits", logits, contiguous=False)
+    B, Nq = offs.shape[:2]
+    M, D, P = int(num_heads), value.shape[-1], int(num_points)
+    if Nq != bev_h * bev_w:
+        raise OccAmdError("tsa_fused_forward: Nq must equal bev_h*bev_w")
+    per = Nq * M * D
+    if shared_queue:
+        if value.numel() != B * per:
+            raise OccAmdError("tsa_fused_forward: shared value must be (B,Nq,M,D)")
+        if B != 1:
+            # entry (b,t) lives at (b*2+t)*stride: aliasing both entries needs stride 0 -> B == 1
+            value = torch.stack([value.view(B, Nq, M, D)] * 2, 1).reshape(B * 2, Nq, M, D).contiguous()
+            stride = per
+        else:
+            stride = 0
+    else:
+        if value.numel() != 2 * B * per:
+            raise OccAmdError("tsa_fused_forward: value must be (B*2,Nq,M,D)")
+        stride = per
+    if tuple(ref_2d.shape) != (B * 2, Nq, 1, 2):
+        raise OccAmdError("tsa_fused_forward: ref_2d must be (B*2,Nq,1,2)")
+    for n, t, w in (("offs", offs, M * 2 * P * 2), ("logits", logits, M * 2 * P)):
+        if t.shape[-1] != w or t.stride(-1) != 1 or t.stride(0) != Nq * t.stride(1):
+            raise OccAmdError(f"tsa_fused_forward: {n} must be (B,Nq,{w}) with unit inner stride")
+    out = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = _lib.lib().occ_tsa_fused_forward_f32(
+            ptr(value), i64(stride), ptr(offs), i64(offs.stride(1)), ptr(logits),
+            i64(logits.stride(1)), ptr(ref_2d), ptr(order), ptr(out), i32(B), i32(Nq), i32(bev_h),
+            i32(bev_w), i32(M), i32(D), i32(P), stream_ptr(value.device))
+    _lib.check(rc, "tsa_fused_forward")
+    return out

@@ -1,0 +1,181 @@
+"""Image backbone + neck named by the occ configs (`ResNet`, `FPN`), restated on stock torch.nn.
+
+Out of the hot path's kernel scope ("backbone/neck stay stock PyTorch-ROCm
+(MIOpen), no custom kernels"); they exist so `build_model(cfg.model)` works and end-to-end samples/s
+(images -> voxels) can be measured.  Module/parameter names follow mmdet's (`conv1`, `bn1`,
+`layer{1..4}.{i}.{conv,bn}{1,2,3}`, `downsample.{0,1}`; `lateral_convs.{i}.conv`, `fpn_convs.{i}.conv`)
+so a reference checkpoint's `img_backbone.*` / `img_neck.*` keys load.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .bricks import BaseModule, ConvModule
+from .registry import BACKBONES, NECKS
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        # style='pytorch': the stride sits on the 3x3 conv
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+@BACKBONES.register_module()
+class ResNet(BaseModule):
+    arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch',
+                 with_cp=False, pretrained=None, in_channels=3, base_channels=64, init_cfg=None,
+                 **kwargs):
+        super().__init__(init_cfg)
+        if depth not in self.arch:
+            raise KeyError(f'invalid depth {depth} for resnet (bottleneck depths only)')
+        assert style == 'pytorch'
+        self.depth, self.num_stages = depth, num_stages
+        self.out_indices, self.frozen_stages, self.norm_eval = out_indices, frozen_stages, norm_eval
+        self.conv1 = nn.Conv2d(in_channels, base_channels, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(base_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inplanes = base_channels
+        self.res_layers = []
+        for i, n in enumerate(self.arch[depth][:num_stages]):
+            planes = base_channels * 2 ** i
+            stride = 1 if i == 0 else 2
+            blocks = []
+            for j in range(n):
+                ds = None
+                if j == 0 and (stride != 1 or inplanes != planes * 4):
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+                blocks.append(Bottleneck(inplanes, planes, stride if j == 0 else 1, ds))
+                inplanes = planes * 4
+            name = f'layer{i + 1}'
+            self.add_module(name, nn.Sequential(*blocks))
+            self.res_layers.append(name)
+        self._freeze_stages()
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            for m in (self.conv1, self.bn1):
+                m.eval()
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+
+@NECKS.register_module()
+class FPN(BaseModule):
+    """1x1 laterals, top-down nearest upsample-add, 3x3 output convs, extra stride-2 levels."""
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1,
+                 add_extra_convs=False, relu_before_extra_convs=False, no_norm_on_lateral=False,
+                 conv_cfg=None, norm_cfg=None, act_cfg=None, upsample_cfg=dict(mode='nearest'),
+                 init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        assert isinstance(in_channels, (list, tuple))
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        self.relu_before_extra_convs = relu_before_extra_convs
+        self.upsample_cfg = dict(upsample_cfg)
+        self.backbone_end_level = self.num_ins if end_level in (-1, self.num_ins - 1) else end_level + 1
+        self.start_level = start_level
+        if add_extra_convs is True:
+            add_extra_convs = 'on_input'
+        assert add_extra_convs in (False, 'on_input', 'on_lateral', 'on_output')
+        self.add_extra_convs = add_extra_convs
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1, conv_cfg=conv_cfg,
+                                                 norm_cfg=None if no_norm_on_lateral else norm_cfg,
+                                                 act_cfg=act_cfg, inplace=False))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1,
+                                             conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg,
+                                             inplace=False))
+        extra_levels = num_outs - self.backbone_end_level + self.start_level
+        if self.add_extra_convs and extra_levels >= 1:
+            for i in range(extra_levels):
+                cin = self.in_channels[self.backbone_end_level - 1] \
+                    if (i == 0 and self.add_extra_convs == 'on_input') else out_channels
+                self.fpn_convs.append(ConvModule(cin, out_channels, 3, stride=2, padding=1,
+                                                 conv_cfg=conv_cfg, norm_cfg=norm_cfg,
+                                                 act_cfg=act_cfg, inplace=False))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+        n = len(laterals)
+        for i in range(n - 1, 0, -1):
+            laterals[i - 1] = laterals[i - 1] + F.interpolate(
+                laterals[i], size=laterals[i - 1].shape[2:], **self.upsample_cfg)
+        outs = [self.fpn_convs[i](laterals[i]) for i in range(n)]
+        if self.num_outs > len(outs):
+            if not self.add_extra_convs:
+                for _ in range(self.num_outs - n):
+                    outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+            else:
+                if self.add_extra_convs == 'on_input':
+                    src = inputs[self.backbone_end_level - 1]
+                elif self.add_extra_convs == 'on_lateral':
+                    src = laterals[-1]
+                else:
+                    src = outs[-1]
+                outs.append(self.fpn_convs[n](src))
+                for i in range(n + 1, self.num_outs):
+                    src = F.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]
+                    outs.append(self.fpn_convs[i](src))
+        return tuple(outs)

@@ -1,0 +1,139 @@
+"""BEVFormerOcc detector shell: images -> ResNet/FPN features (B, N, C, H, W) -> BEVFormerOccHead.
+
+Mirror of the reference's projects/mmdet3d_plugin/bevformer/detectors/bevformer_occ.py (registry
+name, constructor kwargs of the MVXTwoStageDetector call shape, `img_backbone` / `img_neck` /
+`pts_bbox_head` attribute names, forward(return_loss=...) / forward_train / forward_test /
+simple_test / obtain_history_bev contracts).  As in mmdet3d's MVXTwoStageDetector, the `pts` part of
+train_cfg / test_cfg is injected into the head's config.
+"""
+import torch
+
+from .bricks import BaseModule
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+@DETECTORS.register_module()
+class BEVFormerOcc(BaseModule):
+
+    def __init__(self, use_grid_mask=False, pts_voxel_layer=None, pts_voxel_encoder=None,
+                 pts_middle_encoder=None, pts_fusion_layer=None, img_backbone=None,
+                 pts_backbone=None, img_neck=None, pts_neck=None, pts_bbox_head=None,
+                 img_roi_head=None, img_rpn_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, video_test_mode=False):
+        super().__init__()
+        for name, v in (('pts_voxel_layer', pts_voxel_layer), ('pts_voxel_encoder', pts_voxel_encoder),
+                        ('pts_middle_encoder', pts_middle_encoder), ('pts_fusion_layer', pts_fusion_layer),
+                        ('pts_backbone', pts_backbone), ('pts_neck', pts_neck),
+                        ('img_roi_head', img_roi_head), ('img_rpn_head', img_rpn_head)):
+            if v is not None:
+                raise NotImplementedError(f'{name}: the occupancy model is camera-only')
+        if pts_bbox_head:
+            pts_bbox_head = dict(pts_bbox_head)
+            pts_bbox_head.update(train_cfg=train_cfg.get('pts') if train_cfg else None)
+            pts_bbox_head.update(test_cfg=test_cfg.get('pts') if test_cfg else None)
+            self.pts_bbox_head = build_head(pts_bbox_head)
+        if img_backbone:
+            self.img_backbone = build_backbone(img_backbone)
+        if img_neck is not None:
+            self.img_neck = build_neck(img_neck)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        # GridMask is a train-time image augmentation (reference models/utils/grid_mask.py): outside
+        # the forward hot path, accepted and not applied.
+        self.use_grid_mask = use_grid_mask
+        self.fp16_enabled = False
+        self.video_test_mode = video_test_mode
+        self.prev_frame_info = {'prev_bev': None, 'scene_token': None, 'prev_pos': 0, 'prev_angle': 0}
+
+    @property
+    def with_img_neck(self):
+        return hasattr(self, 'img_neck') and self.img_neck is not None
+
+    def init_weights(self):
+        for m in (getattr(self, 'img_backbone', None), getattr(self, 'pts_bbox_head', None)):
+            if m is not None:
+                m.init_weights()
+
+    def extract_img_feat(self, img, img_metas=None, len_queue=None):
+        """img (B, N, 3, H, W) -> list of (B, N, C, h, w) (or (B/len_queue, len_queue, N, C, h, w))."""
+        if img is None:
+            return None
+        B = img.size(0)
+        if img.dim() == 5:
+            B, N, C, H, W = img.size()
+            img = img.reshape(B * N, C, H, W)
+        img_feats = self.img_backbone(img)
+        if isinstance(img_feats, dict):
+            img_feats = list(img_feats.values())
+        if self.with_img_neck:
+            img_feats = self.img_neck(img_feats)
+        out = []
+        for f in img_feats:
+            BN, C, H, W = f.size()
+            if len_queue is not None:
+                out.append(f.view(int(B / len_queue), len_queue, int(BN / B), C, H, W))
+            else:
+                out.append(f.view(B, int(BN / B), C, H, W))
+        return out
+
+    def extract_feat(self, img, img_metas=None, len_queue=None):
+        return self.extract_img_feat(img, img_metas, len_queue=len_queue)
+
+    def forward_pts_train(self, pts_feats, gt_bboxes_3d, gt_labels_3d, voxel_semantics, voxel_flow,
+                          mask_camera, img_metas, gt_bboxes_ignore=None, prev_bev=None):
+        outs = self.pts_bbox_head(pts_feats, img_metas, prev_bev)
+        return self.pts_bbox_head.loss(voxel_semantics, voxel_flow, mask_camera, outs,
+                                       img_metas=img_metas)
+
+    def forward(self, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(**kwargs)
+        return self.forward_test(**kwargs)
+
+    def obtain_history_bev(self, imgs_queue, img_metas_list):
+        """BEV of the history frames, iteratively, without gradients
+        (imgs_queue (bs, len_queue, N, 3, H, W))."""
+        was_training = self.training
+        self.eval()
+        with torch.no_grad():
+            prev_bev = None
+            bs, len_queue, num_cams, C, H, W = imgs_queue.shape
+            imgs_queue = imgs_queue.reshape(bs * len_queue, num_cams, C, H, W)
+            img_feats_list = self.extract_feat(img=imgs_queue, len_queue=len_queue)
+            for i in range(len_queue):
+                img_metas = [each[i] for each in img_metas_list]
+                if not img_metas[0]['prev_bev_exists']:
+                    prev_bev = None
+                img_feats = [each_scale[:, i] for each_scale in img_feats_list]
+                prev_bev = self.pts_bbox_head(img_feats, img_metas, prev_bev, only_bev=True)
+        if was_training:
+            self.train()
+        return prev_bev
+
+    def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None,
+                      voxel_semantics=None, voxel_flow=None, mask_lidar=None, mask_camera=None,
+                      gt_labels=None, gt_bboxes=None, img=None, proposals=None,
+                      gt_bboxes_ignore=None, img_depth=None, img_mask=None):
+        img_feats = self.extract_feat(img=img, img_metas=img_metas)
+        losses = dict()
+        losses.update(self.forward_pts_train(img_feats, gt_bboxes_3d, gt_labels_3d, voxel_semantics,
+                                             voxel_flow, mask_camera, img_metas, gt_bboxes_ignore,
+                                             prev_bev=None))
+        return losses
+
+    def forward_test(self, img_metas, img=None, voxel_semantics=None, mask_lidar=None,
+                     mask_camera=None, **kwargs):
+        if not isinstance(img_metas, list):
+            raise TypeError('img_metas must be a list, but got {}'.format(type(img_metas)))
+        img = [img] if img is None else img
+        new_prev_bev, occ_results, flow_results = self.simple_test(img_metas[0], img[0],
+                                                                   prev_bev=None, **kwargs)
+        return {'occ_results': occ_results.cpu(), 'flow_results': flow_results.cpu()}
+
+    def simple_test_pts(self, x, img_metas, prev_bev=None, rescale=False):
+        outs = self.pts_bbox_head(x, img_metas, prev_bev=prev_bev, test=True)
+        occ, flow = self.pts_bbox_head.get_occ(outs, img_metas, rescale=rescale)
+        return outs['bev_embed'], occ, flow
+
+    def simple_test(self, img_metas, img=None, prev_bev=None, rescale=False):
+        img_feats = self.extract_feat(img=img, img_metas=img_metas)
+        return self.simple_test_pts(img_feats, img_metas, prev_bev, rescale=rescale)

@@ -1,0 +1,303 @@
+"""BEVFormerEncoder / BEVFormerLayer / MyCustomBaseTransformerLayer on the MI355X path.
+
+Mirror of the reference's projects/mmdet3d_plugin/bevformer/modules/encoder.py and
+custom_base_transformer_layer.py: same registry names, constructor kwargs (including the deprecated
+feedforward_channels / ffn_dropout / ffn_num_fcs -> ffn_cfgs mapping), module attribute names
+(`layers`, `attentions`, `ffns`, `norms`) and forward contracts.
+
+What differs is where the work runs: the pillar projection (`point_sampling`, reference
+encoder.py:92-151) is one HIP kernel that also emits the per-query camera-visibility word every
+SpatialCrossAttention layer would otherwise rebuild with nonzero(); the encoder computes it once and
+hands it (plus a cache-friendly query processing order) to all layers through kwargs.
+"""
+import copy
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ext
+from ..synthetic import bev_tile_order
+from .bricks import BaseModule, ModuleList, build_norm_layer
+from .registry import (TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_attention,
+                       build_feedforward_network, build_transformer_layer)
+from .spatial_cross_attention import _require_device
+
+
+@TRANSFORMER_LAYER.register_module()
+class MyCustomBaseTransformerLayer(BaseModule):
+    """Generic transformer layer container: attentions / FFNs / norms built from cfg and applied in
+    `operation_order` (reference: custom_base_transformer_layer.py:37-262)."""
+
+    def __init__(self, attn_cfgs=None,
+                 ffn_cfgs=dict(type='FFN', embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                               ffn_drop=0., act_cfg=dict(type='ReLU', inplace=True)),
+                 operation_order=None, norm_cfg=dict(type='LN'), init_cfg=None, batch_first=True,
+                 **kwargs):
+        ffn_cfgs = copy.deepcopy(ffn_cfgs)
+        for ori_name, new_name in dict(feedforward_channels='feedforward_channels',
+                                       ffn_dropout='ffn_drop', ffn_num_fcs='num_fcs').items():
+            if ori_name in kwargs:
+                ffn_cfgs[new_name] = kwargs[ori_name]
+        super().__init__(init_cfg)
+        self.batch_first = batch_first
+        known = {'self_attn', 'norm', 'ffn', 'cross_attn'}
+        assert set(operation_order) & known == set(operation_order), \
+            f'operation_order of {self.__class__.__name__} may only contain {sorted(known)}'
+        num_attn = operation_order.count('self_attn') + operation_order.count('cross_attn')
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(num_attn)]
+        else:
+            assert num_attn == len(attn_cfgs), \
+                f'{len(attn_cfgs)} attention configs for {num_attn} attentions in {operation_order}'
+            attn_cfgs = [copy.deepcopy(dict(c)) for c in attn_cfgs]
+        self.num_attn = num_attn
+        self.operation_order = operation_order
+        self.norm_cfg = norm_cfg
+        self.pre_norm = operation_order[0] == 'norm'
+        self.attentions = ModuleList()
+        index = 0
+        for operation_name in operation_order:
+            if operation_name in ('self_attn', 'cross_attn'):
+                if 'batch_first' in attn_cfgs[index]:
+                    assert self.batch_first == attn_cfgs[index]['batch_first']
+                else:
+                    attn_cfgs[index]['batch_first'] = self.batch_first
+                attention = build_attention(attn_cfgs[index])
+                attention.operation_name = operation_name
+                self.attentions.append(attention)
+                index += 1
+        self.embed_dims = self.attentions[0].embed_dims
+        self.ffns = ModuleList()
+        num_ffns = operation_order.count('ffn')
+        if isinstance(ffn_cfgs, dict):
+            ffn_cfgs = [copy.deepcopy(ffn_cfgs) for _ in range(num_ffns)]
+        assert len(ffn_cfgs) == num_ffns
+        for ffn_index in range(num_ffns):
+            cfg = dict(ffn_cfgs[ffn_index])
+            cfg.setdefault('type', 'FFN')
+            if 'embed_dims' not in cfg:
+                cfg['embed_dims'] = self.embed_dims
+            else:
+                assert cfg['embed_dims'] == self.embed_dims
+            self.ffns.append(build_feedforward_network(cfg))
+        self.norms = ModuleList()
+        for _ in range(operation_order.count('norm')):
+            self.norms.append(build_norm_layer(norm_cfg, self.embed_dims)[1])
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kwargs):
+        norm_index = attn_index = ffn_index = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None for _ in range(self.num_attn)]
+        elif isinstance(attn_masks, torch.Tensor):
+            attn_masks = [copy.deepcopy(attn_masks) for _ in range(self.num_attn)]
+        else:
+            assert len(attn_masks) == self.num_attn
+        for layer in self.operation_order:
+            if layer == 'self_attn':
+                temp_key = temp_value = query
+                query = self.attentions[attn_index](
+                    query, temp_key, temp_value, identity if self.pre_norm else None,
+                    query_pos=query_pos, key_pos=query_pos, attn_mask=attn_masks[attn_index],
+                    key_padding_mask=query_key_padding_mask, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'norm':
+                query = self.norms[norm_index](query)
+                norm_index += 1
+            elif layer == 'cross_attn':
+                query = self.attentions[attn_index](
+                    query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                    key_pos=key_pos, attn_mask=attn_masks[attn_index],
+                    key_padding_mask=key_padding_mask, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'ffn':
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn_index += 1
+        return query
+
+
+@TRANSFORMER_LAYER.register_module()
+class BEVFormerLayer(MyCustomBaseTransformerLayer):
+    """One encoder layer: TSA -> LN -> SCA -> LN -> FFN -> LN in the base config
+    (reference: encoder.py:242-406)."""
+
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN'), ffn_num_fcs=2,
+                 **kwargs):
+        super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels,
+                         ffn_dropout=ffn_dropout, operation_order=operation_order, act_cfg=act_cfg,
+                         norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
+        self.fp16_enabled = False
+        assert len(operation_order) == 6
+        assert set(operation_order) == set(['self_attn', 'norm', 'cross_attn', 'ffn'])
+
+    def forward(self, query, key=None, value=None, bev_pos=None, query_pos=None, key_pos=None,
+                attn_masks=None, query_key_padding_mask=None, key_padding_mask=None, ref_2d=None,
+                ref_3d=None, bev_h=None, bev_w=None, reference_points_cam=None, mask=None,
+                spatial_shapes=None, level_start_index=None, prev_bev=None, **kwargs):
+        norm_index = attn_index = ffn_index = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None for _ in range(self.num_attn)]
+        elif isinstance(attn_masks, torch.Tensor):
+            attn_masks = [copy.deepcopy(attn_masks) for _ in range(self.num_attn)]
+            warnings.warn(f'Use same attn_mask in all attentions in {self.__class__.__name__} ')
+        else:
+            assert len(attn_masks) == self.num_attn
+        tsa_shapes = kwargs.pop('tsa_spatial_shapes', None)
+        tsa_start = kwargs.pop('tsa_level_start_index', None)
+        for layer in self.operation_order:
+            if layer == 'self_attn':   # temporal self attention: BEV plane is its own single level
+                if tsa_shapes is None:
+                    tsa_shapes = torch.tensor([[bev_h, bev_w]], device=query.device)
+                    tsa_start = torch.tensor([0], device=query.device)
+                query = self.attentions[attn_index](
+                    query, prev_bev, prev_bev, identity if self.pre_norm else None,
+                    query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_index],
+                    key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
+                    spatial_shapes=tsa_shapes, level_start_index=tsa_start, bev_h=bev_h,
+                    bev_w=bev_w, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'norm':
+                query = self.norms[norm_index](query)
+                norm_index += 1
+            elif layer == 'cross_attn':  # spatial cross attention: no positional encoding (query_pos None)
+                query = self.attentions[attn_index](
+                    query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                    key_pos=key_pos, reference_points=ref_3d,
+                    reference_points_cam=reference_points_cam, mask=mask,
+                    attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
+                    spatial_shapes=spatial_shapes, level_start_index=level_start_index, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'ffn':
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn_index += 1
+        return query
+
+
+class TransformerLayerSequence(BaseModule):
+    """mmcv TransformerLayerSequence: `layers` = num_layers deep copies of the layer cfg."""
+
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        else:
+            assert isinstance(transformerlayers, list) and len(transformerlayers) == num_layers
+        self.num_layers = num_layers
+        self.layers = ModuleList()
+        for i in range(num_layers):
+            self.layers.append(build_transformer_layer(transformerlayers[i]))
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module()
+class BEVFormerEncoder(TransformerLayerSequence):
+    """Builds the pillar / BEV-plane reference points, projects the pillars into every camera and
+    runs the layer stack (reference: encoder.py:28-239)."""
+
+    def __init__(self, *args, pc_range=None, num_points_in_pillar=4, return_intermediate=False,
+                 dataset_type='nuscenes', **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+        self.num_points_in_pillar = num_points_in_pillar
+        self.pc_range = pc_range
+        self.fp16_enabled = False
+        self._order_cache = {}
+        self.last_gather_stats = None
+
+    @staticmethod
+    def get_reference_points(H, W, Z=8, num_points_in_pillar=4, dim='3d', bs=1, device='cuda',
+                             dtype=torch.float):
+        """dim='3d': (bs, num_points_in_pillar, H*W, 3) pillar points, normalised; query index
+        q = y*W + x.  dim='2d': (bs, H*W, 1, 2) BEV-plane points (reference :50-89)."""
+        if dim == '3d':
+            zs = torch.linspace(0.5, Z - 0.5, num_points_in_pillar, dtype=dtype, device=device) / Z
+            xs = torch.linspace(0.5, W - 0.5, W, dtype=dtype, device=device) / W
+            ys = torch.linspace(0.5, H - 0.5, H, dtype=dtype, device=device) / H
+            ref_3d = torch.stack((xs.view(1, 1, W).expand(num_points_in_pillar, H, W),
+                                  ys.view(1, H, 1).expand(num_points_in_pillar, H, W),
+                                  zs.view(-1, 1, 1).expand(num_points_in_pillar, H, W)), -1)
+            ref_3d = ref_3d.reshape(num_points_in_pillar, H * W, 3)
+            return ref_3d[None].repeat(bs, 1, 1, 1)
+        elif dim == '2d':
+            ys = torch.linspace(0.5, H - 0.5, H, dtype=dtype, device=device) / H
+            xs = torch.linspace(0.5, W - 0.5, W, dtype=dtype, device=device) / W
+            ref_2d = torch.stack((xs.view(1, W).expand(H, W), ys.view(H, 1).expand(H, W)), -1)
+            return ref_2d.reshape(1, H * W, 2).repeat(bs, 1, 1).unsqueeze(2)
+        raise ValueError(f"dim must be '3d' or '2d', got {dim!r}")
+
+    def point_sampling(self, reference_points, pc_range, img_metas, return_vis=False):
+        """-> reference_points_cam (num_cam, bs, H*W, Z, 2), bev_mask (num_cam, bs, H*W, Z) bool
+        [, vis_bits (bs, H*W) int32].  fp32 (reference :91-92).  `ego2lidar` and `img_shape` are
+        read from img_metas[0] for the whole batch, like the reference (:94, :133-134)."""
+        _require_device(reference_points, 'BEVFormerEncoder.point_sampling')
+        dev = reference_points.device
+        lidar2img = np.asarray([m['lidar2img'] for m in img_metas])
+        lidar2img = torch.as_tensor(lidar2img, dtype=torch.float32).to(dev).contiguous()
+        ego2lidar = torch.as_tensor(np.asarray(img_metas[0]['ego2lidar']), dtype=torch.float32
+                                    ).to(dev).contiguous()
+        img_h, img_w = img_metas[0]['img_shape'][0][0], img_metas[0]['img_shape'][0][1]
+        ref_cam, mask, vis = ext.point_sampling(reference_points.float().contiguous(), lidar2img,
+                                                ego2lidar, pc_range, img_h, img_w)
+        return (ref_cam, mask, vis) if return_vis else (ref_cam, mask)
+
+    def _bev_order(self, bev_h, bev_w, device):
+        key = (bev_h, bev_w, str(device))
+        if key not in self._order_cache:
+            self._order_cache[key] = torch.from_numpy(bev_tile_order(bev_h, bev_w)).to(device)
+        return self._order_cache[key]
+
+    def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
+                spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
+                **kwargs):
+        """bev_query (num_query, bs, C); key/value (num_cam, num_value, bs, C);
+        -> (bs, num_query, C) (or (num_layers, bs, num_query, C) with return_intermediate)."""
+        _require_device(bev_query, 'BEVFormerEncoder')
+        intermediate = []
+        bs = bev_query.size(1)
+        ref_3d = self.get_reference_points(bev_h, bev_w, self.pc_range[5] - self.pc_range[2],
+                                           self.num_points_in_pillar, dim='3d', bs=bs,
+                                           device=bev_query.device, dtype=bev_query.dtype)
+        ref_2d = self.get_reference_points(bev_h, bev_w, dim='2d', bs=bs,
+                                           device=bev_query.device, dtype=bev_query.dtype)
+        reference_points_cam, bev_mask, vis_bits = self.point_sampling(
+            ref_3d, self.pc_range, kwargs['img_metas'], return_vis=True)
+        # the reference keeps `shift_ref_2d = ref_2d.clone()`: no ego-motion shift in this variant
+        shift_ref_2d = ref_2d
+        bev_query = bev_query.permute(1, 0, 2)
+        bev_pos = bev_pos.permute(1, 0, 2)
+        bs, len_bev, num_bev_level, _ = ref_2d.shape
+        if prev_bev is not None:
+            prev_bev = prev_bev.permute(1, 0, 2)
+            prev_bev = torch.stack([prev_bev, bev_query], 1).reshape(bs * 2, len_bev, -1)
+            hybird_ref_2d = torch.stack([shift_ref_2d, ref_2d], 1).reshape(
+                bs * 2, len_bev, num_bev_level, 2)
+        else:
+            hybird_ref_2d = torch.stack([ref_2d, ref_2d], 1).reshape(
+                bs * 2, len_bev, num_bev_level, 2)
+        tsa_shapes = torch.tensor([[bev_h, bev_w]], device=bev_query.device)
+        tsa_start = torch.tensor([0], device=bev_query.device)
+        extra = dict(vis_bits=vis_bits, bev_order=self._bev_order(bev_h, bev_w, bev_query.device),
+                     tsa_spatial_shapes=tsa_shapes, tsa_level_start_index=tsa_start)
+        output = bev_query
+        for lid, layer in enumerate(self.layers):
+            output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
+                           ref_3d=ref_3d, bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
+                           level_start_index=level_start_index,
+                           reference_points_cam=reference_points_cam, bev_mask=bev_mask,
+                           prev_bev=prev_bev, **extra, **kwargs)
+            bev_query = output
+            if self.return_intermediate:
+                intermediate.append(output)
+        if self.return_intermediate:
+            return torch.stack(intermediate)
+        return output

@@ -1,0 +1,264 @@
+"""SpatialCrossAttention / MSDeformableAttention3D on the MI355X kernels.
+
+Mirror of the reference's projects/mmdet3d_plugin/bevformer/modules/spatial_cross_attention.py:
+same registry names, constructor kwargs, parameter names (state_dict layout) and forward() call
+contract.  Two execution paths, both HIP:
+
+* fused (inference, the hot path): the camera-independent query Linears run ONCE per BEV query
+  (the reference recomputes them on every padded per-camera copy of the query), the gather kernel
+  `occ_sca_fused_forward_f32` replaces rebatch + softmax + location arithmetic + deformable attention
+  + scatter-add + camera-count divide (reference :136-173, :338-396).
+* unfused (autograd / shapes without a fused kernel): the reference's own decomposition —
+  rebatch, MSDeformableAttention3D, scatter — with the deformable attention going through
+  MultiScaleDeformableAttnFunction_fp32 (the operator boundary).
+
+There is no CPU branch: host tensors raise (the reference's CPU selector at :386-396 is restated
+only in oracle/).
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ext
+from .._lib import OccAmdError, OccAmdUnsupported
+from .bricks import BaseModule, constant_init, xavier_init
+from .functions import MultiScaleDeformableAttnFunction_fp32
+from .registry import ATTENTION, build_attention
+
+
+def _require_device(t, who):
+    if not t.is_cuda:
+        raise OccAmdError(f"{who}: host tensor given — the MI355X path has no CPU fallback "
+                          "(the CPU restatement lives in oracle/ and is test infrastructure)")
+
+
+class _CatLinearCache:
+    """Concatenated (weight, bias) of several nn.Linear layers, rebuilt when a parameter changes."""
+
+    def __init__(self):
+        self._key, self._w, self._b = None, None, None
+
+    def get(self, linears):
+        key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version)
+                    for l in linears)
+        if key != self._key:
+            self._w = torch.cat([l.weight.detach() for l in linears], 0).contiguous()
+            self._b = torch.cat([l.bias.detach() for l in linears], 0).contiguous()
+            self._key = key
+        return self._w, self._b
+
+
+@ATTENTION.register_module()
+class MSDeformableAttention3D(BaseModule):
+    """Deformable attention over the z-anchor reference points of each BEV pillar
+    (reference :178-400).  No output projection, no residual (output_proj=None, :221)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=8, im2col_step=64,
+                 dropout=0.1, batch_first=True, norm_cfg=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if embed_dims % num_heads != 0:
+            raise ValueError(f'embed_dims must be divisible by num_heads, '
+                             f'but got {embed_dims} and {num_heads}')
+        dim_per_head = embed_dims // num_heads
+        if dim_per_head & (dim_per_head - 1):
+            warnings.warn("the fused gfx950 gather kernels need 32 channels per head; other head "
+                          "sizes run the generic kernel")
+        self.norm_cfg = norm_cfg
+        self.batch_first = batch_first
+        self.output_proj = None
+        self.fp16_enabled = False
+        self.im2col_step = im2col_step
+        self.embed_dims = embed_dims
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self._qcat = _CatLinearCache()
+        self.init_weights()
+
+    def init_weights(self):
+        constant_init(self.sampling_offsets, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(
+            self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid_init[:, :, i, :] *= i + 1
+        self.sampling_offsets.bias.data = grid_init.view(-1)
+        constant_init(self.attention_weights, val=0., bias=0.)
+        xavier_init(self.value_proj, distribution='uniform', bias=0.)
+        xavier_init(self.output_proj, distribution='uniform', bias=0.)  # None -> no-op, as in mmcv
+        self._is_init = True
+
+    def query_linears(self, query):
+        """Both query-side Linears as one GEMM -> (offsets, logits) column views."""
+        w, b = self._qcat.get((self.sampling_offsets, self.attention_weights))
+        out = F.linear(query, w, b)
+        n_off = self.sampling_offsets.out_features
+        return out[..., :n_off], out[..., n_off:]
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                key_padding_mask=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, **kwargs):
+        """Unfused form, reference semantics: query (bs, num_query, C), value (bs, num_value, C),
+        reference_points (bs, num_query, Z, 2) -> (bs, num_query, C)."""
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        _require_device(value, 'MSDeformableAttention3D')
+        bs, num_query, _ = query.shape
+        bs, num_value, _ = value.shape
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, self.num_heads, -1)
+        sampling_offsets = self.sampling_offsets(query).view(
+            bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+        attention_weights = self.attention_weights(query).view(
+            bs, num_query, self.num_heads, self.num_levels * self.num_points)
+        attention_weights = attention_weights.softmax(-1).view(
+            bs, num_query, self.num_heads, self.num_levels, self.num_points)
+        if reference_points.shape[-1] != 2:
+            raise ValueError(f'Last dim of reference_points must be 2, '
+                             f'but get {reference_points.shape[-1]} instead.')
+        # every query owns Z anchors; point p of a level samples around anchor p % Z
+        offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+        Z = reference_points.shape[2]
+        if self.num_points % Z:
+            raise ValueError(f'num_points ({self.num_points}) must be a multiple of the number of '
+                             f'z-anchors ({Z})')
+        sampling_offsets = sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+        sampling_offsets = sampling_offsets.view(bs, num_query, self.num_heads, self.num_levels,
+                                                 self.num_points // Z, Z, 2)
+        sampling_locations = reference_points[:, :, None, None, None, :, :] + sampling_offsets
+        sampling_locations = sampling_locations.view(bs, num_query, self.num_heads, self.num_levels,
+                                                     self.num_points, 2)
+        output = MultiScaleDeformableAttnFunction_fp32.apply(
+            value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+            self.im2col_step)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return output
+
+
+def pack_vis_bits(bev_mask):
+    """bev_mask (num_cams, bs, Nq, Z) bool -> (bs, Nq) int32, bit c = query visible in camera c."""
+    any_z = bev_mask.any(-1)                                         # (NC, bs, Nq)
+    w = (1 << torch.arange(any_z.shape[0], device=any_z.device, dtype=torch.int64)).view(-1, 1, 1)
+    return (any_z.to(torch.int64) * w).sum(0).to(torch.int32).contiguous()
+
+
+@ATTENTION.register_module()
+class SpatialCrossAttention(BaseModule):
+    """Each BEV query attends, through MSDeformableAttention3D, to the cameras its pillar projects
+    into; the per-camera results are averaged over the visible cameras (reference :31-175)."""
+
+    def __init__(self, embed_dims=256, num_cams=6, pc_range=None, dropout=0.1, init_cfg=None,
+                 batch_first=False,
+                 deformable_attention=dict(type='MSDeformableAttention3D', embed_dims=256,
+                                           num_levels=4),
+                 **kwargs):
+        super().__init__(init_cfg)
+        self.init_cfg = init_cfg
+        self.dropout = nn.Dropout(dropout)
+        self.pc_range = pc_range
+        self.fp16_enabled = False
+        self.deformable_attention = build_attention(deformable_attention)
+        self.embed_dims = embed_dims
+        self.num_cams = num_cams
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.batch_first = batch_first
+        self.use_fused = True          # flip to force the unfused (reference-shaped) HIP path
+        self.init_weight()
+
+    def init_weight(self):
+        xavier_init(self.output_proj, distribution='uniform', bias=0.)
+
+    # ------------------------------------------------------------------ fused inference path
+    def _fused_slots(self, query, value, reference_points_cam, bev_mask, spatial_shapes,
+                     level_start_index, vis_bits=None, order=None, stats=None):
+        da = self.deformable_attention
+        num_cams, l, bs, _ = value.shape
+        # (num_cams, l, bs, C) -> (bs*num_cams, l, C): a view when the producer laid it out that way
+        v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
+        v = da.value_proj(v.float()).view(bs * self.num_cams, l, da.num_heads, -1)
+        offs, logits = da.query_linears(query.float())
+        if vis_bits is None:
+            vis_bits = pack_vis_bits(bev_mask)
+        return ext.sca_fused_forward(v, spatial_shapes, level_start_index, offs, logits,
+                                     reference_points_cam.float().contiguous(), vis_bits,
+                                     da.num_heads, da.num_levels, da.num_points, order=order,
+                                     stats=stats)
+
+    # ------------------------------------------------------------------ unfused path
+    def _unfused_slots(self, query, key, value, reference_points_cam, bev_mask, spatial_shapes,
+                       level_start_index):
+        bs, num_query, _ = query.size()
+        D = reference_points_cam.size(3)
+        slots = torch.zeros_like(query)
+        # visible-query lists come from batch element 0's mask (reference :138-140)
+        indexes = [m[0].sum(-1).nonzero().squeeze(-1) for m in bev_mask]
+        max_len = max(len(each) for each in indexes)
+        queries_rebatch = query.new_zeros([bs, self.num_cams, max_len, self.embed_dims])
+        reference_points_rebatch = reference_points_cam.new_zeros([bs, self.num_cams, max_len, D, 2])
+        for i, idx in enumerate(indexes):
+            queries_rebatch[:, i, :len(idx)] = query[:, idx]
+            reference_points_rebatch[:, i, :len(idx)] = reference_points_cam[i][:, idx]
+        num_cams, l, bs, embed_dims = key.shape
+        key = key.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
+        value = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
+        queries = self.deformable_attention(
+            query=queries_rebatch.view(bs * self.num_cams, max_len, self.embed_dims), key=key,
+            value=value,
+            reference_points=reference_points_rebatch.view(bs * self.num_cams, max_len, D, 2),
+            spatial_shapes=spatial_shapes, level_start_index=level_start_index).view(
+                bs, self.num_cams, max_len, self.embed_dims)
+        for i, idx in enumerate(indexes):
+            slots[:, idx] += queries[:, i, :len(idx)]
+        count = (bev_mask.sum(-1) > 0).permute(1, 2, 0).sum(-1)
+        count = torch.clamp(count, min=1.0)
+        return slots / count[..., None]
+
+    def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, reference_points_cam=None,
+                bev_mask=None, level_start_index=None, flag='encoder', **kwargs):
+        """query (bs, num_query, C) [batch-first, as the encoder calls it]; key/value
+        (num_cams, num_value, bs, C); reference_points_cam (num_cams, bs, num_query, Z, 2);
+        bev_mask (num_cams, bs, num_query, Z) -> (bs, num_query, C)."""
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        inp_residual = query if residual is None else residual
+        if query_pos is not None:
+            query = query + query_pos
+        _require_device(query, 'SpatialCrossAttention')
+        needs_grad = torch.is_grad_enabled() and (
+            query.requires_grad or value.requires_grad or
+            any(p.requires_grad for p in self.deformable_attention.parameters()))
+        slots = None
+        if self.use_fused and not needs_grad and key_padding_mask is None:
+            try:
+                slots = self._fused_slots(query, value, reference_points_cam, bev_mask,
+                                          spatial_shapes, level_start_index,
+                                          vis_bits=kwargs.get('vis_bits'),
+                                          order=kwargs.get('bev_order'),
+                                          stats=kwargs.get('gather_stats'))
+            except OccAmdUnsupported:
+                slots = None
+        if slots is None:
+            slots = self._unfused_slots(query, key, value, reference_points_cam, bev_mask,
+                                        spatial_shapes, level_start_index)
+        slots = self.output_proj(slots)
+        return self.dropout(slots) + inp_residual

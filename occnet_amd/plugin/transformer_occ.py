@@ -1,0 +1,186 @@
+"""TransformerOcc on the MI355X path: camera features -> BEV embedding -> voxel features -> heads.
+
+Mirror of the reference's projects/mmdet3d_plugin/bevformer/modules/transformer_occ.py (registry
+name, constructor kwargs incl. the accepted-and-ignored use_shift / use_can_bus / can_bus_norm /
+two_stage_num_proposals / decoder, parameter names `level_embeds`, `cams_embeds`, `encoder`,
+`decoder.{0,1}.{conv,bn}`, `predicter`, `flow_predicter`).
+
+Data layout: the flattened multi-camera key/value tensor is produced directly as
+(bs*num_cams, sum_l H_l*W_l, C) — the (B, Cam, H, W, C) layout the gather kernels want, one pixel's
+256 channels contiguous — and handed to the encoder as a permuted VIEW in the reference's
+(num_cams, sum HW, bs, C) axis order, so SpatialCrossAttention's permute+reshape back is free.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .bricks import BaseModule, ConvModule
+from .registry import TRANSFORMER, build_transformer_layer_sequence
+from .spatial_cross_attention import MSDeformableAttention3D, _require_device
+from .temporal_self_attention import TemporalSelfAttention
+
+
+def rotate_bev_nearest(bev, angle_deg, center):
+    """Rotate a (C, H, W) BEV map by angle_deg (counter-clockwise, degrees) about `center` (x, y) in
+    pixels, nearest-neighbour, zero fill — the operation the reference applies to the history BEV
+    with torchvision's `rotate(img, angle, center=rotate_center)` (transformer_occ.py:195-205)."""
+    import math
+    C, H, W = bev.shape
+    cx, cy = center[0] - W * 0.5, center[1] - H * 0.5
+    a = math.radians(-angle_deg)
+    cos, sin = math.cos(a), math.sin(a)
+    # output pixel (centred coords) -> source pixel: inverse rotation about (cx, cy)
+    xs = torch.arange(W, device=bev.device, dtype=bev.dtype) + 0.5 - W * 0.5
+    ys = torch.arange(H, device=bev.device, dtype=bev.dtype) + 0.5 - H * 0.5
+    gy, gx = torch.meshgrid(ys, xs, indexing='ij')
+    sx = cos * (gx - cx) + sin * (gy - cy) + cx
+    sy = -sin * (gx - cx) + cos * (gy - cy) + cy
+    grid = torch.stack((sx / (0.5 * W), sy / (0.5 * H)), -1)[None]
+    return F.grid_sample(bev[None], grid, mode='nearest', padding_mode='zeros',
+                         align_corners=False)[0]
+
+
+@TRANSFORMER.register_module()
+class TransformerOcc(BaseModule):
+
+    def __init__(self, num_feature_levels=4, num_cams=6, two_stage_num_proposals=300, encoder=None,
+                 decoder=None, embed_dims=256, rotate_prev_bev=True, use_shift=True, use_can_bus=True,
+                 can_bus_norm=True, use_cams_embeds=True, use_3d=False, use_conv=False,
+                 rotate_center=[100, 100], num_classes=18, out_dim=32, pillar_h=16,
+                 act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='BN', ),
+                 norm_cfg_3d=dict(type='BN3d', ), **kwargs):
+        super().__init__(**kwargs)
+        self.encoder = build_transformer_layer_sequence(encoder)
+        self.embed_dims = embed_dims
+        self.num_feature_levels = num_feature_levels
+        self.num_cams = num_cams
+        self.fp16_enabled = False
+        self.rotate_prev_bev = rotate_prev_bev
+        self.use_shift = use_shift          # accepted, unused: this variant applies no ego shift
+        self.use_can_bus = use_can_bus      # accepted, unused: no can-bus MLP in this variant
+        self.can_bus_norm = can_bus_norm
+        self.use_cams_embeds = use_cams_embeds
+        self.use_3d = use_3d
+        self.use_conv = use_conv
+        self.pillar_h = pillar_h
+        self.out_dim = out_dim
+        if not use_3d:
+            if use_conv:
+                use_bias = norm_cfg is None
+                self.decoder = nn.Sequential(
+                    ConvModule(embed_dims, embed_dims, kernel_size=3, stride=1, padding=1,
+                               bias=use_bias, norm_cfg=norm_cfg, act_cfg=act_cfg),
+                    ConvModule(embed_dims, embed_dims * 2, kernel_size=3, stride=1, padding=1,
+                               bias=use_bias, norm_cfg=norm_cfg, act_cfg=act_cfg))
+            else:
+                self.decoder = nn.Sequential(nn.Linear(embed_dims, embed_dims * 2), nn.Softplus(),
+                                             nn.Linear(embed_dims * 2, embed_dims * 2))
+        else:
+            use_bias_3d = norm_cfg_3d is None
+            self.middle_dims = embed_dims // pillar_h
+            self.decoder = nn.Sequential(
+                ConvModule(self.middle_dims, out_dim, kernel_size=3, stride=1, padding=1,
+                           bias=use_bias_3d, conv_cfg=dict(type='Conv3d'), norm_cfg=norm_cfg_3d,
+                           act_cfg=act_cfg),
+                ConvModule(out_dim, out_dim, kernel_size=3, stride=1, padding=1, bias=use_bias_3d,
+                           conv_cfg=dict(type='Conv3d'), norm_cfg=norm_cfg_3d, act_cfg=act_cfg))
+        self.predicter = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
+                                       nn.Linear(out_dim * 2, num_classes))
+        self.flow_predicter = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.ReLU(),
+                                            nn.Linear(out_dim * 2, 2))
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.init_layers()
+        self.rotate_center = rotate_center
+
+    def init_layers(self):
+        self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dims))
+        self.cams_embeds = nn.Parameter(torch.Tensor(self.num_cams, self.embed_dims))
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, (MSDeformableAttention3D, TemporalSelfAttention)):
+                m.init_weights()
+        nn.init.normal_(self.level_embeds)
+        nn.init.normal_(self.cams_embeds)
+
+    def flatten_features(self, mlvl_feats):
+        """list of (bs, num_cam, C, h, w) -> ((bs*num_cam, sum hw, C) with cams/level embeds added,
+        spatial_shapes (L,2) int64, level_start_index (L) int64)."""
+        bs, num_cam, c = mlvl_feats[0].shape[:3]
+        shapes = [(f.shape[3], f.shape[4]) for f in mlvl_feats]
+        total = sum(h * w for h, w in shapes)
+        out = mlvl_feats[0].new_empty((bs * num_cam, total, c))
+        start = 0
+        for lvl, feat in enumerate(mlvl_feats):
+            h, w = shapes[lvl]
+            emb = self.level_embeds[lvl].to(feat.dtype)
+            if self.use_cams_embeds:   # (1, num_cam, 1, C) + (C)
+                emb = self.cams_embeds.to(feat.dtype)[None, :, None, :] + emb
+            else:
+                emb = emb.view(1, 1, 1, c)
+            dst = out[:, start:start + h * w].view(bs, num_cam, h * w, c)
+            src = feat.flatten(3).permute(0, 1, 3, 2)
+            if torch.is_grad_enabled() and (feat.requires_grad or self.level_embeds.requires_grad):
+                dst.copy_(src + emb)            # differentiable (CopySlices)
+            else:
+                torch.add(src, emb, out=dst)    # transpose + embed add in one pass
+            start += h * w
+        dev = mlvl_feats[0].device
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=dev)
+        starts = [0]
+        for h, w in shapes[:-1]:
+            starts.append(starts[-1] + h * w)
+        level_start_index = torch.as_tensor(starts, dtype=torch.long, device=dev)
+        return out, spatial_shapes, level_start_index
+
+    def get_bev_features(self, mlvl_feats, bev_queries, bev_h, bev_w, grid_length=[0.512, 0.512],
+                         bev_pos=None, prev_bev=None, **kwargs):
+        """-> BEV embedding (bs, bev_h*bev_w, C)."""
+        _require_device(mlvl_feats[0], 'TransformerOcc')
+        bs, num_cam = mlvl_feats[0].shape[:2]
+        bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)
+        bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
+        if prev_bev is not None:
+            if prev_bev.shape[1] == bev_h * bev_w:
+                prev_bev = prev_bev.permute(1, 0, 2)
+            elif len(prev_bev.shape) == 4:
+                prev_bev = prev_bev.view(bs, -1, bev_h * bev_w).permute(2, 0, 1)
+            if self.rotate_prev_bev:
+                prev_bev = prev_bev.clone()
+                for i in range(bs):
+                    rotation_angle = kwargs['img_metas'][i]['can_bus'][-1]
+                    tmp = prev_bev[:, i].reshape(bev_h, bev_w, -1).permute(2, 0, 1)
+                    tmp = rotate_bev_nearest(tmp, float(rotation_angle), self.rotate_center)
+                    prev_bev[:, i] = tmp.permute(1, 2, 0).reshape(bev_h * bev_w, -1)
+        flat, spatial_shapes, level_start_index = self.flatten_features(mlvl_feats)
+        # reference axis order (num_cam, sum hw, bs, C) as a view of the (bs*num_cam, sum hw, C) buffer
+        feat_flatten = flat.view(bs, num_cam, flat.shape[1], flat.shape[2]).permute(1, 2, 0, 3)
+        return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w,
+                            bev_pos=bev_pos, spatial_shapes=spatial_shapes,
+                            level_start_index=level_start_index, prev_bev=prev_bev, **kwargs)
+
+    def forward(self, mlvl_feats, bev_queries, object_query_embed, bev_h, bev_w,
+                grid_length=[0.512, 0.512], bev_pos=None, reg_branches=None, cls_branches=None,
+                prev_bev=None, **kwargs):
+        """-> (bev_embed (bs, C, bev_h, bev_w), occ (bs, W, H, Z, num_classes), flow (bs, W, H, Z, 2))."""
+        bev_embed = self.get_bev_features(mlvl_feats, bev_queries, bev_h, bev_w,
+                                          grid_length=grid_length, bev_pos=bev_pos,
+                                          prev_bev=prev_bev, **kwargs)
+        bs = mlvl_feats[0].size(0)
+        bev_embed = bev_embed.permute(0, 2, 1).view(bs, -1, bev_h, bev_w)
+        if self.use_3d:
+            # lifter: channel c -> (feature c // pillar_h, height c % pillar_h): a free view
+            outputs = self.decoder(bev_embed.view(bs, -1, self.pillar_h, bev_h, bev_w))
+            outputs = outputs.permute(0, 4, 3, 2, 1)
+        elif self.use_conv:
+            outputs = self.decoder(bev_embed)
+            outputs = outputs.view(bs, -1, self.pillar_h, bev_h, bev_w).permute(0, 3, 4, 2, 1)
+        else:
+            outputs = self.decoder(bev_embed.permute(0, 2, 3, 1))
+            outputs = outputs.view(bs, bev_h, bev_w, self.pillar_h, self.out_dim)
+        flow_pred = self.flow_predicter(outputs)
+        occ_pred = self.predicter(outputs)
+        return bev_embed, occ_pred, flow_pred

@@ -1,0 +1,279 @@
+#!/usr/bin/env python
+"""Throughput bench of the OccNet / BEVFormer-occ forward path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one forward pass of one nuScenes-shaped sample (6 cameras x 3x928x1600, i.e. 900x1600 padded
+to /32 -> ResNet-50 + FPN -> 4 BEVFormer encoder layers -> lifter + Conv3d decoder -> 200x200x16
+voxels x (17 class logits + 2 flow)) per rank, inputs resident in HBM, synthetic data, random-init
+weights.  Ranks process independent samples (data parallel, no data-path collective for inference);
+the only collectives are the barrier and the MAX-reduce of the elapsed time.  Rank 0 prints ONE JSON
+line.  Extra objects on that line:
+  roofline     the dominant kernel (fused SCA deformable gather): algorithmic bytes per launch
+               (N_in*d*e_v + R*S*12 + R*256*e_v, with R and N_in counted on device for
+               the very inputs being timed) / mean launch duration from HIP events recorded on the
+               launch stream inside the timed region, against 8 TB/s HBM.
+  cpu_baseline the CPU oracle (restated reference path, torch fp32, all host cores) on a bounded
+               sample of the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # B/s, MI355X spec (guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "occ_base_200x200x16.py"))
+    ap.add_argument("--scope", choices=["e2e", "hotpath"], default="e2e",
+                    help="e2e: images -> voxels (backbone included); hotpath: FPN features -> voxels")
+    ap.add_argument("--backbone-dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def build(cfg_path, device):
+    from occnet_amd import synthetic
+    from occnet_amd.plugin import Config, build_model, import_plugin
+    cfg = Config.fromfile(cfg_path)
+    import_plugin(cfg)
+    torch.manual_seed(0)
+    model = build_model(cfg.model)
+    model.init_weights()
+    # make the sampling pattern query dependent (reference init zeroes the offset/weight Linears)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("sampling_offsets.weight") or n.endswith("attention_weights.weight"):
+                p.add_(torch.randn(p.shape, generator=g) * 0.02)
+    model = model.to(device).eval()
+    head = model.pts_bbox_head
+    geo = dict(synthetic.BASE)
+    geo.update(cfg.get("input_geometry", {}))
+    geo.update(bev_h=head.bev_h, bev_w=head.bev_w)
+    return cfg, model, geo
+
+
+class Stepper:
+    def __init__(self, model, geo, scope, backbone_dtype, device, seed):
+        from occnet_amd import synthetic
+        self.model, self.scope, self.device = model, scope, device
+        self.metas = synthetic.make_img_metas(geo, batch=1, seed=seed)
+        self.autocast = backbone_dtype == "bf16"
+        if scope == "e2e" and hasattr(model, "img_backbone"):
+            self.img = synthetic.make_images(geo, batch=1, seed=seed, device=device)
+            if self.autocast:
+                model.img_backbone.to(memory_format=torch.channels_last)
+        else:
+            self.scope = "hotpath"
+            self.feats = synthetic.make_features(geo, batch=1, seed=seed, device=device)
+
+    @torch.no_grad()
+    def __call__(self):
+        m = self.model
+        if self.scope == "e2e":
+            if self.autocast:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    feats = m.extract_feat(img=self.img, img_metas=self.metas)
+                feats = [f.float() for f in feats]
+            else:
+                feats = m.extract_feat(img=self.img, img_metas=self.metas)
+        else:
+            feats = self.feats
+        outs = m.pts_bbox_head(feats, self.metas, prev_bev=None, test=True)
+        occ, flow = m.pts_bbox_head.get_occ(outs, self.metas)
+        return occ, flow
+
+
+def gather_stats(model, stepper):
+    """Visible (camera,query) rows R and in-bounds corners N_in of every SCA layer, counted by the
+    fused kernel itself on the benchmark's inputs (one untimed step)."""
+    from occnet_amd.plugin import SpatialCrossAttention
+    scas = [m for m in model.modules() if isinstance(m, SpatialCrossAttention)]
+    stats = [torch.zeros(2, dtype=torch.int64, device=stepper.device) for _ in scas]
+    originals = [s.forward for s in scas]
+    for s, st, orig in zip(scas, stats, originals):
+        s.forward = (lambda orig, st: (lambda *a, **k: orig(*a, gather_stats=st, **k)))(orig, st)
+    try:
+        stepper()
+        torch.cuda.synchronize()
+    finally:
+        for s, orig in zip(scas, originals):
+            s.forward = orig
+    da = scas[0].deformable_attention
+    return [tuple(int(v) for v in st.cpu().tolist()) for st in stats], da
+
+
+def cpu_baseline(cfg, geo):
+    """Oracle (oracle/model.py, torch fp32, all host cores) on a bounded sample: ONE of the encoder
+    layers plus everything outside the layer stack (feature flatten, reference points, lifter,
+    Conv3d decoder, heads), backbone excluded; scaled to the full layer count."""
+    import copy
+    import oracle.model as om
+    from occnet_amd import synthetic
+    hc = copy.deepcopy(cfg.model.pts_bbox_head.to_dict() if hasattr(cfg.model.pts_bbox_head, "to_dict")
+                       else dict(cfg.model.pts_bbox_head))
+    hc = json.loads(json.dumps(hc))          # plain dicts
+    hc.pop("type")
+    n_layers = hc["transformer"]["encoder"]["num_layers"]
+    hc["transformer"]["encoder"]["num_layers"] = 1
+    hc["transformer"]["encoder"]["transformerlayers"]["operation_order"] = tuple(
+        hc["transformer"]["encoder"]["transformerlayers"]["operation_order"])
+    torch.manual_seed(0)
+    ora = om.BEVFormerOccHead(**hc).eval()
+    ora.init_weights()
+    feats = synthetic.make_features(geo, batch=1, seed=0)
+    metas = synthetic.make_img_metas(geo, batch=1, seed=0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    layer = ora.transformer.encoder.layers[0]
+    t_layer = [0.0]
+    orig = layer.forward
+
+    def timed(*a, **k):
+        t0 = time.perf_counter()
+        out = orig(*a, **k)
+        t_layer[0] += time.perf_counter() - t0
+        return out
+    layer.forward = timed
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ora(feats, metas)
+        t_total = time.perf_counter() - t0
+    t_rest = t_total - t_layer[0]
+    t_sample = t_layer[0] * n_layers + t_rest
+    return {
+        "value": 1.0 / t_sample, "unit": "samples/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle hot path (FPN features -> voxels, backbone excluded): 1 of {n_layers} "
+                   f"encoder layers timed ({t_layer[0]:.2f} s) x{n_layers} + rest of the path "
+                   f"({t_rest:.2f} s), one sample, torch fp32 CPU"),
+        "seconds_per_sample": t_sample,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    if args.cpu_baseline_only:
+        from occnet_amd.plugin import Config
+        from occnet_amd import synthetic
+        cfg = Config.fromfile(args.config)
+        geo = dict(synthetic.BASE)
+        geo.update(cfg.get("input_geometry", {}))
+        print(json.dumps({"cpu_baseline": cpu_baseline(cfg, geo)}))
+        return
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
+                         "there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)   # "nccl" is RCCL on ROCm
+
+    from occnet_amd import ext
+    cfg, model, geo = build(args.config, device)
+    stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank)
+
+    for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
+        stepper()
+    torch.cuda.synchronize()
+    stats, da = gather_stats(model, stepper)
+
+    record = None if args.no_kernel_timing else ext.kernel_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    times = ext.kernel_times_ms(record) if record is not None else {}
+    ext.kernel_timing(False)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "nuScenes samples/sec (6-cam 900x1600 -> 200x200x16 voxels)",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("bevformer_base_occ forward: 6x(3x928x1600) images -> ResNet-50+FPN -> "
+                             "4 BEVFormer layers (TSA+SCA+FFN) -> lifter + 2xConv3d decoder -> "
+                             f"{geo['bev_w']}x{geo['bev_h']}x{model.pts_bbox_head.transformer.pillar_h} "
+                             "voxels x (17 logits + 2 flow)" if stepper.scope == "e2e" else
+                             "bevformer_base_occ hot path only: 4 FPN maps (6 cams) -> voxels"),
+                "scope": stepper.scope, "samples_per_gpu": 1, "global_batch": world,
+                "parallelism": f"dp{world}", "hot_path_dtype": "f32",
+                "backbone_dtype": args.backbone_dtype if stepper.scope == "e2e" else None,
+                "config_file": os.path.relpath(args.config, ROOT),
+            },
+        }
+        sca = times.get("sca_fused_forward", [])
+        if sca:
+            M, D = da.num_heads, da.embed_dims // da.num_heads
+            S = M * da.num_levels * da.num_points
+            n_layers = len(stats)
+            b_alg = [n_in * D * 4 + rows * S * 12 + rows * M * D * 4 for rows, n_in in stats]
+            mean_ms = sum(sca) / len(sca)
+            mean_bytes = sum(b_alg) / n_layers
+            achieved = mean_bytes / (mean_ms * 1e-3)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "sca_gather_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            out["roofline"] = {
+                "kernel": "sca_fused_kernel<4,8> (fused SCA deformable gather, fp32 values)",
+                "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": traffic,
+                "algorithmic_bytes_per_launch": mean_bytes, "launch_ms": mean_ms,
+                "launches_timed": len(sca), "rows_R": [r for r, _ in stats],
+                "n_in_corners": [n for _, n in stats],
+            }
+            tsa = times.get("tsa_fused_forward", [])
+            if tsa:
+                out["roofline"]["tsa_launch_ms"] = sum(tsa) / len(tsa)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, geo)
+            except Exception as e:  # the baseline must never take the measurement down
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,18 +63,6 @@ int occ_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_sh
                                    const float* attn_weight, float* out, int B, int S, int M, int D,
                                    int L, int Lq, int P, int im2col_step, void* stream);
 
-/* Backward of the op above.  The three grad outputs must be pre-zeroed by the caller
- * (the reference allocates them with zeros_like); grad_value is accumulated with atomics.
- *   grad_output (B, Lq, M*D); grad_value like value; grad_sampling_loc like sampling_loc;
- *   grad_attn_weight like attn_weight.
- */
-int occ_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes,
-                                    const int64_t* level_start_index, const float* sampling_loc,
-                                    const float* attn_weight, const float* grad_output,
-                                    float* grad_value, float* grad_sampling_loc,
-                                    float* grad_attn_weight, int B, int S, int M, int D, int L,
-                                    int Lq, int P, int im2col_step, void* stream);
-
 /* ------------------------------------------------------------------------------------------
  * Pillar reference points -> per-camera image coordinates + visibility.
  *   ref_3d     (B, Z, Nq, 3) f32  normalised (x, y, z) in [0,1]
@@ -127,42 +115,6 @@ int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_stride, const
                               int64_t offs_stride, const float* logits, int64_t logits_stride,
                               const float* ref_2d, const int32_t* order, float* out, int B, int Nq,
                               int bev_h, int bev_w, int M, int D, int P, void* stream);
-
-/* ------------------------------------------------------------------------------------------
- * y = x @ W^T + bias on the f32 MFMA path (v_mfma_f32_32x32x2_f32: exact f32 products).
- *   x (Mrows, K) row stride ldx ; W (N, K) row-major (nn.Linear layout) ; bias (N) or NULL ;
- *   y (Mrows, N) row stride ldy ; residual (Mrows, N) row stride ldr or NULL (added after bias) ;
- *   relu != 0 applies max(.,0) last.  K % 4 == 0.
- */
-int occ_linear_f32(const float* x, int64_t ldx, const float* W, const float* bias,
-                   const float* residual, int64_t ldr, float* y, int64_t ldy, int64_t Mrows, int N,
-                   int K, int relu, void* stream);
-
-/* Flatten the FPN maps into the (B*NC, S, C) key/value tensor and add camera/level embeddings.
- *   feats[l] (B, NC, C, H_l, W_l) f32, l < L (array of L device pointers, host array)
- *   cams_embeds (NC, C) or NULL ; level_embeds (L, C) ; out (B*NC, S, C)
- */
-int occ_feat_flatten_f32(const float* const* feats, const int* hs, const int* ws, int L,
-                         const float* cams_embeds, const float* level_embeds, float* out, int B,
-                         int NC, int C, void* stream);
-
-/* Conv3d k=3, stride 1, pad 1, no bias, fused with eval-mode BatchNorm3d (scale/shift) and ReLU.
- *   x (B, Cin, Z, H, W) f32 (the lifter view of the BEV embedding) -> y (B, Cout, Z, H, W)
- *   weight (Cout, Cin, 3, 3, 3) ; scale, shift (Cout): y = relu(conv*scale + shift)
- */
-int occ_conv3d_bn_relu_f32(const float* x, const float* weight, const float* scale,
-                           const float* shift, float* y, int B, int Cin, int Cout, int Z, int H,
-                           int W, void* stream);
-
-/* Occupancy + flow heads on the decoder output, written in the reference's (B, W, H, Z, C) order.
- *   feat (B, C, Z, H, W) f32 ; occ MLP: w1 (Hd, C), b1 (Hd), Softplus, w2 (NCLS, Hd), b2 (NCLS)
- *   flow MLP: fw1 (Hd, C), fb1 (Hd), ReLU, fw2 (2, Hd), fb2 (2)
- *   occ (B, W, H, Z, NCLS) ; flow (B, W, H, Z, 2)
- */
-int occ_occ_heads_f32(const float* feat, const float* w1, const float* b1, const float* w2,
-                      const float* b2, const float* fw1, const float* fb1, const float* fw2,
-                      const float* fb2, float* occ, float* flow, int B, int C, int Hd, int NCLS,
-                      int Z, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

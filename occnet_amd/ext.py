@@ -15,6 +15,38 @@ from . import _lib
 from ._lib import OccAmdError, f32, i32, i64, ptr, stream_ptr
 
 
+_TIMING = None   # None, or {kernel name: [(start_event, end_event), ...]} (bench.py roofline leg)
+
+
+def kernel_timing(enable=True):
+    """Turn HIP-event timing of the fused gather launches on/off.  Events are recorded on the
+    stream the kernel is launched on (torch's current stream).  Returns the record dict."""
+    global _TIMING
+    _TIMING = {} if enable else None
+    return _TIMING
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+
+    def __exit__(self, *exc):
+        if _TIMING is not None:
+            self.ev[1].record()
+            _TIMING.setdefault(self.name, []).append(self.ev)
+        return False
+
+
+def kernel_times_ms(record):
+    """{name: [ms per launch]} from a kernel_timing() record (call after a device synchronize)."""
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in record.items()}
+
+
 def _need_cuda_f32(name, t, contiguous=True):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
@@ -131,7 +163,7 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
     if order is not None and (order.dtype != torch.int32 or order.numel() != Nq):
         raise OccAmdError("sca_fused_forward: order must be int32 (Nq)")
     slots = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
-    with torch.cuda.device(value.device):
+    with torch.cuda.device(value.device), _timed('sca_fused_forward'):
         rc = _lib.lib().occ_sca_fused_forward_f32(
             ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
             i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
@@ -174,7 +206,7 @@ def tsa_fused_forward(value, offs, logits, ref_2d, bev_h, bev_w, num_heads, num_
         if t.shape[-1] != w or t.stride(-1) != 1 or t.stride(0) != Nq * t.stride(1):
             raise OccAmdError(f"tsa_fused_forward: {n} must be (B,Nq,{w}) with unit inner stride")
     out = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
-    with torch.cuda.device(value.device):
+    with torch.cuda.device(value.device), _timed('tsa_fused_forward'):
         rc = _lib.lib().occ_tsa_fused_forward_f32(
             ptr(value), i64(stride), ptr(offs), i64(offs.stride(1)), ptr(logits),
             i64(logits.stride(1)), ptr(ref_2d), ptr(order), ptr(out), i32(B), i32(Nq), i32(bev_h),

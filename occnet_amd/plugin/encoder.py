@@ -212,28 +212,47 @@ class BEVFormerEncoder(TransformerLayerSequence):
         self.pc_range = pc_range
         self.fp16_enabled = False
         self._order_cache = {}
+        self._ref_cache = {}
         self.last_gather_stats = None
 
     @staticmethod
     def get_reference_points(H, W, Z=8, num_points_in_pillar=4, dim='3d', bs=1, device='cuda',
                              dtype=torch.float):
         """dim='3d': (bs, num_points_in_pillar, H*W, 3) pillar points, normalised; query index
-        q = y*W + x.  dim='2d': (bs, H*W, 1, 2) BEV-plane points (reference :50-89)."""
+        q = y*W + x.  dim='2d': (bs, H*W, 1, 2) BEV-plane points (reference :50-89).
+
+        The grids are constants of the geometry: they are evaluated once on the host (so they are
+        bit-identical to the reference's CPU path — torch.linspace rounds differently on the device)
+        and moved to `device`; BEVFormerEncoder.forward caches them."""
         if dim == '3d':
-            zs = torch.linspace(0.5, Z - 0.5, num_points_in_pillar, dtype=dtype, device=device) / Z
-            xs = torch.linspace(0.5, W - 0.5, W, dtype=dtype, device=device) / W
-            ys = torch.linspace(0.5, H - 0.5, H, dtype=dtype, device=device) / H
+            zs = torch.linspace(0.5, Z - 0.5, num_points_in_pillar, dtype=dtype) / Z
+            xs = torch.linspace(0.5, W - 0.5, W, dtype=dtype) / W
+            ys = torch.linspace(0.5, H - 0.5, H, dtype=dtype) / H
             ref_3d = torch.stack((xs.view(1, 1, W).expand(num_points_in_pillar, H, W),
                                   ys.view(1, H, 1).expand(num_points_in_pillar, H, W),
                                   zs.view(-1, 1, 1).expand(num_points_in_pillar, H, W)), -1)
             ref_3d = ref_3d.reshape(num_points_in_pillar, H * W, 3)
-            return ref_3d[None].repeat(bs, 1, 1, 1)
+            return ref_3d[None].repeat(bs, 1, 1, 1).to(device)
         elif dim == '2d':
-            ys = torch.linspace(0.5, H - 0.5, H, dtype=dtype, device=device) / H
-            xs = torch.linspace(0.5, W - 0.5, W, dtype=dtype, device=device) / W
+            ys = torch.linspace(0.5, H - 0.5, H, dtype=dtype) / H
+            xs = torch.linspace(0.5, W - 0.5, W, dtype=dtype) / W
             ref_2d = torch.stack((xs.view(1, W).expand(H, W), ys.view(H, 1).expand(H, W)), -1)
-            return ref_2d.reshape(1, H * W, 2).repeat(bs, 1, 1).unsqueeze(2)
+            return ref_2d.reshape(1, H * W, 2).repeat(bs, 1, 1).unsqueeze(2).to(device)
         raise ValueError(f"dim must be '3d' or '2d', got {dim!r}")
+
+    def _reference_grids(self, bev_h, bev_w, bs, device, dtype):
+        key = (bev_h, bev_w, bs, str(device), dtype)
+        if key not in self._ref_cache:
+            ref_3d = self.get_reference_points(bev_h, bev_w, self.pc_range[5] - self.pc_range[2],
+                                               self.num_points_in_pillar, dim='3d', bs=bs,
+                                               device=device, dtype=dtype)
+            ref_2d = self.get_reference_points(bev_h, bev_w, dim='2d', bs=bs, device=device,
+                                               dtype=dtype)
+            hybrid = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, bev_h * bev_w, 1, 2)
+            self._ref_cache = {key: (ref_3d, ref_2d, hybrid.contiguous(),
+                                     torch.tensor([[bev_h, bev_w]], device=device),
+                                     torch.tensor([0], device=device))}
+        return self._ref_cache[key]
 
     def point_sampling(self, reference_points, pc_range, img_metas, return_vis=False):
         """-> reference_points_cam (num_cam, bs, H*W, Z, 2), bev_mask (num_cam, bs, H*W, Z) bool
@@ -264,11 +283,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
         _require_device(bev_query, 'BEVFormerEncoder')
         intermediate = []
         bs = bev_query.size(1)
-        ref_3d = self.get_reference_points(bev_h, bev_w, self.pc_range[5] - self.pc_range[2],
-                                           self.num_points_in_pillar, dim='3d', bs=bs,
-                                           device=bev_query.device, dtype=bev_query.dtype)
-        ref_2d = self.get_reference_points(bev_h, bev_w, dim='2d', bs=bs,
-                                           device=bev_query.device, dtype=bev_query.dtype)
+        ref_3d, ref_2d, hybrid_same, tsa_shapes, tsa_start = self._reference_grids(
+            bev_h, bev_w, bs, bev_query.device, bev_query.dtype)
         reference_points_cam, bev_mask, vis_bits = self.point_sampling(
             ref_3d, self.pc_range, kwargs['img_metas'], return_vis=True)
         # the reference keeps `shift_ref_2d = ref_2d.clone()`: no ego-motion shift in this variant
@@ -282,10 +298,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
             hybird_ref_2d = torch.stack([shift_ref_2d, ref_2d], 1).reshape(
                 bs * 2, len_bev, num_bev_level, 2)
         else:
-            hybird_ref_2d = torch.stack([ref_2d, ref_2d], 1).reshape(
-                bs * 2, len_bev, num_bev_level, 2)
-        tsa_shapes = torch.tensor([[bev_h, bev_w]], device=bev_query.device)
-        tsa_start = torch.tensor([0], device=bev_query.device)
+            hybird_ref_2d = hybrid_same
         extra = dict(vis_bits=vis_bits, bev_order=self._bev_order(bev_h, bev_w, bev_query.device),
                      tsa_spatial_shapes=tsa_shapes, tsa_level_start_index=tsa_start)
         output = bev_query

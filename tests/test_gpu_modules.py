@@ -27,7 +27,7 @@ def test_point_sampling_matches_oracle():
     enc = BEVFormerEncoder.__new__(BEVFormerEncoder)
     ref_3d_g = BEVFormerEncoder.get_reference_points(g['bev_h'], g['bev_w'], pcr[5] - pcr[2], 8, '3d',
                                                      bs=2, device='cuda')
-    assert torch.equal(ref_3d_g.cpu(), ref_3d)
+    assert torch.equal(ref_3d_g.cpu(), ref_3d)      # host-evaluated grid: bit-identical
     rc, m, vis = BEVFormerEncoder.point_sampling(enc, ref_3d_g, pcr, metas, return_vis=True)
     m, rc, vis = m.cpu(), rc.cpu(), vis.cpu()
     mism = int((m != m_o).sum())

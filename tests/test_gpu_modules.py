@@ -144,3 +144,28 @@ def test_gather_stats_match_oracle_count():
     print(f"rows hip {s[0]} oracle {rows}; N_in hip {s[1]} oracle {n_in}")
     assert s[0] == rows
     assert abs(s[1] - n_in) <= max(8, n_in * 1e-5)
+
+
+@pytest.mark.parametrize('name', ['base_struct_nohist', 'base_struct_hist', 'base_struct_bs2', 'tiny_struct'])
+def test_product_matches_reference_golden(name):
+    """HIP path vs the committed golden vectors (outputs of the reference's own module files,
+    oracle/gen_golden.py) — no oracle in the loop."""
+    import os
+    from occnet_amd.plugin import build_head
+    from tests.golden_cases import CASES, case_inputs, checksum
+    from tests.util import head_cfg, randomize
+    case = CASES[name]
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', f'{name}.npz'))
+    head = build_head(head_cfg(case['geometry']))
+    randomize(head, case['seed'])
+    assert abs(checksum(head.state_dict().values()) - float(gold['weights_checksum'])) < 1e-3
+    head = head.cuda().eval()
+    feats, metas, prev_bev = case_inputs(case)
+    assert abs(checksum(feats) - float(gold['inputs_checksum'])) < 1e-3
+    with torch.no_grad():
+        out = head([f.cuda() for f in feats], metas,
+                   prev_bev=None if prev_bev is None else prev_bev.cuda())
+    for k in ('bev_embed', 'occ', 'flow'):
+        d = float(np.abs(out[k].cpu().numpy() - gold[k]).max())
+        print(f"golden {name}/{k}: max|hip - reference| = {d:.3e}")
+        assert d < TOL

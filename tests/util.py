@@ -54,24 +54,44 @@ def head_cfg(g, num_classes=17):
 
 
 def randomize(module, seed=0):
-    """Reference init, then make the sampling pattern query dependent and BN stats non-trivial
-    (the reference init zeroes the offset/weight Linears)."""
-    g = torch.Generator().manual_seed(seed)
+    """Seeded weights that depend only on (seed, state_dict key), never on construction order or the
+    global RNG, so every implementation sharing the reference's key layout gets identical values.
+    Deterministic parts of the reference init are kept (grid-pattern offset biases, zero attention
+    biases, LayerNorm 1/0); random parts are redrawn per key: xavier-uniform for matrices, N(0,1)
+    for bev/level/camera embeddings, U(0,1) for positional embeddings, N(0, 0.02) on the
+    sampling-offset / attention-weight matrices (the reference zeroes them),
+    non-trivial BatchNorm statistics."""
+    import zlib
     module.init_weights()
+    sd = module.state_dict()
     with torch.no_grad():
-        for name, p in module.named_parameters():
-            if name.endswith('sampling_offsets.weight') or name.endswith('attention_weights.weight'):
-                p.add_(torch.randn(p.shape, generator=g) * 0.02)
-        for name, b in module.named_buffers():
-            if name.endswith('running_mean'):
-                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
-            elif name.endswith('running_var'):
-                b.copy_(torch.rand(b.shape, generator=g) * 0.5 + 0.75)
-        for name, p in module.named_parameters():
-            if '.bn.' in name and name.endswith('weight'):
-                p.copy_(torch.rand(p.shape, generator=g) * 0.5 + 0.75)
-            elif '.bn.' in name and name.endswith('bias'):
-                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        for key in sorted(sd):
+            t = sd[key]
+            if not t.is_floating_point():
+                continue
+            g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(key.encode())) % (2 ** 31))
+            rand = lambda: torch.rand(t.shape, generator=g)
+            randn = lambda: torch.randn(t.shape, generator=g)
+            if key.endswith('running_mean'):
+                t.copy_(randn() * 0.1)
+            elif key.endswith('running_var'):
+                t.copy_(rand() * 0.5 + 0.75)
+            elif '.bn.' in key:
+                t.copy_(rand() * 0.5 + 0.75 if key.endswith('weight') else randn() * 0.1)
+            elif key.endswith('sampling_offsets.weight') or key.endswith('attention_weights.weight'):
+                t.copy_(randn() * 0.02)
+            elif 'bev_embedding' in key or key.endswith('level_embeds') or key.endswith('cams_embeds'):
+                t.copy_(randn())
+            elif 'row_embed' in key or 'col_embed' in key:
+                t.copy_(rand())
+            elif t.dim() > 1:
+                fan_out, fan_in = t.shape[0], t[0].numel()
+                if t.dim() > 2:
+                    fan_out = t.shape[0] * t[0, 0].numel()
+                bound = (6.0 / (fan_in + fan_out)) ** 0.5
+                t.copy_((rand() * 2 - 1) * bound)
+            elif key.endswith('.bias') and not any(s in key for s in ('attentions', 'norms')):
+                t.copy_((rand() * 2 - 1) * 0.05)
 
 
 def build_pair(g, seed=0, device='cuda'):

@@ -19,12 +19,10 @@
  *        offset normalisation, z-anchor add, deformable gather), P/bevformer/modules/spatial_cross_attention.py
  *   occ_tsa_fused_forward_f32        <- TemporalSelfAttention.forward :206-262 (softmax, locations,
  *        gather, mean over the 2-deep BEV queue), P/bevformer/modules/temporal_self_attention.py
- *   occ_linear_f32                   <- nn.Linear call sites on the path (value_proj
- *        spatial_cross_attention.py:334, temporal_self_attention.py:198; query Linears :338-341)
- *   occ_feat_flatten_f32             <- TransformerOcc.get_bev_features feature flatten + cams/level
- *        embeds, P/bevformer/modules/transformer_occ.py:207-227
- *   occ_conv3d_bn_relu_f32, occ_occ_heads_f32 <- TransformerOcc.forward lifter + decoder + heads,
- *        transformer_occ.py:304-321 (modules :106-141)
+ *   occ_conv3d_pack_weight_f32, occ_conv3d_bn_relu_f32 <- TransformerOcc.forward lifter view +
+ *        decoder ConvModule(Conv3d k3 + BN3d + ReLU) x2 + permute, P/bevformer/modules/transformer_occ.py
+ *        :305-308 (modules :106-126)
+ *   occ_occ_heads_f32                <- predicter / flow_predicter MLPs, transformer_occ.py:132-141,318-319
  */
 #ifndef OCCNET_AMD_H_
 #define OCCNET_AMD_H_
@@ -115,6 +113,57 @@ int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_stride, const
                               int64_t offs_stride, const float* logits, int64_t logits_stride,
                               const float* ref_2d, const int32_t* order, float* out, int B, int Nq,
                               int bev_h, int bev_w, int M, int D, int P, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention, backward (mmcv op semantics).  Shapes as in the forward;
+ *   grad_output (B, Lq, M*D) f32 in;  grad_value (B, S, M, D), grad_sampling_loc (B, Lq, M, L, P, 2),
+ *   grad_attn_weight (B, Lq, M, L, P) f32 out — PRE-ZEROED BY THE CALLER (the reference's autograd
+ *   Function allocates them with zeros_like, multi_scale_deformable_attn_function.py:146-148);
+ *   grad_value is accumulated with float atomics (summation order is not deterministic).
+ */
+int occ_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start_index, const float* sampling_loc,
+                                    const float* attn_weight, const float* grad_output,
+                                    float* grad_value, float* grad_sampling_loc,
+                                    float* grad_attn_weight, int B, int S, int M, int D, int L,
+                                    int Lq, int P, int im2col_step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Lifter + Conv3d(k=3, pad=1, stride=1, no bias) + BatchNorm3d(eval) + ReLU, implicit GEMM on the f32
+ * matrix cores (exact f32).  Voxel grid (Z, Y, X) = torch's (D, H, W).
+ *   in        in_layout 0: (B, Y, X, Z, Cin) f32, channels innermost (the layout this op writes)
+ *             in_layout 1: (B, Y, X, Cin, Z) f32 = the lifter view of a (B, Y*X, Cin*Z) BEV embedding,
+ *                          channel c = ci*Z + z (transformer_occ.py:305-307)
+ *   w_packed  weight packed by occ_conv3d_pack_weight_f32 from torch's (Cout, Cin, 3, 3, 3) layout
+ *             (Cout*Cin*27 floats)
+ *   scale, shift (Cout) f32: y = conv*scale + shift  (BN eval: scale = gamma/sqrt(var+eps),
+ *             shift = beta - mean*scale; a conv bias folds into shift)
+ *   out       element (b, y, x, z, co) at b*out_stride_b + y*out_stride_y + x*out_stride_x + z*Cout + co
+ *             (strides in floats): (Y,X)-major for the next conv, (X,Y)-major for the reference's
+ *             permute(0,4,3,2,1) output order (transformer_occ.py:308)
+ * Kernels exist for Cout = 32, Cin % 8 == 0, Z in {4, 8, 16, 32}; otherwise OCC_E_UNSUPPORTED.
+ * occ_conv3d_channel_block(Cin) = input channels contracted per LDS phase (16, 8, or 0 = unsupported).
+ */
+int occ_conv3d_channel_block(int Cin);
+int occ_conv3d_pack_weight_f32(const float* weight, float* packed, int Cin, int Cout, void* stream);
+int occ_conv3d_bn_relu_f32(const float* in, const float* w_packed, const float* scale,
+                           const float* shift, float* out, int B, int Z, int Y, int X, int Cin,
+                           int Cout, int in_layout, int64_t out_stride_b, int64_t out_stride_y,
+                           int64_t out_stride_x, int relu, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Occupancy heads on every voxel feature row:
+ *   occ  = Linear(hidden, num_classes)( Softplus( Linear(C, hidden)(feat) ) )     (predicter)
+ *   flow = Linear(hidden, 2)( ReLU( Linear(C, hidden)(feat) ) )                   (flow_predicter)
+ *   feat (n_rows, C) f32; weights in torch Linear layout (out_features, in_features), f32
+ *   occ_out (n_rows, num_classes) f32 ; flow_out (n_rows, 2) f32
+ * Fused kernel for C = 32, hidden = 64, num_classes <= 30; otherwise OCC_E_UNSUPPORTED.
+ */
+int occ_occ_heads_f32(const float* feat, const float* w1_occ, const float* b1_occ,
+                      const float* w2_occ, const float* b2_occ, const float* w1_flow,
+                      const float* b1_flow, const float* w2_flow, const float* b2_flow,
+                      float* occ_out, float* flow_out, int64_t n_rows, int C, int hidden,
+                      int num_classes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,287 @@
+// BEV -> voxel lifter + 3x3x3 Conv3d + BatchNorm3d(eval) + ReLU as one implicit-GEMM kernel on the
+// gfx950 f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain).
+//
+// Replaces (reference: projects/mmdet3d_plugin/bevformer/modules/transformer_occ.py):
+//   :305-307  bev_embed.permute/view -> (bs, C/Z, Z, H, W)      [the "lifter": channel c of the BEV
+//             embedding is feature c // Z at height c % Z; a free view on our (bs, H*W, C) buffer]
+//   :106-126  ConvModule(Conv3d k3 p1 no-bias + BN3d + ReLU) x2 (self.decoder)
+//   :308      permute(0,4,3,2,1) -> (bs, W, H, Z, C): folded into the output strides of the 2nd conv.
+//
+// GEMM view: M = voxels, N = Cout = 32, K = 27 taps x Cin.  A 32-voxel row tile is PX = 32/Z
+// x-adjacent pillars x all Z heights, so one MFMA D tile (32 voxels x 32 output channels) is whole
+// pillars.  A block of 4 waves owns TY x TX pillars (NACC row tiles per wave, B fragments shared by
+// the NACC accumulators).  Per phase of CH input channels the block stages the (TY+2)x(TX+2)x(Z+2)
+// halo once into LDS — voxel slots of CH+4 floats, pillar stride a multiple of 256 B, so the per-tap
+// ds_read_b128 of the 32 voxels of a row tile is bank-conflict free — and walks the 27 taps with
+// compile-time LDS offsets.  k-pairing inside a tap: lanes 0-31 contract channels [0,CH/2), lanes
+// 32-63 channels [CH/2,CH) (the order of the K sum is free), so a lane's A fragment for one tap is
+// CH/2 contiguous floats of ONE voxel and its B fragment CH/2 contiguous floats of the packed weight.
+// Zero padding of the convolution = zero-filled halo slots.  Epilogue: y = relu(acc*scale + shift)
+// with the eval-mode BatchNorm folded into (scale, shift) per output channel, 128-byte rows per voxel.
+#include "common.h"
+
+namespace occ {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int Z, int CH, int TY, int TX>
+struct ConvGeom {
+  static_assert(32 % Z == 0 && Z % 4 == 0, "Z must be 4, 8, 16 or 32");
+  static_assert(CH == 8 || CH == 16, "CH must be 8 or 16");
+  static constexpr int PX = 32 / Z;                          // pillars per 32-voxel row tile
+  static_assert(TX % PX == 0, "TX must be a multiple of the pillars per row tile");
+  static constexpr int VS = CH + 4;                          // floats per voxel slot in LDS
+  static constexpr int PS = ((Z + 2) * VS + 63) / 64 * 64;   // floats per pillar (256-B multiple)
+  static constexpr int HX = TX + 2, HY = TY + 2;
+  static constexpr int LDS_FLOATS = HY * HX * PS;
+  static constexpr int ROW_TILES = TY * TX / PX;
+  static_assert(ROW_TILES % 4 == 0, "row tiles must split over 4 waves");
+  static constexpr int NACC = ROW_TILES / 4;
+  static constexpr int TXG = TX / PX;                        // row tiles per pillar row
+};
+
+// LAYOUT 0: in[b][y][x][z][Cin]          (channels innermost: output layout of this kernel)
+// LAYOUT 1: in[b][y][x][Cin][Z]          (lifter view of the BEV embedding: c = ci*Z + z)
+template <int Z, int CH, int TY, int TX, int LAYOUT>
+__global__ __launch_bounds__(256) void conv3d_mfma_kernel(
+    const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int Y, int X, int Cin, long out_sb,
+    long out_sy, long out_sx, int relu, int tiles_x, int tiles_y) {
+  using G = ConvGeom<Z, CH, TY, TX>;
+  constexpr int VS = G::VS, PS = G::PS, HX = G::HX, HY = G::HY, NACC = G::NACC, H2 = CH / 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int tx_i = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty_i = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty_i * TY, x0 = tx_i * TX;
+  const float* inb = in + (long)b * Y * X * Z * Cin;
+
+  // z-halo slots (z = -1 and z = Z) of every halo pillar stay zero for all phases
+  for (int i = tid; i < HY * HX * 2 * VS; i += 256) {
+    const int pil = i / (2 * VS), rem = i % (2 * VS);
+    lds[pil * PS + (rem >= VS ? (Z + 1) * VS : 0) + rem % VS] = 0.f;
+  }
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  const int vi = lane & 31, kh = lane >> 5;
+  int abase[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int rt = wave * NACC + a;
+    const int ty = rt / G::TXG, txg = rt % G::TXG;
+    const int px = txg * G::PX + vi / Z, z = vi % Z;
+    abase[a] = (ty * HX + px) * PS + z * VS + kh * H2;  // tap (0,0,0) = halo corner (-1,-1,-1)
+  }
+
+  const int nph = Cin / CH;
+  for (int p = 0; p < nph; ++p) {
+    if (p) __syncthreads();  // every wave is done reading the previous phase's halo
+    // ---- stage CH channels of the halo ------------------------------------------------------
+    if (LAYOUT == 0) {
+      constexpr int PARTS = CH / 4, ITEMS = HY * HX * Z * PARTS, ITERS = (ITEMS + 255) / 256;
+      float4 v[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int part = idx % PARTS, z = (idx / PARTS) % Z, pil = idx / (PARTS * Z);
+        const int gy = y0 + pil / HX - 1, gx = x0 + pil % HX - 1;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < ITEMS && gy >= 0 && gy < Y && gx >= 0 && gx < X)
+          v[it] = *reinterpret_cast<const float4*>(inb + (((long)gy * X + gx) * Z + z) * Cin +
+                                                   p * CH + part * 4);
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int part = idx % PARTS, z = (idx / PARTS) % Z, pil = idx / (PARTS * Z);
+        if (idx < ITEMS)
+          *reinterpret_cast<float4*>(lds + pil * PS + (z + 1) * VS + part * 4) = v[it];
+      }
+    } else {
+      constexpr int Z4 = Z / 4, ITEMS = HY * HX * CH * Z4, ITERS = (ITEMS + 255) / 256;
+      float4 v[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int z4 = idx % Z4, ci = (idx / Z4) % CH, pil = idx / (Z4 * CH);
+        const int gy = y0 + pil / HX - 1, gx = x0 + pil % HX - 1;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < ITEMS && gy >= 0 && gy < Y && gx >= 0 && gx < X)
+          v[it] = *reinterpret_cast<const float4*>(inb + ((long)gy * X + gx) * Z * Cin +
+                                                   (long)(p * CH + ci) * Z + z4 * 4);
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int z4 = idx % Z4, ci = (idx / Z4) % CH, pil = idx / (Z4 * CH);
+        if (idx < ITEMS) {
+          float* d = lds + pil * PS + (z4 * 4 + 1) * VS + ci;
+          d[0] = v[it].x; d[VS] = v[it].y; d[2 * VS] = v[it].z; d[3 * VS] = v[it].w;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 27 taps x CH/2 k-pairs x NACC accumulators ---------------------------------------------
+    const float* wq = wp + (((long)p * 27 * 2 + kh) * 32 + vi) * H2;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+      const int toff = (ky * HX + kx) * PS + kz * VS;
+      float bf[H2];
+#pragma unroll
+      for (int s4 = 0; s4 < H2 / 4; ++s4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wq + (long)t * 2 * 32 * H2 + s4 * 4);
+        bf[s4 * 4 + 0] = w4.x; bf[s4 * 4 + 1] = w4.y; bf[s4 * 4 + 2] = w4.z; bf[s4 * 4 + 3] = w4.w;
+      }
+      float af[NACC][H2];
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int s4 = 0; s4 < H2 / 4; ++s4) {
+          const float4 a4 = *reinterpret_cast<const float4*>(lds + abase[a] + toff + s4 * 4);
+          af[a][s4 * 4 + 0] = a4.x; af[a][s4 * 4 + 1] = a4.y;
+          af[a][s4 * 4 + 2] = a4.z; af[a][s4 * 4 + 3] = a4.w;
+        }
+#pragma unroll
+      for (int s = 0; s < H2; ++s)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[s], acc[a], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: BN(eval) + ReLU, one 128-byte row per voxel ---------------------------------------
+  const float sc = scale[vi], sh = shift[vi];
+  float* outb = out + (long)b * out_sb;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int rt = wave * NACC + a;
+    const int ty = rt / G::TXG, txg = rt % G::TXG;
+    const int gy = y0 + ty;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const int gx = x0 + txg * G::PX + row / Z, z = row % Z;
+      float v = fmaf(acc[a][r], sc, sh);
+      if (relu) v = fmaxf(v, 0.f);
+      if (gy < Y && gx < X) outb[gy * out_sy + gx * out_sx + z * 32 + vi] = v;
+    }
+  }
+}
+
+// (Cout=32, Cin, 3, 3, 3) torch weight -> packed[p][t][kh][co][CH/2], channel = p*CH + kh*CH/2 + s,
+// tap t = (kz*3 + ky)*3 + kx.
+__global__ void conv3d_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed,
+                                          int Cin, int CH) {
+  const int n = 32 * Cin * 27;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int H2 = CH / 2;
+  int r = idx;
+  const int s = r % H2; r /= H2;
+  const int co = r % 32; r /= 32;
+  const int kh = r % 2; r /= 2;
+  const int t = r % 27;
+  const int p = r / 27;
+  const int ci = p * CH + kh * H2 + s;
+  packed[idx] = w[((long)co * Cin + ci) * 27 + t];
+}
+
+template <int Z, int CH, int TY, int TX>
+static int launch_conv(const float* in, const float* wp, const float* scale, const float* shift,
+                       float* out, int B, int Y, int X, int Cin, long out_sb, long out_sy,
+                       long out_sx, int relu, int layout, hipStream_t st) {
+  using G = ConvGeom<Z, CH, TY, TX>;
+  const int tiles_x = (X + TX - 1) / TX, tiles_y = (Y + TY - 1) / TY;
+  const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+  const dim3 grid((unsigned)((long)B * tiles_x * tiles_y));
+  hipError_t e;
+  if (layout == 0) {
+    auto k = conv3d_mfma_kernel<Z, CH, TY, TX, 0>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(k, grid, dim3(256), lds, st, in, wp, scale, shift, out, Y, X, Cin, out_sb,
+                         out_sy, out_sx, relu, tiles_x, tiles_y);
+  } else {
+    auto k = conv3d_mfma_kernel<Z, CH, TY, TX, 1>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(k, grid, dim3(256), lds, st, in, wp, scale, shift, out, Y, X, Cin, out_sb,
+                         out_sy, out_sx, relu, tiles_x, tiles_y);
+  }
+  if (e != hipSuccess) {
+    set_error("conv3d_bn_relu: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return OCC_E_LAUNCH;
+  }
+  OCC_CHECK_LAUNCH("conv3d_bn_relu");
+  return OCC_OK;
+}
+
+}  // namespace occ
+
+extern "C" int occ_conv3d_channel_block(int Cin) { return Cin % 16 == 0 ? 16 : (Cin % 8 == 0 ? 8 : 0); }
+
+extern "C" int occ_conv3d_pack_weight_f32(const float* weight, float* packed, int Cin, int Cout,
+                                          void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(weight && packed, "conv3d_pack_weight: null pointer argument");
+  if (Cout != 32 || occ_conv3d_channel_block(Cin) == 0) {
+    set_error("conv3d_pack_weight: no MFMA kernel for Cin=%d Cout=%d (need Cout=32, Cin %% 8 == 0)",
+              Cin, Cout);
+    return OCC_E_UNSUPPORTED;
+  }
+  const int n = 32 * Cin * 27;
+  hipLaunchKernelGGL(conv3d_pack_weight_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), weight, packed, Cin,
+                     occ_conv3d_channel_block(Cin));
+  OCC_CHECK_LAUNCH("conv3d_pack_weight");
+  return OCC_OK;
+}
+
+extern "C" int occ_conv3d_bn_relu_f32(const float* in, const float* w_packed, const float* scale,
+                                      const float* shift, float* out, int B, int Z, int Y, int X,
+                                      int Cin, int Cout, int in_layout, int64_t out_stride_b,
+                                      int64_t out_stride_y, int64_t out_stride_x, int relu,
+                                      void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(in && w_packed && scale && shift && out, "conv3d_bn_relu: null pointer argument");
+  OCC_CHECK_ARG(B > 0 && Z > 0 && Y > 0 && X > 0 && Cin > 0 && Cout > 0,
+                "conv3d_bn_relu: bad dimension (B=%d Z=%d Y=%d X=%d Cin=%d Cout=%d)", B, Z, Y, X, Cin,
+                Cout);
+  OCC_CHECK_ARG(in_layout == 0 || in_layout == 1, "conv3d_bn_relu: in_layout must be 0 or 1");
+  OCC_CHECK_ARG((long)Y * X * Z * (Cin > Cout ? Cin : Cout) < (1L << 31),
+                "conv3d_bn_relu: one batch entry exceeds 2^31 elements");
+  const int CH = occ_conv3d_channel_block(Cin);
+  if (Cout != 32 || CH == 0 || !(Z == 4 || Z == 8 || Z == 16 || Z == 32)) {
+    set_error("conv3d_bn_relu: no MFMA kernel for Z=%d Cin=%d Cout=%d", Z, Cin, Cout);
+    return OCC_E_UNSUPPORTED;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define OCC_CONV_CASE(ZZ, CC, TTY, TTX)                                                            \
+  if (Z == ZZ && CH == CC)                                                                         \
+    return launch_conv<ZZ, CC, TTY, TTX>(in, w_packed, scale, shift, out, B, Y, X, Cin,            \
+                                         (long)out_stride_b, (long)out_stride_y,                   \
+                                         (long)out_stride_x, relu, in_layout, st);
+  OCC_CONV_CASE(16, 16, 2, 8)
+  OCC_CONV_CASE(16, 8, 2, 8)
+  OCC_CONV_CASE(32, 16, 2, 4)
+  OCC_CONV_CASE(32, 8, 2, 4)
+  OCC_CONV_CASE(8, 16, 2, 16)
+  OCC_CONV_CASE(8, 8, 2, 16)
+  OCC_CONV_CASE(4, 16, 2, 16)
+  OCC_CONV_CASE(4, 8, 2, 16)
+#undef OCC_CONV_CASE
+  set_error("conv3d_bn_relu: no MFMA kernel for Z=%d CH=%d", Z, CH);
+  return OCC_E_UNSUPPORTED;
+}

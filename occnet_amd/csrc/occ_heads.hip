@@ -1,0 +1,162 @@
+// Semantics + flow heads of the occupancy decoder as ONE kernel on the gfx950 f32 matrix cores.
+//
+// Replaces (reference: projects/mmdet3d_plugin/bevformer/modules/transformer_occ.py):
+//   :132-141  predicter      = Linear(32,64) -> Softplus -> Linear(64,num_classes)
+//             flow_predicter = Linear(32,64) -> ReLU     -> Linear(64,2)
+//   :318-319  both applied to every voxel feature (bs, W, H, Z, 32)
+// Five torch launches per MLP (2 GEMMs, activation, 2 bias adds) and a 164 MB hidden tensor become one
+// pass: the hidden layer never leaves registers.
+//
+// Everything is computed TRANSPOSED so that no cross-lane shuffle is needed between the two layers:
+//   H^T (128 x 32 voxels) = W1cat (128 x 32) . X^T      A = W1cat rows, B = X^T   (4 tiles of 32 rows)
+//   O^T ( 32 x 32 voxels) = W2cat ( 32 x 128) . act(H^T) A = W2cat,     B = act(H^T)
+// With v_mfma_f32_32x32x2_f32 a lane's D registers of H^T tile a hold hidden units
+// u = 32a + (r&3) + 8(r>>2) + 4(lane>>5) of voxel (lane&31) — exactly a legal B operand (k = lane>>5
+// picks between two hidden units, j = lane&31 is the voxel) when the k-pairs of the second
+// contraction are enumerated as (a, r).  W1cat = [predicter.0 ; flow_predicter.0], W2cat is block
+// diagonal: rows [0,ncls) read hidden [0,64) from predicter.2, rows ncls, ncls+1 read hidden [64,128)
+// from flow_predicter.2.  Biases enter as one extra k-pair with B = 1.
+// A wave keeps its W1 fragments in registers, W2cat fragments live in LDS (shared by the block), and
+// loops over 32-voxel tiles; outputs go through a small LDS transpose so the global stores are
+// contiguous (32 x ncls floats / 64 floats per tile).
+#include "common.h"
+
+namespace occ {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float softplus_f32(float x) {
+  // torch.nn.Softplus(beta=1, threshold=20)
+  return x > 20.f ? x : log1pf(expf(x));
+}
+
+constexpr int kHeadWaves = 4;
+
+__global__ __launch_bounds__(256) void occ_heads_kernel(
+    const float* __restrict__ feat, const float* __restrict__ w1o, const float* __restrict__ b1o,
+    const float* __restrict__ w2o, const float* __restrict__ b2o, const float* __restrict__ w1f,
+    const float* __restrict__ b1f, const float* __restrict__ w2f, const float* __restrict__ b2f,
+    float* __restrict__ occ, float* __restrict__ flow, long n_rows, int ncls) {
+  constexpr int C = 32, HID = 64;
+  __shared__ float w2s[65 * 64];                    // [step (a*16+r), bias step 64][lane]
+  __shared__ float osm[kHeadWaves][32 * 33];        // per-wave output transpose
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vi = lane & 31, kh = lane >> 5;
+
+  // ---- W2cat fragments -> LDS: A operand of layer 2, lane (i = output row, kh) at step (a, r) --------
+  for (int e = tid; e < 65 * 64; e += 256) {
+    const int step = e >> 6, l = e & 63, o = l & 31, k = l >> 5;
+    float v = 0.f;
+    if (step < 64) {
+      const int a = step >> 4, r = step & 15;
+      const int u = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * k;   // hidden unit in [0,128)
+      if (o < ncls) { if (u < HID) v = w2o[o * HID + u]; }
+      else if (o < ncls + 2) { if (u >= HID) v = w2f[(o - ncls) * HID + (u - HID)]; }
+    } else if (k == 0) {                                       // bias k-pair (B = 1 on k = 0)
+      if (o < ncls) v = b2o[o];
+      else if (o < ncls + 2) v = b2f[o - ncls];
+    }
+    w2s[e] = v;
+  }
+  // ---- W1cat fragments -> registers: A operand of layer 1, lane (i = hidden row, kh), step s ------
+  float w1r[4][16], b1r[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int u = 32 * a + vi;
+    const float* src = (u < HID ? w1o + u * C : w1f + (u - HID) * C) + kh * 16;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(src + s4 * 4);
+      w1r[a][s4 * 4 + 0] = w4.x; w1r[a][s4 * 4 + 1] = w4.y;
+      w1r[a][s4 * 4 + 2] = w4.z; w1r[a][s4 * 4 + 3] = w4.w;
+    }
+    b1r[a] = kh == 0 ? (u < HID ? b1o[u] : b1f[u - HID]) : 0.f;
+  }
+  __syncthreads();
+  const float one = kh == 0 ? 1.f : 0.f;
+  float* sm = osm[wave];
+
+  const long n_tiles = (n_rows + 31) / 32;
+  for (long tile = (long)blockIdx.x * kHeadWaves + wave; tile < n_tiles;
+       tile += (long)gridDim.x * kHeadWaves) {
+    const long row0 = tile * 32;
+    // X^T fragment: lane (j = voxel, kh) holds channels kh*16 .. kh*16+15 of its voxel
+    float xr[16];
+    const long row = row0 + vi;
+    if (row < n_rows) {
+      const float* src = feat + row * C + kh * 16;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 x4 = *reinterpret_cast<const float4*>(src + s4 * 4);
+        xr[s4 * 4 + 0] = x4.x; xr[s4 * 4 + 1] = x4.y; xr[s4 * 4 + 2] = x4.z; xr[s4 * 4 + 3] = x4.w;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) xr[s] = 0.f;
+    }
+    f32x16 h[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[a][r] = 0.f;
+      h[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1r[a], one, h[a], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        h[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[a][s], xr[s], h[a], 0, 0, 0);
+    // activations: hidden [0,64) Softplus (predicter), [64,128) ReLU (flow_predicter)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      h[0][r] = softplus_f32(h[0][r]);
+      h[1][r] = softplus_f32(h[1][r]);
+      h[2][r] = fmaxf(h[2][r], 0.f);
+      h[3][r] = fmaxf(h[3][r], 0.f);
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    o = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[64 * 64 + lane], one, o, 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[(a * 16 + r) * 64 + lane], h[a][r], o, 0, 0, 0);
+    // O^T (row = output channel, col = voxel) -> sm[voxel][channel]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sm[vi * 33 + (r & 3) + 8 * (r >> 2) + 4 * kh] = o[r];
+    wave_lds_sync();
+    const long valid = n_rows - row0 < 32 ? n_rows - row0 : 32;
+    for (int e = lane; e < valid * ncls; e += 64) occ[row0 * ncls + e] = sm[(e / ncls) * 33 + e % ncls];
+    if (lane < valid * 2) flow[row0 * 2 + lane] = sm[(lane >> 1) * 33 + ncls + (lane & 1)];
+    wave_lds_sync();
+  }
+}
+
+}  // namespace occ
+
+extern "C" int occ_occ_heads_f32(const float* feat, const float* w1_occ, const float* b1_occ,
+                                 const float* w2_occ, const float* b2_occ, const float* w1_flow,
+                                 const float* b1_flow, const float* w2_flow, const float* b2_flow,
+                                 float* occ_out, float* flow_out, int64_t n_rows, int C, int hidden,
+                                 int num_classes, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(feat && w1_occ && b1_occ && w2_occ && b2_occ && w1_flow && b1_flow && w2_flow &&
+                    b2_flow && occ_out && flow_out,
+                "occ_heads: null pointer argument");
+  OCC_CHECK_ARG(n_rows > 0 && num_classes > 0, "occ_heads: bad dimension");
+  if (C != 32 || hidden != 64 || num_classes + 2 > 32) {
+    set_error("occ_heads: no fused kernel for C=%d hidden=%d num_classes=%d", C, hidden, num_classes);
+    return OCC_E_UNSUPPORTED;
+  }
+  const long n_tiles = (n_rows + 31) / 32;
+  long blocks = (n_tiles + kHeadWaves - 1) / kHeadWaves;
+  if (blocks > 256 * 4) blocks = 256 * 4;   // persistent waves: W fragments are loaded once per wave
+  hipLaunchKernelGGL(occ_heads_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), feat, w1_occ, b1_occ, w2_occ, b2_occ,
+                     w1_flow, b1_flow, w2_flow, b2_flow, occ_out, flow_out, (long)n_rows,
+                     num_classes);
+  OCC_CHECK_LAUNCH("occ_heads");
+  return OCC_OK;
+}

@@ -213,3 +213,75 @@ def tsa_fused_forward(value, offs, logits, ref_2d, bev_h, bev_w, num_heads, num_
             i32(bev_w), i32(M), i32(D), i32(P), stream_ptr(value.device))
     _lib.check(rc, "tsa_fused_forward")
     return out
+
+
+def conv3d_channel_block(cin):
+    """Input channels contracted per LDS phase by the MFMA Conv3d kernel (0 = unsupported)."""
+    return int(_lib.lib().occ_conv3d_channel_block(i32(int(cin))))
+
+
+def conv3d_pack_weight(weight):
+    """torch Conv3d weight (Cout, Cin, 3, 3, 3) f32 -> packed MFMA B-fragment order (flat tensor)."""
+    _need_cuda_f32("weight", weight)
+    if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
+        raise OccAmdError("conv3d_pack_weight: expected a (Cout, Cin, 3, 3, 3) weight")
+    cout, cin = weight.shape[:2]
+    packed = torch.empty(weight.numel(), dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = _lib.lib().occ_conv3d_pack_weight_f32(ptr(weight), ptr(packed), i32(cin), i32(cout),
+                                                   stream_ptr(weight.device))
+    _lib.check(rc, "conv3d_pack_weight")
+    return packed
+
+
+def conv3d_bn_relu(x, w_packed, scale, shift, Z, Y, X, cin, cout, in_layout, out_xy_major=False,
+                   relu=True):
+    """Lifter/Conv3d(k3,p1)+BN(eval)+ReLU on the f32 matrix cores.
+
+    x: in_layout 0 -> (B, Y, X, Z, cin); in_layout 1 -> (B, Y*X, cin*Z) BEV embedding (lifter view).
+    -> (B, Y, X, Z, cout), or (B, X, Y, Z, cout) with out_xy_major (the reference's
+    permute(0,4,3,2,1) order, transformer_occ.py:308)."""
+    for n, t in (("x", x), ("w_packed", w_packed), ("scale", scale), ("shift", shift)):
+        _need_cuda_f32(n, t)
+    B = x.shape[0]
+    if x.numel() != B * Y * X * Z * cin or w_packed.numel() != cout * cin * 27 \
+            or scale.numel() != cout or shift.numel() != cout:
+        raise OccAmdError("conv3d_bn_relu: inconsistent shapes")
+    if out_xy_major:
+        out = torch.empty((B, X, Y, Z, cout), dtype=torch.float32, device=x.device)
+        sy, sx = Z * cout, Y * Z * cout
+    else:
+        out = torch.empty((B, Y, X, Z, cout), dtype=torch.float32, device=x.device)
+        sy, sx = X * Z * cout, Z * cout
+    with torch.cuda.device(x.device), _timed('conv3d_bn_relu'):
+        rc = _lib.lib().occ_conv3d_bn_relu_f32(
+            ptr(x), ptr(w_packed), ptr(scale), ptr(shift), ptr(out), i32(B), i32(Z), i32(Y), i32(X),
+            i32(cin), i32(cout), i32(int(in_layout)), i64(Y * X * Z * cout), i64(sy), i64(sx),
+            i32(1 if relu else 0), stream_ptr(x.device))
+    _lib.check(rc, "conv3d_bn_relu")
+    return out
+
+
+def occ_heads(feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow):
+    """feat (..., C) -> occ (..., num_classes), flow (..., 2): both decoder MLP heads in one kernel."""
+    ts = (feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow)
+    for n, t in zip(("feat", "w1_occ", "b1_occ", "w2_occ", "b2_occ", "w1_flow", "b1_flow", "w2_flow",
+                     "b2_flow"), ts):
+        _need_cuda_f32(n, t)
+    C = feat.shape[-1]
+    hidden, ncls = w1_occ.shape[0], w2_occ.shape[0]
+    if (tuple(w1_occ.shape) != (hidden, C) or tuple(w1_flow.shape) != (hidden, C) or
+            tuple(w2_occ.shape) != (ncls, hidden) or tuple(w2_flow.shape) != (2, hidden) or
+            b1_occ.numel() != hidden or b1_flow.numel() != hidden or b2_occ.numel() != ncls or
+            b2_flow.numel() != 2):
+        raise OccAmdError("occ_heads: inconsistent weight shapes")
+    n_rows = feat.numel() // C
+    occ = torch.empty(feat.shape[:-1] + (ncls,), dtype=torch.float32, device=feat.device)
+    flow = torch.empty(feat.shape[:-1] + (2,), dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device), _timed('occ_heads'):
+        rc = _lib.lib().occ_occ_heads_f32(
+            ptr(feat), ptr(w1_occ), ptr(b1_occ), ptr(w2_occ), ptr(b2_occ), ptr(w1_flow), ptr(b1_flow),
+            ptr(w2_flow), ptr(b2_flow), ptr(occ), ptr(flow), i64(n_rows), i32(C), i32(hidden),
+            i32(ncls), stream_ptr(feat.device))
+    _lib.check(rc, "occ_heads")
+    return occ, flow

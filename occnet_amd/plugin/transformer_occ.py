@@ -14,6 +14,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ext
+from .._lib import OccAmdUnsupported
 from .bricks import BaseModule, ConvModule
 from .registry import TRANSFORMER, build_transformer_layer_sequence
 from .spatial_cross_attention import MSDeformableAttention3D, _require_device
@@ -91,6 +93,8 @@ class TransformerOcc(BaseModule):
         self.two_stage_num_proposals = two_stage_num_proposals
         self.init_layers()
         self.rotate_center = rotate_center
+        self.use_fused_decoder = True     # flip to force the stock torch (MIOpen) decoder
+        self._dec_key, self._dec_pack = None, None
 
     def init_layers(self):
         self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dims))
@@ -162,6 +166,65 @@ class TransformerOcc(BaseModule):
                             bev_pos=bev_pos, spatial_shapes=spatial_shapes,
                             level_start_index=level_start_index, prev_bev=prev_bev, **kwargs)
 
+    # ------------------------------------------------------------------ fused decoder (inference)
+    def _decoder_pack(self):
+        """Packed Conv3d weights + eval-mode BatchNorm folded to (scale, shift), cached until a
+        parameter or running statistic changes."""
+        mods = [self.decoder[0], self.decoder[1]]
+        ts = []
+        for m in mods:
+            ts += [m.conv.weight, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var]
+            if m.conv.bias is not None:
+                ts.append(m.conv.bias)
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if key != self._dec_key:
+            pack = []
+            with torch.no_grad():
+                for m in mods:
+                    bn = m.norm
+                    scale = (bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps))
+                    shift = bn.bias.float() - bn.running_mean.float() * scale
+                    if m.conv.bias is not None:
+                        shift = shift + m.conv.bias.float() * scale
+                    pack.append((ext.conv3d_pack_weight(m.conv.weight.detach().float().contiguous()),
+                                 scale.contiguous(), shift.contiguous()))
+            self._dec_key, self._dec_pack = key, pack
+        return self._dec_pack
+
+    def _fused_decoder_ok(self, bev):
+        if not (self.use_fused_decoder and self.use_3d and bev.is_cuda and bev.dtype == torch.float32):
+            return False
+        if torch.is_grad_enabled() and (bev.requires_grad or
+                                        any(p.requires_grad for p in self.decoder.parameters())):
+            return False
+        for m in (self.decoder[0], self.decoder[1]):
+            bn = m.norm
+            if not isinstance(bn, nn.BatchNorm3d) or bn.training or bn.running_mean is None \
+                    or not bn.affine or not isinstance(getattr(m, 'activate', None), nn.ReLU):
+                return False
+            c = m.conv
+            if (c.kernel_size, c.stride, c.padding, c.dilation, c.groups) != \
+                    ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 1):
+                return False
+        for head, act in ((self.predicter, nn.Softplus), (self.flow_predicter, nn.ReLU)):
+            if len(head) != 3 or not isinstance(head[1], act):
+                return False
+        sp = self.predicter[1]
+        return sp.beta == 1 and sp.threshold == 20
+
+    def _fused_decoder(self, bev, bev_h, bev_w):
+        """bev (bs, bev_h*bev_w, C) contiguous -> occ (bs, W, H, Z, num_classes), flow (bs, W, H, Z, 2):
+        lifter view + 2x(Conv3d+BN+ReLU) + permute + both MLP heads as three HIP launches."""
+        (w1, s1, t1), (w2, s2, t2) = self._decoder_pack()
+        Z = self.pillar_h
+        x = ext.conv3d_bn_relu(bev, w1, s1, t1, Z, bev_h, bev_w, self.middle_dims, self.out_dim,
+                               in_layout=1)
+        x = ext.conv3d_bn_relu(x, w2, s2, t2, Z, bev_h, bev_w, self.out_dim, self.out_dim,
+                               in_layout=0, out_xy_major=True)
+        p, f = self.predicter, self.flow_predicter
+        return ext.occ_heads(x, p[0].weight, p[0].bias, p[2].weight, p[2].bias,
+                             f[0].weight, f[0].bias, f[2].weight, f[2].bias)
+
     def forward(self, mlvl_feats, bev_queries, object_query_embed, bev_h, bev_w,
                 grid_length=[0.512, 0.512], bev_pos=None, reg_branches=None, cls_branches=None,
                 prev_bev=None, **kwargs):
@@ -170,6 +233,12 @@ class TransformerOcc(BaseModule):
                                           grid_length=grid_length, bev_pos=bev_pos,
                                           prev_bev=prev_bev, **kwargs)
         bs = mlvl_feats[0].size(0)
+        if self._fused_decoder_ok(bev_embed):
+            try:
+                occ_pred, flow_pred = self._fused_decoder(bev_embed.contiguous(), bev_h, bev_w)
+                return bev_embed.permute(0, 2, 1).view(bs, -1, bev_h, bev_w), occ_pred, flow_pred
+            except OccAmdUnsupported:
+                pass
         bev_embed = bev_embed.permute(0, 2, 1).view(bs, -1, bev_h, bev_w)
         if self.use_3d:
             # lifter: channel c -> (feature c // pillar_h, height c % pillar_h): a free view

@@ -94,3 +94,17 @@ def count_inbounds_corners(spatial_shapes, sampling_locations):
         n += int((ok & t & lft).sum() + (ok & t & rgt).sum() + (ok & btm & lft).sum() +
                  (ok & btm & rgt).sum())
     return n
+
+
+def msda_backward_autograd(value, value_spatial_shapes, sampling_locations, attention_weights,
+                           grad_output):
+    """Oracle for `ms_deform_attn_backward` (reference call sites:
+    multi_scale_deformable_attn_function.py:74-84,150-160): torch.autograd through the restated
+    forward above.  SURVEY.md Appendix B.9 records that mmcv's col2im formulas equal this derivative.
+    -> (grad_value, grad_sampling_loc, grad_attn_weight) in the inputs' dtype (use float64)."""
+    v = value.detach().clone().requires_grad_(True)
+    loc = sampling_locations.detach().clone().requires_grad_(True)
+    aw = attention_weights.detach().clone().requires_grad_(True)
+    out = multi_scale_deformable_attn_pytorch(v, value_spatial_shapes, loc, aw)
+    out.backward(grad_output.to(out.dtype))
+    return v.grad, loc.grad, aw.grad

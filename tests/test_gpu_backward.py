@@ -1,0 +1,85 @@
+"""-m gpu: HIP `ms_deform_attn_backward` (through the C ABI and the autograd Function) vs the oracle
+(torch.autograd through the restated mmcv CPU function, float64)."""
+import pytest
+import torch
+
+from oracle import msda as omsda
+from tests.test_gpu_msda import _inputs
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("sca_like", 2, [[12, 20], [6, 10], [3, 5], [2, 3]], 8, 32, 150, 8),
+    ("tsa_like", 2, [[20, 20]], 8, 32, 400, 4),
+    ("ragged_items", 1, [[5, 7], [3, 4]], 3, 32, 13, 5),
+    ("generic_d16", 2, [[9, 11], [4, 6]], 4, 16, 57, 3),
+    ("generic_d24", 1, [[6, 5]], 2, 24, 11, 2),
+    ("single", 1, [[1, 1]], 1, 32, 1, 1),
+]
+
+
+def _interior(loc, shapes):
+    """Move sampling locations off the non-differentiable set (integer pixel coordinates and the
+    admission boundary), where one-sided derivatives of kernel and autograd may legitimately differ."""
+    loc = loc.clone()
+    for l, (H, W) in enumerate(shapes):
+        for d, n in ((0, W), (1, H)):
+            x = loc[:, :, :, l, :, d] * n - 0.5
+            frac = x - torch.floor(x)
+            x = torch.where((frac < 0.05) | (frac > 0.95), torch.floor(x) + 0.5, x)
+            loc[:, :, :, l, :, d] = (x + 0.5) / n
+    return loc
+
+
+@pytest.mark.parametrize("name,B,shapes,M,D,Lq,P", CASES, ids=[c[0] for c in CASES])
+def test_backward_matches_autograd_oracle(name, B, shapes, M, D, Lq, P):
+    from occnet_amd import ext
+    value, shapes_t, start, loc, attn = _inputs(B, shapes, M, D, Lq, P, seed=5, adversarial=False)
+    loc = _interior(loc, shapes)
+    g = torch.Generator().manual_seed(6)
+    grad_out = torch.randn(B, Lq, M * D, generator=g)
+    gv_ref, gl_ref, ga_ref = omsda.msda_backward_autograd(
+        value.double(), shapes_t, loc.double(), attn.double(), grad_out.double())
+    gv = torch.zeros_like(value).cuda()
+    gl = torch.zeros_like(loc).cuda()
+    ga = torch.zeros_like(attn).cuda()
+    ext.ms_deform_attn_backward(value.cuda(), shapes_t.cuda(), start.cuda(), loc.cuda(), attn.cuda(),
+                                grad_out.cuda(), gv, gl, ga, im2col_step=64)
+    torch.cuda.synchronize()
+    for nm, got, ref in (("grad_value", gv, gv_ref), ("grad_loc", gl, gl_ref), ("grad_attn", ga, ga_ref)):
+        scale = max(1.0, float(ref.abs().max()))
+        d = float((got.cpu().double() - ref).abs().max()) / scale
+        print(f"{name} {nm}: max rel diff = {d:.3e} (scale {scale:.2f})")
+        assert d < 1e-4, (name, nm, d)
+
+
+def test_out_of_range_samples_have_zero_gradient():
+    from occnet_amd import ext
+    value, shapes_t, start, loc, attn = _inputs(1, [[6, 8]], 8, 32, 40, 4, seed=7, adversarial=False)
+    loc[:, :20] = 5.0       # far outside: fail the admission test
+    grad_out = torch.ones(1, 40, 8 * 32)
+    gv, gl, ga = (torch.zeros_like(t).cuda() for t in (value, loc, attn))
+    ext.ms_deform_attn_backward(value.cuda(), shapes_t.cuda(), start.cuda(), loc.cuda(), attn.cuda(),
+                                grad_out.cuda(), gv, gl, ga, im2col_step=64)
+    assert float(gl[:, :20].abs().max()) == 0.0 and float(ga[:, :20].abs().max()) == 0.0
+    assert float(ga[:, 20:].abs().max()) > 0.0
+
+
+def test_autograd_function_round_trip():
+    """MultiScaleDeformableAttnFunction_fp32.apply(...).backward() — the reference's call shape
+    (multi_scale_deformable_attn_function.py:90-163)."""
+    from occnet_amd.plugin.functions import MultiScaleDeformableAttnFunction_fp32 as Fn
+    shapes = [[10, 14], [5, 7]]
+    value, shapes_t, start, loc, attn = _inputs(2, shapes, 8, 32, 64, 4, seed=8, adversarial=False)
+    loc = _interior(loc, shapes)
+    v = value.cuda().requires_grad_(True)
+    l = loc.cuda().requires_grad_(True)
+    a = attn.cuda().requires_grad_(True)
+    out = Fn.apply(v, shapes_t.cuda(), start.cuda(), l, a, 64)
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).cuda()
+    (out * w).sum().backward()
+    gv_ref, gl_ref, ga_ref = omsda.msda_backward_autograd(
+        value.double(), shapes_t, loc.double(), attn.double(), w.cpu().double())
+    for got, ref in ((v.grad, gv_ref), (l.grad, gl_ref), (a.grad, ga_ref)):
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((got.cpu().double() - ref).abs().max()) / scale < 1e-4

@@ -1,0 +1,110 @@
+"""-m gpu: lifter + Conv3d/BN/ReLU implicit-GEMM kernel and the fused occupancy heads (through the
+C ABI) vs the oracle (oracle/decoder.py, float64 CPU)."""
+import pytest
+import torch
+
+from oracle import decoder as odec
+
+pytestmark = pytest.mark.gpu
+
+
+def _bn(cout, g):
+    return (torch.rand(cout, generator=g) * 0.5 + 0.75, torch.randn(cout, generator=g) * 0.1,
+            torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) * 0.5 + 0.75)
+
+
+def _fold(bn, eps=1e-5):
+    w, b, mean, var = bn
+    scale = w / torch.sqrt(var + eps)
+    return scale, b - mean * scale
+
+
+CONV_CASES = [
+    # name, B, Z, Y, X, Cin   (Y/X deliberately not multiples of the block tile)
+    ("base_lifter", 1, 16, 9, 21, 16),
+    ("base_conv2", 2, 16, 7, 10, 32),
+    ("tiny_z4", 1, 4, 13, 37, 64),
+    ("hires_z32_c8", 1, 32, 5, 6, 8),
+    ("z8", 1, 8, 6, 19, 32),
+    ("one_pillar", 1, 16, 1, 1, 16),
+]
+
+
+@pytest.mark.parametrize("name,B,Z,Y,X,Cin", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_conv3d_bn_relu_matches_oracle(name, B, Z, Y, X, Cin, layout):
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(20 + layout)
+    cout = 32
+    x = torch.randn(B, Cin, Z, Y, X, generator=g)                  # torch NCDHW
+    w = torch.randn(cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
+    bn = _bn(cout, g)
+    ref = odec.conv3d_bn_relu(x.double(), w.double(), *[t.double() for t in bn])
+    if layout == 0:
+        xin = x.permute(0, 3, 4, 2, 1).contiguous()                # (B, Y, X, Z, Cin)
+    else:
+        xin = x.permute(0, 3, 4, 1, 2).reshape(B, Y * X, Cin * Z).contiguous()   # BEV embedding
+        assert torch.equal(odec.lifter(xin, Z, Y, X), x)           # the lifter view is exactly this
+    scale, shift = _fold(bn)
+    wp = ext.conv3d_pack_weight(w.cuda())
+    for xy_major in (False, True):
+        out = ext.conv3d_bn_relu(xin.cuda(), wp, scale.cuda(), shift.cuda(), Z, Y, X, Cin, cout,
+                                 in_layout=layout, out_xy_major=xy_major)
+        torch.cuda.synchronize()
+        got = out.cpu().double()
+        want = ref.permute(0, 4, 3, 2, 1) if xy_major else ref.permute(0, 3, 4, 2, 1)
+        d = float((got - want).abs().max())
+        print(f"{name} layout={layout} xy_major={xy_major}: max|hip - oracle(f64)| = {d:.3e}")
+        assert got.shape == want.shape
+        assert d < 2e-5
+
+
+def test_conv3d_linearity_full_size():
+    """Base-config size (200x200x16, 32->32): conv is linear before the ReLU — size-independent
+    property checked on the whole grid, plus a spot check of one block against the oracle."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(30)
+    Z, Y, X, C = 16, 200, 200, 32
+    x = torch.randn(1, Y, X, Z, C, generator=g).cuda()
+    w = torch.randn(C, C, 3, 3, 3, generator=g) * 0.05
+    wp = ext.conv3d_pack_weight(w.cuda())
+    one, zero = torch.ones(C).cuda(), torch.zeros(C).cuda()
+    f = lambda t: ext.conv3d_bn_relu(t, wp, one, zero, Z, Y, X, C, C, in_layout=0, relu=False)
+    o1, o2 = f(x), f(x * 2.0)
+    assert torch.allclose(o2, o1 * 2.0, atol=1e-4, rtol=1e-5)
+    ys, xs = slice(90, 100), slice(0, 12)
+    crop = x[:, 88:102, 0:14].cpu().double().permute(0, 4, 3, 1, 2)          # halo included
+    ref = torch.nn.functional.conv3d(crop, w.double(), padding=1)[:, :, :, 2:12, 0:12]
+    got = o1[:, ys, xs].cpu().double().permute(0, 4, 3, 1, 2)
+    d = float((got - ref).abs().max())
+    print(f"full-size crop: max|hip - oracle(f64)| = {d:.3e}")
+    assert d < 5e-5
+
+
+@pytest.mark.parametrize("n_rows,ncls", [(1, 17), (31, 17), (32, 17), (1000, 17), (4099, 18), (77, 3)])
+def test_occ_heads_match_oracle(n_rows, ncls):
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(40 + n_rows)
+    feat = torch.randn(n_rows, 32, generator=g) * 2.0
+    feat[0, :] = 30.0          # drives Softplus past its threshold (x > 20 -> identity)
+    mk = lambda *s: torch.randn(*s, generator=g) * 0.3
+    ws = (mk(64, 32), mk(64), mk(ncls, 64), mk(ncls), mk(64, 32), mk(64), mk(2, 64), mk(2))
+    occ_ref, flow_ref = odec.heads(feat.double(), *[t.double() for t in ws])
+    occ, flow = ext.occ_heads(feat.cuda(), *[t.cuda() for t in ws])
+    torch.cuda.synchronize()
+    d1 = float((occ.cpu().double() - occ_ref).abs().max())
+    d2 = float((flow.cpu().double() - flow_ref).abs().max())
+    print(f"heads n={n_rows} ncls={ncls}: occ {d1:.3e} flow {d2:.3e}")
+    assert occ.shape == (n_rows, ncls) and flow.shape == (n_rows, 2)
+    assert d1 < 5e-5 and d2 < 5e-5
+
+
+def test_unsupported_shapes_raise_unsupported():
+    from occnet_amd import ext
+    from occnet_amd._lib import OccAmdUnsupported
+    with pytest.raises(OccAmdUnsupported):
+        ext.conv3d_pack_weight(torch.randn(16, 16, 3, 3, 3).cuda())      # Cout != 32
+    with pytest.raises(OccAmdUnsupported):
+        ext.occ_heads(torch.randn(8, 16).cuda(), torch.randn(64, 16).cuda(), torch.randn(64).cuda(),
+                      torch.randn(17, 64).cuda(), torch.randn(17).cuda(), torch.randn(64, 16).cuda(),
+                      torch.randn(64).cuda(), torch.randn(2, 64).cuda(), torch.randn(2).cuda())

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Dev probe: time the stock ResNet-50+FPN image backbone (MIOpen) under different torch/MIOpen
+settings.  Not part of the product; informs the defaults bench.py uses for the e2e scope."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--mode", choices=["autocast", "bf16", "fp16", "f32"], default="autocast")
+ap.add_argument("--benchmark", type=int, default=0)
+ap.add_argument("--nhwc", type=int, default=1)
+ap.add_argument("--iters", type=int, default=10)
+args = ap.parse_args()
+
+from occnet_amd import synthetic
+from occnet_amd.plugin import Config, build_model, import_plugin
+
+torch.backends.cudnn.benchmark = bool(args.benchmark)
+cfg = Config.fromfile(os.path.join(ROOT, "configs", "occ_base_200x200x16.py"))
+import_plugin(cfg)
+model = build_model(cfg.model).cuda().eval()
+geo = dict(synthetic.BASE)
+img = synthetic.make_images(geo, batch=1, seed=0, device="cuda")
+B, N, C, H, W = img.shape
+x = img.reshape(B * N, C, H, W)
+bb, neck = model.img_backbone, model.img_neck
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.mode)
+if dt is not None:
+    bb.to(dt); neck.to(dt); x = x.to(dt)
+if args.nhwc:
+    bb.to(memory_format=torch.channels_last); neck.to(memory_format=torch.channels_last)
+    x = x.contiguous(memory_format=torch.channels_last)
+
+
+@torch.no_grad()
+def run():
+    if args.mode == "autocast":
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return neck(bb(x))
+    return neck(bb(x))
+
+
+t0 = time.perf_counter()
+for _ in range(3):
+    out = run()
+torch.cuda.synchronize()
+t_warm = time.perf_counter() - t0
+t0 = time.perf_counter()
+for _ in range(args.iters):
+    out = run()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / args.iters * 1e3
+print(f"backbone mode={args.mode} benchmark={args.benchmark} nhwc={args.nhwc} "
+      f"FIND_MODE={os.environ.get('MIOPEN_FIND_MODE')} : {ms:.2f} ms/forward (warmup {t_warm:.1f} s) "
+      f"out0 {tuple(out[0].shape)} {out[0].dtype} strides {out[0].stride()}", flush=True)

@@ -25,7 +25,6 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

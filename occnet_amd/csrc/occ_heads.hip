@@ -26,8 +26,9 @@ namespace occ {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float softplus_f32(float x) {
-  // torch.nn.Softplus(beta=1, threshold=20)
-  return x > 20.f ? x : log1pf(expf(x));
+  // torch.nn.Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x)), evaluated in the overflow-free
+  // form max(x,0) + log(1 + exp(-|x|)) on the hardware exp/log units (absolute error ~1e-7)
+  return x > 20.f ? x : fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x)));
 }
 
 constexpr int kHeadWaves = 4;

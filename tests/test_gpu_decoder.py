@@ -92,11 +92,14 @@ def test_occ_heads_match_oracle(n_rows, ncls):
     occ_ref, flow_ref = odec.heads(feat.double(), *[t.double() for t in ws])
     occ, flow = ext.occ_heads(feat.cuda(), *[t.cuda() for t in ws])
     torch.cuda.synchronize()
-    d1 = float((occ.cpu().double() - occ_ref).abs().max())
-    d2 = float((flow.cpu().double() - flow_ref).abs().max())
-    print(f"heads n={n_rows} ncls={ncls}: occ {d1:.3e} flow {d2:.3e}")
+    # row 0 (features = 30) produces outputs of magnitude ~1e2: compare relative to the output scale
+    d1 = float((occ.cpu().double() - occ_ref).abs().max()) / max(1.0, float(occ_ref.abs().max()))
+    d2 = float((flow.cpu().double() - flow_ref).abs().max()) / max(1.0, float(flow_ref.abs().max()))
+    print(f"heads n={n_rows} ncls={ncls}: occ {d1:.3e} flow {d2:.3e} (relative to output scale)")
     assert occ.shape == (n_rows, ncls) and flow.shape == (n_rows, 2)
-    assert d1 < 5e-5 and d2 < 5e-5
+    assert d1 < 2e-5 and d2 < 2e-5
+    d_typ = float((occ[1:].cpu().double() - occ_ref[1:]).abs().max()) if n_rows > 1 else 0.0
+    assert d_typ < 5e-5
 
 
 def test_unsupported_shapes_raise_unsupported():

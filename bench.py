@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--scope", choices=["e2e", "hotpath"], default="e2e",
                     help="e2e: images -> voxels (backbone included); hotpath: FPN features -> voxels")
     ap.add_argument("--backbone-dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--no-miopen-fusion", action="store_true",
+                    help="backbone: plain conv + in-place ReLU instead of MIOpen's fused conv+bias+ReLU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -73,15 +75,15 @@ def build(cfg_path, device):
 
 
 class Stepper:
-    def __init__(self, model, geo, scope, backbone_dtype, device, seed):
+    def __init__(self, model, geo, scope, backbone_dtype, device, seed, fused_ops=True):
         from occnet_amd import synthetic
         self.model, self.scope, self.device = model, scope, device
         self.metas = synthetic.make_img_metas(geo, batch=1, seed=seed)
-        self.autocast = backbone_dtype == "bf16"
         if scope == "e2e" and hasattr(model, "img_backbone"):
             self.img = synthetic.make_images(geo, batch=1, seed=seed, device=device)
-            if self.autocast:
-                model.img_backbone.to(memory_format=torch.channels_last)
+            # stock MIOpen backbone, inference plan: BN folded, NHWC, fused conv+bias+ReLU
+            model.enable_fused_backbone(dtype=torch.bfloat16 if backbone_dtype == "bf16" else torch.float32,
+                                        fused_ops=fused_ops)
         else:
             self.scope = "hotpath"
             self.feats = synthetic.make_features(geo, batch=1, seed=seed, device=device)
@@ -90,12 +92,7 @@ class Stepper:
     def __call__(self):
         m = self.model
         if self.scope == "e2e":
-            if self.autocast:
-                with torch.autocast("cuda", dtype=torch.bfloat16):
-                    feats = m.extract_feat(img=self.img, img_metas=self.metas)
-                feats = [f.float() for f in feats]
-            else:
-                feats = m.extract_feat(img=self.img, img_metas=self.metas)
+            feats = m.extract_feat(img=self.img, img_metas=self.metas)
         else:
             feats = self.feats
         outs = m.pts_bbox_head(feats, self.metas, prev_bev=None, test=True)
@@ -109,15 +106,16 @@ def gather_stats(model, stepper):
     from occnet_amd.plugin import SpatialCrossAttention
     scas = [m for m in model.modules() if isinstance(m, SpatialCrossAttention)]
     stats = [torch.zeros(2, dtype=torch.int64, device=stepper.device) for _ in scas]
-    originals = [s.forward for s in scas]
-    for s, st, orig in zip(scas, stats, originals):
-        s.forward = (lambda orig, st: (lambda *a, **k: orig(*a, gather_stats=st, **k)))(orig, st)
+    originals = [(s.forward, s.forward_fused) for s in scas]
+    wrap = lambda f, st: (lambda *a, **k: f(*a, **{**k, 'gather_stats': st}))
+    for s, st, (f, ff) in zip(scas, stats, originals):
+        s.forward, s.forward_fused = wrap(f, st), wrap(ff, st)
     try:
         stepper()
         torch.cuda.synchronize()
     finally:
-        for s, orig in zip(scas, originals):
-            s.forward = orig
+        for s in scas:
+            del s.forward, s.forward_fused      # drop the instance attributes: class methods again
     da = scas[0].deformable_attention
     return [tuple(int(v) for v in st.cpu().tolist()) for st in stats], da
 
@@ -194,7 +192,8 @@ def main():
 
     from occnet_amd import ext
     cfg, model, geo = build(args.config, device)
-    stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank)
+    stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank,
+                      fused_ops=not args.no_miopen_fusion)
 
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         stepper()
@@ -264,6 +263,27 @@ def main():
             tsa = times.get("tsa_fused_forward", [])
             if tsa:
                 out["roofline"]["tsa_launch_ms"] = sum(tsa) / len(tsa)
+            # the MFMA-bound kernels of the path (f32 matrix cores, 157.3 TFLOP/s dense peak)
+            head = model.pts_bbox_head
+            tr = head.transformer
+            conv = times.get("conv3d_bn_relu", [])
+            if conv and tr.use_3d and len(conv) % 2 == 0:
+                vox = head.bev_h * head.bev_w * tr.pillar_h
+                fl = [2.0 * vox * 27 * tr.middle_dims * tr.out_dim, 2.0 * vox * 27 * tr.out_dim * tr.out_dim]
+                ms = [sum(conv[0::2]) / (len(conv) // 2), sum(conv[1::2]) / (len(conv) // 2)]
+                out["mfma_kernels"] = {
+                    "peak_tflops_f32": 157.3,
+                    "conv3d_lifter": {"launch_ms": ms[0], "tflops": fl[0] / ms[0] / 1e9,
+                                      "frac": fl[0] / ms[0] / 1e9 / 157.3},
+                    "conv3d_2": {"launch_ms": ms[1], "tflops": fl[1] / ms[1] / 1e9,
+                                 "frac": fl[1] / ms[1] / 1e9 / 157.3},
+                }
+                hd = times.get("occ_heads", [])
+                if hd:
+                    out["mfma_kernels"]["occ_heads_launch_ms"] = sum(hd) / len(hd)
+                lin = times.get("linear", [])
+                if lin:
+                    out["mfma_kernels"]["linear_ms_per_step"] = sum(lin) / args.steps
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, geo)

@@ -165,6 +165,25 @@ int occ_occ_heads_f32(const float* feat, const float* w1_occ, const float* b1_oc
                       float* occ_out, float* flow_out, int64_t n_rows, int C, int hidden,
                       int num_classes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * nn.Linear on the f32 matrix cores (exact f32) with the encoder's elementwise tail fused:
+ *   out = LayerNorm( residual + act( [A1 | A2 (+ A2add)] @ W^T + bias ) )
+ *   a1 (M, K1) row stride lda1 ; optional second K segment a2 (M, K2) row stride lda2 with an optional
+ *   addend a2_add of the same shape/stride (the TSA query `cat([value, query + query_pos], -1)`,
+ *   temporal_self_attention.py:197) ; weight (N, K1+K2) torch Linear layout ; bias (N) or NULL ;
+ *   act 0 = none, 1 = ReLU ; residual (M, N) row stride ldres or NULL (added after act) ;
+ *   ln_gamma / ln_beta (N) or both NULL, ln_eps: LayerNorm over the N outputs ; out (M, N) row stride ldo.
+ * Requires K1, K2 multiples of 32, N % 4 == 0, 16-byte aligned rows, N <= 256 with LayerNorm;
+ * otherwise OCC_E_UNSUPPORTED (the caller keeps the library GEMM).
+ * Call sites replaced: value_proj / sampling_offsets / attention_weights / output_proj Linears
+ * (spatial_cross_attention.py:334-341,173 ; temporal_self_attention.py:198-209,266), mmcv FFN + the three
+ * LayerNorms of a BEVFormerLayer (encoder.py:377-404).
+ */
+int occ_linear_f32(const float* a1, int64_t lda1, int K1, const float* a2, const float* a2_add,
+                   int64_t lda2, int K2, const float* weight, const float* bias, int act,
+                   const float* residual, int64_t ldres, const float* ln_gamma, const float* ln_beta,
+                   float ln_eps, float* out, int64_t ldo, int M, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ The remaining functions expose the fused MI355X kernels (no counterpart in mmcv.
 import torch
 
 from . import _lib
-from ._lib import OccAmdError, f32, i32, i64, ptr, stream_ptr
+from ._lib import OccAmdError, OccAmdUnsupported, f32, i32, i64, ptr, stream_ptr
 
 
 _TIMING = None   # None, or {kernel name: [(start_event, end_event), ...]} (bench.py roofline leg)
@@ -285,3 +285,76 @@ def occ_heads(feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b
             i32(ncls), stream_ptr(feat.device))
     _lib.check(rc, "occ_heads")
     return occ, flow
+
+
+def _rows2d(name, t, k=None):
+    """(…, K) tensor -> (data tensor, M, K, row stride) for the Linear kernel: rows must be uniformly
+    strided, unit inner stride, 16-byte aligned."""
+    _need_cuda_f32(name, t, contiguous=False)
+    K = t.shape[-1]
+    if k is not None and K != k:
+        raise OccAmdError(f"linear: {name} has {K} columns, expected {k}")
+    if t.dim() == 2 and t.stride(1) == 1:
+        ld = t.stride(0)
+    elif t.is_contiguous():
+        ld = K
+    else:
+        raise OccAmdError(f"linear: {name} must be contiguous or a 2-D row-strided view")
+    M = t.numel() // K
+    if t.data_ptr() % 16 or ld % 4:
+        raise OccAmdUnsupported(f"linear: {name} rows are not 16-byte aligned")
+    return t, M, K, ld
+
+
+def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, ln=None):
+    """out = LayerNorm(residual + act([a | a2 (+ a2_add)] @ weight^T + bias)) on the f32 matrix cores.
+
+    a (…, K1); a2 / a2_add (…, K2) optional second K segment (+ addend); weight (N, K1+K2) and bias (N)
+    in torch Linear layout; act None | 'relu'; residual (…, N); ln = (gamma, beta, eps) or an
+    nn.LayerNorm.  -> (…, N) float32.  Raises OccAmdUnsupported for shapes without an MFMA kernel."""
+    a_, M, K1, lda1 = _rows2d("a", a)
+    K2, lda2 = 0, 0
+    if a2 is not None:
+        a2_, M2, K2, lda2 = _rows2d("a2", a2)
+        if M2 != M:
+            raise OccAmdError("linear: a and a2 differ in rows")
+        if a2_add is not None:
+            _, M3, _, lda3 = _rows2d("a2_add", a2_add, K2)
+            if M3 != M or lda3 != lda2:
+                raise OccAmdError("linear: a2_add must match a2's shape and row stride")
+    elif a2_add is not None:
+        raise OccAmdError("linear: a2_add without a2")
+    _need_cuda_f32("weight", weight)
+    N = weight.shape[0]
+    if weight.dim() != 2 or weight.shape[1] != K1 + K2:
+        raise OccAmdError("linear: weight must be (N, K1+K2)")
+    if bias is not None:
+        _need_cuda_f32("bias", bias)
+        if bias.numel() != N:
+            raise OccAmdError("linear: bias must have N entries")
+    ldres = 0
+    if residual is not None:
+        _, Mr, _, ldres = _rows2d("residual", residual, N)
+        if Mr != M:
+            raise OccAmdError("linear: residual differs in rows")
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        if isinstance(ln, torch.nn.LayerNorm):
+            if tuple(ln.normalized_shape) != (N,) or ln.weight is None or ln.bias is None:
+                raise OccAmdUnsupported("linear: LayerNorm must be affine over the N outputs")
+            g, b, eps = ln.weight, ln.bias, ln.eps
+        else:
+            g, b, eps = ln
+        _need_cuda_f32("ln_gamma", g)
+        _need_cuda_f32("ln_beta", b)
+    if act not in (None, 'relu'):
+        raise OccAmdError("linear: act must be None or 'relu'")
+    out = torch.empty(a.shape[:-1] + (N,), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device), _timed('linear'):
+        rc = _lib.lib().occ_linear_f32(
+            ptr(a_), i64(lda1), i32(K1), ptr(a2), ptr(a2_add), i64(lda2), i32(K2), ptr(weight),
+            ptr(bias), i32(1 if act == 'relu' else 0), ptr(residual), i64(ldres), ptr(g), ptr(b),
+            f32(float(eps)), ptr(out), i64(N), i32(M), i32(N), stream_ptr(a.device))
+    _lib.check(rc, "linear")
+    return out

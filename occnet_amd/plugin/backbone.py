@@ -179,3 +179,103 @@ class FPN(BaseModule):
                     src = F.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]
                     outs.append(self.fpn_convs[i](src))
         return tuple(outs)
+
+
+class FusedInferenceBackbone(nn.Module):
+    """Inference-time execution plan for ResNet + FPN on stock PyTorch-ROCm / MIOpen ops: eval-mode
+    BatchNorm folded into the preceding convolution (`fuse_conv_bn_weights`), convolution + bias +
+    ReLU and convolution + bias + residual + ReLU issued as MIOpen's fused forward
+    (`torch.miopen_convolution_relu` / `torch.miopen_convolution_add_relu`) when `fused_ops`, in one
+    dtype and channels_last (NHWC) memory so the FPN outputs are already in the (Cam, H, W, C) layout
+    the gather kernels want.  Built from the live modules' parameters (it owns folded COPIES: rebuild
+    after changing weights); no custom kernels — the backbone stays outside the hand-written scope."""
+
+    def __init__(self, backbone, neck, dtype=torch.bfloat16, fused_ops=True):
+        super().__init__()
+        from torch.nn.utils.fusion import fuse_conv_bn_weights
+        assert not backbone.training or backbone.norm_eval, "folding BN needs eval-mode statistics"
+        self.dtype, self.fused_ops = dtype, fused_ops
+        self.out_indices = backbone.out_indices
+        self._convs = []
+
+        def fold(conv, bn):
+            w, b = fuse_conv_bn_weights(conv.weight, conv.bias, bn.running_mean, bn.running_var,
+                                        bn.eps, bn.weight, bn.bias)
+            return self._add(w, b, conv)
+
+        self.stem = fold(backbone.conv1, backbone.bn1)
+        self.stages = []
+        for name in backbone.res_layers:
+            blocks = []
+            for blk in getattr(backbone, name):
+                ds = None if blk.downsample is None else fold(blk.downsample[0], blk.downsample[1])
+                blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2),
+                               fold(blk.conv3, blk.bn3), ds))
+            self.stages.append(blocks)
+        self.neck = neck
+        self.laterals = [self._add(m.conv.weight, m.conv.bias, m.conv) for m in neck.lateral_convs]
+        self.fpn = [self._add(m.conv.weight, m.conv.bias, m.conv) for m in neck.fpn_convs]
+        for m in list(neck.lateral_convs) + list(neck.fpn_convs):
+            assert not m.with_norm and not m.with_activation, "FPN ConvModules with norm/act not folded"
+
+    def _add(self, w, b, conv):
+        w = w.detach().to(self.dtype).contiguous(memory_format=torch.channels_last)
+        if b is None:
+            b = torch.zeros(w.shape[0], device=w.device)
+        b = b.detach().to(self.dtype)
+        idx = len(self._convs)
+        self.register_buffer(f'w{idx}', w, persistent=False)
+        self.register_buffer(f'b{idx}', b, persistent=False)
+        self._convs.append((conv.stride, conv.padding, conv.dilation, conv.groups))
+        return idx
+
+    def _conv(self, i, x, relu=False, add=None):
+        w, b = getattr(self, f'w{i}'), getattr(self, f'b{i}')
+        s, p, d, g = self._convs[i]
+        if self.fused_ops and add is not None:
+            return torch.miopen_convolution_add_relu(x, w, add, 1.0, b, s, p, d, g)
+        if self.fused_ops and relu:
+            return torch.miopen_convolution_relu(x, w, b, s, p, d, g)
+        y = F.conv2d(x, w, b, s, p, d, g)
+        if add is not None:
+            y = y.add_(add)
+        return y.relu_() if (relu or add is not None) else y
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x (N, 3, H, W) any float dtype -> tuple of FPN maps (N, C, h, w), dtype self.dtype, NHWC."""
+        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        x = F.max_pool2d(self._conv(self.stem, x, relu=True), kernel_size=3, stride=2, padding=1)
+        feats = []
+        for si, blocks in enumerate(self.stages):
+            for c1, c2, c3, ds in blocks:
+                identity = x if ds is None else self._conv(ds, x)
+                y = self._conv(c2, self._conv(c1, x, relu=True), relu=True)
+                x = self._conv(c3, y, add=identity)
+            if si in self.out_indices:
+                feats.append(x)
+        nk = self.neck
+        inputs = feats
+        lat = [self._conv(self.laterals[i], inputs[i + nk.start_level])
+               for i in range(len(self.laterals))]
+        n = len(lat)
+        for i in range(n - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:],
+                                                    **nk.upsample_cfg)
+        outs = [self._conv(self.fpn[i], lat[i]) for i in range(n)]
+        if nk.num_outs > n:
+            if not nk.add_extra_convs:
+                for _ in range(nk.num_outs - n):
+                    outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+            else:
+                if nk.add_extra_convs == 'on_input':
+                    src = inputs[nk.backbone_end_level - 1]
+                elif nk.add_extra_convs == 'on_lateral':
+                    src = lat[-1]
+                else:
+                    src = outs[-1]
+                outs.append(self._conv(self.fpn[n], src))
+                for i in range(n + 1, nk.num_outs):
+                    src = F.relu(outs[-1]) if nk.relu_before_extra_convs else outs[-1]
+                    outs.append(self._conv(self.fpn[i], src))
+        return tuple(outs)

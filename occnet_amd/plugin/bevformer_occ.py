@@ -61,11 +61,15 @@ class BEVFormerOcc(BaseModule):
         if img.dim() == 5:
             B, N, C, H, W = img.size()
             img = img.reshape(B * N, C, H, W)
-        img_feats = self.img_backbone(img)
-        if isinstance(img_feats, dict):
-            img_feats = list(img_feats.values())
-        if self.with_img_neck:
-            img_feats = self.img_neck(img_feats)
+        plan = getattr(self, '_inference_backbone', None)
+        if plan is not None and not self.training and not torch.is_grad_enabled():
+            img_feats = plan(img)       # BN-folded, NHWC, MIOpen fused conv+bias+ReLU (stock ops)
+        else:
+            img_feats = self.img_backbone(img)
+            if isinstance(img_feats, dict):
+                img_feats = list(img_feats.values())
+            if self.with_img_neck:
+                img_feats = self.img_neck(img_feats)
         out = []
         for f in img_feats:
             BN, C, H, W = f.size()
@@ -74,6 +78,18 @@ class BEVFormerOcc(BaseModule):
             else:
                 out.append(f.view(B, int(BN / B), C, H, W))
         return out
+
+    def enable_fused_backbone(self, dtype=torch.bfloat16, fused_ops=True):
+        """Inference-only: run ResNet+FPN through FusedInferenceBackbone (eval BN folded into the
+        convolutions, NHWC, MIOpen's fused conv+bias(+add)+ReLU).  Call again after changing backbone
+        weights; pass dtype=None to disable."""
+        from .backbone import FusedInferenceBackbone
+        object.__setattr__(self, '_inference_backbone', None)
+        if dtype is not None:
+            plan = FusedInferenceBackbone(self.img_backbone, self.img_neck, dtype=dtype,
+                                          fused_ops=fused_ops)
+            object.__setattr__(self, '_inference_backbone', plan)   # not a sub-module: owns copies
+        return self
 
     def extract_feat(self, img, img_metas=None, len_queue=None):
         return self.extract_img_feat(img, img_metas, len_queue=len_queue)

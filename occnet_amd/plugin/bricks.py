@@ -106,6 +106,23 @@ class FFN(BaseModule):
         self.dropout_layer = nn.Identity()
         self.add_identity = add_identity
 
+    def forward_fused(self, x, identity=None, post_norm=None):
+        """Inference form on the MFMA Linear kernel: Linear+ReLU, then Linear + residual + the layer's
+        following LayerNorm as one epilogue.  -> tensor, or None when the FFN is not the plain
+        2-layer ReLU form / a shape has no fused kernel."""
+        from .. import ext
+        from .._lib import OccAmdUnsupported
+        if not (self.num_fcs == 2 and self.add_identity and isinstance(self.layers[0][1], nn.ReLU)
+                and isinstance(self.dropout_layer, nn.Identity)):
+            return None
+        try:
+            fc1, fc2 = self.layers[0][0], self.layers[1]
+            h = ext.linear(x.contiguous(), fc1.weight, fc1.bias, act='relu')
+            return ext.linear(h, fc2.weight, fc2.bias,
+                              residual=(x if identity is None else identity).contiguous(), ln=post_norm)
+        except OccAmdUnsupported:
+            return None
+
     def forward(self, x, identity=None):
         out = self.layers(x)
         if not self.add_identity:

@@ -133,6 +133,7 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                          ffn_dropout=ffn_dropout, operation_order=operation_order, act_cfg=act_cfg,
                          norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
         self.fp16_enabled = False
+        self.use_fused = True     # flip to force the op-by-op (reference-shaped) execution
         assert len(operation_order) == 6
         assert set(operation_order) == set(['self_attn', 'norm', 'cross_attn', 'ffn'])
 
@@ -151,34 +152,85 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
             assert len(attn_masks) == self.num_attn
         tsa_shapes = kwargs.pop('tsa_spatial_shapes', None)
         tsa_start = kwargs.pop('tsa_level_start_index', None)
-        for layer in self.operation_order:
+        # inference: op + residual + the LayerNorm that follows it run as MFMA-Linear epilogues
+        fuse = (self.use_fused and not self.pre_norm and not self.training and query.is_cuda
+                and query.dtype == torch.float32 and query_key_padding_mask is None
+                and key_padding_mask is None and all(m is None for m in attn_masks)
+                and not (torch.is_grad_enabled() and (query.requires_grad or any(
+                    p.requires_grad for p in self.parameters()))))
+        ops = self.operation_order
+        i = 0
+        while i < len(ops):
+            layer = ops[i]
+            post_norm = None
+            if fuse and i + 1 < len(ops) and ops[i + 1] == 'norm' \
+                    and isinstance(self.norms[norm_index], nn.LayerNorm):
+                post_norm = self.norms[norm_index]
             if layer == 'self_attn':   # temporal self attention: BEV plane is its own single level
-                if tsa_shapes is None:
-                    tsa_shapes = torch.tensor([[bev_h, bev_w]], device=query.device)
-                    tsa_start = torch.tensor([0], device=query.device)
-                query = self.attentions[attn_index](
-                    query, prev_bev, prev_bev, identity if self.pre_norm else None,
-                    query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_index],
-                    key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
-                    spatial_shapes=tsa_shapes, level_start_index=tsa_start, bev_h=bev_h,
-                    bev_w=bev_w, **kwargs)
+                attn = self.attentions[attn_index]
+                out = None
+                if post_norm is not None and hasattr(attn, 'forward_fused'):
+                    out = attn.forward_fused(query, prev_bev, query_pos=bev_pos, reference_points=ref_2d,
+                                             bev_h=bev_h, bev_w=bev_w,
+                                             bev_order=kwargs.get('bev_order'), post_norm=post_norm)
+                if out is not None:
+                    query = out
+                    norm_index += 1
+                    i += 1
+                else:
+                    if tsa_shapes is None:
+                        tsa_shapes = torch.tensor([[bev_h, bev_w]], device=query.device)
+                        tsa_start = torch.tensor([0], device=query.device)
+                    query = attn(
+                        query, prev_bev, prev_bev, identity if self.pre_norm else None,
+                        query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_index],
+                        key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
+                        spatial_shapes=tsa_shapes, level_start_index=tsa_start, bev_h=bev_h,
+                        bev_w=bev_w, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == 'norm':
                 query = self.norms[norm_index](query)
                 norm_index += 1
             elif layer == 'cross_attn':  # spatial cross attention: no positional encoding (query_pos None)
-                query = self.attentions[attn_index](
-                    query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
-                    key_pos=key_pos, reference_points=ref_3d,
-                    reference_points_cam=reference_points_cam, mask=mask,
-                    attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
-                    spatial_shapes=spatial_shapes, level_start_index=level_start_index, **kwargs)
+                attn = self.attentions[attn_index]
+                out = None
+                if post_norm is not None and query_pos is None and hasattr(attn, 'forward_fused') \
+                        and value is not None:
+                    out = attn.forward_fused(query, value, reference_points_cam=reference_points_cam,
+                                             bev_mask=kwargs.get('bev_mask'),
+                                             spatial_shapes=spatial_shapes,
+                                             level_start_index=level_start_index,
+                                             vis_bits=kwargs.get('vis_bits'),
+                                             bev_order=kwargs.get('bev_order'),
+                                             gather_stats=kwargs.get('gather_stats'),
+                                             post_norm=post_norm)
+                if out is not None:
+                    query = out
+                    norm_index += 1
+                    i += 1
+                else:
+                    query = attn(
+                        query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                        key_pos=key_pos, reference_points=ref_3d,
+                        reference_points_cam=reference_points_cam, mask=mask,
+                        attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
+                        spatial_shapes=spatial_shapes, level_start_index=level_start_index, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == 'ffn':
-                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn = self.ffns[ffn_index]
+                out = None
+                if post_norm is not None and hasattr(ffn, 'forward_fused'):
+                    out = ffn.forward_fused(query, None, post_norm=post_norm)
+                if out is not None:
+                    query = out
+                    norm_index += 1
+                    i += 1
+                else:
+                    query = ffn(query, identity if self.pre_norm else None)
                 ffn_index += 1
+            i += 1
         return query
 
 

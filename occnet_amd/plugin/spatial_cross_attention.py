@@ -201,6 +201,35 @@ class SpatialCrossAttention(BaseModule):
                                      da.num_heads, da.num_levels, da.num_points, order=order,
                                      stats=stats)
 
+    def forward_fused(self, query, value, reference_points_cam=None, bev_mask=None,
+                      spatial_shapes=None, level_start_index=None, vis_bits=None, bev_order=None,
+                      gather_stats=None, post_norm=None):
+        """Inference form with every dense op on the MFMA Linear kernel (value_proj over all camera
+        pixels, the query-side Linears, output_proj + residual + the layer's following LayerNorm as one
+        epilogue) around the fused gather.  -> LayerNorm(output_proj(slots) + query), or None when a
+        shape has no fused kernel."""
+        da = self.deformable_attention
+        if not isinstance(da, MSDeformableAttention3D):
+            return None
+        num_cams, l, bs, _ = value.shape
+        try:
+            v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
+            v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
+            v = v.view(bs * self.num_cams, l, da.num_heads, -1)
+            w, b = da._qcat.get((da.sampling_offsets, da.attention_weights))
+            lin = ext.linear(query.contiguous(), w, b)
+            n_off = da.sampling_offsets.out_features
+            if vis_bits is None:
+                vis_bits = pack_vis_bits(bev_mask)
+            slots = ext.sca_fused_forward(v, spatial_shapes, level_start_index, lin[..., :n_off],
+                                          lin[..., n_off:], reference_points_cam.float().contiguous(),
+                                          vis_bits, da.num_heads, da.num_levels, da.num_points,
+                                          order=bev_order, stats=gather_stats)
+            return ext.linear(slots, self.output_proj.weight, self.output_proj.bias,
+                              residual=query.contiguous(), ln=post_norm)
+        except OccAmdUnsupported:
+            return None
+
     # ------------------------------------------------------------------ unfused path
     def _unfused_slots(self, query, key, value, reference_points_cam, bev_mask, spatial_shapes,
                        level_start_index):

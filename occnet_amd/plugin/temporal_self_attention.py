@@ -87,6 +87,39 @@ class TemporalSelfAttention(BaseModule):
                                      self.num_heads, self.num_points, shared_queue=shared,
                                      order=order)
 
+    def forward_fused(self, query, value=None, query_pos=None, reference_points=None, bev_h=None,
+                      bev_w=None, bev_order=None, post_norm=None):
+        """Inference form with every dense op on the MFMA Linear kernel: the cat([value, query+pos])
+        feeding the offset/weight Linears is read as two K segments, output_proj + residual + the
+        layer's following LayerNorm are one epilogue.  Same arguments/semantics as forward() (value
+        None = no history).  -> LayerNorm(output_proj(attn) + query), or None when a shape has no
+        fused kernel (the caller then takes forward())."""
+        if not (self.batch_first and self.num_levels == 1 and self.num_bev_queue == 2
+                and reference_points is not None and reference_points.shape[-1] == 2):
+            return None
+        bs, num_query, c = query.shape
+        shared = value is None
+        if shared and bs > 1:   # interleaved (b0,b0,b1,b1,..) stack, as in forward()
+            value = torch.stack([query, query], 1).reshape(bs * 2, num_query, c)
+            shared = False
+        value_first = query if shared else value[:bs]
+        try:
+            w, b = self._qcat.get((self.sampling_offsets, self.attention_weights))
+            lin = ext.linear(value_first.contiguous(), w, b, a2=query.contiguous(),
+                             a2_add=None if query_pos is None else query_pos.contiguous())
+            n_off = self.sampling_offsets.out_features
+            vsrc = (value_first if shared else value).contiguous()
+            v = ext.linear(vsrc, self.value_proj.weight, self.value_proj.bias)
+            v = v.view(v.shape[0], num_query, self.num_heads, -1)
+            out = ext.tsa_fused_forward(v, lin[..., :n_off], lin[..., n_off:],
+                                        reference_points.float().contiguous(), bev_h, bev_w,
+                                        self.num_heads, self.num_points, shared_queue=shared,
+                                        order=bev_order)
+            return ext.linear(out, self.output_proj.weight, self.output_proj.bias,
+                              residual=query.contiguous(), ln=post_norm)
+        except OccAmdUnsupported:
+            return None
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, flag='decoder', **kwargs):

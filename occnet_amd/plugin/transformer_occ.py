@@ -116,13 +116,15 @@ class TransformerOcc(BaseModule):
         bs, num_cam, c = mlvl_feats[0].shape[:3]
         shapes = [(f.shape[3], f.shape[4]) for f in mlvl_feats]
         total = sum(h * w for h, w in shapes)
-        out = mlvl_feats[0].new_empty((bs * num_cam, total, c))
+        # the hot path computes in fp32: a half-precision backbone's maps are widened here, in the same
+        # pass that transposes them and adds the (fp32) embeddings
+        out = mlvl_feats[0].new_empty((bs * num_cam, total, c), dtype=self.level_embeds.dtype)
         start = 0
         for lvl, feat in enumerate(mlvl_feats):
             h, w = shapes[lvl]
-            emb = self.level_embeds[lvl].to(feat.dtype)
+            emb = self.level_embeds[lvl]
             if self.use_cams_embeds:   # (1, num_cam, 1, C) + (C)
-                emb = self.cams_embeds.to(feat.dtype)[None, :, None, :] + emb
+                emb = self.cams_embeds[None, :, None, :] + emb
             else:
                 emb = emb.view(1, 1, 1, c)
             dst = out[:, start:start + h * w].view(bs, num_cam, h * w, c)

@@ -1,0 +1,101 @@
+"""-m gpu: the MFMA Linear kernel with fused bias / ReLU / residual / LayerNorm epilogues (through the
+C ABI) vs the oracle (oracle/dense.py, float64 CPU)."""
+import pytest
+import torch
+
+from oracle import dense as odense
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(g, *shape, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+CASES = [
+    # name,            M,    K1,  K2,  N,  bias, act,    addend, residual, ln
+    ("plain",          100,  256, 0,   256, False, None,  False,  False,    False),
+    ("value_proj",     1031, 256, 0,   256, True,  None,  False,  False,    False),
+    ("ffn1_relu",      333,  256, 0,   512, True,  'relu', False, False,    False),
+    ("ffn2_res_ln",    333,  512, 0,   256, True,  None,  False,  True,     True),
+    ("tsa_query",      257,  256, 256, 192, True,  None,  True,   False,    False),
+    ("sca_query",      64,   256, 0,   768, True,  None,  False,  False,    False),
+    ("small_n_ln",     45,   64,  0,   128, True,  None,  False,  True,     True),
+    ("n_100_ln",       70,   32,  0,   100, True,  'relu', False, True,     True),
+    ("two_seg_noadd",  33,   32,  64,  36,  False, None,  False,  True,     False),
+    ("one_row",        1,    256, 0,   256, True,  None,  False,  True,     True),
+]
+
+
+@pytest.mark.parametrize("name,M,K1,K2,N,bias,act,addend,residual,ln", CASES, ids=[c[0] for c in CASES])
+def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, ln):
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(50)
+    a = _mk(g, M, K1)
+    a2 = _mk(g, M, K2) if K2 else None
+    a2_add = _mk(g, M, K2) if (K2 and addend) else None
+    w = _mk(g, N, K1 + K2, scale=(1.0 / (K1 + K2)) ** 0.5)
+    b = _mk(g, N, scale=0.1) if bias else None
+    res = _mk(g, M, N) if residual else None
+    lnp = (torch.rand(N, generator=g) + 0.5, _mk(g, N, scale=0.1), 1e-5) if ln else None
+    d64 = lambda t: None if t is None else t.double()
+    ref = odense.linear_chain(d64(a), d64(w), d64(b), d64(a2), d64(a2_add), act, d64(res),
+                              None if lnp is None else (lnp[0].double(), lnp[1].double(), lnp[2]))
+    c = lambda t: None if t is None else t.cuda()
+    out = ext.linear(c(a), c(w), c(b), a2=c(a2), a2_add=c(a2_add), act=act, residual=c(res),
+                     ln=None if lnp is None else (lnp[0].cuda(), lnp[1].cuda(), lnp[2]))
+    torch.cuda.synchronize()
+    d = float((out.cpu().double() - ref).abs().max())
+    print(f"{name}: max|hip - oracle(f64)| = {d:.3e}")
+    assert out.shape == (M, N)
+    assert d < 2e-5
+
+
+def test_linear_strided_rows_and_3d_shapes():
+    """A given as a column slice of a wider buffer (row stride > K) and as a (bs, nq, K) tensor."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(51)
+    wide = _mk(g, 90, 768).cuda()
+    w = _mk(g, 64, 256, scale=0.06).cuda()
+    out = ext.linear(wide[:, 256:512], w)
+    ref = torch.nn.functional.linear(wide[:, 256:512].cpu().double(), w.cpu().double())
+    assert float((out.cpu().double() - ref).abs().max()) < 2e-5
+    x = _mk(g, 2, 45, 256).cuda()
+    out3 = ext.linear(x, w)
+    assert out3.shape == (2, 45, 64)
+    ref3 = torch.nn.functional.linear(x.cpu().double(), w.cpu().double())
+    assert float((out3.cpu().double() - ref3).abs().max()) < 2e-5
+
+
+def test_linear_full_size_value_proj_linearity():
+    """Base-config value projection (6 x 30825 rows, 256 -> 256): size-independent properties
+    (linearity in A, bias shift) on the full problem + a row sample against the oracle."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(52)
+    M = 6 * 30825
+    a = torch.randn(M, 256, generator=g).cuda()
+    w = (_mk(g, 256, 256, scale=1 / 16)).cuda()
+    b = _mk(g, 256, scale=0.1).cuda()
+    o1 = ext.linear(a, w, b)
+    o2 = ext.linear(a * 2.0, w, b)
+    assert torch.allclose(o2 - b, (o1 - b) * 2.0, atol=2e-5, rtol=1e-5)
+    idx = torch.randint(0, M, (512,), generator=g)
+    ref = torch.nn.functional.linear(a[idx.cuda()].cpu().double(), w.cpu().double(), b.cpu().double())
+    d = float((o1[idx.cuda()].cpu().double() - ref).abs().max())
+    print(f"value_proj full size: row-sample max|hip - oracle(f64)| = {d:.3e}")
+    assert d < 2e-5
+
+
+def test_linear_unsupported_and_errors():
+    from occnet_amd import ext
+    from occnet_amd._lib import OccAmdError, OccAmdUnsupported
+    x = torch.randn(8, 48).cuda()
+    with pytest.raises(OccAmdUnsupported):       # K not a multiple of 32
+        ext.linear(x, torch.randn(16, 48).cuda())
+    with pytest.raises(OccAmdUnsupported):       # LayerNorm over more than 256 outputs
+        ext.linear(torch.randn(8, 64).cuda(), torch.randn(512, 64).cuda(),
+                   ln=(torch.ones(512).cuda(), torch.zeros(512).cuda(), 1e-5))
+    with pytest.raises(OccAmdError):             # host tensor
+        ext.linear(torch.randn(8, 64), torch.randn(16, 64).cuda())
+    with pytest.raises(OccAmdError):             # weight shape mismatch
+        ext.linear(torch.randn(8, 64).cuda(), torch.randn(16, 32).cuda())

@@ -99,8 +99,10 @@ def test_tiny_config_matches_oracle():
 
 
 def test_unfused_path_matches_fused():
-    """The reference-shaped decomposition (rebatch + operator boundary) and the fused kernels agree."""
-    from occnet_amd.plugin import SpatialCrossAttention, TemporalSelfAttention
+    """Three execution levels agree: (a) everything fused (MFMA Linear epilogues, fused gathers, MFMA
+    decoder), (b) fused gathers with library GEMMs / torch LayerNorm / MIOpen decoder, (c) the
+    reference-shaped decomposition (rebatch + operator boundary)."""
+    from occnet_amd.plugin import BEVFormerLayer, SpatialCrossAttention, TemporalSelfAttention
     g = small_cfg()
     prod, ora = build_pair(g)
     feats = [f.cuda() for f in synthetic.make_features(g)]
@@ -108,13 +110,18 @@ def test_unfused_path_matches_fused():
     with torch.no_grad():
         a = prod(feats, metas)
         for m in prod.modules():
+            if isinstance(m, BEVFormerLayer):
+                m.use_fused = False
+        prod.transformer.use_fused_decoder = False
+        b = prod(feats, metas)
+        for m in prod.modules():
             if isinstance(m, (SpatialCrossAttention, TemporalSelfAttention)):
                 m.use_fused = False
-        b = prod(feats, metas)
+        c = prod(feats, metas)
     for k in ('bev_embed', 'occ', 'flow'):
-        d = maxdiff(a[k], b[k])
-        print(f"fused vs unfused {k}: {d:.3e}")
-        assert d < 2e-4
+        d1, d2 = maxdiff(a[k], b[k]), maxdiff(b[k], c[k])
+        print(f"all-fused vs gather-fused {k}: {d1:.3e}; gather-fused vs unfused {k}: {d2:.3e}")
+        assert d1 < 2e-4 and d2 < 2e-4
 
 
 def test_gather_stats_match_oracle_count():
@@ -128,8 +135,9 @@ def test_gather_stats_match_oracle_count():
     stats = torch.zeros(2, dtype=torch.int64, device='cuda')
     enc = prod.transformer.encoder
     sca = enc.layers[0].attentions[1]
-    orig = sca.forward
-    sca.forward = lambda *a, **k: orig(*a, gather_stats=stats, **k)
+    orig, orig_f = sca.forward, sca.forward_fused
+    sca.forward = lambda *a, **k: orig(*a, **{**k, 'gather_stats': stats})
+    sca.forward_fused = lambda *a, **k: orig_f(*a, **{**k, 'gather_stats': stats})
     with torch.no_grad():
         prod([f.cuda() for f in feats], metas)
         ora(feats, metas)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--mode", choices=["autocast", "bf16", "fp16", "f32"], default="autocast")
+ap.add_argument("--mode", choices=["autocast", "bf16", "fp16", "f32", "plan", "plan_fused", "plan_fused_fp16"], default="autocast")
 ap.add_argument("--benchmark", type=int, default=0)
 ap.add_argument("--nhwc", type=int, default=1)
 ap.add_argument("--iters", type=int, default=10)
@@ -30,6 +30,23 @@ img = synthetic.make_images(geo, batch=1, seed=0, device="cuda")
 B, N, C, H, W = img.shape
 x = img.reshape(B * N, C, H, W)
 bb, neck = model.img_backbone, model.img_neck
+plan = None
+if args.mode.startswith("plan"):
+    from occnet_amd.plugin.backbone import FusedInferenceBackbone
+    # non-trivial BN statistics so the fold is exercised
+    g = torch.Generator().manual_seed(0)
+    for m in bb.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g).cuda() * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g).cuda() * 0.5 + 0.75)
+    with torch.no_grad():
+        ref = [t.float() for t in neck(bb(x[:1]))]
+    plan = FusedInferenceBackbone(bb, neck, dtype=torch.float16 if args.mode.endswith("fp16") else torch.bfloat16,
+                                  fused_ops="fused" in args.mode)
+    with torch.no_grad():
+        got = plan(x[:1])
+    for a, b in zip(ref, got):
+        print(f"  plan vs f32 modules: max|diff| {float((a - b.float()).abs().max()):.3e} of max {float(a.abs().max()):.3e}")
 dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.mode)
 if dt is not None:
     bb.to(dt); neck.to(dt); x = x.to(dt)
@@ -40,6 +57,8 @@ if args.nhwc:
 
 @torch.no_grad()
 def run():
+    if plan is not None:
+        return plan(x)
     if args.mode == "autocast":
         with torch.autocast("cuda", dtype=torch.bfloat16):
             return neck(bb(x))

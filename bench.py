@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--scope", choices=["e2e", "hotpath"], default="e2e",
                     help="e2e: images -> voxels (backbone included); hotpath: FPN features -> voxels")
     ap.add_argument("--backbone-dtype", choices=["bf16", "f32"], default="bf16")
-    ap.add_argument("--no-miopen-fusion", action="store_true",
-                    help="backbone: plain conv + in-place ReLU instead of MIOpen's fused conv+bias+ReLU")
+    ap.add_argument("--backbone-plan", choices=["autocast", "folded"], default="autocast",
+                    help="autocast: stock modules under torch.autocast(bf16), NHWC; folded: eval BN "
+                         "folded into the convolutions, pure bf16 NHWC")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -75,15 +76,20 @@ def build(cfg_path, device):
 
 
 class Stepper:
-    def __init__(self, model, geo, scope, backbone_dtype, device, seed, fused_ops=True):
+    def __init__(self, model, geo, scope, backbone_dtype, device, seed, plan="autocast"):
         from occnet_amd import synthetic
         self.model, self.scope, self.device = model, scope, device
         self.metas = synthetic.make_img_metas(geo, batch=1, seed=seed)
+        self.autocast = False
         if scope == "e2e" and hasattr(model, "img_backbone"):
             self.img = synthetic.make_images(geo, batch=1, seed=seed, device=device)
-            # stock MIOpen backbone, inference plan: BN folded, NHWC, fused conv+bias+ReLU
-            model.enable_fused_backbone(dtype=torch.bfloat16 if backbone_dtype == "bf16" else torch.float32,
-                                        fused_ops=fused_ops)
+            self.autocast = backbone_dtype == "bf16" and plan == "autocast"
+            if plan == "folded":   # stock MIOpen ops, eval BN folded into the convolutions, NHWC
+                model.enable_fused_backbone(
+                    dtype=torch.bfloat16 if backbone_dtype == "bf16" else torch.float32)
+            elif self.autocast:
+                model.img_backbone.to(memory_format=torch.channels_last)
+                model.img_neck.to(memory_format=torch.channels_last)
         else:
             self.scope = "hotpath"
             self.feats = synthetic.make_features(geo, batch=1, seed=seed, device=device)
@@ -92,7 +98,11 @@ class Stepper:
     def __call__(self):
         m = self.model
         if self.scope == "e2e":
-            feats = m.extract_feat(img=self.img, img_metas=self.metas)
+            if self.autocast:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    feats = m.extract_feat(img=self.img, img_metas=self.metas)
+            else:
+                feats = m.extract_feat(img=self.img, img_metas=self.metas)
         else:
             feats = self.feats
         outs = m.pts_bbox_head(feats, self.metas, prev_bev=None, test=True)
@@ -193,7 +203,7 @@ def main():
     from occnet_amd import ext
     cfg, model, geo = build(args.config, device)
     stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank,
-                      fused_ops=not args.no_miopen_fusion)
+                      plan=args.backbone_plan)
 
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         stepper()

@@ -183,14 +183,14 @@ class FPN(BaseModule):
 
 class FusedInferenceBackbone(nn.Module):
     """Inference-time execution plan for ResNet + FPN on stock PyTorch-ROCm / MIOpen ops: eval-mode
-    BatchNorm folded into the preceding convolution (`fuse_conv_bn_weights`), convolution + bias +
-    ReLU and convolution + bias + residual + ReLU issued as MIOpen's fused forward
-    (`torch.miopen_convolution_relu` / `torch.miopen_convolution_add_relu`) when `fused_ops`, in one
-    dtype and channels_last (NHWC) memory so the FPN outputs are already in the (Cam, H, W, C) layout
+    BatchNorm folded into the preceding convolution (`fuse_conv_bn_weights`), in one dtype and
+    channels_last (NHWC) memory; `fused_ops=True` additionally issues convolution + bias (+ residual) +
+    ReLU as MIOpen's fused forward (`torch.miopen_convolution_relu` / `_add_relu`) — measured on MI355X /
+    ROCm 7.2 this falls back to MIOpen's naive bf16 NHWC kernel (1.7 s per forward), so it is off by default so the FPN outputs are already in the (Cam, H, W, C) layout
     the gather kernels want.  Built from the live modules' parameters (it owns folded COPIES: rebuild
     after changing weights); no custom kernels — the backbone stays outside the hand-written scope."""
 
-    def __init__(self, backbone, neck, dtype=torch.bfloat16, fused_ops=True):
+    def __init__(self, backbone, neck, dtype=torch.bfloat16, fused_ops=False):
         super().__init__()
         from torch.nn.utils.fusion import fuse_conv_bn_weights
         assert not backbone.training or backbone.norm_eval, "folding BN needs eval-mode statistics"

@@ -79,7 +79,7 @@ class BEVFormerOcc(BaseModule):
                 out.append(f.view(B, int(BN / B), C, H, W))
         return out
 
-    def enable_fused_backbone(self, dtype=torch.bfloat16, fused_ops=True):
+    def enable_fused_backbone(self, dtype=torch.bfloat16, fused_ops=False):
         """Inference-only: run ResNet+FPN through FusedInferenceBackbone (eval BN folded into the
         convolutions, NHWC, MIOpen's fused conv+bias(+add)+ReLU).  Call again after changing backbone
         weights; pass dtype=None to disable."""

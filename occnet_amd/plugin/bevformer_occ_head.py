@@ -48,7 +48,9 @@ class BEVFormerOccHead(BaseModule):
         """mlvl_feats: list of (B, N, C, H, W) -> {'bev_embed','occ','flow'}; with only_bev the
         (bs, H*W, C) BEV embedding alone (history frames)."""
         bs = mlvl_feats[0].shape[0]
-        dtype = mlvl_feats[0].dtype
+        # the reference takes the feature dtype (bevformer_occ_head.py:118); the MI355X hot path always
+        # computes in fp32 (a half-precision backbone's maps are widened when they are flattened)
+        dtype = mlvl_feats[0].dtype if mlvl_feats[0].dtype == torch.float64 else torch.float32
         bev_queries = self.bev_embedding.weight.to(dtype)
         bev_mask = torch.zeros((bs, self.bev_h, self.bev_w), device=bev_queries.device).to(dtype)
         bev_pos = self.positional_encoding(bev_mask).to(dtype)

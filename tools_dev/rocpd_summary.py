@@ -20,5 +20,21 @@ def main():
               f"{mx / 1e3:10.1f}  {name[:150]}")
 
 
+def dump(db, pattern, limit=80):
+    """Per-dispatch durations (launch order) of kernels whose name matches `pattern`."""
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    gx = "grid_size_x" if "grid_size_x" in cols else ("grid_x" if "grid_x" in cols else None)
+    gy = "grid_size_y" if "grid_size_y" in cols else ("grid_y" if "grid_y" in cols else None)
+    sel = "name, end-start" + (f", {gx}, {gy}" if gx and gy else "")
+    rows = list(cur.execute(f"select {sel} from kernels where name like ? order by start", (f"%{pattern}%",)))
+    print(f"# per-dispatch: {len(rows)} launches matching {pattern!r}; columns {cols}")
+    for r in rows[-limit:]:
+        print(f"{r[1] / 1e3:9.1f} us  grid {r[2:] if len(r) > 2 else ''}  {r[0][:60]}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[2] == "--dump":
+        dump(sys.argv[1], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 80)
+        sys.exit(0)
     main()

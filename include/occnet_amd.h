@@ -173,7 +173,7 @@ int occ_occ_heads_f32(const float* feat, const float* w1_occ, const float* b1_oc
  *   temporal_self_attention.py:197) ; weight (N, K1+K2) torch Linear layout ; bias (N) or NULL ;
  *   act 0 = none, 1 = ReLU ; residual (M, N) row stride ldres or NULL (added after act) ;
  *   ln_gamma / ln_beta (N) or both NULL, ln_eps: LayerNorm over the N outputs ; out (M, N) row stride ldo.
- * Requires K1, K2 multiples of 32, N % 4 == 0, 16-byte aligned rows, N <= 256 with LayerNorm;
+ * Requires K1, K2 multiples of 16, N % 4 == 0, 16-byte aligned rows, N <= 256 with LayerNorm;
  * otherwise OCC_E_UNSUPPORTED (the caller keeps the library GEMM).
  * Call sites replaced: value_proj / sampling_offsets / attention_weights / output_proj Linears
  * (spatial_cross_attention.py:334-341,173 ; temporal_self_attention.py:198-209,266), mmcv FFN + the three

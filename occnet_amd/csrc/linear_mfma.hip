@@ -13,20 +13,23 @@
 // ATen GEMM is the order of the K sum.
 //
 // Block = 4 waves, tile BM = 32 rows x BN = 128*NT columns (NT 32-column MFMA tiles per wave; wave w
-// owns columns [w*32*NT, (w+1)*32*NT)).  Per K chunk of 32: A tile (32 x 32) and W tile (BN x 32) are
-// staged row-major into LDS with a 36-float row stride (144 B: the 32 rows a ds_read_b128 touches land
-// on distinct 16-byte bank slots).  k-pairing as in the Conv3d kernel: lanes 0-31 contract the chunk's
-// first 16 k, lanes 32-63 the last 16, so a lane's fragment is 16 contiguous floats of one row.
-// Epilogue: the accumulators are transposed through LDS into row-major; every wave then owns 8 rows,
-// 4 consecutive columns per lane (coalesced float4 traffic for bias / residual / output) and the
-// LayerNorm statistics are two wave reductions per row (two-pass variance, as ATen's kernel).
+// owns columns [w*32*NT, (w+1)*32*NT)).  The main loop has NO block barrier: every wave stages what it
+// contracts — the 32 x 16 A chunk (redundantly per wave, it comes from L1/L2) and its own 32*NT x 16
+// slice of W — into a private LDS region (20-float row stride = 80 B: the 32 rows a ds_read_b128
+// touches land on distinct 16-byte bank slots), so the 16 waves a CU holds free-run against each other
+// and hide one another's global-load and LDS round trips; the next chunk's global loads are issued
+// before the current chunk's MFMAs.  k-pairing as in the Conv3d kernel: lanes 0-31 contract the chunk's
+// first 8 k, lanes 32-63 the last 8, so a lane's fragment is 8 contiguous floats of one row.
+// Epilogue (one __syncthreads): the accumulators are transposed through LDS into row-major; every wave
+// then owns 8 rows, 4 consecutive columns per lane (coalesced float4 traffic for bias / residual /
+// output) and the LayerNorm statistics are two wave reductions per row (two-pass variance, as ATen).
 #include "common.h"
 
 namespace occ {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kLinBM = 32, kLinBK = 32, kLinLD = 36;
+constexpr int kLinBM = 32, kLinBK = 16, kLinLD = 20;
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -41,15 +44,17 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(
     const float* __restrict__ bias, int act, const float* __restrict__ residual, long ldres,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
     float* __restrict__ out, long ldo, int M, int N) {
-  constexpr int BN = 128 * NT, LD = kLinLD, OLD = BN + 4;
-  constexpr int STAGE_FLOATS = (kLinBM + BN) * LD, OUT_FLOATS = kLinBM * OLD;
+  constexpr int BN = 128 * NT, LD = kLinLD, OLD = BN + 4, WR = 32 * NT;   // W rows per wave
+  constexpr int WAVE_FLOATS = (kLinBM + WR) * LD;
+  constexpr int STAGE_FLOATS = 4 * WAVE_FLOATS, OUT_FLOATS = kLinBM * OLD;
   __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS > OUT_FLOATS ? STAGE_FLOATS : OUT_FLOATS];
-  float* sA = lds;
-  float* sW = lds + kLinBM * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kh = lane >> 5;
+  float* sA = lds + wave * WAVE_FLOATS;
+  float* sW = sA + kLinBM * LD;
   const long m0 = (long)blockIdx.x * kLinBM;
   const int n0 = blockIdx.y * BN;
+  const int nw0 = n0 + wave * WR;          // first W row (output column) of this wave
   const int K = K1 + K2;
 
   f32x16 acc[NT];
@@ -58,56 +63,84 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  // staging roles: thread -> (row, 16-byte part); A: 1 float4 per thread, W: BN/32 float4 per thread
-  const int srow = tid >> 3, spart = tid & 7;
-  for (int k0 = 0; k0 < K; k0 += kLinBK) {
-    float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m0 + srow < M) {
-      if (k0 < K1) {
-        va = *reinterpret_cast<const float4*>(a1 + (m0 + srow) * lda1 + k0 + spart * 4);
-      } else {
-        const long o = (m0 + srow) * lda2 + (k0 - K1) + spart * 4;
-        va = *reinterpret_cast<const float4*>(a2 + o);
-        if (a2add) {
-          const float4 vb = *reinterpret_cast<const float4*>(a2add + o);
-          va.x += vb.x; va.y += vb.y; va.z += vb.z; va.w += vb.w;
-        }
-      }
-    }
-    float4 vw[BN / 32];
-#pragma unroll
-    for (int it = 0; it < BN / 32; ++it) {
-      const int n = n0 + srow + 32 * it;
-      vw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N) vw[it] = *reinterpret_cast<const float4*>(w + (long)n * K + k0 + spart * 4);
-    }
-    if (k0) __syncthreads();   // previous chunk's fragments have been read
-    *reinterpret_cast<float4*>(sA + srow * LD + spart * 4) = va;
-#pragma unroll
-    for (int it = 0; it < BN / 32; ++it)
-      *reinterpret_cast<float4*>(sW + (srow + 32 * it) * LD + spart * 4) = vw[it];
-    __syncthreads();
+  // staging roles inside the wave: lane -> (row = lane/4 + 16*it, 16-byte part = lane%4)
+  const int srow = lane >> 2, spart = lane & 3;
+  // All loads are UNCONDITIONAL (row / column indices clamped instead of predicated, the addend read
+  // from a valid alias and scaled by 0/1): a branch around a load makes hipcc drain vmcnt(0) at the
+  // join and serialises the prefetch.  Rows >= M and columns >= N compute garbage that is never stored.
+  // The prefetch registers are named scalars, not arrays: loop-carried arrays indexed by a
+  // template-dependent trip count were left in scratch by hipcc (ROCm 7.2).
+  const long mr0 = m0 + srow, mr1 = m0 + srow + 16;
+  const long arow0 = mr0 < M ? mr0 : (long)M - 1, arow1 = mr1 < M ? mr1 : (long)M - 1;
+  const long wo0 = (long)min(nw0 + srow, N - 1) * K + spart * 4;
+  const long wo1 = (long)min(nw0 + srow + 16, N - 1) * K + spart * 4;
+  const long wo2 = (long)min(nw0 + srow + 32, N - 1) * K + spart * 4;   // NT == 2 only
+  const long wo3 = (long)min(nw0 + srow + 48, N - 1) * K + spart * 4;
+  float4 va0, va1, vd0, vd1, vw0, vw1, vw2, vw3;
+  float addscale = 0.f;
+#define OCC_LIN_ISSUE_LOADS(K0)                                                                   \
+  {                                                                                               \
+    const int k0_ = (K0);                                                                         \
+    const bool seg2 = k0_ >= K1; /* wave-uniform scalar selects */                                \
+    const float* ab = (seg2 ? a2 + (k0_ - K1) : a1 + k0_) + spart * 4;                            \
+    const long lda = seg2 ? lda2 : lda1;                                                          \
+    const bool add = seg2 && a2add != nullptr;                                                    \
+    const float* addb = add ? a2add + (k0_ - K1) + spart * 4 : ab;                                \
+    addscale = add ? 1.f : 0.f;                                                                   \
+    va0 = *reinterpret_cast<const float4*>(ab + arow0 * lda);                                     \
+    va1 = *reinterpret_cast<const float4*>(ab + arow1 * lda);                                     \
+    vd0 = *reinterpret_cast<const float4*>(addb + arow0 * lda);                                   \
+    vd1 = *reinterpret_cast<const float4*>(addb + arow1 * lda);                                   \
+    vw0 = *reinterpret_cast<const float4*>(w + wo0 + k0_);                                        \
+    vw1 = *reinterpret_cast<const float4*>(w + wo1 + k0_);                                        \
+    if (NT == 2) {                                                                                \
+      vw2 = *reinterpret_cast<const float4*>(w + wo2 + k0_);                                      \
+      vw3 = *reinterpret_cast<const float4*>(w + wo3 + k0_);                                      \
+    }                                                                                             \
+  }
 
-    float af[16], bf[NT][16];
+  OCC_LIN_ISSUE_LOADS(0)
+  for (int k0 = 0; k0 < K; k0 += kLinBK) {
+    // registers (chunk k0) -> this wave's LDS region; its previous fragment reads have completed
+    va0.x = fmaf(addscale, vd0.x, va0.x); va0.y = fmaf(addscale, vd0.y, va0.y);
+    va0.z = fmaf(addscale, vd0.z, va0.z); va0.w = fmaf(addscale, vd0.w, va0.w);
+    va1.x = fmaf(addscale, vd1.x, va1.x); va1.y = fmaf(addscale, vd1.y, va1.y);
+    va1.z = fmaf(addscale, vd1.z, va1.z); va1.w = fmaf(addscale, vd1.w, va1.w);
+    *reinterpret_cast<float4*>(sA + srow * LD + spart * 4) = va0;
+    *reinterpret_cast<float4*>(sA + (srow + 16) * LD + spart * 4) = va1;
+    *reinterpret_cast<float4*>(sW + srow * LD + spart * 4) = vw0;
+    *reinterpret_cast<float4*>(sW + (srow + 16) * LD + spart * 4) = vw1;
+    if (NT == 2) {
+      *reinterpret_cast<float4*>(sW + (srow + 32) * LD + spart * 4) = vw2;
+      *reinterpret_cast<float4*>(sW + (srow + 48) * LD + spart * 4) = vw3;
+    }
+    wave_lds_sync();
+    // next chunk's loads stay in flight during this chunk's MFMAs (the last iteration re-reads its own
+    // chunk: an unconditional prefetch keeps the schedule branch-free)
+    OCC_LIN_ISSUE_LOADS(k0 + kLinBK < K ? k0 + kLinBK : k0)
+
+    float af[8], bf[NT][8];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const float4 x = *reinterpret_cast<const float4*>(sA + vi * LD + kh * 16 + s4 * 4);
+    for (int s4 = 0; s4 < 2; ++s4) {
+      const float4 x = *reinterpret_cast<const float4*>(sA + vi * LD + kh * 8 + s4 * 4);
       af[s4 * 4 + 0] = x.x; af[s4 * 4 + 1] = x.y; af[s4 * 4 + 2] = x.z; af[s4 * 4 + 3] = x.w;
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const float4 x = *reinterpret_cast<const float4*>(sW + ((wave * NT + t) * 32 + vi) * LD +
-                                                          kh * 16 + s4 * 4);
+      for (int s4 = 0; s4 < 2; ++s4) {
+        const float4 x = *reinterpret_cast<const float4*>(sW + (t * 32 + vi) * LD + kh * 8 + s4 * 4);
         bf[t][s4 * 4 + 0] = x.x; bf[t][s4 * 4 + 1] = x.y; bf[t][s4 * 4 + 2] = x.z; bf[t][s4 * 4 + 3] = x.w;
       }
+    wave_lds_sync();   // fragment reads retire before the next iteration overwrites the region
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int s = 0; s < 8; ++s)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[t][s], acc[t], 0, 0, 0);
   }
+
+#undef OCC_LIN_ISSUE_LOADS
 
   // ---- epilogue: accumulators -> LDS row-major tile -> 8 rows per wave ------------------------------
   __syncthreads();
@@ -178,7 +211,7 @@ extern "C" int occ_linear_f32(const float* a1, int64_t lda1, int K1, const float
                 "linear: leading dimension smaller than the row");
   if (K1 % kLinBK || K2 % kLinBK || N % 4 || lda1 % 4 || lda2 % 4 || ldo % 4 || ldres % 4 ||
       (ln_gamma && N > 256)) {
-    set_error("linear: no MFMA kernel for K1=%d K2=%d N=%d (need K %% 32 == 0, N %% 4 == 0, 16-byte "
+    set_error("linear: no MFMA kernel for K1=%d K2=%d N=%d (need K %% 16 == 0, N %% 4 == 0, 16-byte "
               "aligned rows, N <= 256 with LayerNorm)", K1, K2, N);
     return OCC_E_UNSUPPORTED;
   }

@@ -342,7 +342,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         # the reference keeps `shift_ref_2d = ref_2d.clone()`: no ego-motion shift in this variant
         shift_ref_2d = ref_2d
         bev_query = bev_query.permute(1, 0, 2)
-        bev_pos = bev_pos.permute(1, 0, 2)
+        bev_pos = bev_pos.permute(1, 0, 2).contiguous()   # one copy per forward, read by every layer
         bs, len_bev, num_bev_level, _ = ref_2d.shape
         if prev_bev is not None:
             prev_bev = prev_bev.permute(1, 0, 2)

@@ -23,6 +23,7 @@ CASES = [
     ("small_n_ln",     45,   64,  0,   128, True,  None,  False,  True,     True),
     ("n_100_ln",       70,   32,  0,   100, True,  'relu', False, True,     True),
     ("two_seg_noadd",  33,   32,  64,  36,  False, None,  False,  True,     False),
+    ("k16_chunks",     50,   48,  16,  64,  True,  None,  True,   False,    False),
     ("one_row",        1,    256, 0,   256, True,  None,  False,  True,     True),
 ]
 
@@ -89,9 +90,9 @@ def test_linear_full_size_value_proj_linearity():
 def test_linear_unsupported_and_errors():
     from occnet_amd import ext
     from occnet_amd._lib import OccAmdError, OccAmdUnsupported
-    x = torch.randn(8, 48).cuda()
-    with pytest.raises(OccAmdUnsupported):       # K not a multiple of 32
-        ext.linear(x, torch.randn(16, 48).cuda())
+    x = torch.randn(8, 40).cuda()
+    with pytest.raises(OccAmdUnsupported):       # K not a multiple of 16
+        ext.linear(x, torch.randn(16, 40).cuda())
     with pytest.raises(OccAmdUnsupported):       # LayerNorm over more than 256 outputs
         ext.linear(torch.randn(8, 64).cuda(), torch.randn(512, 64).cuda(),
                    ln=(torch.ones(512).cuda(), torch.zeros(512).cuda(), 1e-5))

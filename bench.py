@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--backbone-plan", choices=["autocast", "folded"], default="autocast",
                     help="autocast: stock modules under torch.autocast(bf16), NHWC; folded: eval BN "
                          "folded into the convolutions, pure bf16 NHWC")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer (default, the BASELINE metric): forward pass; train: forward + loss + "
+                         "backward + DDP/RCCL gradient all-reduce + clip + AdamW step per sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -108,6 +111,35 @@ class Stepper:
         outs = m.pts_bbox_head(feats, self.metas, prev_bev=None, test=True)
         occ, flow = m.pts_bbox_head.get_occ(outs, self.metas)
         return occ, flow
+
+
+class TrainStepper:
+    """One optimisation step per call (occnet_amd/train.py): forward, CE + L1 loss, backward through
+    the HIP deformable-attention backward kernel, DDP gradient all-reduce over RCCL (the path's only
+    collective), grad-clip 35, AdamW."""
+
+    def __init__(self, model, geo, backbone_dtype, device, seed, world):
+        from occnet_amd import synthetic
+        from occnet_amd.train import make_optimizer, synthetic_targets, wrap_ddp
+        self.scope = "e2e"
+        self.device = device
+        self.net = model.train()
+        self.model = wrap_ddp(model, device) if world > 1 else model
+        self.opt = make_optimizer(self.model)
+        self.metas = synthetic.make_img_metas(geo, batch=1, seed=seed)
+        self.img = synthetic.make_images(geo, batch=1, seed=seed, device=device)
+        head = model.pts_bbox_head
+        self.targets = synthetic_targets(head.bev_h, head.bev_w, head.transformer.pillar_h,
+                                         num_classes=head.num_classes, seed=seed, device=device)
+        self.autocast = backbone_dtype == "bf16"
+        if self.autocast:
+            model.img_backbone.to(memory_format=torch.channels_last)
+            model.img_neck.to(memory_format=torch.channels_last)
+
+    def __call__(self):
+        from occnet_amd.train import train_step
+        return train_step(self.model, self.opt, self.img, self.metas, *self.targets,
+                          autocast_backbone=self.autocast)
 
 
 def gather_stats(model, stepper):
@@ -202,13 +234,16 @@ def main():
 
     from occnet_amd import ext
     cfg, model, geo = build(args.config, device)
-    stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank,
-                      plan=args.backbone_plan)
+    if args.mode == "train":
+        stepper = TrainStepper(model, geo, args.backbone_dtype, device, seed=rank, world=world)
+    else:
+        stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank,
+                          plan=args.backbone_plan)
 
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         stepper()
     torch.cuda.synchronize()
-    stats, da = gather_stats(model, stepper)
+    stats, da = gather_stats(model, stepper) if args.mode == "infer" else ([], None)
 
     record = None if args.no_kernel_timing else ext.kernel_timing(True)
     if world > 1:
@@ -232,7 +267,9 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         out = {
-            "metric": "nuScenes samples/sec (6-cam 900x1600 -> 200x200x16 voxels)",
+            "metric": ("nuScenes samples/sec (6-cam 900x1600 -> 200x200x16 voxels)" if args.mode == "infer"
+                       else "nuScenes TRAINING samples/sec (6-cam 900x1600 -> 200x200x16 voxels, "
+                            "fwd+bwd+DDP all-reduce+AdamW)"),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -242,7 +279,7 @@ def main():
                              f"{geo['bev_w']}x{geo['bev_h']}x{model.pts_bbox_head.transformer.pillar_h} "
                              "voxels x (17 logits + 2 flow)" if stepper.scope == "e2e" else
                              "bevformer_base_occ hot path only: 4 FPN maps (6 cams) -> voxels"),
-                "scope": stepper.scope, "samples_per_gpu": 1, "global_batch": world,
+                "mode": args.mode, "scope": stepper.scope, "samples_per_gpu": 1, "global_batch": world,
                 "parallelism": f"dp{world}", "hot_path_dtype": "f32",
                 "backbone_dtype": args.backbone_dtype if stepper.scope == "e2e" else None,
                 "config_file": os.path.relpath(args.config, ROOT),

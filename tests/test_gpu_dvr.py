@@ -92,3 +92,28 @@ def test_process_one_sample_and_score_match_oracle():
     assert abs(res['miou'] - miou) < 1e-12 and abs(res['mave'] - mave) < 1e-9
     assert abs(res['occ_score'] - score) < 1e-9
     assert 0.0 < res['miou'] <= 1.0
+
+
+def test_submission_file_round_trip(tmp_path):
+    """format_submission (nuscenes_occ.py:189-257): deterministic gzip(pickle) with int8 / float16 payloads."""
+    _lib_or_skip()
+    from occnet_amd import io as oio
+    rng = np.random.default_rng(5)
+    sem = np.full((200, 200, 16), 16, dtype=np.uint8)
+    sem[:, :, :2] = 11
+    sem[60:90, 100:130, 2:5] = 3
+    flow = rng.normal(size=(200, 200, 16, 2)).astype(np.float32)
+    origins = torch.tensor([[[0.98, 0.0, 1.84]]])
+    samples = [('tok_a', sem.reshape(-1), flow.reshape(-1), origins), ('tok_b', sem, flow, origins)]
+    p1 = oio.format_submission(samples, str(tmp_path / 's1'))
+    p2 = oio.format_submission(samples, str(tmp_path / 's2'))
+    assert open(p1, 'rb').read() == open(p2, 'rb').read()             # mtime=0 -> byte-identical
+    sub = oio.read_submission(p1)
+    assert set(sub) >= {'method', 'team', 'results'} and set(sub['results']) == {'tok_a', 'tok_b'}
+    r = sub['results']['tok_a']
+    assert r['pcd_cls'].dtype == np.int8 and r['pcd_dist'].dtype == np.float16 and r['pcd_flow'].dtype == np.float16
+    assert r['pcd_cls'].shape == (14040,) and r['pcd_flow'].shape == (14040, 2)
+    from occnet_amd.metrics import generate_lidar_rays
+    ref = oref.process_one_sample(sem, torch.from_numpy(generate_lidar_rays()), origins, flow)
+    assert np.array_equal(r['pcd_cls'], ref[:, 0].astype(np.int8))
+    assert np.array_equal(r['pcd_dist'], ref[:, 1].astype(np.float16))

@@ -44,9 +44,10 @@ def parse():
     ap.add_argument("--scope", choices=["e2e", "hotpath"], default="e2e",
                     help="e2e: images -> voxels (backbone included); hotpath: FPN features -> voxels")
     ap.add_argument("--backbone-dtype", choices=["bf16", "f32"], default="bf16")
-    ap.add_argument("--backbone-plan", choices=["autocast", "folded"], default="autocast",
-                    help="autocast: stock modules under torch.autocast(bf16), NHWC; folded: eval BN "
-                         "folded into the convolutions, pure bf16 NHWC")
+    ap.add_argument("--backbone-plan", choices=["autocast", "folded"], default="folded",
+                    help="folded (default): eval BN folded into the MIOpen convolutions, pure bf16 NHWC, one "
+                         "HIP bias/residual/ReLU launch per convolution; autocast: stock modules under "
+                         "torch.autocast(bf16), NHWC")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer (default, the BASELINE metric): forward pass; train: forward + loss + "
                          "backward + DDP/RCCL gradient all-reduce + clip + AdamW step per sample")

@@ -200,6 +200,15 @@ int occ_dvr_render_forward_f32(const float* sigma, const float* origin, const fl
                                float* coord_index, int N, int T, int Z, int Y, int X, int M,
                                int point_stride, int train_phase, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backbone tail (outside the hand-written hot path): in place x = relu?(x + bias[c] (+ residual)) on an
+ * NHWC bf16 activation of `rows` = N*H*W pixels x C channels (C % 8 == 0, 16-byte aligned).  Replaces the
+ * BatchNorm / ReLU / residual-add launches after each MIOpen convolution of the ResNet-50 bottlenecks once
+ * eval-mode BatchNorm is folded into the convolution weights.
+ */
+int occ_bias_act_nhwc_bf16(void* x, const float* bias, const void* residual, int64_t rows, int C, int relu,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

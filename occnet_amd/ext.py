@@ -391,3 +391,23 @@ def dvr_render_forward(sigma, origin, points, tindex, grid=None, phase_name="tes
             i32(1 if phase_name == "train" else 0), stream_ptr(dev))
     _lib.check(rc, "dvr_render_forward")
     return pred, gt, coord
+
+
+def bias_act_nhwc_(x, bias, residual=None, relu=True):
+    """In place x = relu?(x + bias[c] (+ residual)) on a channels_last bf16 (N, C, H, W) tensor (memory
+    order N, H, W, C).  bias (C) float32.  Returns x."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        raise OccAmdUnsupported("bias_act_nhwc_: x must be a channels_last bfloat16 device tensor")
+    _need_cuda_f32("bias", bias)
+    N, C, H, W = x.shape
+    if bias.numel() != C:
+        raise OccAmdError("bias_act_nhwc_: bias must have C entries")
+    if residual is not None and not (residual.dtype == torch.bfloat16 and residual.shape == x.shape and
+                                     residual.is_contiguous(memory_format=torch.channels_last)):
+        raise OccAmdUnsupported("bias_act_nhwc_: residual must match x (channels_last bfloat16)")
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().occ_bias_act_nhwc_bf16(ptr(x), ptr(bias), ptr(residual), i64(N * H * W), i32(C),
+                                               i32(1 if relu else 0), stream_ptr(x.device))
+    _lib.check(rc, "bias_act_nhwc_")
+    return x

@@ -190,8 +190,11 @@ class FusedInferenceBackbone(nn.Module):
     the gather kernels want.  Built from the live modules' parameters (it owns folded COPIES: rebuild
     after changing weights); no custom kernels — the backbone stays outside the hand-written scope."""
 
-    def __init__(self, backbone, neck, dtype=torch.bfloat16, fused_ops=False):
+    def __init__(self, backbone, neck, dtype=torch.bfloat16, fused_ops=False, hip_tail=True):
         super().__init__()
+        # hip_tail: bias + (residual) + ReLU after each convolution as ONE in-place HIP launch
+        # (occ_bias_act_nhwc_bf16) instead of PyTorch's add / add_ / relu_ launches (bf16 only)
+        self.hip_tail = hip_tail and dtype == torch.bfloat16
         from torch.nn.utils.fusion import fuse_conv_bn_weights
         assert not backbone.training or backbone.norm_eval, "folding BN needs eval-mode statistics"
         self.dtype, self.fused_ops = dtype, fused_ops
@@ -222,7 +225,7 @@ class FusedInferenceBackbone(nn.Module):
         w = w.detach().to(self.dtype).contiguous(memory_format=torch.channels_last)
         if b is None:
             b = torch.zeros(w.shape[0], device=w.device)
-        b = b.detach().to(self.dtype)
+        b = b.detach().float() if self.hip_tail else b.detach().to(self.dtype)
         idx = len(self._convs)
         self.register_buffer(f'w{idx}', w, persistent=False)
         self.register_buffer(f'b{idx}', b, persistent=False)
@@ -233,10 +236,18 @@ class FusedInferenceBackbone(nn.Module):
         w, b = getattr(self, f'w{i}'), getattr(self, f'b{i}')
         s, p, d, g = self._convs[i]
         if self.fused_ops and add is not None:
-            return torch.miopen_convolution_add_relu(x, w, add, 1.0, b, s, p, d, g)
+            return torch.miopen_convolution_add_relu(x, w, add, 1.0, b.to(w.dtype), s, p, d, g)
         if self.fused_ops and relu:
-            return torch.miopen_convolution_relu(x, w, b, s, p, d, g)
-        y = F.conv2d(x, w, b, s, p, d, g)
+            return torch.miopen_convolution_relu(x, w, b.to(w.dtype), s, p, d, g)
+        if self.hip_tail and w.shape[0] % 8 == 0:
+            from .. import ext
+            y = F.conv2d(x, w, None, s, p, d, g)
+            if y.is_contiguous(memory_format=torch.channels_last) and \
+                    (add is None or add.is_contiguous(memory_format=torch.channels_last)):
+                return ext.bias_act_nhwc_(y, b, residual=add, relu=relu or add is not None)
+            y = y + b.to(y.dtype).view(1, -1, 1, 1)
+        else:
+            y = F.conv2d(x, w, b.to(w.dtype), s, p, d, g)
         if add is not None:
             y = y.add_(add)
         return y.relu_() if (relu or add is not None) else y

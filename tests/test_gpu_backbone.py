@@ -1,0 +1,52 @@
+"""-m gpu: the inference execution plan of the stock ResNet-50 + FPN backbone (eval BatchNorm folded into the
+convolutions, NHWC bf16, one HIP bias/residual/ReLU launch per convolution) vs the fp32 modules."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bias_act_nhwc_matches_torch():
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(0)
+    for (N, C, H, W) in [(2, 64, 7, 9), (1, 256, 5, 3), (3, 8, 1, 1)]:
+        x = torch.randn(N, C, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(
+            memory_format=torch.channels_last)
+        r = torch.randn(N, C, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(
+            memory_format=torch.channels_last)
+        b = torch.randn(C, generator=g).cuda()
+        for res, relu in ((None, True), (r, True), (None, False)):
+            want = x.float() + b.view(1, -1, 1, 1)
+            if res is not None:
+                want = want + res.float()
+            if relu:
+                want = want.relu()
+            got = ext.bias_act_nhwc_(x.clone(memory_format=torch.channels_last), b, residual=res, relu=relu)
+            assert torch.equal(got, want.to(torch.bfloat16))        # fp32 math, one RNE rounding: exact
+
+
+def test_folded_plan_matches_fp32_modules():
+    from occnet_amd.plugin.backbone import FPN, FusedInferenceBackbone, ResNet
+    torch.manual_seed(0)
+    bb = ResNet(depth=50, num_stages=4, out_indices=(1, 2, 3), frozen_stages=1, norm_eval=True).eval()
+    bb.init_weights()
+    g = torch.Generator().manual_seed(1)
+    for m in bb.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.75)
+    nk = FPN(in_channels=[512, 1024, 2048], out_channels=256, start_level=0, add_extra_convs='on_output',
+             num_outs=4, relu_before_extra_convs=True).eval()
+    bb, nk = bb.cuda(), nk.cuda()
+    x = torch.randn(2, 3, 96, 160, generator=g).cuda() * 50.0
+    with torch.no_grad():
+        ref = nk(bb(x))
+        for hip_tail in (True, False):
+            plan = FusedInferenceBackbone(bb, nk, dtype=torch.bfloat16, hip_tail=hip_tail)
+            out = plan(x)
+            for a, b in zip(ref, out):
+                assert b.dtype == torch.bfloat16 and b.shape == a.shape
+                assert b.is_contiguous(memory_format=torch.channels_last)
+                rel = float((a - b.float()).abs().max() / a.abs().max())
+                print(f"hip_tail={hip_tail} level {tuple(a.shape)}: max rel diff {rel:.3e}")
+                assert rel < 0.06       # bf16 through 53 convolutions

@@ -44,6 +44,25 @@ class BEVFormerOccHead(BaseModule):
     def init_weights(self):
         self.transformer.init_weights()
 
+    def _bev_pos(self, bs, device, dtype):
+        """Learned positional encoding of the BEV plane, (bs, C, bev_h, bev_w).  It depends only on the two
+        embedding tables, so without autograd the SAME tensor is handed out until they change: downstream
+        caches (the encoder's query-major copy, the TSA position term) key on its identity."""
+        pe = self.positional_encoding
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in pe.parameters())
+        key = None
+        if not needs_grad:
+            key = (bs, str(device), dtype) + tuple((p.data_ptr(), p._version) for p in pe.parameters())
+            if getattr(self, '_pos_key', None) == key:
+                return self._pos_val
+        bev_mask = torch.zeros((bs, self.bev_h, self.bev_w), device=device).to(dtype)
+        bev_pos = pe(bev_mask).to(dtype)
+        if key is not None:
+            bev_pos = bev_pos.detach()
+            object.__setattr__(self, '_pos_key', key)
+            object.__setattr__(self, '_pos_val', bev_pos)
+        return bev_pos
+
     def forward(self, mlvl_feats, img_metas, prev_bev=None, only_bev=False, test=False):
         """mlvl_feats: list of (B, N, C, H, W) -> {'bev_embed','occ','flow'}; with only_bev the
         (bs, H*W, C) BEV embedding alone (history frames)."""
@@ -52,8 +71,7 @@ class BEVFormerOccHead(BaseModule):
         # computes in fp32 (a half-precision backbone's maps are widened when they are flattened)
         dtype = mlvl_feats[0].dtype if mlvl_feats[0].dtype == torch.float64 else torch.float32
         bev_queries = self.bev_embedding.weight.to(dtype)
-        bev_mask = torch.zeros((bs, self.bev_h, self.bev_w), device=bev_queries.device).to(dtype)
-        bev_pos = self.positional_encoding(bev_mask).to(dtype)
+        bev_pos = self._bev_pos(bs, bev_queries.device, dtype)
         grid_length = (self.real_h / self.bev_h, self.real_w / self.bev_w)
         if only_bev:
             return self.transformer.get_bev_features(

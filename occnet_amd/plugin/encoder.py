@@ -321,6 +321,16 @@ class BEVFormerEncoder(TransformerLayerSequence):
                                                 ego2lidar, pc_range, img_h, img_w)
         return (ref_cam, mask, vis) if return_vis else (ref_cam, mask)
 
+    def _query_major_pos(self, bev_pos):
+        """(nq, bs, C) positional encoding -> contiguous (bs, nq, C).  The head hands out the same
+        tensor while its embedding tables are unchanged (inference): keep the transposed copy."""
+        if torch.is_grad_enabled() and bev_pos.requires_grad:
+            return bev_pos.permute(1, 0, 2).contiguous()
+        key = (bev_pos.data_ptr(), bev_pos._version, tuple(bev_pos.shape), tuple(bev_pos.stride()))
+        if getattr(self, '_pos_key', None) != key:
+            self._pos_key, self._pos_qm = key, bev_pos.permute(1, 0, 2).contiguous()
+        return self._pos_qm
+
     def _bev_order(self, bev_h, bev_w, device):
         key = (bev_h, bev_w, str(device))
         if key not in self._order_cache:
@@ -342,7 +352,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         # the reference keeps `shift_ref_2d = ref_2d.clone()`: no ego-motion shift in this variant
         shift_ref_2d = ref_2d
         bev_query = bev_query.permute(1, 0, 2)
-        bev_pos = bev_pos.permute(1, 0, 2).contiguous()   # one copy per forward, read by every layer
+        bev_pos = self._query_major_pos(bev_pos)          # (bs, nq, C) contiguous, cached while constant
         bs, len_bev, num_bev_level, _ = ref_2d.shape
         if prev_bev is not None:
             prev_bev = prev_bev.permute(1, 0, 2)

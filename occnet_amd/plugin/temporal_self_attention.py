@@ -87,6 +87,16 @@ class TemporalSelfAttention(BaseModule):
                                      self.num_heads, self.num_points, shared_queue=shared,
                                      order=order)
 
+    def _folded_query_weights(self, w, b, query_pos):
+        c = self.embed_dims
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version, query_pos.data_ptr(),
+               query_pos._version, tuple(query_pos.shape))
+        if getattr(self, '_fold_key', None) != key:
+            w_sum = (w[:, :c] + w[:, c:]).contiguous()
+            pos_term = ext.linear(query_pos.contiguous(), w[:, c:].contiguous(), b)
+            self._fold_key, self._fold_val = key, (w_sum, pos_term)
+        return self._fold_val
+
     def forward_fused(self, query, value=None, query_pos=None, reference_points=None, bev_h=None,
                       bev_w=None, bev_order=None, post_norm=None):
         """Inference form with every dense op on the MFMA Linear kernel: the cat([value, query+pos])
@@ -105,8 +115,14 @@ class TemporalSelfAttention(BaseModule):
         value_first = query if shared else value[:bs]
         try:
             w, b = self._qcat.get((self.sampling_offsets, self.attention_weights))
-            lin = ext.linear(value_first.contiguous(), w, b, a2=query.contiguous(),
-                             a2_add=None if query_pos is None else query_pos.contiguous())
+            if shared and query_pos is not None:
+                # no history: cat([q, q + pos]) @ W^T + b = q @ (Wa + Wb)^T + (pos @ Wb^T + b); the
+                # position term is constant while weights and positional encoding are (inference)
+                w_sum, pos_term = self._folded_query_weights(w, b, query_pos)
+                lin = ext.linear(query.contiguous(), w_sum, None, residual=pos_term)
+            else:
+                lin = ext.linear(value_first.contiguous(), w, b, a2=query.contiguous(),
+                                 a2_add=None if query_pos is None else query_pos.contiguous())
             n_off = self.sampling_offsets.out_features
             vsrc = (value_first if shared else value).contiguous()
             v = ext.linear(vsrc, self.value_proj.weight, self.value_proj.bias)

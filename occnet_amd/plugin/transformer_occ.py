@@ -147,7 +147,10 @@ class TransformerOcc(BaseModule):
         """-> BEV embedding (bs, bev_h*bev_w, C)."""
         _require_device(mlvl_feats[0], 'TransformerOcc')
         bs, num_cam = mlvl_feats[0].shape[:2]
-        bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)
+        if bs == 1 and not (torch.is_grad_enabled() and bev_queries.requires_grad):
+            bev_queries = bev_queries.unsqueeze(1)      # (nq, 1, C) view: the encoder only reads it
+        else:
+            bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)
         bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
         if prev_bev is not None:
             if prev_bev.shape[1] == bev_h * bev_w:

@@ -332,6 +332,10 @@ def main():
                 lin = times.get("linear", [])
                 if lin:
                     out["mfma_kernels"]["linear_ms_per_step"] = sum(lin) / args.steps
+                    fl = times.get("linear_flops", [])
+                    if fl:
+                        out["mfma_kernels"]["linear_precision"] = ext.LINEAR_PRECISION
+                        out["mfma_kernels"]["linear_tflops"] = sum(fl) / (sum(lin) * 1e-3) / 1e12
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, geo)

@@ -187,6 +187,19 @@ int occ_linear_f32(const float* a1, int64_t lda1, int K1, const float* a2, const
                    float ln_eps, float* out, int64_t ldo, int M, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * occ_linear_f32's fast variant on the bf16 matrix cores ("bf16x3"): every f32 operand is split into
+ * hi + lo bf16 and A.W^T ~= Ah.Wh^T + Ah.Wl^T + Al.Wh^T is accumulated in f32 (relative error of a product
+ * <= 2^-16).  Same arguments, except that the weight is given PACKED by occ_linear_pack_weight_bf16x3:
+ * packed[n][K/16][hi16 | lo16] bf16 (N*K*2 16-bit words; K % 16 == 0).
+ */
+int occ_linear_pack_weight_bf16x3(const float* weight, void* packed, int N, int K, void* stream);
+int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2, const float* a2_add,
+                          int64_t lda2, int K2, const void* weight_packed, const float* bias, int act,
+                          const float* residual, int64_t ldres, const float* ln_gamma,
+                          const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Ray casting through an occupancy grid (RayIoU metric) — replaces the reference's `dvr.render_forward`
  * (tools/ray_iou/lib/dvr/dvr.cpp:68-72 binding, dvr.cu:70-388), called at
  * projects/mmdet3d_plugin/datasets/ray_metrics.py:116-123.

@@ -43,8 +43,10 @@ class _timed:
 
 
 def kernel_times_ms(record):
-    """{name: [ms per launch]} from a kernel_timing() record (call after a device synchronize)."""
-    return {k: [a.elapsed_time(b) for a, b in v] for k, v in record.items()}
+    """{name: [ms per launch]} from a kernel_timing() record (call after a device synchronize); entries
+    that are plain numbers (e.g. 'linear_flops') pass through."""
+    return {k: [a.elapsed_time(b) for a, b in v] if v and isinstance(v[0], tuple) else list(v)
+            for k, v in record.items()}
 
 
 def _need_cuda_f32(name, t, contiguous=True):
@@ -306,12 +308,46 @@ def _rows2d(name, t, k=None):
     return t, M, K, ld
 
 
-def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, ln=None):
+# Precision of the MFMA Linear kernel: 'f32' = v_mfma_f32_32x32x2_f32 (exact fp32, bitwise an fmaf
+# chain), 'bf16x3' = three bf16 MFMAs on hi/lo-split operands with f32 accumulation (relative error of a
+# product <= 2^-16; 2-3x faster).  The default can be overridden with OCC_LINEAR_PRECISION.
+import os as _os
+LINEAR_PRECISION = _os.environ.get("OCC_LINEAR_PRECISION", "bf16x3")
+_PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight (small LRU)
+
+
+def linear_pack_weight_bf16x3(weight):
+    """(N, K) float32 Linear weight -> packed[n][K/16][hi16 | lo16] bf16 split (int16 storage), cached."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
+    hit = _PACKED_W.get(key)
+    if hit is not None:
+        return hit[1]
+    _need_cuda_f32("weight", weight)
+    N, K = weight.shape
+    packed = torch.empty(N * K * 2, dtype=torch.int16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = _lib.lib().occ_linear_pack_weight_bf16x3(ptr(weight), ptr(packed), i32(N), i32(K),
+                                                      stream_ptr(weight.device))
+    _lib.check(rc, "linear_pack_weight_bf16x3")
+    if len(_PACKED_W) >= 256:
+        _PACKED_W.pop(next(iter(_PACKED_W)))
+    # the entry keeps the weight tensor alive: while it is cached its address cannot be recycled by
+    # another tensor, so (data_ptr, version) identifies the contents
+    _PACKED_W[key] = (weight, packed)
+    return packed
+
+
+def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, ln=None,
+           precision=None):
     """out = LayerNorm(residual + act([a | a2 (+ a2_add)] @ weight^T + bias)) on the f32 matrix cores.
 
     a (…, K1); a2 / a2_add (…, K2) optional second K segment (+ addend); weight (N, K1+K2) and bias (N)
     in torch Linear layout; act None | 'relu'; residual (…, N); ln = (gamma, beta, eps) or an
-    nn.LayerNorm.  -> (…, N) float32.  Raises OccAmdUnsupported for shapes without an MFMA kernel."""
+    nn.LayerNorm; precision 'f32' | 'bf16x3' (None = LINEAR_PRECISION).  -> (…, N) float32.  Raises
+    OccAmdUnsupported for shapes without an MFMA kernel."""
+    precision = precision or LINEAR_PRECISION
+    if precision not in ("f32", "bf16x3"):
+        raise OccAmdError(f"linear: unknown precision {precision!r}")
     a_, M, K1, lda1 = _rows2d("a", a)
     K2, lda2 = 0, 0
     if a2 is not None:
@@ -350,12 +386,17 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
         _need_cuda_f32("ln_beta", b)
     if act not in (None, 'relu'):
         raise OccAmdError("linear: act must be None or 'relu'")
+    if not weight.is_contiguous():
+        raise OccAmdError("linear: weight must be contiguous")
+    wdev = linear_pack_weight_bf16x3(weight) if precision == "bf16x3" and (K1 + K2) % 16 == 0 else weight
+    fn = _lib.lib().occ_linear_bf16x3_f32 if wdev is not weight else _lib.lib().occ_linear_f32
     out = torch.empty(a.shape[:-1] + (N,), dtype=torch.float32, device=a.device)
+    if _TIMING is not None:
+        _TIMING.setdefault('linear_flops', []).append(2.0 * M * N * (K1 + K2))
     with torch.cuda.device(a.device), _timed('linear'):
-        rc = _lib.lib().occ_linear_f32(
-            ptr(a_), i64(lda1), i32(K1), ptr(a2), ptr(a2_add), i64(lda2), i32(K2), ptr(weight),
-            ptr(bias), i32(1 if act == 'relu' else 0), ptr(residual), i64(ldres), ptr(g), ptr(b),
-            f32(float(eps)), ptr(out), i64(N), i32(M), i32(N), stream_ptr(a.device))
+        rc = fn(ptr(a_), i64(lda1), i32(K1), ptr(a2), ptr(a2_add), i64(lda2), i32(K2), ptr(wdev),
+                ptr(bias), i32(1 if act == 'relu' else 0), ptr(residual), i64(ldres), ptr(g), ptr(b),
+                f32(float(eps)), ptr(out), i64(N), i32(M), i32(N), stream_ptr(a.device))
     _lib.check(rc, "linear")
     return out
 

@@ -328,7 +328,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
             return bev_pos.permute(1, 0, 2).contiguous()
         key = (bev_pos.data_ptr(), bev_pos._version, tuple(bev_pos.shape), tuple(bev_pos.stride()))
         if getattr(self, '_pos_key', None) != key:
-            self._pos_key, self._pos_qm = key, bev_pos.permute(1, 0, 2).contiguous()
+            # keep `bev_pos` referenced: its address cannot be recycled while this entry is live
+            self._pos_key, self._pos_src, self._pos_qm = key, bev_pos, bev_pos.permute(1, 0, 2).contiguous()
         return self._pos_qm
 
     def _bev_order(self, bev_h, bev_w, device):

@@ -94,7 +94,8 @@ class TemporalSelfAttention(BaseModule):
         if getattr(self, '_fold_key', None) != key:
             w_sum = (w[:, :c] + w[:, c:]).contiguous()
             pos_term = ext.linear(query_pos.contiguous(), w[:, c:].contiguous(), b)
-            self._fold_key, self._fold_val = key, (w_sum, pos_term)
+            # the keyed tensors stay referenced so their addresses cannot be recycled under the cache
+            self._fold_key, self._fold_src, self._fold_val = key, (w, b, query_pos), (w_sum, pos_term)
         return self._fold_val
 
     def forward_fused(self, query, value=None, query_pos=None, reference_points=None, bev_h=None,

@@ -28,8 +28,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("name,M,K1,K2,N,bias,act,addend,residual,ln", CASES, ids=[c[0] for c in CASES])
-def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, ln):
+def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, ln, precision):
     from occnet_amd import ext
     g = torch.Generator().manual_seed(50)
     a = _mk(g, M, K1)
@@ -44,12 +45,14 @@ def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, 
                               None if lnp is None else (lnp[0].double(), lnp[1].double(), lnp[2]))
     c = lambda t: None if t is None else t.cuda()
     out = ext.linear(c(a), c(w), c(b), a2=c(a2), a2_add=c(a2_add), act=act, residual=c(res),
-                     ln=None if lnp is None else (lnp[0].cuda(), lnp[1].cuda(), lnp[2]))
+                     ln=None if lnp is None else (lnp[0].cuda(), lnp[1].cuda(), lnp[2]),
+                     precision=precision)
     torch.cuda.synchronize()
     d = float((out.cpu().double() - ref).abs().max())
-    print(f"{name}: max|hip - oracle(f64)| = {d:.3e}")
+    print(f"{name}/{precision}: max|hip - oracle(f64)| = {d:.3e}")
     assert out.shape == (M, N)
-    assert d < 2e-5
+    # f32: fp32 roundoff; bf16x3: 2^-16 per product on O(1) operands, K <= 512 (bound 1e-3 end to end)
+    assert d < (2e-5 if precision == "f32" else 2e-4)
 
 
 def test_linear_strided_rows_and_3d_shapes():
@@ -58,14 +61,25 @@ def test_linear_strided_rows_and_3d_shapes():
     g = torch.Generator().manual_seed(51)
     wide = _mk(g, 90, 768).cuda()
     w = _mk(g, 64, 256, scale=0.06).cuda()
-    out = ext.linear(wide[:, 256:512], w)
+    out = ext.linear(wide[:, 256:512], w, precision="f32")
     ref = torch.nn.functional.linear(wide[:, 256:512].cpu().double(), w.cpu().double())
     assert float((out.cpu().double() - ref).abs().max()) < 2e-5
     x = _mk(g, 2, 45, 256).cuda()
-    out3 = ext.linear(x, w)
+    out3 = ext.linear(x, w, precision="f32")
     assert out3.shape == (2, 45, 64)
     ref3 = torch.nn.functional.linear(x.cpu().double(), w.cpu().double())
     assert float((out3.cpu().double() - ref3).abs().max()) < 2e-5
+    out4 = ext.linear(wide[:, 256:512], w, precision="bf16x3")
+    assert float((out4.cpu().double() - ref).abs().max()) < 2e-4
+
+
+def test_bf16x3_asymmetric_identity():
+    """A = I with an asymmetric W: catches row/column or k-ordering mistakes in the MFMA fragment layout."""
+    from occnet_amd import ext
+    K = N = 64
+    w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 64.0 - 1.0   # exactly bf16x2-representable
+    out = ext.linear(torch.eye(K).cuda(), w.cuda(), precision="bf16x3")
+    assert torch.equal(out.cpu(), w.t().contiguous())
 
 
 def test_linear_full_size_value_proj_linearity():
@@ -77,14 +91,15 @@ def test_linear_full_size_value_proj_linearity():
     a = torch.randn(M, 256, generator=g).cuda()
     w = (_mk(g, 256, 256, scale=1 / 16)).cuda()
     b = _mk(g, 256, scale=0.1).cuda()
-    o1 = ext.linear(a, w, b)
-    o2 = ext.linear(a * 2.0, w, b)
-    assert torch.allclose(o2 - b, (o1 - b) * 2.0, atol=2e-5, rtol=1e-5)
     idx = torch.randint(0, M, (512,), generator=g)
     ref = torch.nn.functional.linear(a[idx.cuda()].cpu().double(), w.cpu().double(), b.cpu().double())
-    d = float((o1[idx.cuda()].cpu().double() - ref).abs().max())
-    print(f"value_proj full size: row-sample max|hip - oracle(f64)| = {d:.3e}")
-    assert d < 2e-5
+    for precision, tol in (("f32", 2e-5), ("bf16x3", 2e-4)):
+        o1 = ext.linear(a, w, b, precision=precision)
+        o2 = ext.linear(a * 2.0, w, b, precision=precision)       # scaling by 2 is exact in both splits
+        assert torch.allclose(o2 - b, (o1 - b) * 2.0, atol=2e-5, rtol=1e-5)
+        d = float((o1[idx.cuda()].cpu().double() - ref).abs().max())
+        print(f"value_proj full size/{precision}: row-sample max|hip - oracle(f64)| = {d:.3e}")
+        assert d < tol
 
 
 def test_linear_unsupported_and_errors():

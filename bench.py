@@ -228,10 +228,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
                          "there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # OCC_BENCH_SHARE_GPU=1 (single-GPU smoke test of the multi-rank plumbing only): every rank uses
+    # cuda:0 and the process group runs over gloo, since RCCL refuses two ranks on one device
+    share = os.environ.get("OCC_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)   # "nccl" is RCCL on ROCm
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)   # "nccl" is RCCL on ROCm
 
     from occnet_amd import ext
     cfg, model, geo = build(args.config, device)
@@ -258,7 +265,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     times = ext.kernel_times_ms(record) if record is not None else {}

@@ -96,3 +96,26 @@ def test_hires_full_size_fused_vs_library_ops():
         d = maxdiff(a[k], b[k])
         print(f"hires 400x400x32 {k}: fused vs library ops max diff = {d:.3e}")
         assert d < 2e-4
+
+
+def test_bench_multi_rank_plumbing(tmp_path):
+    """`bench.py` as the driver launches it for N > 1 (torch.distributed.run, one process per rank): rank
+    env parsing, barrier + MAX-over-ranks timing, whole-job value = N*K/t, ONE JSON line from rank 0.  Run
+    with 2 ranks sharing the single GPU of the test box (OCC_BENCH_SHARE_GPU=1 -> gloo group); the real
+    multi-GPU run uses the same code path with RCCL."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, OCC_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--scope", "hotpath", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert abs(out["value"] - 2 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-6
+    assert "roofline" in out and "cpu_baseline" not in out

@@ -6,5 +6,3 @@ timeout 900 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out
 tail -1 gpurun_out/bench12_e2e.log | cut -c1-250
 timeout 300 python bench.py --scope hotpath --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench12_hot.log 2>&1
 tail -1 gpurun_out/bench12_hot.log | cut -c1-200
-MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC=0 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench12_e2e_nogtc.log 2>&1
-echo "no-gtc:"; tail -1 gpurun_out/bench12_e2e_nogtc.log | cut -c1-200

@@ -222,6 +222,16 @@ int occ_dvr_render_forward_f32(const float* sigma, const float* origin, const fl
 int occ_bias_act_nhwc_bf16(void* x, const float* bias, const void* residual, int64_t rows, int C, int relu,
                            void* stream);
 
+/* Backbone 1x1 convolution on NHWC bf16 (outside the hand-written hot path, like the call above):
+ * out[(n,yo,xo), co] = relu?( sum_ci x[(n, yo*stride, xo*stride), ci] * weight[co, ci] + bias[co]
+ *                             (+ residual[(n,yo,xo), co]) ), bf16 in, f32 accumulate, bf16 out.
+ *   x (batch, Hin, Win, Cin) bf16 ; weight (Cout, Cin) bf16 ; bias (Cout) f32 ; residual / out
+ *   (batch, Hout, Wout, Cout) bf16 with Hout = (Hin-1)/stride + 1.  Needs Cin % 32 == 0, Cout % 8 == 0.
+ */
+int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const float* bias, const void* residual,
+                          void* out, int batch, int Hin, int Win, int Cin, int Cout, int stride, int relu,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -452,3 +452,32 @@ def bias_act_nhwc_(x, bias, residual=None, relu=True):
                                                i32(1 if relu else 0), stream_ptr(x.device))
     _lib.check(rc, "bias_act_nhwc_")
     return x
+
+
+def conv1x1_nhwc(x, weight2d, bias, residual=None, relu=False, stride=1):
+    """1x1 convolution + bias (+ residual) (+ ReLU) on a channels_last bf16 activation, one launch.
+    x (N, Cin, H, W) channels_last bf16; weight2d (Cout, Cin) bf16 contiguous; bias (Cout) f32;
+    residual (N, Cout, Ho, Wo) channels_last bf16 or None -> (N, Cout, Ho, Wo) channels_last bf16."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        raise OccAmdUnsupported("conv1x1_nhwc: x must be a channels_last bfloat16 device tensor")
+    if not (weight2d.dtype == torch.bfloat16 and weight2d.dim() == 2 and weight2d.is_contiguous()):
+        raise OccAmdError("conv1x1_nhwc: weight must be a contiguous (Cout, Cin) bfloat16 matrix")
+    _need_cuda_f32("bias", bias)
+    N, Cin, H, W = x.shape
+    Cout = weight2d.shape[0]
+    if weight2d.shape[1] != Cin or bias.numel() != Cout:
+        raise OccAmdError("conv1x1_nhwc: inconsistent shapes")
+    s = int(stride)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    out = torch.empty((N, Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device,
+                      memory_format=torch.channels_last)
+    if residual is not None and not (residual.dtype == torch.bfloat16 and residual.shape == out.shape and
+                                     residual.is_contiguous(memory_format=torch.channels_last)):
+        raise OccAmdUnsupported("conv1x1_nhwc: residual must match the output (channels_last bfloat16)")
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().occ_conv1x1_nhwc_bf16(ptr(x), ptr(weight2d), ptr(bias), ptr(residual), ptr(out),
+                                              i32(N), i32(H), i32(W), i32(Cin), i32(Cout), i32(s),
+                                              i32(1 if relu else 0), stream_ptr(x.device))
+    _lib.check(rc, "conv1x1_nhwc")
+    return out

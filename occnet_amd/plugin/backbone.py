@@ -229,7 +229,15 @@ class FusedInferenceBackbone(nn.Module):
         idx = len(self._convs)
         self.register_buffer(f'w{idx}', w, persistent=False)
         self.register_buffer(f'b{idx}', b, persistent=False)
+        # 1x1 convolutions become the fused bf16 GEMM (occ_conv1x1_nhwc_bf16): (Cout, Cin) weight matrix
+        gemm = (self.hip_tail and tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0)
+                and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.stride[0] == conv.stride[1]
+                and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0)
+        if gemm:
+            self.register_buffer(f'm{idx}', w.reshape(w.shape[0], w.shape[1]).contiguous(), persistent=False)
         self._convs.append((conv.stride, conv.padding, conv.dilation, conv.groups))
+        self._gemm = getattr(self, '_gemm', {})
+        self._gemm[idx] = gemm
         return idx
 
     def _conv(self, i, x, relu=False, add=None):
@@ -239,6 +247,11 @@ class FusedInferenceBackbone(nn.Module):
             return torch.miopen_convolution_add_relu(x, w, add, 1.0, b.to(w.dtype), s, p, d, g)
         if self.fused_ops and relu:
             return torch.miopen_convolution_relu(x, w, b.to(w.dtype), s, p, d, g)
+        if self._gemm.get(i) and x.is_contiguous(memory_format=torch.channels_last) and \
+                (add is None or add.is_contiguous(memory_format=torch.channels_last)):
+            from .. import ext
+            return ext.conv1x1_nhwc(x, getattr(self, f'm{i}'), b, residual=add,
+                                    relu=relu or add is not None, stride=s[0])
         if self.hip_tail and w.shape[0] % 8 == 0:
             from .. import ext
             y = F.conv2d(x, w, None, s, p, d, g)

@@ -25,6 +25,31 @@ def test_bias_act_nhwc_matches_torch():
             assert torch.equal(got, want.to(torch.bfloat16))        # fp32 math, one RNE rounding: exact
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,stride,res,relu", [
+    (2, 64, 256, 9, 13, 1, True, True), (1, 256, 64, 7, 5, 1, False, True), (3, 512, 1024, 6, 7, 2, False, False),
+    (1, 2048, 512, 3, 4, 1, False, True), (2, 32, 8, 5, 5, 1, True, False), (1, 1024, 2048, 5, 8, 2, False, False)])
+def test_conv1x1_nhwc_matches_torch(N, Cin, Cout, H, W, stride, res, relu):
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(Cin + Cout)
+    cl = lambda t: t.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = cl(torch.randn(N, Cin, H, W, generator=g))
+    w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).cuda().to(torch.bfloat16)
+    b = torch.randn(Cout, generator=g).cuda()
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = cl(torch.randn(N, Cout, Ho, Wo, generator=g)) if res else None
+    got = ext.conv1x1_nhwc(x, w, b, residual=r, relu=relu, stride=stride)
+    want = torch.nn.functional.conv2d(x.float(), w.float().view(Cout, Cin, 1, 1), b, stride=stride)
+    if res:
+        want = want + r.float()
+    if relu:
+        want = want.relu()
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    d = float((got.float() - want).abs().max())
+    scale = float(want.abs().max())
+    print(f"conv1x1 {Cin}->{Cout} s{stride}: max diff {d:.3e} (scale {scale:.2f})")
+    assert d <= scale * 2 ** -8 + 1e-6          # one bf16 rounding of the f32-accumulated result
+
+
 def test_folded_plan_matches_fp32_modules():
     from occnet_amd.plugin.backbone import FPN, FusedInferenceBackbone, ResNet
     torch.manual_seed(0)

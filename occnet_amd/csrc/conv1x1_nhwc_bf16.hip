@@ -140,21 +140,27 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
       for (int r = 0; r < 16; ++r)
         sO[((r & 3) + 8 * (r >> 2) + 4 * kb) * OLD + (wave * NT + t) * 32 + vi] = acc[rt][t][r];
     __syncthreads();
+    // all 8 residual rows of this wave are requested before any is consumed (clamped, unconditional):
+    // a load inside the row loop would serialise 8 dependent memory round trips per pass
+    uint2 rv[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      long m = m0 + rt * 32 + wave * 8 + rr;
+      if (m >= M) m = M - 1;
+      rv[rr] = make_uint2(0u, 0u);
+      if (residual != nullptr && col_live) rv[rr] = *reinterpret_cast<const uint2*>(residual + m * N + n0 + c);
+    }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int row = wave * 8 + rr;
       const long m = m0 + rt * 32 + row;
-      if (m >= M) break;                       // wave-uniform
-      if (col_live) {
+      if (m < M && col_live) {
         float4 v = *reinterpret_cast<const float4*>(sO + row * OLD + c);
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        if (residual) {
-          const uint2 rv = *reinterpret_cast<const uint2*>(residual + m * N + n0 + c);
-          v.x += c1_bf16_to_f32((unsigned short)(rv.x & 0xffffu));
-          v.y += c1_bf16_to_f32((unsigned short)(rv.x >> 16));
-          v.z += c1_bf16_to_f32((unsigned short)(rv.y & 0xffffu));
-          v.w += c1_bf16_to_f32((unsigned short)(rv.y >> 16));
-        }
+        v.x += c1_bf16_to_f32((unsigned short)(rv[rr].x & 0xffffu));
+        v.y += c1_bf16_to_f32((unsigned short)(rv[rr].x >> 16));
+        v.z += c1_bf16_to_f32((unsigned short)(rv[rr].y & 0xffffu));
+        v.w += c1_bf16_to_f32((unsigned short)(rv[rr].y >> 16));
         if (relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }

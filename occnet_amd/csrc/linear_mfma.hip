@@ -163,6 +163,17 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(
     }
   }
   const float inv_n = 1.f / (float)N;
+  // all 8 residual rows of this wave are requested before any is consumed (clamped, unconditional):
+  // a load inside the row loop would serialise 8 dependent memory round trips
+  float4 rres[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    long m = m0 + wave * 8 + rr;
+    if (m >= M) m = M - 1;
+    rres[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (residual != nullptr && col_live)
+      rres[rr] = *reinterpret_cast<const float4*>(residual + m * ldres + n0 + c);
+  }
 #pragma unroll
   for (int rr = 0; rr < 8; ++rr) {
     const int row = wave * 8 + rr;
@@ -175,10 +186,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(
       if (act == 1) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
-      if (residual) {
-        const float4 rv = *reinterpret_cast<const float4*>(residual + m * ldres + n0 + c);
-        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-      }
+      v.x += rres[rr].x; v.y += rres[rr].y; v.z += rres[rr].z; v.w += rres[rr].w;
     }
     if (ln_g) {                              // LayerNorm over the N columns (N <= BN, one column block)
       const float mean = wave_sum(col_live ? (v.x + v.y) + (v.z + v.w) : 0.f) * inv_n;

@@ -280,7 +280,11 @@ def main():
                             "fwd+bwd+DDP all-reduce+AdamW)"),
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            # hot path: fp32 storage and accumulation everywhere; Conv3d/heads exact-f32 MFMA; encoder Linears
+            # per ext.LINEAR_PRECISION (bf16x3 = hi/lo-split bf16 MFMA, 16 mantissa bits); backbone bf16
+            "dtype": "f32" if ext.LINEAR_PRECISION == "f32" else "f32 (Linear operands bf16x3-split)",
+            "data": "synthetic",
             "config": {
                 "workload": ("bevformer_base_occ forward: 6x(3x928x1600) images -> ResNet-50+FPN -> "
                              "4 BEVFormer layers (TSA+SCA+FFN) -> lifter + 2xConv3d decoder -> "
@@ -289,6 +293,7 @@ def main():
                              "bevformer_base_occ hot path only: 4 FPN maps (6 cams) -> voxels"),
                 "mode": args.mode, "scope": stepper.scope, "samples_per_gpu": 1, "global_batch": world,
                 "parallelism": f"dp{world}", "hot_path_dtype": "f32",
+                "linear_precision": ext.LINEAR_PRECISION,
                 "backbone_dtype": args.backbone_dtype if stepper.scope == "e2e" else None,
                 "config_file": os.path.relpath(args.config, ROOT),
             },

@@ -136,6 +136,8 @@ class TrainStepper:
         if self.autocast:
             model.img_backbone.to(memory_format=torch.channels_last)
             model.img_neck.to(memory_format=torch.channels_last)
+            # mixed precision like the backbone: MIOpen's fp32 Conv3d backward alone is 196 ms per step
+            head.transformer.decoder_autocast_dtype = torch.bfloat16
 
     def __call__(self):
         from occnet_amd.train import train_step

@@ -42,6 +42,11 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
   const float* vb = value + voff;
   float* gvb = grad_value + voff;
   const float4 top = *reinterpret_cast<const float4*>(grad_out + item * D + c4 * 4);
+  // an item whose 32 output gradients are all zero (the padded rebatch rows of SpatialCrossAttention's
+  // autograd path, a quarter of all rows) contributes nothing: the caller pre-zeroed the three grad tensors
+  const bool nz = top.x != 0.f || top.y != 0.f || top.z != 0.f || top.w != 0.f;
+  const unsigned long long any = __ballot(nz);
+  if (((any >> (threadIdx.x & 56)) & 0xffull) == 0ull) return;
   const int LP = L * P;
   for (int s = 0; s < LP; ++s) {
     const int l = s / P;

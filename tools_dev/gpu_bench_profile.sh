@@ -1,0 +1,28 @@
+#!/bin/bash
+# bench (e2e + hot path) and rocprofv3 evidence on the GPU box; summaries land in gpurun_out/ (copy the ones
+# to keep into profiles/).   usage: gpurun -- 'bash tools_dev/gpu_bench_profile.sh [bench|trace|pmc|train ...]'
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+export TMPDIR=/tmp
+KR="sca_fused|tsa_fused|conv3d_mfma|occ_heads|linear_bf16x3|linear_mfma"
+for what in "${@:-bench trace}"; do
+case $what in
+bench)
+  timeout 900 python bench.py --steps 30 --warmup 5 > gpurun_out/bench_e2e.log 2>&1; tail -1 gpurun_out/bench_e2e.log | cut -c1-240
+  timeout 300 python bench.py --scope hotpath --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_hot.log 2>&1; tail -1 gpurun_out/bench_hot.log | cut -c1-200 ;;
+train)
+  timeout 900 python bench.py --mode train --steps 5 --warmup 3 --no-cpu-baseline > gpurun_out/bench_train.log 2>&1; tail -1 gpurun_out/bench_train.log | cut -c1-240 ;;
+trace)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_e2e -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/trace_e2e.log 2>&1)
+  DB=$(find /tmp/prof_e2e -name "*.db" | head -1)
+  # steady state only: the first warm-up step contains MIOpen's find (naive reference kernels)
+  python tools_dev/rocpd_summary.py $DB 60 --last-ms 100 > gpurun_out/trace_e2e_summary.txt 2>&1; head -40 gpurun_out/trace_e2e_summary.txt | cut -c1-160 ;;
+pmc)
+  i=0
+  for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES" "TA_TA_BUSY_sum TA_BUSY_avr"; do
+    i=$((i+1))
+    (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv --kernel-include-regex "$KR" -d /tmp/pmc_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --scope hotpath --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/gpurun_out/pmc_$i.log 2>&1)
+    f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/pmc_${i}_counters.csv
+  done
+  python tools_dev/pmc_summary.py gpurun_out/pmc_*_counters.csv > gpurun_out/pmc_summary.txt; tail -50 gpurun_out/pmc_summary.txt ;;
+esac
+done

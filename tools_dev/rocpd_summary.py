@@ -1,18 +1,23 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / mean duration.
-usage: rocpd_summary.py results.db [top_n]"""
+usage: rocpd_summary.py results.db [top_n] [--last-ms X] | results.db --dump <name substring> [limit]"""
 import sqlite3
 import sys
 
 
 def main():
     db = sys.argv[1]
-    top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    top = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 40
     cur = sqlite3.connect(db).cursor()
+    where, note = "", ""
+    if "--last-ms" in sys.argv:       # only dispatches in the last X ms of the trace (steady state)
+        ms = float(sys.argv[sys.argv.index("--last-ms") + 1])
+        t1 = list(cur.execute("select max(end) from kernels"))[0][0]
+        where, note = f" where start >= {t1 - int(ms * 1e6)}", f" (last {ms:g} ms of the trace)"
     rows = list(cur.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), "
-                            "max(end-start) from kernels group by name order by 3 desc"))
+                            f"max(end-start) from kernels{where} group by name order by 3 desc"))
     total = sum(r[2] for r in rows)
-    print(f"# rocprofv3 --kernel-trace --stats summary of {db}")
+    print(f"# rocprofv3 --kernel-trace --stats summary of {db}{note}")
     print(f"# total kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
     print(f"{'total_ms':>10} {'pct':>6} {'calls':>6} {'avg_us':>10} {'min_us':>10} {'max_us':>10}  kernel")
     for name, n, tot, avg, mn, mx in rows[:top]:

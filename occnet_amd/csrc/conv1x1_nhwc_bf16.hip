@@ -10,9 +10,10 @@
 // (MIOpen kernel + its zero-fill / cast helpers + the elementwise tail).
 //
 // Decomposition: block = 4 waves x 64 rows (pixels) x 128*NT output channels; K chunk = 32 input channels;
-// every wave stages the 64 x 32 activation chunk and its own 32*NT x 32 weight slice as plain 16-byte
-// copies into a private LDS region (80-byte row stride, conflict-free ds_read_b128), no block barrier in the
-// K loop, next chunk's loads in flight during the MFMAs (v_mfma_f32_32x32x16_bf16, 2 k-steps per chunk).
+// the 64 x 32 activation chunk is staged once per block (double buffered in LDS, one barrier per chunk) and
+// every wave stages its own 32*NT x 32 weight slice — all plain 16-byte copies, 80-byte row stride =
+// conflict-free ds_read_b128; next chunk's loads in flight during the MFMAs (v_mfma_f32_32x32x16_bf16, 2
+// k-steps per chunk).
 // Strided 1x1 convolutions (the downsample branch) only change which input pixel a row reads.
 #include "common.h"
 
@@ -38,13 +39,13 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
     int Hin, int Win, int Hout, int Wout, int stride, int relu) {
   constexpr int RT = 2, BM = 64, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
   constexpr int A_BYTES = BM * kCLD, W_BYTES = WR * kCLD;
-  constexpr int WAVE_BYTES = A_BYTES + W_BYTES;
-  constexpr int STAGE_BYTES = 4 * WAVE_BYTES, OUT_BYTES = 32 * OLD * 4;
+  // LDS: the activation chunk is staged ONCE per block (double buffered, one barrier per chunk) and read by
+  // all four waves; every wave keeps a private region for its own weight slice
+  constexpr int STAGE_BYTES = 2 * A_BYTES + 4 * W_BYTES, OUT_BYTES = 32 * OLD * 4;
   __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kb = lane >> 5;
-  char* sA = lds + wave * WAVE_BYTES;
-  char* sW = sA + A_BYTES;
+  char* sW = lds + 2 * A_BYTES + wave * W_BYTES;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int nw0 = n0 + wave * WR;
@@ -58,12 +59,12 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
-  // staging roles: lane -> (row = lane/4 + 16*it, 16-byte piece = lane%4); unconditional clamped loads
-  const int srow = lane >> 2, sp = lane & 3;
-  long aofs[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    long m = m0 + srow + 16 * it;
+  // A: thread -> (row = tid/4, 16-byte piece = tid%4) of the block's 64 rows; W: lane -> (row = lane/4 +
+  // 16*it, piece = lane%4) of the wave's slice.  Unconditional clamped loads.
+  const int arow = tid >> 2, sp = tid & 3, srow = lane >> 2;
+  long aofs;
+  {
+    long m = m0 + arow;
     if (m >= M) m = M - 1;
     long pix = m;
     if (stride != 1) {           // output pixel (n, yo, xo) reads input pixel (n, yo*stride, xo*stride)
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
       const int yo = (int)(rem / Wout), xo = (int)(rem % Wout);
       pix = (n * Hin + (long)yo * stride) * Win + (long)xo * stride;
     }
-    aofs[it] = pix * KQ + sp;
+    aofs = pix * KQ + sp;
   }
   long wofs[2 * NT];
 #pragma unroll
@@ -80,28 +81,27 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
     const int n = nw0 + srow + 16 * it;
     wofs[it] = (long)(n < N ? n : N - 1) * KQ + sp;
   }
-  uint4 va0, va1, va2, va3, vw0, vw1, vw2, vw3;
+  uint4 va, vw0, vw1, vw2, vw3;
 #define OCC_C1_ISSUE(K0)                                                                          \
   {                                                                                               \
     const long kq = (K0) / 8;                                                                     \
-    va0 = x[aofs[0] + kq]; va1 = x[aofs[1] + kq]; va2 = x[aofs[2] + kq]; va3 = x[aofs[3] + kq];  \
+    va = x[aofs + kq];                                                                            \
     vw0 = w[wofs[0] + kq]; vw1 = w[wofs[1] + kq];                                                 \
     if (NT == 2) { vw2 = w[wofs[2 * NT - 2] + kq]; vw3 = w[wofs[2 * NT - 1] + kq]; }              \
   }
 
   OCC_C1_ISSUE(0)
-  for (int k0 = 0; k0 < K; k0 += 32) {
-    *reinterpret_cast<uint4*>(sA + (srow) * kCLD + sp * 16) = va0;
-    *reinterpret_cast<uint4*>(sA + (srow + 16) * kCLD + sp * 16) = va1;
-    *reinterpret_cast<uint4*>(sA + (srow + 32) * kCLD + sp * 16) = va2;
-    *reinterpret_cast<uint4*>(sA + (srow + 48) * kCLD + sp * 16) = va3;
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += 32, buf ^= 1) {
+    char* sA = lds + buf * A_BYTES;
+    *reinterpret_cast<uint4*>(sA + arow * kCLD + sp * 16) = va;
     *reinterpret_cast<uint4*>(sW + (srow) * kCLD + sp * 16) = vw0;
     *reinterpret_cast<uint4*>(sW + (srow + 16) * kCLD + sp * 16) = vw1;
     if (NT == 2) {
       *reinterpret_cast<uint4*>(sW + (srow + 32) * kCLD + sp * 16) = vw2;
       *reinterpret_cast<uint4*>(sW + (srow + 48) * kCLD + sp * 16) = vw3;
     }
-    wave_lds_sync();
+    __syncthreads();   // chunk visible to every wave; the other A buffer is free for the next iteration
     OCC_C1_ISSUE(k0 + 32 < K ? k0 + 32 : k0)
     bf16x8 af[RT][2], wf[NT][2];
 #pragma unroll

@@ -11,10 +11,11 @@
 // Layout: the weight is split and packed ONCE on the device (occ_linear_pack_weight_bf16x3):
 //   packed[n][K/16][ hi[16] | lo[16] ] bf16  — the same 4 bytes per weight as f32, so staging a weight
 // slice is a plain 16-byte-per-lane copy into LDS; activations are split on the fly while staged.
-// Decomposition as in linear_mfma.hip: block = 4 waves x (32*RT rows) x (128*NT columns), no block barrier
-// in the K loop (each wave stages the A chunk and its own W slice into a private LDS region, 48-byte row
-// stride = conflict-free ds_read_b128), next chunk's global loads in flight during the MFMAs, epilogue
-// (bias, ReLU, residual, two-pass LayerNorm) on row-major rows through an LDS transpose.
+// Decomposition: block = 4 waves x (32*RT rows) x (128*NT columns); per 16-k chunk the activation rows are
+// split and staged once per block (double buffered, one barrier per chunk) and every wave stages its own W
+// slice into a private LDS region (48-byte row stride = conflict-free ds_read_b128); next chunk's global
+// loads in flight during the MFMAs; epilogue (bias, ReLU, residual, two-pass LayerNorm) on row-major rows
+// through an LDS transpose.
 #include "common.h"
 
 namespace occ {
@@ -64,14 +65,13 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
     float* __restrict__ out, long ldo, int M, int N) {
   constexpr int BM = 32 * RT, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
   constexpr int A_BYTES = BM * kXLD, W_BYTES = WR * kXLD;            // one plane (hi or lo)
-  constexpr int WAVE_BYTES = 2 * A_BYTES + 2 * W_BYTES;
-  constexpr int STAGE_BYTES = 4 * WAVE_BYTES, OUT_BYTES = 32 * OLD * 4;
+  // LDS: the activation chunk (hi + lo planes) is split and staged ONCE per block (double buffered, one
+  // barrier per chunk) and read by all four waves; every wave keeps a private region for its weight slice
+  constexpr int STAGE_BYTES = 2 * (2 * A_BYTES) + 4 * (2 * W_BYTES), OUT_BYTES = 32 * OLD * 4;
   __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kb = lane >> 5;
-  char* sAh = lds + wave * WAVE_BYTES;
-  char* sAl = sAh + A_BYTES;
-  char* sWh = sAl + A_BYTES;
+  char* sWh = lds + 4 * A_BYTES + wave * 2 * W_BYTES;
   char* sWl = sWh + W_BYTES;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
@@ -86,23 +86,21 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
-  // staging roles: lane -> (row = lane/4 + 16*it, 16-byte piece = lane%4).  All loads unconditional
+  // A: thread -> (row = tid/4, 4 k = tid%4) of the block's rows (threads beyond BM rows idle in staging);
+  // W: lane -> (row = lane/4 + 16*it, 16-byte piece = lane%4) of the wave's slice.  All loads unconditional
   // (clamped indices, 0/1-scaled addend alias) and held in named registers — see linear_mfma.hip.
-  const int srow = lane >> 2, sp = lane & 3;
-  long arow[2 * RT];
-#pragma unroll
-  for (int it = 0; it < 2 * RT; ++it) {
-    const long m = m0 + srow + 16 * it;
-    arow[it] = m < M ? m : (long)M - 1;
-  }
+  const int arow = tid >> 2, sp = tid & 3, srow = lane >> 2;
+  const bool a_live = arow < BM;
+  long am = m0 + (a_live ? arow : 0);
+  if (am >= M) am = (long)M - 1;
   long wofs[2 * NT];   // uint4 index of this lane's piece in chunk 0
 #pragma unroll
   for (int it = 0; it < 2 * NT; ++it) {
     const int n = nw0 + srow + 16 * it;
     wofs[it] = ((long)(n < N ? n : N - 1) * KC) * 4 + sp;
   }
-  float4 va0, va1, va2, va3;                       // A rows it = 0..3 (it >= 2 only for RT == 2)
-  float4 vd0 = make_float4(0.f, 0.f, 0.f, 0.f), vd1 = vd0, vd2 = vd0, vd3 = vd0;   // addend (ADD only)
+  float4 va;
+  float4 vd = make_float4(0.f, 0.f, 0.f, 0.f);     // addend (ADD only)
   uint4 vw0, vw1, vw2, vw3;                        // W rows it = 0..3 (it >= 2 only for NT == 2)
   float addscale = 0.f;
 #define OCC_X3_ISSUE(K0)                                                                          \
@@ -114,20 +112,8 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
     const bool add = seg2 && a2add != nullptr;                                                    \
     const float* addb = add ? a2add + (k0_ - K1) + sp * 4 : ab;                                   \
     addscale = add ? 1.f : 0.f;                                                                   \
-    va0 = *reinterpret_cast<const float4*>(ab + arow[0] * lda);                                   \
-    va1 = *reinterpret_cast<const float4*>(ab + arow[1] * lda);                                   \
-    if (ADD) { /* compile-time: GEMMs without an addend do not pay the alias loads */            \
-      vd0 = *reinterpret_cast<const float4*>(addb + arow[0] * lda);                               \
-      vd1 = *reinterpret_cast<const float4*>(addb + arow[1] * lda);                               \
-    }                                                                                             \
-    if (RT == 2) {                                                                                \
-      va2 = *reinterpret_cast<const float4*>(ab + arow[2 * RT - 2] * lda);                        \
-      va3 = *reinterpret_cast<const float4*>(ab + arow[2 * RT - 1] * lda);                        \
-      if (ADD) {                                                                                  \
-        vd2 = *reinterpret_cast<const float4*>(addb + arow[2 * RT - 2] * lda);                    \
-        vd3 = *reinterpret_cast<const float4*>(addb + arow[2 * RT - 1] * lda);                    \
-      }                                                                                           \
-    }                                                                                             \
+    va = *reinterpret_cast<const float4*>(ab + am * lda);                                         \
+    if (ADD) vd = *reinterpret_cast<const float4*>(addb + am * lda); /* compile-time */           \
     const long kc4 = (long)(k0_ / 16) * 4;                                                        \
     vw0 = wp[wofs[0] + kc4];                                                                      \
     vw1 = wp[wofs[1] + kc4];                                                                      \
@@ -136,28 +122,23 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
       vw3 = wp[wofs[2 * NT - 1] + kc4];                                                           \
     }                                                                                             \
   }
-  // f32 x4 (+ addend) -> 4 hi bf16 + 4 lo bf16, written to the two A planes of row `ROW`
-#define OCC_X3_PUT_A(V, D, ROW)                                                                   \
-  {                                                                                               \
-    const float f0 = ADD ? fmaf(addscale, D.x, V.x) : V.x, f1 = ADD ? fmaf(addscale, D.y, V.y) : V.y; \
-    const float f2 = ADD ? fmaf(addscale, D.z, V.z) : V.z, f3 = ADD ? fmaf(addscale, D.w, V.w) : V.w; \
-    unsigned short h0, h1, h2, h3, l0, l1, l2, l3;                                                \
-    x3_split(f0, h0, l0); x3_split(f1, h1, l1); x3_split(f2, h2, l2); x3_split(f3, h3, l3);      \
-    *reinterpret_cast<uint2*>(sAh + (ROW) * kXLD + sp * 8) =                                      \
-        make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));     \
-    *reinterpret_cast<uint2*>(sAl + (ROW) * kXLD + sp * 8) =                                      \
-        make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));     \
-  }
 #define OCC_X3_PUT_W(V, ROW)                                                                      \
   *reinterpret_cast<uint4*>((sp < 2 ? sWh : sWl) + (ROW) * kXLD + (sp & 1) * 16) = V;
 
   OCC_X3_ISSUE(0)
-  for (int k0 = 0; k0 < K; k0 += kXBK) {
-    OCC_X3_PUT_A(va0, vd0, srow)
-    OCC_X3_PUT_A(va1, vd1, srow + 16)
-    if (RT == 2) {
-      OCC_X3_PUT_A(va2, vd2, srow + 32)
-      OCC_X3_PUT_A(va3, vd3, srow + 48)
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += kXBK, buf ^= 1) {
+    char* sAh = lds + buf * 2 * A_BYTES;
+    char* sAl = sAh + A_BYTES;
+    if (a_live) {   // f32 x4 (+ addend) -> 4 hi bf16 + 4 lo bf16 into the two A planes
+      const float f0 = ADD ? fmaf(addscale, vd.x, va.x) : va.x, f1 = ADD ? fmaf(addscale, vd.y, va.y) : va.y;
+      const float f2 = ADD ? fmaf(addscale, vd.z, va.z) : va.z, f3 = ADD ? fmaf(addscale, vd.w, va.w) : va.w;
+      unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+      x3_split(f0, h0, l0); x3_split(f1, h1, l1); x3_split(f2, h2, l2); x3_split(f3, h3, l3);
+      *reinterpret_cast<uint2*>(sAh + arow * kXLD + sp * 8) =
+          make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
+      *reinterpret_cast<uint2*>(sAl + arow * kXLD + sp * 8) =
+          make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
     }
     OCC_X3_PUT_W(vw0, srow)
     OCC_X3_PUT_W(vw1, srow + 16)
@@ -165,7 +146,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
       OCC_X3_PUT_W(vw2, srow + 32)
       OCC_X3_PUT_W(vw3, srow + 48)
     }
-    wave_lds_sync();
+    __syncthreads();   // chunk visible to every wave; the other A buffer is free for the next iteration
     OCC_X3_ISSUE(k0 + kXBK < K ? k0 + kXBK : k0)   // unconditional prefetch (last one re-reads its chunk)
 
     bf16x8 ah[RT], al[RT], wh[NT], wl[NT];
@@ -190,7 +171,6 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
       }
   }
 #undef OCC_X3_ISSUE
-#undef OCC_X3_PUT_A
 #undef OCC_X3_PUT_W
 
   // ---- epilogue, 32 rows at a time: accumulators -> LDS row-major tile -> 8 rows per wave ------------

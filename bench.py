@@ -48,6 +48,8 @@ def parse():
                     help="folded (default): eval BN folded into the MIOpen convolutions, pure bf16 NHWC, one "
                          "HIP bias/residual/ReLU launch per convolution; autocast: stock modules under "
                          "torch.autocast(bf16), NHWC")
+    ap.add_argument("--backbone-graph", action="store_true",
+                    help="replay the folded backbone plan as one hipGraph (static shapes)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer (default, the BASELINE metric): forward pass; train: forward + loss + "
                          "backward + DDP/RCCL gradient all-reduce + clip + AdamW step per sample")
@@ -80,7 +82,7 @@ def build(cfg_path, device):
 
 
 class Stepper:
-    def __init__(self, model, geo, scope, backbone_dtype, device, seed, plan="autocast"):
+    def __init__(self, model, geo, scope, backbone_dtype, device, seed, plan="autocast", graph=False):
         from occnet_amd import synthetic
         self.model, self.scope, self.device = model, scope, device
         self.metas = synthetic.make_img_metas(geo, batch=1, seed=seed)
@@ -90,7 +92,7 @@ class Stepper:
             self.autocast = backbone_dtype == "bf16" and plan == "autocast"
             if plan == "folded":   # stock MIOpen ops, eval BN folded into the convolutions, NHWC
                 model.enable_fused_backbone(
-                    dtype=torch.bfloat16 if backbone_dtype == "bf16" else torch.float32)
+                    dtype=torch.bfloat16 if backbone_dtype == "bf16" else torch.float32, use_graph=graph)
             elif self.autocast:
                 model.img_backbone.to(memory_format=torch.channels_last)
                 model.img_neck.to(memory_format=torch.channels_last)
@@ -248,7 +250,7 @@ def main():
         stepper = TrainStepper(model, geo, args.backbone_dtype, device, seed=rank, world=world)
     else:
         stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank,
-                          plan=args.backbone_plan)
+                          plan=args.backbone_plan, graph=args.backbone_graph)
 
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         stepper()

@@ -195,6 +195,8 @@ class FusedInferenceBackbone(nn.Module):
         # hip_tail: bias + (residual) + ReLU after each convolution as ONE in-place HIP launch
         # (occ_bias_act_nhwc_bf16) instead of PyTorch's add / add_ / relu_ launches (bf16 only)
         self.hip_tail = hip_tail and dtype == torch.bfloat16
+        self.use_graph = False      # set True to replay the plan as one hipGraph per input shape
+        self._graphs = {}
         from torch.nn.utils.fusion import fuse_conv_bn_weights
         assert not backbone.training or backbone.norm_eval, "folding BN needs eval-mode statistics"
         self.dtype, self.fused_ops = dtype, fused_ops
@@ -267,7 +269,29 @@ class FusedInferenceBackbone(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        """x (N, 3, H, W) any float dtype -> tuple of FPN maps (N, C, h, w), dtype self.dtype, NHWC."""
+        """x (N, 3, H, W) any float dtype -> tuple of FPN maps (N, C, h, w), dtype self.dtype, NHWC.
+        With `use_graph` the whole plan (≈ 120 short launches) is captured into one hipGraph per input
+        shape after two eager warm-up calls (MIOpen's find must not run under capture) and replayed; the
+        returned maps are then the graph's static output buffers, valid until the next call."""
+        if not getattr(self, 'use_graph', False) or not x.is_cuda:
+            return self._forward_eager(x)
+        key = (tuple(x.shape), x.dtype, str(x.device))
+        st = self._graphs.setdefault(key, dict(calls=0))
+        st['calls'] += 1
+        if st['calls'] <= 2:
+            return self._forward_eager(x)
+        if 'graph' not in st:
+            st['in'] = x.clone()
+            torch.cuda.synchronize(x.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st['out'] = self._forward_eager(st['in'])
+            st['graph'] = g
+        st['in'].copy_(x)
+        st['graph'].replay()
+        return st['out']
+
+    def _forward_eager(self, x):
         x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
         x = F.max_pool2d(self._conv(self.stem, x, relu=True), kernel_size=3, stride=2, padding=1)
         feats = []

@@ -1,0 +1,252 @@
+// Backbone 3x3 / stride-1 / pad-1 convolutions (NHWC bf16) as an implicit GEMM on the gfx950 bf16 matrix
+// cores with bias + ReLU fused: out = relu?( conv3x3(x, W) + bias ), bf16 in / f32 accumulate / bf16 out.
+//
+// NOT part of the hand-written hot path: it replaces MIOpen's igemm kernel plus its
+// zero-fill / cast helpers plus the elementwise tail for the stride-1 3x3 convolutions of the reference's
+// ResNet-50 (mmdet Bottleneck conv2, style='pytorch') and FPN output convolutions, when Cout % 128 == 0 and
+// Cin % 32 == 0; other convolutions (7x7 stem, stride-2, 64-channel layer1) stay on MIOpen.
+//
+// GEMM view: M = output pixels, N = Cout, K = 9 taps x Cin.  Block = 4 waves x (8 x 16 output pixels = four
+// 32-pixel MFMA row tiles of two image rows each) x 128*NT output channels; waves split N.  Per chunk of 32
+// input channels the (8+2) x (16+2) pixel halo is staged ONCE into LDS (zero-filled outside the image =
+// the convolution's padding; double buffered; 80-byte pixel slots, 1536-byte halo rows: conflict-free
+// ds_read_b128) and reused by the 9 taps with compile-time offsets; every wave streams its own 32*NT x 32
+// weight slice per tap through a private double-buffered LDS region (packed [co][chunk][tap][32 ci], so a
+// lane's pieces of consecutive taps are 64 B apart).  v_mfma_f32_32x32x16_bf16, 2 k-steps per (chunk, tap).
+#include "common.h"
+
+namespace occ {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kC3TH = 8, kC3TW = 16;                  // output tile
+constexpr int kC3HH = kC3TH + 2, kC3HW = kC3TW + 2;   // halo
+constexpr int kC3PX = 80;                             // bytes per halo pixel slot (32 bf16 + 16 pad)
+constexpr int kC3ROW = 1536;                          // bytes per halo row (18 x 80 = 1440 -> 1536)
+
+__device__ __forceinline__ unsigned short c3_f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// torch weight (Cout, Cin, 3, 3) f32/any -> packed[co][Cin/32][tap = ky*3+kx][32 ci] bf16
+__global__ void conv3x3_pack_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed,
+                                           int Cout, int Cin) {
+  const long n = (long)Cout * Cin * 9;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  long r = idx;
+  const int ci32 = (int)(r % 32); r /= 32;
+  const int tap = (int)(r % 9); r /= 9;
+  const int chunk = (int)(r % (Cin / 32));
+  const int co = (int)(r / (Cin / 32));
+  const int ci = chunk * 32 + ci32;
+  packed[idx] = c3_f32_to_bf16(w[((long)co * Cin + ci) * 9 + tap]);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
+    const uint4* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ bias,
+    unsigned short* __restrict__ out, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int relu) {
+  constexpr int RT = 4, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
+  constexpr int HALO_BYTES = kC3HH * kC3ROW;                 // 15 360
+  constexpr int W_BYTES = WR * kC3PX;                        // one tap's slice of one wave
+  constexpr int STAGE_BYTES = 2 * HALO_BYTES + 4 * 2 * W_BYTES, OUT_BYTES = 32 * OLD * 4;
+  __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vi = lane & 31, kb = lane >> 5;
+  char* sW = lds + 2 * HALO_BYTES + wave * 2 * W_BYTES;
+  int bid = blockIdx.x;
+  const int tx_i = bid % tiles_x; bid /= tiles_x;
+  const int ty_i = bid % tiles_y;
+  const int img = bid / tiles_y;
+  const int y0 = ty_i * kC3TH, x0 = tx_i * kC3TW;
+  const int n0 = blockIdx.y * BN, nw0 = n0 + wave * WR;
+  const int CQ = Cin / 8, NCH = Cin / 32;
+
+  f32x16 acc[RT][NT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
+
+  // halo staging roles: 180 pixels x 4 pieces = 720 items over 256 threads (3 per thread, clamped +
+  // zero-selected, unconditional loads)
+  // (named scalars: small per-thread arrays written in a loop end up in scratch with hipcc / ROCm 7.2)
+  long hofs0, hofs1, hofs2;
+  int hdst0, hdst1, hdst2;
+  bool hin0, hin1, hin2, hlive0, hlive1, hlive2;
+#define OCC_C3_HALO_ROLE(K, OFS, DST, IN, LIVE)                                                   \
+  {                                                                                               \
+    const int idx = tid + 256 * (K);                                                              \
+    LIVE = idx < kC3HH * kC3HW * 4;                                                               \
+    const int p = LIVE ? idx >> 2 : 0, piece = idx & 3;                                           \
+    const int hy = p / kC3HW, hx = p % kC3HW;                                                     \
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;                                                 \
+    IN = LIVE && iy >= 0 && iy < H && ix >= 0 && ix < W;                                          \
+    const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);                           \
+    OFS = (((long)img * H + cy) * W + cx) * CQ + piece;                                           \
+    DST = hy * kC3ROW + hx * kC3PX + piece * 16;                                                  \
+  }
+  OCC_C3_HALO_ROLE(0, hofs0, hdst0, hin0, hlive0)
+  OCC_C3_HALO_ROLE(1, hofs1, hdst1, hin1, hlive1)
+  OCC_C3_HALO_ROLE(2, hofs2, hdst2, hin2, hlive2)
+#undef OCC_C3_HALO_ROLE
+  // weight staging roles: lane -> (row = lane/4 + 16*it, piece = lane%4)
+  const int srow = lane >> 2, sp = lane & 3;
+  long wofs[2 * NT];
+#pragma unroll
+  for (int it = 0; it < 2 * NT; ++it) {
+    const int n = nw0 + srow + 16 * it;
+    wofs[it] = (long)(n < Cout ? n : Cout - 1) * NCH * 36 + sp;      // 9 taps x 4 pieces per (co, chunk)
+  }
+  // A fragment base offsets (bytes) of this lane's pixel in each row tile, tap (0,0), k-step 0
+  int abase[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+    abase[rt] = (2 * rt + (vi >> 4)) * kC3ROW + (vi & 15) * kC3PX + kb * 16;
+
+  uint4 vh0, vh1, vh2, vw0, vw1, vw2, vw3;
+  const unsigned hm0 = hin0 ? 0xffffffffu : 0u, hm1 = hin1 ? 0xffffffffu : 0u, hm2 = hin2 ? 0xffffffffu : 0u;
+#define OCC_C3_ISSUE_HALO(CH)                                                                     \
+  {                                                                                               \
+    const long cq = (long)(CH) * 4;                                                               \
+    vh0 = x[hofs0 + cq]; vh1 = x[hofs1 + cq]; vh2 = x[hofs2 + cq];                                \
+  }
+#define OCC_C3_ISSUE_W(CH, TAP)                                                                   \
+  {                                                                                               \
+    const long o = ((long)(CH) * 9 + (TAP)) * 4;                                                  \
+    vw0 = wp[wofs[0] + o]; vw1 = wp[wofs[1] + o];                                                 \
+    if (NT == 2) { vw2 = wp[wofs[2 * NT - 2] + o]; vw3 = wp[wofs[2 * NT - 1] + o]; }              \
+  }
+
+  OCC_C3_ISSUE_HALO(0)
+  OCC_C3_ISSUE_W(0, 0)
+  for (int ch = 0; ch < NCH; ++ch) {
+    char* sH = lds + (ch & 1) * HALO_BYTES;
+    // out-of-image pixels are zero (the convolution's padding): AND with an all-ones / all-zeros mask (a
+    // select between two uint4 values is lowered to an indexed scratch array by hipcc)
+    if (hlive0) *reinterpret_cast<uint4*>(sH + hdst0) = make_uint4(vh0.x & hm0, vh0.y & hm0, vh0.z & hm0, vh0.w & hm0);
+    if (hlive1) *reinterpret_cast<uint4*>(sH + hdst1) = make_uint4(vh1.x & hm1, vh1.y & hm1, vh1.z & hm1, vh1.w & hm1);
+    if (hlive2) *reinterpret_cast<uint4*>(sH + hdst2) = make_uint4(vh2.x & hm2, vh2.y & hm2, vh2.z & hm2, vh2.w & hm2);
+    __syncthreads();   // halo chunk visible; the other halo buffer is free for the next chunk
+    OCC_C3_ISSUE_HALO(ch + 1 < NCH ? ch + 1 : ch)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      char* sWt = sW + (tap & 1) * W_BYTES;
+      *reinterpret_cast<uint4*>(sWt + (srow) * kC3PX + sp * 16) = vw0;
+      *reinterpret_cast<uint4*>(sWt + (srow + 16) * kC3PX + sp * 16) = vw1;
+      if (NT == 2) {
+        *reinterpret_cast<uint4*>(sWt + (srow + 32) * kC3PX + sp * 16) = vw2;
+        *reinterpret_cast<uint4*>(sWt + (srow + 48) * kC3PX + sp * 16) = vw3;
+      }
+      wave_lds_sync();
+      {   // next (chunk, tap)'s weights in flight during this tap's MFMAs
+        const int nt = tap + 1 < 9 ? tap + 1 : 0;
+        const int nc = tap + 1 < 9 ? ch : (ch + 1 < NCH ? ch + 1 : ch);
+        OCC_C3_ISSUE_W(nc, nt)
+      }
+      const int toff = (tap / 3) * kC3ROW + (tap % 3) * kC3PX;
+      bf16x8 af[RT][2], wf[NT][2];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          af[rt][ks] = *reinterpret_cast<const bf16x8*>(sH + abase[rt] + toff + ks * 32);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          wf[t][ks] = *reinterpret_cast<const bf16x8*>(sWt + (t * 32 + vi) * kC3PX + ks * 32 + kb * 16);
+      wave_lds_sync();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][ks], wf[t][ks], acc[rt][t], 0, 0, 0);
+    }
+  }
+#undef OCC_C3_ISSUE_HALO
+#undef OCC_C3_ISSUE_W
+
+  // ---- epilogue, one 32-pixel row tile (two image rows) at a time through an LDS transpose -------------
+  const int c = lane * 4;
+  const bool col_live = c < BN && n0 + c < Cout;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col_live) bv = *reinterpret_cast<const float4*>(bias + n0 + c);
+  float* sO = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sO[((r & 3) + 8 * (r >> 2) + 4 * kb) * OLD + (wave * NT + t) * 32 + vi] = acc[rt][t][r];
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;                       // pixel inside the row tile
+      const int oy = y0 + 2 * rt + (row >> 4), ox = x0 + (row & 15);
+      if (oy < H && ox < W && col_live) {
+        float4 v = *reinterpret_cast<const float4*>(sO + row * OLD + c);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        const uint2 o = make_uint2((unsigned)c3_f32_to_bf16(v.x) | ((unsigned)c3_f32_to_bf16(v.y) << 16),
+                                   (unsigned)c3_f32_to_bf16(v.z) | ((unsigned)c3_f32_to_bf16(v.w) << 16));
+        *reinterpret_cast<uint2*>(out + (((long)img * H + oy) * W + ox) * Cout + n0 + c) = o;
+      }
+    }
+  }
+}
+
+}  // namespace occ
+
+extern "C" int occ_conv3x3_pack_weight_bf16(const float* weight, void* packed, int Cout, int Cin,
+                                            void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(weight && packed, "conv3x3_pack_weight_bf16: null pointer argument");
+  if (Cin % 32 || Cout % 128) {
+    set_error("conv3x3_pack_weight_bf16: no kernel for Cin=%d Cout=%d (need Cin %% 32 == 0, Cout %% 128 == 0)",
+              Cin, Cout);
+    return OCC_E_UNSUPPORTED;
+  }
+  const long n = (long)Cout * Cin * 9;
+  hipLaunchKernelGGL(conv3x3_pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), weight,
+                     reinterpret_cast<unsigned short*>(packed), Cout, Cin);
+  OCC_CHECK_LAUNCH("conv3x3_pack_weight_bf16");
+  return OCC_OK;
+}
+
+extern "C" int occ_conv3x3_nhwc_bf16(const void* x, const void* weight_packed, const float* bias, void* out,
+                                     int batch, int H, int W, int Cin, int Cout, int relu, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(x && weight_packed && bias && out, "conv3x3_nhwc_bf16: null pointer argument");
+  OCC_CHECK_ARG(batch > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_nhwc_bf16: bad dimension");
+  if (Cin % 32 || Cout % 128) {
+    set_error("conv3x3_nhwc_bf16: no kernel for Cin=%d Cout=%d (need Cin %% 32 == 0, Cout %% 128 == 0)", Cin,
+              Cout);
+    return OCC_E_UNSUPPORTED;
+  }
+  const int tiles_x = (W + kC3TW - 1) / kC3TW, tiles_y = (H + kC3TH - 1) / kC3TH;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned gx = (unsigned)((long)batch * tiles_x * tiles_y);
+#define OCC_C3_LAUNCH(NTT, BNN)                                                                     \
+  hipLaunchKernelGGL((conv3x3_nhwc_bf16_kernel<NTT>), dim3(gx, (unsigned)(Cout / BNN)), dim3(256), 0, st, \
+                     reinterpret_cast<const uint4*>(x), reinterpret_cast<const uint4*>(weight_packed), \
+                     bias, reinterpret_cast<unsigned short*>(out), H, W, Cin, Cout, tiles_x, tiles_y, relu)
+  if (Cout % 256 == 0) OCC_C3_LAUNCH(2, 256); else OCC_C3_LAUNCH(1, 128);
+#undef OCC_C3_LAUNCH
+  OCC_CHECK_LAUNCH("conv3x3_nhwc_bf16");
+  return OCC_OK;
+}

@@ -481,3 +481,38 @@ def conv1x1_nhwc(x, weight2d, bias, residual=None, relu=False, stride=1):
                                               i32(1 if relu else 0), stream_ptr(x.device))
     _lib.check(rc, "conv1x1_nhwc")
     return out
+
+
+def conv3x3_pack_weight(weight):
+    """torch Conv2d weight (Cout, Cin, 3, 3) float32 -> packed bf16 [co][Cin/32][tap][32] (int16 storage)."""
+    _need_cuda_f32("weight", weight)
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
+        raise OccAmdError("conv3x3_pack_weight: expected a (Cout, Cin, 3, 3) weight")
+    cout, cin = weight.shape[:2]
+    packed = torch.empty(weight.numel(), dtype=torch.int16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = _lib.lib().occ_conv3x3_pack_weight_bf16(ptr(weight), ptr(packed), i32(cout), i32(cin),
+                                                     stream_ptr(weight.device))
+    _lib.check(rc, "conv3x3_pack_weight")
+    return packed
+
+
+def conv3x3_nhwc(x, w_packed, bias, cout, relu=False):
+    """3x3 / stride 1 / pad 1 convolution + bias (+ ReLU) on a channels_last bf16 activation, one launch.
+    x (N, Cin, H, W) channels_last bf16; w_packed from conv3x3_pack_weight; bias (Cout) f32
+    -> (N, Cout, H, W) channels_last bf16."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        raise OccAmdUnsupported("conv3x3_nhwc: x must be a channels_last bfloat16 device tensor")
+    _need_cuda_f32("bias", bias)
+    N, Cin, H, W = x.shape
+    if w_packed.numel() != cout * Cin * 9 or bias.numel() != cout:
+        raise OccAmdError("conv3x3_nhwc: inconsistent shapes")
+    out = torch.empty((N, cout, H, W), dtype=torch.bfloat16, device=x.device,
+                      memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().occ_conv3x3_nhwc_bf16(ptr(x), ptr(w_packed), ptr(bias), ptr(out), i32(N), i32(H),
+                                              i32(W), i32(Cin), i32(cout), i32(1 if relu else 0),
+                                              stream_ptr(x.device))
+    _lib.check(rc, "conv3x3_nhwc")
+    return out

@@ -237,9 +237,18 @@ class FusedInferenceBackbone(nn.Module):
                 and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0)
         if gemm:
             self.register_buffer(f'm{idx}', w.reshape(w.shape[0], w.shape[1]).contiguous(), persistent=False)
+        # stride-1 3x3 convolutions with >= 128 output channels: own implicit-GEMM kernel (bias+ReLU fused)
+        c3 = (self.hip_tail and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
+              and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+              and w.shape[1] % 32 == 0 and w.shape[0] % 128 == 0 and w.is_cuda)
+        if c3:
+            from .. import ext
+            self.register_buffer(f'p{idx}', ext.conv3x3_pack_weight(w.float().contiguous()), persistent=False)
         self._convs.append((conv.stride, conv.padding, conv.dilation, conv.groups))
         self._gemm = getattr(self, '_gemm', {})
         self._gemm[idx] = gemm
+        self._c3 = getattr(self, '_c3', {})
+        self._c3[idx] = c3
         return idx
 
     def _conv(self, i, x, relu=False, add=None):
@@ -254,6 +263,9 @@ class FusedInferenceBackbone(nn.Module):
             from .. import ext
             return ext.conv1x1_nhwc(x, getattr(self, f'm{i}'), b, residual=add,
                                     relu=relu or add is not None, stride=s[0])
+        if self._c3.get(i) and add is None and x.is_contiguous(memory_format=torch.channels_last):
+            from .. import ext
+            return ext.conv3x3_nhwc(x, getattr(self, f'p{i}'), b, w.shape[0], relu=relu)
         if self.hip_tail and w.shape[0] % 8 == 0:
             from .. import ext
             y = F.conv2d(x, w, None, s, p, d, g)

@@ -50,6 +50,28 @@ def test_conv1x1_nhwc_matches_torch(N, Cin, Cout, H, W, stride, res, relu):
     assert d <= scale * 2 ** -8 + 1e-6          # one bf16 rounding of the f32-accumulated result
 
 
+@pytest.mark.parametrize("N,C,Cout,H,W,relu", [
+    (2, 128, 128, 9, 21, True), (1, 256, 256, 16, 32, False), (1, 512, 512, 5, 7, True),
+    (3, 64, 256, 8, 16, True), (1, 32, 128, 1, 1, False), (1, 256, 128, 29, 50, True)])
+def test_conv3x3_nhwc_matches_torch(N, C, Cout, H, W, relu):
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(C + Cout + H)
+    x = torch.randn(N, C, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda()
+    w_bf = w.to(torch.bfloat16).float()                       # the kernel rounds the weights to bf16
+    b = torch.randn(Cout, generator=g).cuda()
+    got = ext.conv3x3_nhwc(x, ext.conv3x3_pack_weight(w), b, Cout, relu=relu)
+    want = torch.nn.functional.conv2d(x.float(), w_bf, b, padding=1)
+    if relu:
+        want = want.relu()
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    d = float((got.float() - want).abs().max())
+    scale = float(want.abs().max())
+    print(f"conv3x3 {C}->{Cout} {H}x{W}: max diff {d:.3e} (scale {scale:.2f})")
+    assert d <= scale * 2 ** -8 + 1e-5          # one bf16 rounding of the f32-accumulated result
+
+
 def test_folded_plan_matches_fp32_modules():
     from occnet_amd.plugin.backbone import FPN, FusedInferenceBackbone, ResNet
     torch.manual_seed(0)

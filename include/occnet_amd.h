@@ -190,7 +190,7 @@ int occ_linear_f32(const float* a1, int64_t lda1, int K1, const float* a2, const
  * occ_linear_f32's fast variant on the bf16 matrix cores ("bf16x3"): every f32 operand is split into
  * hi + lo bf16 and A.W^T ~= Ah.Wh^T + Ah.Wl^T + Al.Wh^T is accumulated in f32 (relative error of a product
  * <= 2^-16).  Same arguments, except that the weight is given PACKED by occ_linear_pack_weight_bf16x3:
- * packed[n][K/16][hi16 | lo16] bf16 (N*K*2 16-bit words; K % 16 == 0).
+ * packed[K/16][n][hi16 | lo16] bf16 (N*K*2 16-bit words; K % 16 == 0).
  */
 int occ_linear_pack_weight_bf16x3(const float* weight, void* packed, int N, int K, void* stream);
 int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2, const float* a2_add,
@@ -225,7 +225,8 @@ int occ_bias_act_nhwc_bf16(void* x, const float* bias, const void* residual, int
 /* Backbone 1x1 convolution on NHWC bf16 (outside the hand-written hot path, like the call above):
  * out[(n,yo,xo), co] = relu?( sum_ci x[(n, yo*stride, xo*stride), ci] * weight[co, ci] + bias[co]
  *                             (+ residual[(n,yo,xo), co]) ), bf16 in, f32 accumulate, bf16 out.
- *   x (batch, Hin, Win, Cin) bf16 ; weight (Cout, Cin) bf16 ; bias (Cout) f32 ; residual / out
+ *   x (batch, Hin, Win, Cin) bf16 ; weight CHUNK-major [Cin/32][Cout][32] bf16 (from the (Cout, Cin) matrix:
+ *   w.view(Cout, Cin/32, 32).permute(1, 0, 2)) ; bias (Cout) f32 ; residual / out
  *   (batch, Hout, Wout, Cout) bf16 with Hout = (Hin-1)/stride + 1.  Needs Cin % 32 == 0, Cout % 8 == 0.
  */
 int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const float* bias, const void* residual,

@@ -245,7 +245,8 @@ extern "C" int occ_conv3x3_nhwc_bf16(const void* x, const void* weight_packed, c
   hipLaunchKernelGGL((conv3x3_nhwc_bf16_kernel<NTT>), dim3(gx, (unsigned)(Cout / BNN)), dim3(256), 0, st, \
                      reinterpret_cast<const uint4*>(x), reinterpret_cast<const uint4*>(weight_packed), \
                      bias, reinterpret_cast<unsigned short*>(out), H, W, Cin, Cout, tiles_x, tiles_y, relu)
-  if (Cout % 256 == 0) OCC_C3_LAUNCH(2, 256); else OCC_C3_LAUNCH(1, 128);
+  // 256-channel blocks only while they still give every CU two blocks; small maps take 128-channel blocks
+  if (Cout % 256 == 0 && (long)gx * (Cout / 256) >= 2L * 256) OCC_C3_LAUNCH(2, 256); else OCC_C3_LAUNCH(1, 128);
 #undef OCC_C3_LAUNCH
   OCC_CHECK_LAUNCH("conv3x3_nhwc_bf16");
   return OCC_OK;

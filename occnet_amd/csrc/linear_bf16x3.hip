@@ -9,8 +9,10 @@
 // xf32/TF32 matrix instruction, so this is the only way to get fp32-like GEMMs off the 157 TFLOP/s f32 rate.
 //
 // Layout: the weight is split and packed ONCE on the device (occ_linear_pack_weight_bf16x3):
-//   packed[n][K/16][ hi[16] | lo[16] ] bf16  — the same 4 bytes per weight as f32, so staging a weight
-// slice is a plain 16-byte-per-lane copy into LDS; activations are split on the fly while staged.
+//   packed[K/16][n][ hi[16] | lo[16] ] bf16  — the same 4 bytes per weight as f32; CHUNK-major, so the
+// slice a wave stages per K chunk is contiguous (rows at a 1-2 KB stride would all land on a few L2
+// channels while every block walks K in lockstep); staging is a plain 16-byte-per-lane copy into LDS.
+// Activations are split on the fly while staged.
 // Decomposition: block = 4 waves x (32*RT rows) x (128*NT columns); per 16-k chunk the activation rows are
 // split and staged once per block (double buffered, one barrier per chunk) and every wave stages its own W
 // slice into a private LDS region (48-byte row stride = conflict-free ds_read_b128); next chunk's global
@@ -41,17 +43,17 @@ __device__ __forceinline__ float x3_wave_sum(float v) {
   return v;
 }
 
-// (N, K) f32 -> packed[n][K/16][hi16 | lo16] bf16
+// (N, K) f32 -> packed[K/16][n][hi16 | lo16] bf16
 __global__ void linear_pack_weight_bf16x3_kernel(const float* __restrict__ w,
                                                  unsigned short* __restrict__ packed, long n_elem,
-                                                 int K) {
+                                                 int K, int N) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_elem) return;
   const long n = idx / K;
   const int k = (int)(idx % K);
   unsigned short hi, lo;
   x3_split(w[idx], hi, lo);
-  unsigned short* dst = packed + (n * (K / 16) + k / 16) * 32 + (k % 16);
+  unsigned short* dst = packed + ((long)(k / 16) * N + n) * 32 + (k % 16);
   dst[0] = hi;
   dst[16] = lo;
 }
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
   const int nw0 = n0 + wave * WR;
-  const int K = K1 + K2, KC = K / 16;
+  const int K = K1 + K2;
 
   f32x16 acc[RT][NT];
 #pragma unroll
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
 #pragma unroll
   for (int it = 0; it < 2 * NT; ++it) {
     const int n = nw0 + srow + 16 * it;
-    wofs[it] = ((long)(n < N ? n : N - 1) * KC) * 4 + sp;
+    wofs[it] = (long)(n < N ? n : N - 1) * 4 + sp;
   }
   float4 va;
   float4 vd = make_float4(0.f, 0.f, 0.f, 0.f);     // addend (ADD only)
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
     addscale = add ? 1.f : 0.f;                                                                   \
     va = *reinterpret_cast<const float4*>(ab + am * lda);                                         \
     if (ADD) vd = *reinterpret_cast<const float4*>(addb + am * lda); /* compile-time */           \
-    const long kc4 = (long)(k0_ / 16) * 4;                                                        \
+    const long kc4 = (long)(k0_ / 16) * N * 4; /* chunk-major packed weights */                   \
     vw0 = wp[wofs[0] + kc4];                                                                      \
     vw1 = wp[wofs[1] + kc4];                                                                      \
     if (NT == 2) {                                                                                \
@@ -125,9 +127,13 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
 #define OCC_X3_PUT_W(V, ROW)                                                                      \
   *reinterpret_cast<uint4*>((sp < 2 ? sWh : sWl) + (ROW) * kXLD + (sp & 1) * 16) = V;
 
-  OCC_X3_ISSUE(0)
+  // every block walks the K chunks in a rotated order (see conv1x1_nhwc_bf16.hip): blocks launched together
+  // would otherwise request the same weight chunk / same-stride activation columns at the same time
+  const int NCHK = K / kXBK;
+  const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)NCHK);
+  OCC_X3_ISSUE((rot % NCHK) * kXBK)
   int buf = 0;
-  for (int k0 = 0; k0 < K; k0 += kXBK, buf ^= 1) {
+  for (int ci = 0; ci < NCHK; ++ci, buf ^= 1) {
     char* sAh = lds + buf * 2 * A_BYTES;
     char* sAl = sAh + A_BYTES;
     if (a_live) {   // f32 x4 (+ addend) -> 4 hi bf16 + 4 lo bf16 into the two A planes
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
       OCC_X3_PUT_W(vw3, srow + 48)
     }
     __syncthreads();   // chunk visible to every wave; the other A buffer is free for the next iteration
-    OCC_X3_ISSUE(k0 + kXBK < K ? k0 + kXBK : k0)   // unconditional prefetch (last one re-reads its chunk)
+    OCC_X3_ISSUE((((ci + 1 < NCHK ? ci + 1 : ci) + rot) % NCHK) * kXBK)   // unconditional prefetch
 
     bf16x8 ah[RT], al[RT], wh[NT], wl[NT];
 #pragma unroll
@@ -247,7 +253,7 @@ extern "C" int occ_linear_pack_weight_bf16x3(const float* weight, void* packed, 
   const long n = (long)N * K;
   hipLaunchKernelGGL(linear_pack_weight_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), weight,
-                     reinterpret_cast<unsigned short*>(packed), n, K);
+                     reinterpret_cast<unsigned short*>(packed), n, K, N);
   OCC_CHECK_LAUNCH("linear_pack_weight_bf16x3");
   return OCC_OK;
 }

@@ -317,7 +317,7 @@ _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight
 
 
 def linear_pack_weight_bf16x3(weight):
-    """(N, K) float32 Linear weight -> packed[n][K/16][hi16 | lo16] bf16 split (int16 storage), cached."""
+    """(N, K) float32 Linear weight -> packed[K/16][n][hi16 | lo16] bf16 split (int16 storage), cached."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
     hit = _PACKED_W.get(key)
     if hit is not None:
@@ -454,19 +454,29 @@ def bias_act_nhwc_(x, bias, residual=None, relu=True):
     return x
 
 
+def conv1x1_pack_weight(weight2d):
+    """(Cout, Cin) bf16 matrix -> chunk-major [Cin/32][Cout][32] (what conv1x1_nhwc takes): a K chunk of all
+    output channels is contiguous."""
+    cout, cin = weight2d.shape
+    if cin % 32:
+        raise OccAmdUnsupported("conv1x1_pack_weight: Cin must be a multiple of 32")
+    return weight2d.to(torch.bfloat16).view(cout, cin // 32, 32).permute(1, 0, 2).contiguous()
+
+
 def conv1x1_nhwc(x, weight2d, bias, residual=None, relu=False, stride=1):
     """1x1 convolution + bias (+ residual) (+ ReLU) on a channels_last bf16 activation, one launch.
-    x (N, Cin, H, W) channels_last bf16; weight2d (Cout, Cin) bf16 contiguous; bias (Cout) f32;
+    x (N, Cin, H, W) channels_last bf16; weight2d = conv1x1_pack_weight((Cout, Cin) matrix); bias (Cout) f32;
     residual (N, Cout, Ho, Wo) channels_last bf16 or None -> (N, Cout, Ho, Wo) channels_last bf16."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)):
         raise OccAmdUnsupported("conv1x1_nhwc: x must be a channels_last bfloat16 device tensor")
-    if not (weight2d.dtype == torch.bfloat16 and weight2d.dim() == 2 and weight2d.is_contiguous()):
-        raise OccAmdError("conv1x1_nhwc: weight must be a contiguous (Cout, Cin) bfloat16 matrix")
+    if not (weight2d.dtype == torch.bfloat16 and weight2d.dim() == 3 and weight2d.is_contiguous()
+            and weight2d.shape[2] == 32):
+        raise OccAmdError("conv1x1_nhwc: weight must come from conv1x1_pack_weight ([Cin/32][Cout][32] bf16)")
     _need_cuda_f32("bias", bias)
     N, Cin, H, W = x.shape
-    Cout = weight2d.shape[0]
-    if weight2d.shape[1] != Cin or bias.numel() != Cout:
+    Cout = weight2d.shape[1]
+    if weight2d.shape[0] * 32 != Cin or bias.numel() != Cout:
         raise OccAmdError("conv1x1_nhwc: inconsistent shapes")
     s = int(stride)
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1

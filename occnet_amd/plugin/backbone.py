@@ -236,7 +236,9 @@ class FusedInferenceBackbone(nn.Module):
                 and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.stride[0] == conv.stride[1]
                 and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0)
         if gemm:
-            self.register_buffer(f'm{idx}', w.reshape(w.shape[0], w.shape[1]).contiguous(), persistent=False)
+            from .. import ext
+            self.register_buffer(f'm{idx}', ext.conv1x1_pack_weight(w.reshape(w.shape[0], w.shape[1])),
+                                 persistent=False)
         # stride-1 3x3 convolutions with >= 128 output channels: own implicit-GEMM kernel (bias+ReLU fused)
         c3 = (self.hip_tail and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
               and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1

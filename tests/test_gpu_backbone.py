@@ -37,7 +37,7 @@ def test_conv1x1_nhwc_matches_torch(N, Cin, Cout, H, W, stride, res, relu):
     b = torch.randn(Cout, generator=g).cuda()
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     r = cl(torch.randn(N, Cout, Ho, Wo, generator=g)) if res else None
-    got = ext.conv1x1_nhwc(x, w, b, residual=r, relu=relu, stride=stride)
+    got = ext.conv1x1_nhwc(x, ext.conv1x1_pack_weight(w), b, residual=r, relu=relu, stride=stride)
     want = torch.nn.functional.conv2d(x.float(), w.float().view(Cout, Cin, 1, 1), b, stride=stride)
     if res:
         want = want + r.float()

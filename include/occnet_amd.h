@@ -235,7 +235,7 @@ int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const float* bias, 
 
 /* Backbone 3x3 stride-1 pad-1 convolution on NHWC bf16 with bias (+ ReLU) fused (outside the hand-written hot
  * path).  x (batch, H, W, Cin) bf16 ; weight packed by occ_conv3x3_pack_weight_bf16 from torch's
- * (Cout, Cin, 3, 3) f32 layout to [co][Cin/32][tap][32] bf16 ; bias (Cout) f32 ; out (batch, H, W, Cout) bf16.
+ * (Cout, Cin, 3, 3) f32 layout to [Cin/32][tap][co][32] bf16 ; bias (Cout) f32 ; out (batch, H, W, Cout) bf16.
  * Needs Cin % 32 == 0 and Cout % 128 == 0, otherwise OCC_E_UNSUPPORTED (the caller keeps MIOpen).
  */
 int occ_conv3x3_pack_weight_bf16(const float* weight, void* packed, int Cout, int Cin, void* stream);

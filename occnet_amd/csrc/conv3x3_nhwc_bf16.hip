@@ -11,8 +11,8 @@
 // input channels the (8+2) x (16+2) pixel halo is staged ONCE into LDS (zero-filled outside the image =
 // the convolution's padding; double buffered; 80-byte pixel slots, 1536-byte halo rows: conflict-free
 // ds_read_b128) and reused by the 9 taps with compile-time offsets; every wave streams its own 32*NT x 32
-// weight slice per tap through a private double-buffered LDS region (packed [co][chunk][tap][32 ci], so a
-// lane's pieces of consecutive taps are 64 B apart).  v_mfma_f32_32x32x16_bf16, 2 k-steps per (chunk, tap).
+// weight slice per tap through a private double-buffered LDS region (packed [chunk][tap][co][32 ci]: contiguous
+// per (chunk, tap)); the chunk order is rotated per block (L2 channel hot-spotting, see conv1x1_nhwc_bf16.hip).  v_mfma_f32_32x32x16_bf16, 2 k-steps per (chunk, tap).
 #include "common.h"
 
 namespace occ {
@@ -32,7 +32,8 @@ __device__ __forceinline__ unsigned short c3_f32_to_bf16(float f) {
   return (unsigned short)(u >> 16);
 }
 
-// torch weight (Cout, Cin, 3, 3) f32/any -> packed[co][Cin/32][tap = ky*3+kx][32 ci] bf16
+// torch weight (Cout, Cin, 3, 3) f32 -> packed[Cin/32][tap = ky*3+kx][co][32 ci] bf16 (chunk/tap-major: the
+// slice a wave stages per (chunk, tap) is contiguous)
 __global__ void conv3x3_pack_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed,
                                            int Cout, int Cin) {
   const long n = (long)Cout * Cin * 9;
@@ -40,9 +41,9 @@ __global__ void conv3x3_pack_weight_kernel(const float* __restrict__ w, unsigned
   if (idx >= n) return;
   long r = idx;
   const int ci32 = (int)(r % 32); r /= 32;
-  const int tap = (int)(r % 9); r /= 9;
-  const int chunk = (int)(r % (Cin / 32));
-  const int co = (int)(r / (Cin / 32));
+  const int co = (int)(r % Cout); r /= Cout;
+  const int tap = (int)(r % 9);
+  const int chunk = (int)(r / 9);
   const int ci = chunk * 32 + ci32;
   packed[idx] = c3_f32_to_bf16(w[((long)co * Cin + ci) * 9 + tap]);
 }
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
 #pragma unroll
   for (int it = 0; it < 2 * NT; ++it) {
     const int n = nw0 + srow + 16 * it;
-    wofs[it] = (long)(n < Cout ? n : Cout - 1) * NCH * 36 + sp;      // 9 taps x 4 pieces per (co, chunk)
+    wofs[it] = (long)(n < Cout ? n : Cout - 1) * 4 + sp;             // + (chunk*9 + tap) * Cout * 4
   }
   // A fragment base offsets (bytes) of this lane's pixel in each row tile, tap (0,0), k-step 0
   int abase[RT];
@@ -120,13 +121,15 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
   }
 #define OCC_C3_ISSUE_W(CH, TAP)                                                                   \
   {                                                                                               \
-    const long o = ((long)(CH) * 9 + (TAP)) * 4;                                                  \
+    const long o = ((long)(CH) * 9 + (TAP)) * Cout * 4;                                           \
     vw0 = wp[wofs[0] + o]; vw1 = wp[wofs[1] + o];                                                 \
     if (NT == 2) { vw2 = wp[wofs[2 * NT - 2] + o]; vw3 = wp[wofs[2 * NT - 1] + o]; }              \
   }
 
-  OCC_C3_ISSUE_HALO(0)
-  OCC_C3_ISSUE_W(0, 0)
+  const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)NCH);
+#define OCC_C3_CH(CI) (((CI) + rot) % NCH)
+  OCC_C3_ISSUE_HALO(OCC_C3_CH(0))
+  OCC_C3_ISSUE_W(OCC_C3_CH(0), 0)
   for (int ch = 0; ch < NCH; ++ch) {
     char* sH = lds + (ch & 1) * HALO_BYTES;
     // out-of-image pixels are zero (the convolution's padding): AND with an all-ones / all-zeros mask (a
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
     if (hlive1) *reinterpret_cast<uint4*>(sH + hdst1) = make_uint4(vh1.x & hm1, vh1.y & hm1, vh1.z & hm1, vh1.w & hm1);
     if (hlive2) *reinterpret_cast<uint4*>(sH + hdst2) = make_uint4(vh2.x & hm2, vh2.y & hm2, vh2.z & hm2, vh2.w & hm2);
     __syncthreads();   // halo chunk visible; the other halo buffer is free for the next chunk
-    OCC_C3_ISSUE_HALO(ch + 1 < NCH ? ch + 1 : ch)
+    OCC_C3_ISSUE_HALO(OCC_C3_CH(ch + 1 < NCH ? ch + 1 : ch))
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       char* sWt = sW + (tap & 1) * W_BYTES;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
       {   // next (chunk, tap)'s weights in flight during this tap's MFMAs
         const int nt = tap + 1 < 9 ? tap + 1 : 0;
         const int nc = tap + 1 < 9 ? ch : (ch + 1 < NCH ? ch + 1 : ch);
-        OCC_C3_ISSUE_W(nc, nt)
+        OCC_C3_ISSUE_W(OCC_C3_CH(nc), nt)
       }
       const int toff = (tap / 3) * kC3ROW + (tap % 3) * kC3PX;
       bf16x8 af[RT][2], wf[NT][2];
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
   }
 #undef OCC_C3_ISSUE_HALO
 #undef OCC_C3_ISSUE_W
+#undef OCC_C3_CH
 
   // ---- epilogue, one 32-pixel row tile (two image rows) at a time through an LDS transpose -------------
   const int c = lane * 4;

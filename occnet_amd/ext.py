@@ -494,7 +494,7 @@ def conv1x1_nhwc(x, weight2d, bias, residual=None, relu=False, stride=1):
 
 
 def conv3x3_pack_weight(weight):
-    """torch Conv2d weight (Cout, Cin, 3, 3) float32 -> packed bf16 [co][Cin/32][tap][32] (int16 storage)."""
+    """torch Conv2d weight (Cout, Cin, 3, 3) float32 -> packed bf16 [Cin/32][tap][co][32] (int16 storage)."""
     _need_cuda_f32("weight", weight)
     if weight.dim() != 4 or tuple(weight.shape[2:]) != (3, 3):
         raise OccAmdError("conv3x3_pack_weight: expected a (Cout, Cin, 3, 3) weight")

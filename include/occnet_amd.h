@@ -242,6 +242,26 @@ int occ_conv3x3_pack_weight_bf16(const float* weight, void* packed, int Cout, in
 int occ_conv3x3_nhwc_bf16(const void* x, const void* weight_packed, const float* bias, void* out, int batch,
                           int H, int W, int Cin, int Cout, int relu, void* stream);
 
+/* MFMA B-operand packing: f32 row-major (N, K) matrix -> bf16 in v_mfma_f32_32x32x16_bf16 fragment order
+ * packed[((ks * N/32 + nt) * 64 + lane) * 8 + j] = w[nt*32 + (lane & 31)][ks*16 + (lane >> 5)*8 + j], so a wave
+ * loads its operand of (k-step ks, column tile nt) as one coalesced 1 KB read.  Needs N % 32 == 0, K % 16 == 0.
+ */
+int occ_mfma_pack_b_frag_bf16(const float* weight, void* packed, int N, int K, void* stream);
+
+/* One whole 64-mid-channel ResNet bottleneck (mmdet Bottleneck, style='pytorch', stride 1, eval BatchNorm
+ * folded; outside the hand-written hot path) on NHWC bf16 in ONE launch — the 64-channel intermediates stay in
+ * LDS:  out = relu( conv1x1( relu(conv3x3( relu(conv1x1(x,W1)+b1), W2)+b2), W3) + b3 + identity ).
+ *   x (batch, H, W, Cin) bf16 ; out (batch, H, W, 256) bf16 ; b1, b2 (64) f32 ; b3 (256) f32
+ *   w1_frag = pack_b_frag(W1 (64, Cin)) ; w2_frag = pack_b_frag(W2 as (64, 9*64) with k = (ky*3+kx)*64 + ci)
+ *   downsample == 0 (Cin == 256): identity = x,  w3_frag = pack_b_frag(W3 (256, 64))
+ *   downsample == 1 (Cin == 64):  identity = conv1x1(x, Wds) + bds,  w3_frag = pack_b_frag([W3 | Wds] (256, 128)),
+ *                                 b3 := b3 + bds
+ * Other channel counts: OCC_E_UNSUPPORTED (the caller keeps the per-layer kernels).
+ */
+int occ_bottleneck64_nhwc_bf16(const void* x, const void* w1_frag, const float* b1, const void* w2_frag,
+                               const float* b2, const void* w3_frag, const float* b3, void* out, int batch,
+                               int H, int W, int Cin, int downsample, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

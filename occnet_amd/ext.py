@@ -493,6 +493,62 @@ def conv1x1_nhwc(x, weight2d, bias, residual=None, relu=False, stride=1):
     return out
 
 
+def mfma_pack_b_frag(weight2d):
+    """(N, K) float32 device matrix -> bf16 in MFMA B-fragment order (int16 storage, N*K elements): what the
+    fused bottleneck kernel streams straight from global memory."""
+    _need_cuda_f32("weight", weight2d)
+    if weight2d.dim() != 2:
+        raise OccAmdError("mfma_pack_b_frag: expected a (N, K) matrix")
+    weight2d = weight2d.contiguous()
+    n, k = weight2d.shape
+    packed = torch.empty(n * k, dtype=torch.int16, device=weight2d.device)
+    with torch.cuda.device(weight2d.device):
+        rc = _lib.lib().occ_mfma_pack_b_frag_bf16(ptr(weight2d), ptr(packed), i32(n), i32(k),
+                                                  stream_ptr(weight2d.device))
+    _lib.check(rc, "mfma_pack_b_frag")
+    return packed
+
+
+def bottleneck64_pack(w1, b1, w2, b2, w3, b3, wds=None, bds=None):
+    """Folded (BatchNorm already merged) weights of one 64-mid-channel bottleneck -> the operand set of
+    bottleneck64_nhwc.  w1 (64, Cin[,1,1]), w2 (64, 64, 3, 3), w3 (256, 64[,1,1]), optional projection
+    wds (256, Cin[,1,1]) / bds; biases float32.  Cin = 256 without projection, 64 with."""
+    w1 = w1.float().reshape(w1.shape[0], -1)
+    w3 = w3.float().reshape(w3.shape[0], -1)
+    if tuple(w2.shape) != (64, 64, 3, 3) or w1.shape[0] != 64 or tuple(w3.shape) != (256, 64):
+        raise OccAmdUnsupported("bottleneck64_pack: only 64 mid / 256 output channels")
+    ds = wds is not None
+    cin = w1.shape[1]
+    if (ds and cin != 64) or (not ds and cin != 256):
+        raise OccAmdUnsupported("bottleneck64_pack: Cin must be 256 (identity) or 64 (projection)")
+    w2m = w2.float().permute(0, 2, 3, 1).reshape(64, 9 * 64)          # k = (ky*3 + kx)*64 + ci
+    b3 = b3.float()
+    if ds:
+        w3 = torch.cat([w3, wds.float().reshape(256, 64)], dim=1)
+        b3 = b3 + bds.float()
+    return dict(w1=mfma_pack_b_frag(w1), b1=b1.float().contiguous(), w2=mfma_pack_b_frag(w2m),
+                b2=b2.float().contiguous(), w3=mfma_pack_b_frag(w3), b3=b3.contiguous(), cin=cin, ds=ds)
+
+
+def bottleneck64_nhwc(x, pack):
+    """One whole stride-1 ResNet bottleneck (64 mid channels) on a channels_last bf16 activation, one launch.
+    x (N, Cin, H, W) channels_last bf16; pack from bottleneck64_pack -> (N, 256, H, W) channels_last bf16."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        raise OccAmdUnsupported("bottleneck64_nhwc: x must be a channels_last bfloat16 device tensor")
+    N, Cin, H, W = x.shape
+    if Cin != pack['cin']:
+        raise OccAmdError("bottleneck64_nhwc: x has %d channels, the pack was built for %d" % (Cin, pack['cin']))
+    out = torch.empty((N, 256, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().occ_bottleneck64_nhwc_bf16(ptr(x), ptr(pack['w1']), ptr(pack['b1']), ptr(pack['w2']),
+                                                   ptr(pack['b2']), ptr(pack['w3']), ptr(pack['b3']), ptr(out),
+                                                   i32(N), i32(H), i32(W), i32(Cin), i32(1 if pack['ds'] else 0),
+                                                   stream_ptr(x.device))
+    _lib.check(rc, "bottleneck64_nhwc")
+    return out
+
+
 def conv3x3_pack_weight(weight):
     """torch Conv2d weight (Cout, Cin, 3, 3) float32 -> packed bf16 [Cin/32][tap][co][32] (int16 storage)."""
     _need_cuda_f32("weight", weight)

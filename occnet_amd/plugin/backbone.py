@@ -190,7 +190,8 @@ class FusedInferenceBackbone(nn.Module):
     the gather kernels want.  Built from the live modules' parameters (it owns folded COPIES: rebuild
     after changing weights); no custom kernels — the backbone stays outside the hand-written scope."""
 
-    def __init__(self, backbone, neck, dtype=torch.bfloat16, fused_ops=False, hip_tail=True):
+    def __init__(self, backbone, neck, dtype=torch.bfloat16, fused_ops=False, hip_tail=True,
+                 fused_bottleneck=True):
         super().__init__()
         # hip_tail: bias + (residual) + ReLU after each convolution as ONE in-place HIP launch
         # (occ_bias_act_nhwc_bf16) instead of PyTorch's add / add_ / relu_ launches (bf16 only)
@@ -217,6 +218,27 @@ class FusedInferenceBackbone(nn.Module):
                 blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2),
                                fold(blk.conv3, blk.bn3), ds))
             self.stages.append(blocks)
+        # whole-bottleneck kernel for the 64-mid-channel stride-1 blocks (ResNet-50 layer1: every layer of those
+        # blocks is HBM-bound at stride 4, the fused kernel keeps the 64-channel intermediates in LDS)
+        self._bneck = {}
+        if fused_bottleneck and self.hip_tail and getattr(self, f'w{self.stem}').is_cuda:
+            from .. import ext
+            for si, blocks in enumerate(self.stages):
+                for bi, (c1, c2, c3, ds) in enumerate(blocks):
+                    w1, w2, w3 = (getattr(self, f'w{i}') for i in (c1, c2, c3))
+                    ok = (tuple(w2.shape) == (64, 64, 3, 3) and tuple(w3.shape[:2]) == (256, 64)
+                          and self._convs[c2][0] == (1, 1) and self._convs[c2][1] == (1, 1)
+                          and ((ds is None and w1.shape[1] == 256) or
+                               (ds is not None and w1.shape[1] == 64 and self._convs[ds][0] == (1, 1))))
+                    if not ok:
+                        continue
+                    pk = ext.bottleneck64_pack(
+                        w1, getattr(self, f'b{c1}'), w2, getattr(self, f'b{c2}'), w3, getattr(self, f'b{c3}'),
+                        None if ds is None else getattr(self, f'w{ds}'),
+                        None if ds is None else getattr(self, f'b{ds}'))
+                    for k in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3'):
+                        self.register_buffer(f'k{si}_{bi}_{k}', pk[k], persistent=False)
+                    self._bneck[(si, bi)] = (pk['cin'], pk['ds'])
         self.neck = neck
         self.laterals = [self._add(m.conv.weight, m.conv.bias, m.conv) for m in neck.lateral_convs]
         self.fpn = [self._add(m.conv.weight, m.conv.bias, m.conv) for m in neck.fpn_convs]
@@ -310,7 +332,14 @@ class FusedInferenceBackbone(nn.Module):
         x = F.max_pool2d(self._conv(self.stem, x, relu=True), kernel_size=3, stride=2, padding=1)
         feats = []
         for si, blocks in enumerate(self.stages):
-            for c1, c2, c3, ds in blocks:
+            for bi, (c1, c2, c3, ds) in enumerate(blocks):
+                if (si, bi) in self._bneck and x.is_contiguous(memory_format=torch.channels_last):
+                    from .. import ext
+                    cin, has_ds = self._bneck[(si, bi)]
+                    pk = {k: getattr(self, f'k{si}_{bi}_{k}') for k in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3')}
+                    pk.update(cin=cin, ds=has_ds)
+                    x = ext.bottleneck64_nhwc(x, pk)
+                    continue
                 identity = x if ds is None else self._conv(ds, x)
                 y = self._conv(c2, self._conv(c1, x, relu=True), relu=True)
                 x = self._conv(c3, y, add=identity)

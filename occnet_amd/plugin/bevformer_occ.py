@@ -79,7 +79,8 @@ class BEVFormerOcc(BaseModule):
                 out.append(f.view(B, int(BN / B), C, H, W))
         return out
 
-    def enable_fused_backbone(self, dtype=torch.bfloat16, fused_ops=False, hip_tail=True, use_graph=False):
+    def enable_fused_backbone(self, dtype=torch.bfloat16, fused_ops=False, hip_tail=True, use_graph=False,
+                              fused_bottleneck=True):
         """Inference-only: run ResNet+FPN through FusedInferenceBackbone (eval BN folded into the
         convolutions, NHWC, MIOpen's fused conv+bias(+add)+ReLU).  Call again after changing backbone
         weights; pass dtype=None to disable."""
@@ -87,7 +88,8 @@ class BEVFormerOcc(BaseModule):
         object.__setattr__(self, '_inference_backbone', None)
         if dtype is not None:
             plan = FusedInferenceBackbone(self.img_backbone, self.img_neck, dtype=dtype,
-                                          fused_ops=fused_ops, hip_tail=hip_tail)
+                                          fused_ops=fused_ops, hip_tail=hip_tail,
+                                          fused_bottleneck=fused_bottleneck)
             plan.use_graph = use_graph
             object.__setattr__(self, '_inference_backbone', plan)   # not a sub-module: owns copies
         return self

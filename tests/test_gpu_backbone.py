@@ -72,6 +72,76 @@ def test_conv3x3_nhwc_matches_torch(N, C, Cout, H, W, relu):
     assert d <= scale * 2 ** -8 + 1e-5          # one bf16 rounding of the f32-accumulated result
 
 
+def _bottleneck_reference(x, w1, b1, w2, b2, w3, b3, wds=None, bds=None):
+    """fp32 torch restatement of what the fused kernel computes: bf16 weights, f32 accumulation, the two
+    64-channel intermediates rounded to bf16 (they are bf16 tensors in the unfused plan too)."""
+    r = lambda t: t.to(torch.bfloat16).float()
+    F = torch.nn.functional
+    xf = x.float()
+    c1 = r(F.conv2d(xf, r(w1), b1).relu())
+    c2 = r(F.conv2d(c1, r(w2), b2, padding=1).relu())
+    idn = xf if wds is None else F.conv2d(xf, r(wds), bds)
+    return (F.conv2d(c2, r(w3), b3) + idn).relu()
+
+
+@pytest.mark.parametrize("cin,ds,N,H,W", [
+    (256, False, 2, 24, 48),     # whole tiles
+    (256, False, 1, 13, 21),     # ragged right / bottom tiles
+    (64, True, 2, 16, 32),       # first block: projection shortcut folded into the third GEMM
+    (64, True, 1, 9, 17),
+    (256, False, 1, 3, 5),       # smaller than one tile
+])
+def test_bottleneck64_fused_matches_torch(cin, ds, N, H, W):
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(cin + H * W)
+    x = torch.randn(N, cin, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    w1 = (torch.randn(64, cin, 1, 1, generator=g) / cin ** 0.5).cuda()
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).cuda()
+    w3 = (torch.randn(256, 64, 1, 1, generator=g) / 8.0).cuda()
+    b1, b2, b3 = (torch.randn(n, generator=g).cuda() * 0.3 for n in (64, 64, 256))
+    wds = (torch.randn(256, cin, 1, 1, generator=g) / cin ** 0.5).cuda() if ds else None
+    bds = torch.randn(256, generator=g).cuda() * 0.3 if ds else None
+    pack = ext.bottleneck64_pack(w1, b1, w2, b2, w3, b3, wds, bds)
+    got = ext.bottleneck64_nhwc(x, pack)
+    want = _bottleneck_reference(x, w1, b1, w2, b2, w3, b3, wds, bds)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    d = float((got.float() - want).abs().max())
+    scale = float(want.abs().max())
+    print(f"bottleneck64 cin={cin} ds={ds} {N}x{H}x{W}: max diff {d:.3e} (scale {scale:.2f})")
+    # one bf16 rounding of the output + rounding flips of the bf16 intermediates (f32 summation order differs)
+    assert d <= scale * 2 ** -7 + 1e-5
+    assert float((got.float() - want).abs().mean()) <= scale * 2 ** -11
+
+
+def test_bottleneck64_rejects_other_shapes():
+    from occnet_amd import ext
+    with pytest.raises(ext.OccAmdUnsupported):
+        ext.bottleneck64_pack(torch.zeros(64, 128, 1, 1).cuda(), torch.zeros(64).cuda(),
+                              torch.zeros(64, 64, 3, 3).cuda(), torch.zeros(64).cuda(),
+                              torch.zeros(256, 64, 1, 1).cuda(), torch.zeros(256).cuda())
+
+
+def test_fused_bottleneck_plan_matches_layerwise_plan():
+    """The plan with the whole-bottleneck kernel against the same plan built layer by layer."""
+    from occnet_amd.plugin.backbone import FPN, FusedInferenceBackbone, ResNet
+    torch.manual_seed(0)
+    bb = ResNet(depth=50, num_stages=4, out_indices=(1, 2, 3), frozen_stages=1, norm_eval=True).eval()
+    bb.init_weights()
+    nk = FPN(in_channels=[512, 1024, 2048], out_channels=256, start_level=0, add_extra_convs='on_output',
+             num_outs=4, relu_before_extra_convs=True).eval()
+    bb, nk = bb.cuda(), nk.cuda()
+    x = torch.randn(2, 3, 96, 160).cuda() * 50.0
+    with torch.no_grad():
+        a = FusedInferenceBackbone(bb, nk, fused_bottleneck=True)
+        b = FusedInferenceBackbone(bb, nk, fused_bottleneck=False)
+        assert len(a._bneck) == 3 and not b._bneck
+        for u, v in zip(a(x), b(x)):
+            rel = float((u.float() - v.float()).abs().max() / v.float().abs().max())
+            print(f"level {tuple(u.shape)}: fused vs layerwise max rel diff {rel:.3e}")
+            assert rel < 0.03
+
+
 def test_folded_plan_matches_fp32_modules():
     from occnet_amd.plugin.backbone import FPN, FusedInferenceBackbone, ResNet
     torch.manual_seed(0)

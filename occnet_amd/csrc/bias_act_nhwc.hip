@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_bf16_kernel(
         hi += bf16_to_f32((unsigned short)(rr[k] >> 16));
       }
       if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-      vv[k] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+      vv[k] = pack_bf16x2_rne(lo, hi);
     }
     x[i] = make_uint4(vv[0], vv[1], vv[2], vv[3]);
   }

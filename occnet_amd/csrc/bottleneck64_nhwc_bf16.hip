@@ -40,12 +40,7 @@ constexpr int kBnC2 = 128 * kBnMS;           // 18 432
 constexpr int kBnOLD = 256 + 4;              // epilogue transpose row stride (floats)
 
 __device__ __forceinline__ float bn_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-__device__ __forceinline__ unsigned short bn_f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short bn_f32_to_bf16(float f) { return bf16_rne(f); }
 
 // f32 row-major weight (N, K) -> bf16 MFMA B-fragment order: packed[((ks * N/32 + nt) * 64 + lane) * 8 + j]
 // = w[nt*32 + (lane & 31)][ks*16 + (lane >> 5)*8 + j]   (v_mfma_f32_32x32x16_bf16 operand of lane `lane`)
@@ -104,8 +99,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_nhwc_bf16_kernel(
   OCC_BN_ROLE(2, hofs2, hdst2, hin2, hlive2)
 #undef OCC_BN_ROLE
   const unsigned hm0 = hin0 ? 0xffffffffu : 0u, hm1 = hin1 ? 0xffffffffu : 0u, hm2 = hin2 ? 0xffffffffu : 0u;
-  // two register sets: the x prefetch runs two chunks ahead
-  uint4 vh0_0, vh1_0, vh2_0, vh0_1, vh1_1, vh2_1;
+  // four register sets: the x prefetch runs four chunks ahead (two blocks per CU and ~2 us of HBM latency
+  // under load: with two chunks in flight the phase was latency-bound)
+  uint4 vh0_0, vh1_0, vh2_0, vh0_1, vh1_1, vh2_1, vh0_2, vh1_2, vh2_2, vh0_3, vh1_3, vh2_3;
 #define OCC_BN_ISSUE_X(S, CH)                                                                     \
   {                                                                                               \
     const long cq = (long)(CH) * 4;                                                               \
@@ -115,72 +111,93 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_nhwc_bf16_kernel(
   // variant keeps chunk c in buffer c for phase C
   const int rot = DS ? 0 : (int)((blockIdx.x * 5u) % (unsigned)NCH);
 #define OCC_BN_CH(CI) (((CI) + rot) % NCH)
-  OCC_BN_ISSUE_X(0, OCC_BN_CH(0))
-  OCC_BN_ISSUE_X(1, OCC_BN_CH(NCH > 1 ? 1 : 0))
 
   const int ntA = wave & 1, mtA0 = 3 * (wave >> 1);
+  const int ntB = wave & 1, mtB0 = 2 * (wave >> 1);
+  // The MFMAs of phases A and B are issued with the WEIGHTS as the row operand: D[channel][pixel], so a lane
+  // ends up with ONE pixel (column = lane & 31) and four groups of 4 consecutive channels
+  // (8g + 4*(lane>>5) + 0..3): the bf16 intermediates go to LDS as 8-byte stores of v_cvt_pk pairs and the
+  // per-pixel bookkeeping (in-image test) is done once per row tile, not once per element.
+  // Biases of this lane's channels, requested first (an in-order vmcnt wait on them later would otherwise
+  // also wait for every weight prefetch issued in between)
+  float4 bA[4], bB[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bA[g] = *reinterpret_cast<const float4*>(b1 + ntA * 32 + 8 * g + 4 * kb);
+    bB[g] = *reinterpret_cast<const float4*>(b2 + ntB * 32 + 8 * g + 4 * kb);
+  }
   f32x16 acc1[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
-  // W1 fragments of the current and the next chunk (2 k-steps each)
-  uint4 wa[2][2];
+  // W1 fragments travel with the x chunk of the same index (four sets in flight): vmcnt retires in order,
+  // a weight load younger than the x prefetches would drain them all
+  uint4 wa[4][2];
 #define OCC_BN_ISSUE_W1(SLOT, CH)                                                                 \
   {                                                                                               \
     wa[SLOT][0] = w1p[(((long)(CH) * 2 + 0) * 2 + ntA) * 64 + lane];                              \
     wa[SLOT][1] = w1p[(((long)(CH) * 2 + 1) * 2 + ntA) * 64 + lane];                              \
   }
-  OCC_BN_ISSUE_W1(0, OCC_BN_CH(0))
+#define OCC_BN_ISSUE_XW(S, CH) { OCC_BN_ISSUE_W1(S, CH) OCC_BN_ISSUE_X(S, CH) }
+  OCC_BN_ISSUE_XW(0, OCC_BN_CH(0))
+  OCC_BN_ISSUE_XW(1, OCC_BN_CH(NCH > 1 ? 1 : 0))
+  if (NCH > 2) {
+    OCC_BN_ISSUE_XW(2, OCC_BN_CH(NCH > 2 ? 2 : 0))
+    OCC_BN_ISSUE_XW(3, OCC_BN_CH(NCH > 3 ? 3 : 0))
+  }
 #define OCC_BN_STEP_A(S, CI)                                                                      \
   {                                                                                               \
     char* sX = lds + ((CI) & 1) * kBnXA;                                                          \
     if (hlive0) *reinterpret_cast<uint4*>(sX + hdst0) = make_uint4(vh0_##S.x & hm0, vh0_##S.y & hm0, vh0_##S.z & hm0, vh0_##S.w & hm0); \
     if (hlive1) *reinterpret_cast<uint4*>(sX + hdst1) = make_uint4(vh1_##S.x & hm1, vh1_##S.y & hm1, vh1_##S.z & hm1, vh1_##S.w & hm1); \
     if (hlive2) *reinterpret_cast<uint4*>(sX + hdst2) = make_uint4(vh2_##S.x & hm2, vh2_##S.y & hm2, vh2_##S.z & hm2, vh2_##S.w & hm2); \
+    const bf16x8 wf0 = __builtin_bit_cast(bf16x8, wa[S][0]), wf1 = __builtin_bit_cast(bf16x8, wa[S][1]); \
     __syncthreads();                                                                              \
-    OCC_BN_ISSUE_X(S, OCC_BN_CH((CI) + 2 < NCH ? (CI) + 2 : NCH - 1))                             \
-    OCC_BN_ISSUE_W1(((CI) + 1) & 1, OCC_BN_CH((CI) + 1 < NCH ? (CI) + 1 : NCH - 1))               \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
-      const bf16x8 wf = __builtin_bit_cast(bf16x8, wa[(CI) & 1][ks]);                             \
-      _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                             \
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(sX + ((mtA0 + j) * 32 + vi) * kBnXS + ks * 32 + kb * 16); \
-        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf, acc1[j], 0, 0, 0);              \
-      }                                                                                           \
+    if ((CI) + 4 < NCH) OCC_BN_ISSUE_XW(S, OCC_BN_CH((CI) + 4 < NCH ? (CI) + 4 : NCH - 1))        \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                               \
+      const bf16x8 af0 = *reinterpret_cast<const bf16x8*>(sX + ((mtA0 + j) * 32 + vi) * kBnXS + kb * 16);      \
+      const bf16x8 af1 = *reinterpret_cast<const bf16x8*>(sX + ((mtA0 + j) * 32 + vi) * kBnXS + 32 + kb * 16); \
+      acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, af0, acc1[j], 0, 0, 0);              \
+      acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, af1, acc1[j], 0, 0, 0);              \
     }                                                                                             \
   }
 #pragma unroll
-  for (int ci = 0; ci < NCH; ci += 2) {
+  for (int ci = 0; ci < NCH; ci += 4) {
     OCC_BN_STEP_A(0, ci)
     if (ci + 1 < NCH) OCC_BN_STEP_A(1, ci + 1)
+    if (ci + 2 < NCH) OCC_BN_STEP_A(2, ci + 2)
+    if (ci + 3 < NCH) OCC_BN_STEP_A(3, ci + 3)
   }
 #undef OCC_BN_STEP_A
+#undef OCC_BN_ISSUE_XW
 #undef OCC_BN_ISSUE_W1
 #undef OCC_BN_ISSUE_X
 #undef OCC_BN_CH
 
   // first W2 fragments in flight while c1 is written
-  const int ntB = wave & 1, mtB0 = 2 * (wave >> 1);
-  constexpr int PFB = 6;
+  constexpr int PFB = 12;
   uint4 wr[PFB];
 #pragma unroll
   for (int s = 0; s < PFB; ++s) wr[s] = w2p[((long)s * 2 + ntB) * 64 + lane];
 
-  {   // c1 halo: bias + ReLU, zero outside the image (conv2's zero padding applies to c1, not to x)
-    const float bv = b1[ntA * 32 + vi];
+  // c1 halo: bias + ReLU, zero outside the image (conv2's zero padding applies to c1, not to x); the halo
+  // slot of pixel p = hy*18 + hx is simply p * 144 bytes
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < 3; ++j) {
+    const int p = (mtA0 + j) * 32 + vi;
+    const int hy = p / kBnHW, hx = p - hy * kBnHW;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const float m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
+    if (p < kBnNP) {
+      char* dst = sH1 + p * kBnMS + (ntA * 32 + 4 * kb) * 2;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int p = (mtA0 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-        if (p < kBnNP) {
-          const int hy = p / kBnHW, hx = p - hy * kBnHW;
-          const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-          const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
-          const float v = in ? fmaxf(acc1[j][r] + bv, 0.f) : 0.f;
-          *reinterpret_cast<unsigned short*>(sH1 + hy * kBnH1ROW + hx * kBnMS + (ntA * 32 + vi) * 2) = bn_f32_to_bf16(v);
-        }
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = fmaxf(acc1[j][4 * g + 0] + bA[g].x, 0.f) * m, v1 = fmaxf(acc1[j][4 * g + 1] + bA[g].y, 0.f) * m;
+        const float v2 = fmaxf(acc1[j][4 * g + 2] + bA[g].z, 0.f) * m, v3 = fmaxf(acc1[j][4 * g + 3] + bA[g].w, 0.f) * m;
+        *reinterpret_cast<uint2*>(dst + 16 * g) = make_uint2(pack_bf16x2_rne(v0, v1), pack_bf16x2_rne(v2, v3));
       }
+    }
   }
   __syncthreads();
 
@@ -192,20 +209,30 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_nhwc_bf16_kernel(
     for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
   const int ab0 = (2 * mtB0 + (vi >> 4)) * kBnH1ROW + (vi & 15) * kBnMS + kb * 16;
   const int ab1 = ab0 + 2 * kBnH1ROW;
+  {
+    bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sH1 + ab0), a1 = *reinterpret_cast<const bf16x8*>(sH1 + ab1);
 #pragma unroll
-  for (int s = 0; s < 36; ++s) {
-    const int tap = s >> 2, ks = s & 3;
-    const int toff = (tap / 3) * kBnH1ROW + (tap % 3) * kBnMS + ks * 32;
-    const bf16x8 wf = __builtin_bit_cast(bf16x8, wr[s % PFB]);
-    if (s + PFB < 36) wr[s % PFB] = w2p[((long)(s + PFB) * 2 + ntB) * 64 + lane];
-    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sH1 + ab0 + toff);
-    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sH1 + ab1 + toff);
-    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf, acc2[0], 0, 0, 0);
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf, acc2[1], 0, 0, 0);
+    for (int s = 0; s < 36; ++s) {
+      const bf16x8 wf = __builtin_bit_cast(bf16x8, wr[s % PFB]);
+      // the ring keeps PFB weight loads in flight; the scheduling barrier keeps hipcc from sinking them
+      // behind the MFMAs (it would otherwise run the phase with two loads in flight, L2-latency-bound)
+      if (s + PFB < 36) wr[s % PFB] = w2p[((long)(s + PFB) * 2 + ntB) * 64 + lane];
+      bf16x8 a0n = a0, a1n = a1;
+      if (s + 1 < 36) {   // next k-step's pixel fragments while this step's MFMAs run
+        const int tap = (s + 1) >> 2, ks = (s + 1) & 3;
+        const int toff = (tap / 3) * kBnH1ROW + (tap % 3) * kBnMS + ks * 32;
+        a0n = *reinterpret_cast<const bf16x8*>(sH1 + ab0 + toff);
+        a1n = *reinterpret_cast<const bf16x8*>(sH1 + ab1 + toff);
+      }
+      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a0, acc2[0], 0, 0, 0);
+      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, a1, acc2[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a0n; a1 = a1n;
+    }
   }
-  // first W3 fragments in flight while c2 is written
+  // W3 fragments (ring of 4 k-steps) in flight while c2 is written
   constexpr int KS3 = DS ? 8 : 4;
-  uint4 w3r[2][2];
+  uint4 w3r[4][2];
 #define OCC_BN_ISSUE_W3(SLOT, KS)                                                                 \
   {                                                                                               \
     w3r[SLOT][0] = w3p[((long)(KS) * 8 + 2 * wave + 0) * 64 + lane];                              \
@@ -213,20 +240,22 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_nhwc_bf16_kernel(
   }
   OCC_BN_ISSUE_W3(0, 0)
   OCC_BN_ISSUE_W3(1, 1)
-  {
-    const float bv = b2[ntB * 32 + vi];
+  OCC_BN_ISSUE_W3(2, 2)
+  OCC_BN_ISSUE_W3(3, 3)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 2; ++j) {
+    char* dst = sC2 + ((mtB0 + j) * 32 + vi) * kBnMS + (ntB * 32 + 4 * kb) * 2;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int px = (mtB0 + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-        *reinterpret_cast<unsigned short*>(sC2 + px * kBnMS + (ntB * 32 + vi) * 2) =
-            bn_f32_to_bf16(fmaxf(acc2[j][r] + bv, 0.f));
-      }
+    for (int g = 0; g < 4; ++g) {
+      const float v0 = fmaxf(acc2[j][4 * g + 0] + bB[g].x, 0.f), v1 = fmaxf(acc2[j][4 * g + 1] + bB[g].y, 0.f);
+      const float v2 = fmaxf(acc2[j][4 * g + 2] + bB[g].z, 0.f), v3 = fmaxf(acc2[j][4 * g + 3] + bB[g].w, 0.f);
+      *reinterpret_cast<uint2*>(dst + 16 * g) = make_uint2(pack_bf16x2_rne(v0, v1), pack_bf16x2_rne(v2, v3));
+    }
   }
   __syncthreads();
 
   // ================= phase C: out = relu(c2 . W3^T (+ x . Wds^T) + b3 (+ x)) ==============================
+  // (pixels as the row operand again: the epilogue wants D[pixel][channel])
   f32x16 acc3[4][2];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
@@ -236,9 +265,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_nhwc_bf16_kernel(
       for (int r = 0; r < 16; ++r) acc3[rt][t][r] = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS3; ++ks) {
-    const bf16x8 wf0 = __builtin_bit_cast(bf16x8, w3r[ks & 1][0]);
-    const bf16x8 wf1 = __builtin_bit_cast(bf16x8, w3r[ks & 1][1]);
-    if (ks + 2 < KS3) OCC_BN_ISSUE_W3(ks & 1, ks + 2)
+    const bf16x8 wf0 = __builtin_bit_cast(bf16x8, w3r[ks & 3][0]);
+    const bf16x8 wf1 = __builtin_bit_cast(bf16x8, w3r[ks & 3][1]);
+    if (ks + 4 < KS3) OCC_BN_ISSUE_W3(ks & 3, ks + 4)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       bf16x8 af;
@@ -259,6 +288,18 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_nhwc_bf16_kernel(
   const float4 bv = *reinterpret_cast<const float4*>(b3 + c);
   float* sO = reinterpret_cast<float*>(lds);
   const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
+  // identity = x (Cin == 256): the 8 rows a wave adds in pass rt are requested one pass ahead
+  uint2 rv[8], rn[8];
+#define OCC_BN_ISSUE_RES(DST, RT)                                                                 \
+  _Pragma("unroll") for (int rr = 0; rr < 8; ++rr) {                                              \
+    DST[rr] = make_uint2(0u, 0u);                                                                 \
+    if (!DS) {                                                                                    \
+      const int row = wave * 8 + rr;                                                              \
+      const int cy = min(y0 + 2 * (RT) + (row >> 4), H - 1), cx = min(x0 + (row & 15), W - 1);    \
+      DST[rr] = *reinterpret_cast<const uint2*>(xs + (((long)img * H + cy) * W + cx) * CIN + c);  \
+    }                                                                                             \
+  }
+  OCC_BN_ISSUE_RES(rn, 0)
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     __syncthreads();
@@ -267,17 +308,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_nhwc_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         sO[((r & 3) + 8 * (r >> 2) + 4 * kb) * kBnOLD + (wave * 2 + t) * 32 + vi] = acc3[rt][t][r];
-    __syncthreads();
-    uint2 rv[8];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      rv[rr] = make_uint2(0u, 0u);
-      if (!DS) {   // identity = x (Cin == 256): all 8 rows requested before any is consumed
-        const int row = wave * 8 + rr;
-        const int cy = min(y0 + 2 * rt + (row >> 4), H - 1), cx = min(x0 + (row & 15), W - 1);
-        rv[rr] = *reinterpret_cast<const uint2*>(xs + (((long)img * H + cy) * W + cx) * CIN + c);
-      }
-    }
+    for (int rr = 0; rr < 8; ++rr) rv[rr] = rn[rr];
+    if (rt + 1 < 4) OCC_BN_ISSUE_RES(rn, rt + 1)
+    __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int row = wave * 8 + rr;
@@ -289,12 +323,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck64_nhwc_bf16_kernel(
         v.z += bv.z + bn_bf16_to_f32((unsigned short)(rv[rr].y & 0xffffu));
         v.w += bv.w + bn_bf16_to_f32((unsigned short)(rv[rr].y >> 16));
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        const uint2 o = make_uint2((unsigned)bn_f32_to_bf16(v.x) | ((unsigned)bn_f32_to_bf16(v.y) << 16),
-                                   (unsigned)bn_f32_to_bf16(v.z) | ((unsigned)bn_f32_to_bf16(v.w) << 16));
+        const uint2 o = make_uint2(pack_bf16x2_rne(v.x, v.y), pack_bf16x2_rne(v.z, v.w));
         *reinterpret_cast<uint2*>(out + (((long)img * H + oy) * W + ox) * 256 + c) = o;
       }
     }
   }
+#undef OCC_BN_ISSUE_RES
 }
 
 }  // namespace occ

@@ -60,6 +60,19 @@ __device__ __forceinline__ int bilinear_setup(float loc_x, float loc_y, float at
   return n_in;
 }
 
+// f32 -> bf16, round to nearest even, two values per instruction: gfx950's v_cvt_pk_bf16_f32 (one VALU op
+// instead of ~7 per value for the integer restatement of RNE; the epilogues of the bf16 kernels are
+// VALU-issue-bound otherwise).  Result: lo in bits 0..15, hi in bits 16..31.
+__device__ __forceinline__ unsigned pack_bf16x2_rne(float lo, float hi) {
+  typedef float occ_f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 occ_bf16x2 __attribute__((ext_vector_type(2)));
+  const occ_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, occ_bf16x2));
+}
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+  return (unsigned short)(pack_bf16x2_rne(f, 0.f) & 0xffffu);
+}
+
 // Orders this wave's LDS writes before its later LDS reads (cross-lane hand-off inside ONE wave:
 // the hardware executes a wave's DS instructions in order, the fences only pin the compiler).
 __device__ __forceinline__ void wave_lds_sync() {

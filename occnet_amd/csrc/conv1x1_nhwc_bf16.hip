@@ -27,12 +27,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int KC> struct C1Geom { static constexpr int LD = KC * 2 + 16, PIECES = KC / 8; };
 
 __device__ __forceinline__ float c1_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-__device__ __forceinline__ unsigned short c1_f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
 
 template <int NT, int RT, int KC>
 __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
@@ -207,8 +201,7 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
         if (relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        const uint2 o = make_uint2((unsigned)c1_f32_to_bf16(v.x) | ((unsigned)c1_f32_to_bf16(v.y) << 16),
-                                   (unsigned)c1_f32_to_bf16(v.z) | ((unsigned)c1_f32_to_bf16(v.w) << 16));
+        const uint2 o = make_uint2(pack_bf16x2_rne(v.x, v.y), pack_bf16x2_rne(v.z, v.w));
         *reinterpret_cast<uint2*>(out + m * N + n0 + c) = o;
       }
     }

@@ -25,12 +25,7 @@ constexpr int kC3HH = kC3TH + 2, kC3HW = kC3TW + 2;   // halo
 constexpr int kC3PX = 80;                             // bytes per halo pixel slot (32 bf16 + 16 pad)
 constexpr int kC3ROW = 1536;                          // bytes per halo row (18 x 80 = 1440 -> 1536)
 
-__device__ __forceinline__ unsigned short c3_f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short c3_f32_to_bf16(float f) { return bf16_rne(f); }
 
 // torch weight (Cout, Cin, 3, 3) f32 -> packed[Cin/32][tap = ky*3+kx][co][32 ci] bf16 (chunk/tap-major: the
 // slice a wave stages per (chunk, tap) is contiguous)
@@ -205,8 +200,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
         if (relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        const uint2 o = make_uint2((unsigned)c3_f32_to_bf16(v.x) | ((unsigned)c3_f32_to_bf16(v.y) << 16),
-                                   (unsigned)c3_f32_to_bf16(v.z) | ((unsigned)c3_f32_to_bf16(v.w) << 16));
+        const uint2 o = make_uint2(pack_bf16x2_rne(v.x, v.y), pack_bf16x2_rne(v.z, v.w));
         *reinterpret_cast<uint2*>(out + (((long)img * H + oy) * W + ox) * Cout + n0 + c) = o;
       }
     }

@@ -28,14 +28,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kXBK = 16;          // k per chunk = one 32x32x16 MFMA step
 constexpr int kXLD = 48;          // LDS row stride in BYTES: 16 bf16 (32 B) + 16 B pad
 
-__device__ __forceinline__ unsigned short x3_bf16_rne(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short x3_bf16_rne(float f) { return bf16_rne(f); }
+// two values at once: hi pair = cvt_pk(x0, x1), lo pair = cvt_pk(x0 - hi0, x1 - hi1)   (6 VALU ops per pair)
 __device__ __forceinline__ void x3_split(float x, unsigned short& hi, unsigned short& lo) {
   hi = x3_bf16_rne(x);
   lo = x3_bf16_rne(x - __uint_as_float((unsigned)hi << 16));
+}
+__device__ __forceinline__ void x3_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2_rne(x0, x1);
+  lo = pack_bf16x2_rne(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
 }
 __device__ __forceinline__ float x3_wave_sum(float v) {
 #pragma unroll
@@ -139,12 +140,10 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
     if (a_live) {   // f32 x4 (+ addend) -> 4 hi bf16 + 4 lo bf16 into the two A planes
       const float f0 = ADD ? fmaf(addscale, vd.x, va.x) : va.x, f1 = ADD ? fmaf(addscale, vd.y, va.y) : va.y;
       const float f2 = ADD ? fmaf(addscale, vd.z, va.z) : va.z, f3 = ADD ? fmaf(addscale, vd.w, va.w) : va.w;
-      unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-      x3_split(f0, h0, l0); x3_split(f1, h1, l1); x3_split(f2, h2, l2); x3_split(f3, h3, l3);
-      *reinterpret_cast<uint2*>(sAh + arow * kXLD + sp * 8) =
-          make_uint2((unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16));
-      *reinterpret_cast<uint2*>(sAl + arow * kXLD + sp * 8) =
-          make_uint2((unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16));
+      unsigned h01, h23, l01, l23;
+      x3_split2(f0, f1, h01, l01); x3_split2(f2, f3, h23, l23);
+      *reinterpret_cast<uint2*>(sAh + arow * kXLD + sp * 8) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(sAl + arow * kXLD + sp * 8) = make_uint2(l01, l23);
     }
     OCC_X3_PUT_W(vw0, srow)
     OCC_X3_PUT_W(vw1, srow + 16)

@@ -222,6 +222,13 @@ int occ_dvr_render_forward_f32(const float* sigma, const float* origin, const fl
 int occ_bias_act_nhwc_bf16(void* x, const float* bias, const void* residual, int64_t rows, int C, int relu,
                            void* stream);
 
+/* Stem tail in one pass: out = max_pool2d(relu(y + bias), kernel 3, stride 2, padding 1) on NHWC bf16
+ * (outside the hand-written hot path).  y (batch, H, W, C) bf16 raw convolution output ; bias (C) f32 ;
+ * out (batch, (H-1)/2+1, (W-1)/2+1, C) bf16.  Needs C % 8 == 0.
+ */
+int occ_bias_relu_maxpool_nhwc_bf16(const void* y, const float* bias, void* out, int batch, int H, int W, int C,
+                                    void* stream);
+
 /* Backbone 1x1 convolution on NHWC bf16 (outside the hand-written hot path, like the call above):
  * out[(n,yo,xo), co] = relu?( sum_ci x[(n, yo*stride, xo*stride), ci] * weight[co, ci] + bias[co]
  *                             (+ residual[(n,yo,xo), co]) ), bf16 in, f32 accumulate, bf16 out.
@@ -233,14 +240,15 @@ int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const float* bias, 
                           void* out, int batch, int Hin, int Win, int Cin, int Cout, int stride, int relu,
                           void* stream);
 
-/* Backbone 3x3 stride-1 pad-1 convolution on NHWC bf16 with bias (+ ReLU) fused (outside the hand-written hot
- * path).  x (batch, H, W, Cin) bf16 ; weight packed by occ_conv3x3_pack_weight_bf16 from torch's
- * (Cout, Cin, 3, 3) f32 layout to [Cin/32][tap][co][32] bf16 ; bias (Cout) f32 ; out (batch, H, W, Cout) bf16.
- * Needs Cin % 32 == 0 and Cout % 128 == 0, otherwise OCC_E_UNSUPPORTED (the caller keeps MIOpen).
+/* Backbone 3x3 pad-1 convolution, stride 1 or 2, on NHWC bf16 with bias (+ ReLU) fused (outside the
+ * hand-written hot path).  x (batch, H, W, Cin) bf16 ; weight packed by occ_conv3x3_pack_weight_bf16 from
+ * torch's (Cout, Cin, 3, 3) f32 layout to [Cin/32][tap][co][32] bf16 ; bias (Cout) f32 ;
+ * out (batch, (H-1)/stride+1, (W-1)/stride+1, Cout) bf16.
+ * Needs Cin % 32 == 0, Cout % 128 == 0, stride in {1, 2}, otherwise OCC_E_UNSUPPORTED (the caller keeps MIOpen).
  */
 int occ_conv3x3_pack_weight_bf16(const float* weight, void* packed, int Cout, int Cin, void* stream);
 int occ_conv3x3_nhwc_bf16(const void* x, const void* weight_packed, const float* bias, void* out, int batch,
-                          int H, int W, int Cin, int Cout, int relu, void* stream);
+                          int H, int W, int Cin, int Cout, int stride, int relu, void* stream);
 
 /* MFMA B-operand packing: f32 row-major (N, K) matrix -> bf16 in v_mfma_f32_32x32x16_bf16 fragment order
  * packed[((ks * N/32 + nt) * 64 + lane) * 8 + j] = w[nt*32 + (lane & 31)][ks*16 + (lane >> 5)*8 + j], so a wave

@@ -11,13 +11,6 @@
 namespace occ {
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                                   // RNE
-  return (unsigned short)(u >> 16);
-}
-
 __global__ __launch_bounds__(256) void bias_act_nhwc_bf16_kernel(
     uint4* __restrict__ x, const float* __restrict__ bias, const uint4* __restrict__ residual, long n_vec,
     int C, int relu) {
@@ -46,6 +39,46 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_bf16_kernel(
   }
 }
 
+// Stem tail: out = maxpool3x3/s2/p1( relu(y + bias) ) in ONE pass over the raw convolution output
+// (= relu(max(y) + bias): bias and ReLU are monotonic), instead of the in-place bias/ReLU pass plus PyTorch's
+// pooling kernel.  One lane = one output pixel x 8 channels: nine 16-byte loads (padding taps skipped, as
+// max_pool2d pads with -inf), fp32 max, one 16-byte store.  HBM-bound on reading y once.
+__global__ __launch_bounds__(256) void bias_relu_maxpool_nhwc_bf16_kernel(
+    const uint4* __restrict__ y, const float* __restrict__ bias, uint4* __restrict__ out, long n_vec, int H,
+    int W, int C8, int Ho, int Wo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_vec) return;
+  const int cg = (int)(i % C8);
+  long r = i / C8;
+  const int ox = (int)(r % Wo); r /= Wo;
+  const int oy = (int)(r % Ho);
+  const long n = r / Ho;
+  float m[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const uint4 v = y[((n * H + iy) * W + ix) * C8 + cg];
+        const unsigned vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          m[2 * k] = fmaxf(m[2 * k], __uint_as_float(vv[k] << 16));
+          m[2 * k + 1] = fmaxf(m[2 * k + 1], __uint_as_float(vv[k] & 0xffff0000u));
+        }
+      }
+    }
+  const float4 b0 = *reinterpret_cast<const float4*>(bias + cg * 8);
+  const float4 b1 = *reinterpret_cast<const float4*>(bias + cg * 8 + 4);
+  out[i] = make_uint4(pack_bf16x2_rne(fmaxf(m[0] + b0.x, 0.f), fmaxf(m[1] + b0.y, 0.f)),
+                      pack_bf16x2_rne(fmaxf(m[2] + b0.z, 0.f), fmaxf(m[3] + b0.w, 0.f)),
+                      pack_bf16x2_rne(fmaxf(m[4] + b1.x, 0.f), fmaxf(m[5] + b1.y, 0.f)),
+                      pack_bf16x2_rne(fmaxf(m[6] + b1.z, 0.f), fmaxf(m[7] + b1.w, 0.f)));
+}
+
 }  // namespace occ
 
 extern "C" int occ_bias_act_nhwc_bf16(void* x, const float* bias, const void* residual, int64_t rows,
@@ -64,5 +97,23 @@ extern "C" int occ_bias_act_nhwc_bf16(void* x, const float* bias, const void* re
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<uint4*>(x), bias,
                      reinterpret_cast<const uint4*>(residual), n_vec, C, relu);
   OCC_CHECK_LAUNCH("bias_act_nhwc_bf16");
+  return OCC_OK;
+}
+
+extern "C" int occ_bias_relu_maxpool_nhwc_bf16(const void* y, const float* bias, void* out, int batch, int H,
+                                               int W, int C, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(y && bias && out, "bias_relu_maxpool_nhwc_bf16: null pointer argument");
+  OCC_CHECK_ARG(batch > 0 && H > 0 && W > 0 && C > 0, "bias_relu_maxpool_nhwc_bf16: bad dimension");
+  if (C % 8) {
+    set_error("bias_relu_maxpool_nhwc_bf16: channel count %d is not a multiple of 8", C);
+    return OCC_E_UNSUPPORTED;
+  }
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;      // floor((H + 2 - 3) / 2) + 1
+  const long n_vec = (long)batch * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(bias_relu_maxpool_nhwc_bf16_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint4*>(y), bias,
+                     reinterpret_cast<uint4*>(out), n_vec, H, W, C / 8, Ho, Wo);
+  OCC_CHECK_LAUNCH("bias_relu_maxpool_nhwc_bf16");
   return OCC_OK;
 }

@@ -1,10 +1,11 @@
-// Backbone 3x3 / stride-1 / pad-1 convolutions (NHWC bf16) as an implicit GEMM on the gfx950 bf16 matrix
+// Backbone 3x3 / pad-1 convolutions, stride 1 or 2 (NHWC bf16) as an implicit GEMM on the gfx950 bf16 matrix
 // cores with bias + ReLU fused: out = relu?( conv3x3(x, W) + bias ), bf16 in / f32 accumulate / bf16 out.
 //
 // NOT part of the hand-written hot path: it replaces MIOpen's igemm kernel plus its
 // zero-fill / cast helpers plus the elementwise tail for the stride-1 3x3 convolutions of the reference's
-// ResNet-50 (mmdet Bottleneck conv2, style='pytorch') and FPN output convolutions, when Cout % 128 == 0 and
-// Cin % 32 == 0; other convolutions (7x7 stem, stride-2, 64-channel layer1) stay on MIOpen.
+// ResNet-50 (mmdet Bottleneck conv2, style='pytorch', incl. the stride-2 first blocks of layer2..4) and the
+// FPN output / extra-level convolutions, when Cout % 128 == 0 and Cin % 32 == 0; the 7x7 stem stays on MIOpen
+// (the 64-channel layer1 blocks have their own whole-bottleneck kernel).
 //
 // GEMM view: M = output pixels, N = Cout, K = 9 taps x Cin.  Block = 4 waves x (8 x 16 output pixels = four
 // 32-pixel MFMA row tiles of two image rows each) x 128*NT output channels; waves split N.  Per chunk of 32
@@ -20,10 +21,18 @@ namespace occ {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kC3TH = 8, kC3TW = 16;                  // output tile
-constexpr int kC3HH = kC3TH + 2, kC3HW = kC3TW + 2;   // halo
+constexpr int kC3TW = 16;                             // output tile width (one MFMA row tile = 2 x 16 pixels)
 constexpr int kC3PX = 80;                             // bytes per halo pixel slot (32 bf16 + 16 pad)
-constexpr int kC3ROW = 1536;                          // bytes per halo row (18 x 80 = 1440 -> 1536)
+// Tile geometry per stride S: output tile TH x 16, input halo HH x HW.  Stride 2 keeps the halo columns
+// DE-INTERLEAVED in LDS (17 even columns, then 17 odd-column slots): for a fixed tap the 16 output pixels of a
+// row then read 16 CONSECUTIVE 80-byte slots, conflict-free like stride 1 (a 160-byte lane stride is not).
+template <int S> struct C3Geom {
+  static constexpr int TH = S == 1 ? 8 : 4, RT = TH / 2;
+  static constexpr int HH = (TH - 1) * S + 3, HW = (kC3TW - 1) * S + 3;     // 10 x 18  /  9 x 33
+  static constexpr int ROW = S == 1 ? 1536 : 34 * kC3PX;                    // bytes per halo row
+  static constexpr int ITEMS = HH * HW * 4, NR = (ITEMS + 255) / 256;       // 16-byte staging items / roles
+  __device__ static constexpr int slot(int hx) { return S == 1 ? hx : (hx & 1) * 17 + (hx >> 1); }
+};
 
 __device__ __forceinline__ unsigned short c3_f32_to_bf16(float f) { return bf16_rne(f); }
 
@@ -43,12 +52,15 @@ __global__ void conv3x3_pack_weight_kernel(const float* __restrict__ w, unsigned
   packed[idx] = c3_f32_to_bf16(w[((long)co * Cin + ci) * 9 + tap]);
 }
 
-template <int NT>
+template <int NT, int S>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ bias,
-    unsigned short* __restrict__ out, int H, int W, int Cin, int Cout, int tiles_x, int tiles_y, int relu) {
-  constexpr int RT = 4, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
-  constexpr int HALO_BYTES = kC3HH * kC3ROW;                 // 15 360
+    unsigned short* __restrict__ out, int H, int W, int Ho, int Wo, int Cin, int Cout, int tiles_x,
+    int tiles_y, int relu) {
+  using G = C3Geom<S>;
+  constexpr int RT = G::RT, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
+  constexpr int kC3ROW = G::ROW, kC3TH = G::TH;
+  constexpr int HALO_BYTES = G::HH * kC3ROW;                 // 15 360 (stride 1) / 24 480 (stride 2)
   constexpr int W_BYTES = WR * kC3PX;                        // one tap's slice of one wave
   constexpr int STAGE_BYTES = 2 * HALO_BYTES + 4 * 2 * W_BYTES, OUT_BYTES = 32 * OLD * 4;
   __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
@@ -71,27 +83,31 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
-  // halo staging roles: 180 pixels x 4 pieces = 720 items over 256 threads (3 per thread, clamped +
-  // zero-selected, unconditional loads)
+  // halo staging roles: HH x HW pixels x 4 pieces of 16 B over 256 threads (3 per thread at stride 1, 5 at
+  // stride 2; clamped + zero-masked, unconditional loads)
   // (named scalars: small per-thread arrays written in a loop end up in scratch with hipcc / ROCm 7.2)
-  long hofs0, hofs1, hofs2;
-  int hdst0, hdst1, hdst2;
-  bool hin0, hin1, hin2, hlive0, hlive1, hlive2;
+  constexpr int NR = G::NR;
+  static_assert(NR <= 5, "halo staging register budget");
+  long hofs0, hofs1, hofs2, hofs3 = 0, hofs4 = 0;
+  int hdst0, hdst1, hdst2, hdst3 = 0, hdst4 = 0;
+  bool hin0, hin1, hin2, hin3 = false, hin4 = false, hlive0, hlive1, hlive2, hlive3 = false, hlive4 = false;
 #define OCC_C3_HALO_ROLE(K, OFS, DST, IN, LIVE)                                                   \
   {                                                                                               \
     const int idx = tid + 256 * (K);                                                              \
-    LIVE = idx < kC3HH * kC3HW * 4;                                                               \
+    LIVE = idx < G::ITEMS;                                                                        \
     const int p = LIVE ? idx >> 2 : 0, piece = idx & 3;                                           \
-    const int hy = p / kC3HW, hx = p % kC3HW;                                                     \
-    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;                                                 \
+    const int hy = p / G::HW, hx = p % G::HW;                                                     \
+    const int iy = y0 * S - 1 + hy, ix = x0 * S - 1 + hx;                                         \
     IN = LIVE && iy >= 0 && iy < H && ix >= 0 && ix < W;                                          \
     const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);                           \
     OFS = (((long)img * H + cy) * W + cx) * CQ + piece;                                           \
-    DST = hy * kC3ROW + hx * kC3PX + piece * 16;                                                  \
+    DST = hy * kC3ROW + G::slot(hx) * kC3PX + piece * 16;                                         \
   }
   OCC_C3_HALO_ROLE(0, hofs0, hdst0, hin0, hlive0)
   OCC_C3_HALO_ROLE(1, hofs1, hdst1, hin1, hlive1)
   OCC_C3_HALO_ROLE(2, hofs2, hdst2, hin2, hlive2)
+  if (NR > 3) OCC_C3_HALO_ROLE(3, hofs3, hdst3, hin3, hlive3)
+  if (NR > 4) OCC_C3_HALO_ROLE(4, hofs4, hdst4, hin4, hlive4)
 #undef OCC_C3_HALO_ROLE
   // weight staging roles: lane -> (row = lane/4 + 16*it, piece = lane%4)
   const int srow = lane >> 2, sp = lane & 3;
@@ -105,14 +121,17 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
   int abase[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
-    abase[rt] = (2 * rt + (vi >> 4)) * kC3ROW + (vi & 15) * kC3PX + kb * 16;
+    abase[rt] = (2 * rt + (vi >> 4)) * S * kC3ROW + (vi & 15) * kC3PX + kb * 16;
 
-  uint4 vh0, vh1, vh2, vw0, vw1, vw2, vw3;
+  uint4 vh0, vh1, vh2, vh3, vh4, vw0, vw1, vw2, vw3;
   const unsigned hm0 = hin0 ? 0xffffffffu : 0u, hm1 = hin1 ? 0xffffffffu : 0u, hm2 = hin2 ? 0xffffffffu : 0u;
+  const unsigned hm3 = hin3 ? 0xffffffffu : 0u, hm4 = hin4 ? 0xffffffffu : 0u;
 #define OCC_C3_ISSUE_HALO(CH)                                                                     \
   {                                                                                               \
     const long cq = (long)(CH) * 4;                                                               \
     vh0 = x[hofs0 + cq]; vh1 = x[hofs1 + cq]; vh2 = x[hofs2 + cq];                                \
+    if (NR > 3) vh3 = x[hofs3 + cq];                                                              \
+    if (NR > 4) vh4 = x[hofs4 + cq];                                                              \
   }
 #define OCC_C3_ISSUE_W(CH, TAP)                                                                   \
   {                                                                                               \
@@ -132,6 +151,8 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
     if (hlive0) *reinterpret_cast<uint4*>(sH + hdst0) = make_uint4(vh0.x & hm0, vh0.y & hm0, vh0.z & hm0, vh0.w & hm0);
     if (hlive1) *reinterpret_cast<uint4*>(sH + hdst1) = make_uint4(vh1.x & hm1, vh1.y & hm1, vh1.z & hm1, vh1.w & hm1);
     if (hlive2) *reinterpret_cast<uint4*>(sH + hdst2) = make_uint4(vh2.x & hm2, vh2.y & hm2, vh2.z & hm2, vh2.w & hm2);
+    if (NR > 3 && hlive3) *reinterpret_cast<uint4*>(sH + hdst3) = make_uint4(vh3.x & hm3, vh3.y & hm3, vh3.z & hm3, vh3.w & hm3);
+    if (NR > 4 && hlive4) *reinterpret_cast<uint4*>(sH + hdst4) = make_uint4(vh4.x & hm4, vh4.y & hm4, vh4.z & hm4, vh4.w & hm4);
     __syncthreads();   // halo chunk visible; the other halo buffer is free for the next chunk
     OCC_C3_ISSUE_HALO(OCC_C3_CH(ch + 1 < NCH ? ch + 1 : ch))
 #pragma unroll
@@ -149,7 +170,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
         const int nc = tap + 1 < 9 ? ch : (ch + 1 < NCH ? ch + 1 : ch);
         OCC_C3_ISSUE_W(OCC_C3_CH(nc), nt)
       }
-      const int toff = (tap / 3) * kC3ROW + (tap % 3) * kC3PX;
+      const int toff = (tap / 3) * kC3ROW + G::slot(tap % 3) * kC3PX;
       bf16x8 af[RT][2], wf[NT][2];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -194,14 +215,14 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_bf16_kernel(
     for (int rr = 0; rr < 8; ++rr) {
       const int row = wave * 8 + rr;                       // pixel inside the row tile
       const int oy = y0 + 2 * rt + (row >> 4), ox = x0 + (row & 15);
-      if (oy < H && ox < W && col_live) {
+      if (oy < Ho && ox < Wo && col_live) {
         float4 v = *reinterpret_cast<const float4*>(sO + row * OLD + c);
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         if (relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         const uint2 o = make_uint2(pack_bf16x2_rne(v.x, v.y), pack_bf16x2_rne(v.z, v.w));
-        *reinterpret_cast<uint2*>(out + (((long)img * H + oy) * W + ox) * Cout + n0 + c) = o;
+        *reinterpret_cast<uint2*>(out + (((long)img * Ho + oy) * Wo + ox) * Cout + n0 + c) = o;
       }
     }
   }
@@ -227,24 +248,31 @@ extern "C" int occ_conv3x3_pack_weight_bf16(const float* weight, void* packed, i
 }
 
 extern "C" int occ_conv3x3_nhwc_bf16(const void* x, const void* weight_packed, const float* bias, void* out,
-                                     int batch, int H, int W, int Cin, int Cout, int relu, void* stream) {
+                                     int batch, int H, int W, int Cin, int Cout, int stride, int relu,
+                                     void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(x && weight_packed && bias && out, "conv3x3_nhwc_bf16: null pointer argument");
   OCC_CHECK_ARG(batch > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_nhwc_bf16: bad dimension");
-  if (Cin % 32 || Cout % 128) {
-    set_error("conv3x3_nhwc_bf16: no kernel for Cin=%d Cout=%d (need Cin %% 32 == 0, Cout %% 128 == 0)", Cin,
-              Cout);
+  if (Cin % 32 || Cout % 128 || (stride != 1 && stride != 2)) {
+    set_error("conv3x3_nhwc_bf16: no kernel for Cin=%d Cout=%d stride=%d (need Cin %% 32 == 0, Cout %% 128 == 0, "
+              "stride 1 or 2)", Cin, Cout, stride);
     return OCC_E_UNSUPPORTED;
   }
-  const int tiles_x = (W + kC3TW - 1) / kC3TW, tiles_y = (H + kC3TH - 1) / kC3TH;
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;     // floor((H + 2 - 3) / stride) + 1
+  const int TH = stride == 1 ? C3Geom<1>::TH : C3Geom<2>::TH;
+  const int tiles_x = (Wo + kC3TW - 1) / kC3TW, tiles_y = (Ho + TH - 1) / TH;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const unsigned gx = (unsigned)((long)batch * tiles_x * tiles_y);
-#define OCC_C3_LAUNCH(NTT, BNN)                                                                     \
-  hipLaunchKernelGGL((conv3x3_nhwc_bf16_kernel<NTT>), dim3(gx, (unsigned)(Cout / BNN)), dim3(256), 0, st, \
+#define OCC_C3_LAUNCH(NTT, BNN, SS)                                                                 \
+  hipLaunchKernelGGL((conv3x3_nhwc_bf16_kernel<NTT, SS>), dim3(gx, (unsigned)(Cout / BNN)), dim3(256), 0, st, \
                      reinterpret_cast<const uint4*>(x), reinterpret_cast<const uint4*>(weight_packed), \
-                     bias, reinterpret_cast<unsigned short*>(out), H, W, Cin, Cout, tiles_x, tiles_y, relu)
-  // 256-channel blocks only while they still give every CU two blocks; small maps take 128-channel blocks
-  if (Cout % 256 == 0 && (long)gx * (Cout / 256) >= 2L * 256) OCC_C3_LAUNCH(2, 256); else OCC_C3_LAUNCH(1, 128);
+                     bias, reinterpret_cast<unsigned short*>(out), H, W, Ho, Wo, Cin, Cout, tiles_x, tiles_y, relu)
+  if (stride == 2) {
+    OCC_C3_LAUNCH(1, 128, 2);
+  } else {
+    // 256-channel blocks only while they still give every CU two blocks; small maps take 128-channel blocks
+    if (Cout % 256 == 0 && (long)gx * (Cout / 256) >= 2L * 256) OCC_C3_LAUNCH(2, 256, 1); else OCC_C3_LAUNCH(1, 128, 1);
+  }
 #undef OCC_C3_LAUNCH
   OCC_CHECK_LAUNCH("conv3x3_nhwc_bf16");
   return OCC_OK;

@@ -454,6 +454,25 @@ def bias_act_nhwc_(x, bias, residual=None, relu=True):
     return x
 
 
+def bias_relu_maxpool_nhwc(y, bias):
+    """max_pool2d(relu(y + bias), 3, stride 2, padding 1) in one launch on a channels_last bf16 activation
+    (the ResNet stem's tail).  y (N, C, H, W) channels_last bf16 raw convolution output; bias (C) f32."""
+    if not (y.is_cuda and y.dtype == torch.bfloat16 and y.dim() == 4
+            and y.is_contiguous(memory_format=torch.channels_last)):
+        raise OccAmdUnsupported("bias_relu_maxpool_nhwc: y must be a channels_last bfloat16 device tensor")
+    _need_cuda_f32("bias", bias)
+    N, C, H, W = y.shape
+    if bias.numel() != C:
+        raise OccAmdError("bias_relu_maxpool_nhwc: bias must have C entries")
+    out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.bfloat16, device=y.device,
+                      memory_format=torch.channels_last)
+    with torch.cuda.device(y.device):
+        rc = _lib.lib().occ_bias_relu_maxpool_nhwc_bf16(ptr(y), ptr(bias), ptr(out), i32(N), i32(H), i32(W),
+                                                        i32(C), stream_ptr(y.device))
+    _lib.check(rc, "bias_relu_maxpool_nhwc")
+    return out
+
+
 def conv1x1_pack_weight(weight2d):
     """(Cout, Cin) bf16 matrix -> chunk-major [Cin/32][Cout][32] (what conv1x1_nhwc takes): a K chunk of all
     output channels is contiguous."""
@@ -563,10 +582,10 @@ def conv3x3_pack_weight(weight):
     return packed
 
 
-def conv3x3_nhwc(x, w_packed, bias, cout, relu=False):
-    """3x3 / stride 1 / pad 1 convolution + bias (+ ReLU) on a channels_last bf16 activation, one launch.
+def conv3x3_nhwc(x, w_packed, bias, cout, relu=False, stride=1):
+    """3x3 / pad 1 / stride 1 or 2 convolution + bias (+ ReLU) on a channels_last bf16 activation, one launch.
     x (N, Cin, H, W) channels_last bf16; w_packed from conv3x3_pack_weight; bias (Cout) f32
-    -> (N, Cout, H, W) channels_last bf16."""
+    -> (N, Cout, (H-1)//stride+1, (W-1)//stride+1) channels_last bf16."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)):
         raise OccAmdUnsupported("conv3x3_nhwc: x must be a channels_last bfloat16 device tensor")
@@ -574,11 +593,14 @@ def conv3x3_nhwc(x, w_packed, bias, cout, relu=False):
     N, Cin, H, W = x.shape
     if w_packed.numel() != cout * Cin * 9 or bias.numel() != cout:
         raise OccAmdError("conv3x3_nhwc: inconsistent shapes")
-    out = torch.empty((N, cout, H, W), dtype=torch.bfloat16, device=x.device,
+    st = int(stride)
+    if st not in (1, 2):
+        raise OccAmdUnsupported("conv3x3_nhwc: stride must be 1 or 2")
+    out = torch.empty((N, cout, (H - 1) // st + 1, (W - 1) // st + 1), dtype=torch.bfloat16, device=x.device,
                       memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         rc = _lib.lib().occ_conv3x3_nhwc_bf16(ptr(x), ptr(w_packed), ptr(bias), ptr(out), i32(N), i32(H),
-                                              i32(W), i32(Cin), i32(cout), i32(1 if relu else 0),
+                                              i32(W), i32(Cin), i32(cout), i32(st), i32(1 if relu else 0),
                                               stream_ptr(x.device))
     _lib.check(rc, "conv3x3_nhwc")
     return out

@@ -261,9 +261,9 @@ class FusedInferenceBackbone(nn.Module):
             from .. import ext
             self.register_buffer(f'm{idx}', ext.conv1x1_pack_weight(w.reshape(w.shape[0], w.shape[1])),
                                  persistent=False)
-        # stride-1 3x3 convolutions with >= 128 output channels: own implicit-GEMM kernel (bias+ReLU fused)
+        # 3x3 convolutions (stride 1 or 2) with >= 128 output channels: own implicit-GEMM kernel (bias+ReLU fused)
         c3 = (self.hip_tail and tuple(conv.kernel_size) == (3, 3) and tuple(conv.padding) == (1, 1)
-              and tuple(conv.stride) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+              and tuple(conv.stride) in ((1, 1), (2, 2)) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
               and w.shape[1] % 32 == 0 and w.shape[0] % 128 == 0 and w.is_cuda)
         if c3:
             from .. import ext
@@ -289,7 +289,7 @@ class FusedInferenceBackbone(nn.Module):
                                     relu=relu or add is not None, stride=s[0])
         if self._c3.get(i) and add is None and x.is_contiguous(memory_format=torch.channels_last):
             from .. import ext
-            return ext.conv3x3_nhwc(x, getattr(self, f'p{i}'), b, w.shape[0], relu=relu)
+            return ext.conv3x3_nhwc(x, getattr(self, f'p{i}'), b, w.shape[0], relu=relu, stride=s[0])
         if self.hip_tail and w.shape[0] % 8 == 0:
             from .. import ext
             y = F.conv2d(x, w, None, s, p, d, g)
@@ -329,7 +329,19 @@ class FusedInferenceBackbone(nn.Module):
 
     def _forward_eager(self, x):
         x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        x = F.max_pool2d(self._conv(self.stem, x, relu=True), kernel_size=3, stride=2, padding=1)
+        sw = getattr(self, f'w{self.stem}')
+        if self.hip_tail and sw.shape[0] % 8 == 0 and x.is_cuda:
+            # stem tail (bias + ReLU + 3x3/s2 max pooling) as one pass over the raw convolution output
+            from .. import ext
+            s, p, d, g = self._convs[self.stem]
+            y = F.conv2d(x, sw, None, s, p, d, g)
+            if y.is_contiguous(memory_format=torch.channels_last):
+                x = ext.bias_relu_maxpool_nhwc(y, getattr(self, f'b{self.stem}'))
+            else:
+                x = F.max_pool2d((y + getattr(self, f'b{self.stem}').to(y.dtype).view(1, -1, 1, 1)).relu_(),
+                                 kernel_size=3, stride=2, padding=1)
+        else:
+            x = F.max_pool2d(self._conv(self.stem, x, relu=True), kernel_size=3, stride=2, padding=1)
         feats = []
         for si, blocks in enumerate(self.stages):
             for bi, (c1, c2, c3, ds) in enumerate(blocks):

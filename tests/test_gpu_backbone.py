@@ -50,26 +50,42 @@ def test_conv1x1_nhwc_matches_torch(N, Cin, Cout, H, W, stride, res, relu):
     assert d <= scale * 2 ** -8 + 1e-6          # one bf16 rounding of the f32-accumulated result
 
 
-@pytest.mark.parametrize("N,C,Cout,H,W,relu", [
-    (2, 128, 128, 9, 21, True), (1, 256, 256, 16, 32, False), (1, 512, 512, 5, 7, True),
-    (3, 64, 256, 8, 16, True), (1, 32, 128, 1, 1, False), (1, 256, 128, 29, 50, True)])
-def test_conv3x3_nhwc_matches_torch(N, C, Cout, H, W, relu):
+@pytest.mark.parametrize("N,C,Cout,H,W,relu,stride", [
+    (2, 128, 128, 9, 21, True, 1), (1, 256, 256, 16, 32, False, 1), (1, 512, 512, 5, 7, True, 1),
+    (3, 64, 256, 8, 16, True, 1), (1, 32, 128, 1, 1, False, 1), (1, 256, 128, 29, 50, True, 1),
+    # stride 2 (first blocks of layer2..4, FPN extra level): even / odd sizes, ragged tiles, tiny maps
+    (2, 128, 128, 16, 64, True, 2), (1, 256, 256, 29, 50, True, 2), (1, 512, 512, 7, 9, False, 2),
+    (2, 64, 128, 1, 1, True, 2), (1, 128, 256, 58, 100, True, 2), (1, 32, 128, 2, 3, False, 2)])
+def test_conv3x3_nhwc_matches_torch(N, C, Cout, H, W, relu, stride):
     from occnet_amd import ext
-    g = torch.Generator().manual_seed(C + Cout + H)
+    g = torch.Generator().manual_seed(N * 1000 + C + H * W + stride)
     x = torch.randn(N, C, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(
         memory_format=torch.channels_last)
     w = (torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda()
     w_bf = w.to(torch.bfloat16).float()                       # the kernel rounds the weights to bf16
     b = torch.randn(Cout, generator=g).cuda()
-    got = ext.conv3x3_nhwc(x, ext.conv3x3_pack_weight(w), b, Cout, relu=relu)
-    want = torch.nn.functional.conv2d(x.float(), w_bf, b, padding=1)
+    got = ext.conv3x3_nhwc(x, ext.conv3x3_pack_weight(w), b, Cout, relu=relu, stride=stride)
+    want = torch.nn.functional.conv2d(x.float(), w_bf, b, padding=1, stride=stride)
     if relu:
         want = want.relu()
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     d = float((got.float() - want).abs().max())
     scale = float(want.abs().max())
-    print(f"conv3x3 {C}->{Cout} {H}x{W}: max diff {d:.3e} (scale {scale:.2f})")
+    print(f"conv3x3 {C}->{Cout} {H}x{W} s{stride}: max diff {d:.3e} (scale {scale:.2f})")
     assert d <= scale * 2 ** -8 + 1e-5          # one bf16 rounding of the f32-accumulated result
+
+
+def test_bias_relu_maxpool_matches_torch():
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(3)
+    for (N, C, H, W) in [(2, 64, 12, 20), (1, 8, 7, 9), (1, 16, 1, 1), (3, 64, 5, 2)]:
+        y = torch.randn(N, C, H, W, generator=g).cuda().to(torch.bfloat16).contiguous(
+            memory_format=torch.channels_last)
+        b = torch.randn(C, generator=g).cuda()
+        got = ext.bias_relu_maxpool_nhwc(y, b)
+        want = torch.nn.functional.max_pool2d((y.float() + b.view(1, -1, 1, 1)).relu(), 3, 2, 1)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(got, want.to(torch.bfloat16))         # one RNE rounding of the same fp32 value
 
 
 def _bottleneck_reference(x, w1, b1, w2, b2, w3, b3, wds=None, bds=None):

@@ -232,9 +232,9 @@ int occ_bias_relu_maxpool_nhwc_bf16(const void* y, const float* bias, void* out,
 /* Backbone 1x1 convolution on NHWC bf16 (outside the hand-written hot path, like the call above):
  * out[(n,yo,xo), co] = relu?( sum_ci x[(n, yo*stride, xo*stride), ci] * weight[co, ci] + bias[co]
  *                             (+ residual[(n,yo,xo), co]) ), bf16 in, f32 accumulate, bf16 out.
- *   x (batch, Hin, Win, Cin) bf16 ; weight CHUNK-major [Cin/32][Cout][32] bf16 (from the (Cout, Cin) matrix:
- *   w.view(Cout, Cin/32, 32).permute(1, 0, 2)) ; bias (Cout) f32 ; residual / out
- *   (batch, Hout, Wout, Cout) bf16 with Hout = (Hin-1)/stride + 1.  Needs Cin % 32 == 0, Cout % 8 == 0.
+ *   x (batch, Hin, Win, Cin) bf16 ; weight = occ_mfma_pack_b_frag_bf16 of the (Cout, Cin) matrix (MFMA
+ *   B-fragment order, read straight from global memory) ; bias (Cout) f32 ; residual / out
+ *   (batch, Hout, Wout, Cout) bf16 with Hout = (Hin-1)/stride + 1.  Needs Cin % 32 == 0, Cout % 32 == 0.
  */
 int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const float* bias, const void* residual,
                           void* out, int batch, int Hin, int Win, int Cin, int Cout, int stride, int relu,

@@ -9,13 +9,12 @@
 // ReLU in the epilogue, so the activation makes ONE trip through HBM per layer instead of three
 // (MIOpen kernel + its zero-fill / cast helpers + the elementwise tail).
 //
-// Decomposition: block = 4 waves x 32*RT rows (pixels; 64 or 128) x 128*NT output channels; K chunk = 32 or 64 input channels;
-// the rows x 32 activation chunk is staged once per block (double buffered in LDS, one barrier per chunk) and
-// every wave stages its own 32*NT x 32 weight slice — all plain 16-byte copies, 80-byte row stride =
-// conflict-free ds_read_b128; next chunk's loads in flight during the MFMAs (v_mfma_f32_32x32x16_bf16, 2
-// k-steps per chunk).
-// Strided 1x1 convolutions (the downsample branch) only change which input pixel a row reads.  The weight is
-// given chunk-major [Cin/32][Cout][32], so the slice a wave stages per chunk is contiguous.
+// Decomposition: block = 4 waves x 64 rows (pixels) x 128*NT output channels; K chunk = 32 input channels.
+// The 64 x 32 activation chunk is staged once per block (double buffered in LDS, one barrier per chunk, 80-byte
+// row stride = conflict-free ds_read_b128).  The weight is given in MFMA B-fragment order
+// (occ_mfma_pack_b_frag_bf16: [K/16][Cout/32][lane][8 bf16]) and goes global -> registers directly, three chunks
+// deep; v_mfma_f32_32x32x16_bf16, 2 k-steps per chunk.
+// Strided 1x1 convolutions (the downsample branch) only change which input pixel a row reads.
 #include "common.h"
 
 namespace occ {
@@ -23,31 +22,31 @@ namespace occ {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// LDS row stride in bytes for a K chunk of KC bf16: KC*2 + 16 B pad (80 / 144: conflict-free ds_read_b128)
-template <int KC> struct C1Geom { static constexpr int LD = KC * 2 + 16, PIECES = KC / 8; };
 
 __device__ __forceinline__ float c1_bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-template <int NT, int RT, int KC>
+template <int NT, int RT>
 __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ w, const float* __restrict__ bias,
     const unsigned short* __restrict__ residual, unsigned short* __restrict__ out, long M, int N, int K,
     int Hin, int Win, int Hout, int Wout, int stride, int relu) {
-  constexpr int kCLD = C1Geom<KC>::LD, PC = C1Geom<KC>::PIECES;    // PC 16-byte pieces per row per chunk
+  constexpr int KC = 32, kCLD = KC * 2 + 16, PC = KC / 8;           // 80-byte LDS rows, 4 pieces of 16 B
   constexpr int BM = 32 * RT, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
-  constexpr int AP = BM * PC / 256, WP = WR * PC / 64;   // A pieces per thread, W pieces per lane
-  constexpr int A_BYTES = BM * kCLD, W_BYTES = WR * kCLD;
-  // LDS: the activation chunk is staged ONCE per block (double buffered, one barrier per chunk) and read by
-  // all four waves; every wave keeps a private region for its own weight slice
-  constexpr int STAGE_BYTES = 2 * A_BYTES + 4 * W_BYTES, OUT_BYTES = 32 * OLD * 4;
+  constexpr int AP = BM * PC / 256;                                 // A pieces per thread per chunk
+  constexpr int A_BYTES = BM * kCLD;
+  // LDS carries ONLY the activation chunk (staged once per block, double buffered, one barrier per chunk, read
+  // by all four waves).  The weights never touch it: they are pre-packed in MFMA B-fragment order, so a wave's
+  // operand for (k-step, column tile) is one coalesced 1 KB global load straight into registers (each wave owns
+  // its own 32*NT columns — there is nothing to share; going through LDS was only a layout transposer and made
+  // the kernel LDS-bound: 13 KB of LDS traffic per wave and chunk for 8 MFMAs, now 5 KB).
+  constexpr int STAGE_BYTES = 2 * A_BYTES, OUT_BYTES = 32 * OLD * 4;
   __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kb = lane >> 5;
-  char* sW = lds + 2 * A_BYTES + wave * W_BYTES;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int nw0 = n0 + wave * WR;
   const int KQ = K / 8;            // uint4 (8 bf16) per row
+  const int NT32 = N / 32;         // 32-column tiles in the packed weight
 
   f32x16 acc[RT][NT];
 #pragma unroll
@@ -57,9 +56,8 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
-  // A: thread item j -> (row = j / PC, piece = j % PC), j = tid + 256*ap; W: lane item j -> (row, piece) of the
-  // wave's slice, j = lane + 64*wq.  Unconditional clamped loads, named registers (max 4 A + 8 W pieces).
-  static_assert(AP <= 4 && WP <= 8, "staging register budget");
+  // A: thread item j -> (row = j / PC, piece = j % PC), j = tid + 256*ap.  Unconditional clamped loads.
+  static_assert(AP >= 1 && AP <= 2 && NT <= 2, "staging register budget");
   long aofs[AP];
   int adst[AP];
 #pragma unroll
@@ -78,72 +76,49 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
     aofs[ap] = pix * KQ + piece;
     adst[ap] = row * kCLD + piece * 16;
   }
-  long wofs[WP];
-  int wdst[WP];
-#pragma unroll
-  for (int wq = 0; wq < WP; ++wq) {
-    const int j = lane + 64 * wq;
-    const int row = j / PC, piece = j % PC;
-    const int n = nw0 + row;
-    wofs[wq] = (long)(n < N ? n : N - 1) * PC + piece;     // chunk-major weights: + chunk * N * PC
-    wdst[wq] = row * kCLD + piece * 16;
-  }
-  // Two register sets (S = 0 / 1) hold the next TWO K chunks: with few blocks per CU the kernel is bound by
-  // the number of loads in flight, not by bandwidth, so the prefetch runs two chunks ahead.
-  uint4 va0_0, va1_0, va2_0, va3_0, vw0_0, vw1_0, vw2_0, vw3_0, vw4_0, vw5_0, vw6_0, vw7_0;
-  uint4 va0_1, va1_1, va2_1, va3_1, vw0_1, vw1_1, vw2_1, vw3_1, vw4_1, vw5_1, vw6_1, vw7_1;
-#define OCC_C1_ISSUE(S, K0)                                                                       \
+  // this wave's column tiles in the packed weight (clamped: a wave past the last tile recomputes it, its
+  // columns are masked in the epilogue)
+  const int nt0 = min((n0 + wave * WR) / 32, NT32 - 1), nt1 = min((n0 + wave * WR) / 32 + (NT - 1), NT32 - 1);
+  const long wl0 = (long)nt0 * 64 + lane, wl1 = (long)nt1 * 64 + lane;
+  // Registers: two activation sets (prefetch two chunks ahead) and three weight sets (the set of chunk c+2 is
+  // requested while the MFMAs of chunk c still read theirs); loads are issued per chunk as one group
+  // {A(c+2), W(c+2)} so the in-order vmcnt wait for chunk c never drains younger prefetches.
+  uint4 va0_0, va1_0, va0_1, va1_1;
+  uint4 wa0_0, wa1_0, wb0_0, wb1_0, wa0_1, wa1_1, wb0_1, wb1_1, wa0_2, wa1_2, wb0_2, wb1_2;   // w{ks a/b}{t}_{set}
+#define OCC_C1_ISSUE_A(S, K0)                                                                     \
   {                                                                                               \
     const long kq = (K0) / 8;                                                                     \
-    const long wq_ = (long)((K0) / KC) * N * PC;                                                  \
     va0_##S = x[aofs[0] + kq];                                                                    \
     if (AP > 1) va1_##S = x[aofs[AP > 1 ? 1 : 0] + kq];                                           \
-    if (AP > 2) { va2_##S = x[aofs[AP > 2 ? 2 : 0] + kq]; va3_##S = x[aofs[AP > 3 ? 3 : 0] + kq]; } \
-    vw0_##S = w[wofs[0] + wq_]; vw1_##S = w[wofs[1] + wq_];                                         \
-    if (WP > 2) { vw2_##S = w[wofs[WP > 2 ? 2 : 0] + wq_]; vw3_##S = w[wofs[WP > 3 ? 3 : 0] + wq_]; } \
-    if (WP > 4) {                                                                                 \
-      vw4_##S = w[wofs[WP > 4 ? 4 : 0] + wq_]; vw5_##S = w[wofs[WP > 5 ? 5 : 0] + wq_];             \
-      vw6_##S = w[wofs[WP > 6 ? 6 : 0] + wq_]; vw7_##S = w[wofs[WP > 7 ? 7 : 0] + wq_];             \
-    }                                                                                             \
   }
-  // one K chunk: registers of set S -> LDS (A buffer BUF), barrier, refill set S with chunk K_NEXT, MFMAs
-#define OCC_C1_STEP(S, BUF, K_NEXT)                                                               \
+#define OCC_C1_ISSUE_W(S, K0)                                                                     \
+  {                                                                                               \
+    const long k0 = (long)((K0) / 16) * NT32 * 64, k1 = k0 + (long)NT32 * 64;                     \
+    wa0_##S = w[k0 + wl0]; wb0_##S = w[k1 + wl0];                                                 \
+    if (NT > 1) { wa1_##S = w[k0 + wl1]; wb1_##S = w[k1 + wl1]; }                                 \
+  }
+  // one K chunk: A registers of set SA -> LDS buffer BUF, barrier, request chunk c+2 (A into set SA, W into
+  // set SWN), MFMAs of chunk c with the weights of set SW
+#define OCC_C1_STEP(SA, SW, SWN, BUF, K_NEXT)                                                     \
   {                                                                                               \
     char* sA = lds + (BUF) * A_BYTES;                                                             \
-    *reinterpret_cast<uint4*>(sA + adst[0]) = va0_##S;                                            \
-    if (AP > 1) *reinterpret_cast<uint4*>(sA + adst[AP > 1 ? 1 : 0]) = va1_##S;                   \
-    if (AP > 2) {                                                                                 \
-      *reinterpret_cast<uint4*>(sA + adst[AP > 2 ? 2 : 0]) = va2_##S;                             \
-      *reinterpret_cast<uint4*>(sA + adst[AP > 3 ? 3 : 0]) = va3_##S;                             \
-    }                                                                                             \
-    *reinterpret_cast<uint4*>(sW + wdst[0]) = vw0_##S;                                            \
-    *reinterpret_cast<uint4*>(sW + wdst[1]) = vw1_##S;                                            \
-    if (WP > 2) {                                                                                 \
-      *reinterpret_cast<uint4*>(sW + wdst[WP > 2 ? 2 : 0]) = vw2_##S;                             \
-      *reinterpret_cast<uint4*>(sW + wdst[WP > 3 ? 3 : 0]) = vw3_##S;                             \
-    }                                                                                             \
-    if (WP > 4) {                                                                                 \
-      *reinterpret_cast<uint4*>(sW + wdst[WP > 4 ? 4 : 0]) = vw4_##S;                             \
-      *reinterpret_cast<uint4*>(sW + wdst[WP > 5 ? 5 : 0]) = vw5_##S;                             \
-      *reinterpret_cast<uint4*>(sW + wdst[WP > 6 ? 6 : 0]) = vw6_##S;                             \
-      *reinterpret_cast<uint4*>(sW + wdst[WP > 7 ? 7 : 0]) = vw7_##S;                             \
-    }                                                                                             \
+    *reinterpret_cast<uint4*>(sA + adst[0]) = va0_##SA;                                           \
+    if (AP > 1) *reinterpret_cast<uint4*>(sA + adst[AP > 1 ? 1 : 0]) = va1_##SA;                  \
     __syncthreads(); /* chunk visible to every wave; the other A buffer is free */                \
-    OCC_C1_ISSUE(S, K_NEXT)                                                                       \
-    _Pragma("unroll") for (int kh = 0; kh < KC / 32; ++kh) {                                      \
-      bf16x8 af[RT][2], wf[NT][2];                                                                \
-      _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                           \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                          \
-          af[rt][ks] = *reinterpret_cast<const bf16x8*>(sA + (rt * 32 + vi) * kCLD + kh * 64 + ks * 32 + kb * 16); \
-      _Pragma("unroll") for (int t = 0; t < NT; ++t)                                              \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                          \
-          wf[t][ks] = *reinterpret_cast<const bf16x8*>(sW + (t * 32 + vi) * kCLD + kh * 64 + ks * 32 + kb * 16); \
+    OCC_C1_ISSUE_A(SA, K_NEXT)                                                                    \
+    OCC_C1_ISSUE_W(SWN, K_NEXT)                                                                   \
+    bf16x8 af[RT][2];                                                                             \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                             \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
-        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                         \
-          _Pragma("unroll") for (int t = 0; t < NT; ++t)                                          \
-            acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][ks], wf[t][ks], acc[rt][t], 0, 0, 0); \
+        af[rt][ks] = *reinterpret_cast<const bf16x8*>(sA + (rt * 32 + vi) * kCLD + ks * 32 + kb * 16); \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
+      acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], __builtin_bit_cast(bf16x8, wa0_##SW), acc[rt][0], 0, 0, 0); \
+      if (NT > 1) acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][0], __builtin_bit_cast(bf16x8, wa1_##SW), acc[rt][NT - 1], 0, 0, 0); \
     }                                                                                             \
-    wave_lds_sync();                                                                              \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
+      acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], __builtin_bit_cast(bf16x8, wb0_##SW), acc[rt][0], 0, 0, 0); \
+      if (NT > 1) acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][1], __builtin_bit_cast(bf16x8, wb1_##SW), acc[rt][NT - 1], 0, 0, 0); \
+    }                                                                                             \
   }
 
   // every block walks the K chunks in a rotated order (start depends on the block): blocks launched
@@ -151,16 +126,23 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
   // same time (L2 channel hot-spotting); the K sum is order-independent up to f32 rounding
   const int NCHK = K / KC;
   const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)NCHK);
-#define OCC_C1_K(CI) ((((CI) + rot) % NCHK) * KC)    /* chunk index -> k offset (clamped index re-reads) */
-  OCC_C1_ISSUE(0, OCC_C1_K(0))
-  OCC_C1_ISSUE(1, OCC_C1_K(NCHK > 1 ? 1 : 0))
-  for (int ci = 0; ci < NCHK; ci += 2) {
-    OCC_C1_STEP(0, 0, OCC_C1_K(min(ci + 2, NCHK - 1)))
-    if (ci + 1 < NCHK) OCC_C1_STEP(1, 1, OCC_C1_K(min(ci + 3, NCHK - 1)))
+#define OCC_C1_K(CI) ((((CI) < NCHK ? (CI) : NCHK - 1) + rot) % NCHK * KC)   /* chunk index -> k offset (clamped) */
+  OCC_C1_ISSUE_A(0, OCC_C1_K(0))
+  OCC_C1_ISSUE_W(0, OCC_C1_K(0))
+  OCC_C1_ISSUE_A(1, OCC_C1_K(1))
+  OCC_C1_ISSUE_W(1, OCC_C1_K(1))
+  for (int ci = 0; ci < NCHK; ci += 6) {
+    OCC_C1_STEP(0, 0, 2, 0, OCC_C1_K(ci + 2))
+    if (ci + 1 < NCHK) OCC_C1_STEP(1, 1, 0, 1, OCC_C1_K(ci + 3))
+    if (ci + 2 < NCHK) OCC_C1_STEP(0, 2, 1, 0, OCC_C1_K(ci + 4))
+    if (ci + 3 < NCHK) OCC_C1_STEP(1, 0, 2, 1, OCC_C1_K(ci + 5))
+    if (ci + 4 < NCHK) OCC_C1_STEP(0, 1, 0, 0, OCC_C1_K(ci + 6))
+    if (ci + 5 < NCHK) OCC_C1_STEP(1, 2, 1, 1, OCC_C1_K(ci + 7))
   }
 #undef OCC_C1_K
 #undef OCC_C1_STEP
-#undef OCC_C1_ISSUE
+#undef OCC_C1_ISSUE_A
+#undef OCC_C1_ISSUE_W
 
   // ---- epilogue, 32 rows at a time through an LDS transpose: bias, residual, ReLU, bf16 store --------
   const int c = lane * 4;
@@ -217,36 +199,24 @@ extern "C" int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const fl
   OCC_CHECK_ARG(x && weight && bias && out, "conv1x1_nhwc_bf16: null pointer argument");
   OCC_CHECK_ARG(batch > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && stride > 0,
                 "conv1x1_nhwc_bf16: bad dimension");
-  if (Cin % 32 || Cout % 8) {
-    set_error("conv1x1_nhwc_bf16: no kernel for Cin=%d Cout=%d (need Cin %% 32 == 0, Cout %% 8 == 0)", Cin,
+  if (Cin % 32 || Cout % 32) {
+    set_error("conv1x1_nhwc_bf16: no kernel for Cin=%d Cout=%d (need Cin %% 32 == 0, Cout %% 32 == 0)", Cin,
               Cout);
     return OCC_E_UNSUPPORTED;
   }
   const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
   const long M = (long)batch * Hout * Wout;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define OCC_C1_LAUNCH_(NTT, RTT, BNN, KCC)                                                          \
-  hipLaunchKernelGGL((conv1x1_nhwc_bf16_kernel<NTT, RTT, KCC>),                                     \
+#define OCC_C1_LAUNCH(NTT, RTT, BNN)                                                                \
+  hipLaunchKernelGGL((conv1x1_nhwc_bf16_kernel<NTT, RTT>),                                          \
                      dim3((unsigned)((M + 32 * RTT - 1) / (32 * RTT)), (unsigned)((Cout + BNN - 1) / BNN)), \
                      dim3(256), 0, st, reinterpret_cast<const uint4*>(x),                           \
                      reinterpret_cast<const uint4*>(weight), bias,                                  \
                      reinterpret_cast<const unsigned short*>(residual),                             \
                      reinterpret_cast<unsigned short*>(out), M, Cout, Cin, Hin, Win, Hout, Wout, stride, relu)
-  // K chunk of 32 input channels (64 was measured and is not faster); the prefetch runs two chunks ahead
-#define OCC_C1_LAUNCH(NTT, RTT, BNN)                                                                \
-  do {                                                                                              \
-    OCC_C1_LAUNCH_(NTT, RTT, BNN, 32); /* KC = 64 measured: not faster */                          \
-  } while (0)
-  // 64-row blocks.  128-row blocks (RT = 4: weight slice staged once per 128 pixels) were measured on the
-  // ResNet-50 shapes and are not faster (87.4 vs 88.9 samples/s end to end: 2 instead of 4 blocks per CU).
-  const bool big = false;
-  if (Cout <= 128) {
-    if (big) OCC_C1_LAUNCH(1, 4, 128); else OCC_C1_LAUNCH(1, 2, 128);
-  } else {
-    if (big) OCC_C1_LAUNCH(2, 4, 256); else OCC_C1_LAUNCH(2, 2, 256);
-  }
+  // 64-row blocks (128-row blocks were measured on the ResNet-50 shapes and are not faster)
+  if (Cout <= 128) OCC_C1_LAUNCH(1, 2, 128); else OCC_C1_LAUNCH(2, 2, 256);
 #undef OCC_C1_LAUNCH
-#undef OCC_C1_LAUNCH_
   OCC_CHECK_LAUNCH("conv1x1_nhwc_bf16");
   return OCC_OK;
 }

@@ -474,29 +474,27 @@ def bias_relu_maxpool_nhwc(y, bias):
 
 
 def conv1x1_pack_weight(weight2d):
-    """(Cout, Cin) bf16 matrix -> chunk-major [Cin/32][Cout][32] (what conv1x1_nhwc takes): a K chunk of all
-    output channels is contiguous."""
+    """(Cout, Cin) weight matrix (any float dtype, on the device) -> bf16 in MFMA B-fragment order (what
+    conv1x1_nhwc takes; see mfma_pack_b_frag): a wave reads its operand straight from global memory."""
     cout, cin = weight2d.shape
-    if cin % 32:
-        raise OccAmdUnsupported("conv1x1_pack_weight: Cin must be a multiple of 32")
-    return weight2d.to(torch.bfloat16).view(cout, cin // 32, 32).permute(1, 0, 2).contiguous()
+    if cin % 32 or cout % 32:
+        raise OccAmdUnsupported("conv1x1_pack_weight: Cin and Cout must be multiples of 32")
+    return mfma_pack_b_frag(weight2d.float().contiguous())
 
 
-def conv1x1_nhwc(x, weight2d, bias, residual=None, relu=False, stride=1):
+def conv1x1_nhwc(x, weight_frag, bias, residual=None, relu=False, stride=1):
     """1x1 convolution + bias (+ residual) (+ ReLU) on a channels_last bf16 activation, one launch.
-    x (N, Cin, H, W) channels_last bf16; weight2d = conv1x1_pack_weight((Cout, Cin) matrix); bias (Cout) f32;
+    x (N, Cin, H, W) channels_last bf16; weight_frag = conv1x1_pack_weight((Cout, Cin) matrix); bias (Cout) f32;
     residual (N, Cout, Ho, Wo) channels_last bf16 or None -> (N, Cout, Ho, Wo) channels_last bf16."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)):
         raise OccAmdUnsupported("conv1x1_nhwc: x must be a channels_last bfloat16 device tensor")
-    if not (weight2d.dtype == torch.bfloat16 and weight2d.dim() == 3 and weight2d.is_contiguous()
-            and weight2d.shape[2] == 32):
-        raise OccAmdError("conv1x1_nhwc: weight must come from conv1x1_pack_weight ([Cin/32][Cout][32] bf16)")
     _need_cuda_f32("bias", bias)
     N, Cin, H, W = x.shape
-    Cout = weight2d.shape[1]
-    if weight2d.shape[0] * 32 != Cin or bias.numel() != Cout:
-        raise OccAmdError("conv1x1_nhwc: inconsistent shapes")
+    Cout = bias.numel()
+    if not (weight_frag.dtype == torch.int16 and weight_frag.dim() == 1 and weight_frag.is_contiguous()
+            and weight_frag.numel() == Cout * Cin):
+        raise OccAmdError("conv1x1_nhwc: weight must come from conv1x1_pack_weight (Cout*Cin bf16, fragment order)")
     s = int(stride)
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
     out = torch.empty((N, Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device,
@@ -505,7 +503,7 @@ def conv1x1_nhwc(x, weight2d, bias, residual=None, relu=False, stride=1):
                                      residual.is_contiguous(memory_format=torch.channels_last)):
         raise OccAmdUnsupported("conv1x1_nhwc: residual must match the output (channels_last bfloat16)")
     with torch.cuda.device(x.device):
-        rc = _lib.lib().occ_conv1x1_nhwc_bf16(ptr(x), ptr(weight2d), ptr(bias), ptr(residual), ptr(out),
+        rc = _lib.lib().occ_conv1x1_nhwc_bf16(ptr(x), ptr(weight_frag), ptr(bias), ptr(residual), ptr(out),
                                               i32(N), i32(H), i32(W), i32(Cin), i32(Cout), i32(s),
                                               i32(1 if relu else 0), stream_ptr(x.device))
     _lib.check(rc, "conv1x1_nhwc")

@@ -256,7 +256,7 @@ class FusedInferenceBackbone(nn.Module):
         # 1x1 convolutions become the fused bf16 GEMM (occ_conv1x1_nhwc_bf16): (Cout, Cin) weight matrix
         gemm = (self.hip_tail and tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0)
                 and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.stride[0] == conv.stride[1]
-                and w.shape[1] % 32 == 0 and w.shape[0] % 8 == 0)
+                and w.shape[1] % 32 == 0 and w.shape[0] % 32 == 0 and w.is_cuda)
         if gemm:
             from .. import ext
             self.register_buffer(f'm{idx}', ext.conv1x1_pack_weight(w.reshape(w.shape[0], w.shape[1])),

@@ -27,7 +27,9 @@ def test_bias_act_nhwc_matches_torch():
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,stride,res,relu", [
     (2, 64, 256, 9, 13, 1, True, True), (1, 256, 64, 7, 5, 1, False, True), (3, 512, 1024, 6, 7, 2, False, False),
-    (1, 2048, 512, 3, 4, 1, False, True), (2, 32, 8, 5, 5, 1, True, False), (1, 1024, 2048, 5, 8, 2, False, False)])
+    (1, 2048, 512, 3, 4, 1, False, True), (2, 32, 32, 5, 5, 1, True, False), (1, 1024, 2048, 5, 8, 2, False, False),
+    # K chunk counts that are not multiples of the unroll, column tiles that do not fill the block
+    (2, 96, 160, 5, 5, 1, True, True), (1, 224, 96, 4, 4, 1, False, False), (1, 160, 416, 3, 3, 1, True, True)])
 def test_conv1x1_nhwc_matches_torch(N, Cin, Cout, H, W, stride, res, relu):
     from occnet_amd import ext
     g = torch.Generator().manual_seed(Cin + Cout)

@@ -189,8 +189,9 @@ int occ_linear_f32(const float* a1, int64_t lda1, int K1, const float* a2, const
 /* ------------------------------------------------------------------------------------------
  * occ_linear_f32's fast variant on the bf16 matrix cores ("bf16x3"): every f32 operand is split into
  * hi + lo bf16 and A.W^T ~= Ah.Wh^T + Ah.Wl^T + Al.Wh^T is accumulated in f32 (relative error of a product
- * <= 2^-16).  Same arguments, except that the weight is given PACKED by occ_linear_pack_weight_bf16x3:
- * packed[K/16][n][hi16 | lo16] bf16 (N*K*2 16-bit words; K % 16 == 0).
+ * <= 2^-16).  Same arguments, except that the weight is given PACKED by occ_linear_pack_weight_bf16x3 in
+ * MFMA fragment order: packed[K/16][ceil(N/32)][hi, lo][lane][8] bf16 = ceil(N/32)*32 * K * 2 16-bit words
+ * (columns zero-padded to a multiple of 32; K % 16 == 0).
  */
 int occ_linear_pack_weight_bf16x3(const float* weight, void* packed, int N, int K, void* stream);
 int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2, const float* a2_add,

@@ -8,16 +8,17 @@
 // at 2^-16 (1.5e-5; the f32 kernel: 6e-8), far inside the path's 1e-3 parity budget.  gfx950 has no
 // xf32/TF32 matrix instruction, so this is the only way to get fp32-like GEMMs off the 157 TFLOP/s f32 rate.
 //
-// Layout: the weight is split and packed ONCE on the device (occ_linear_pack_weight_bf16x3):
-//   packed[K/16][n][ hi[16] | lo[16] ] bf16  — the same 4 bytes per weight as f32; CHUNK-major, so the
-// slice a wave stages per K chunk is contiguous (rows at a 1-2 KB stride would all land on a few L2
-// channels while every block walks K in lockstep); staging is a plain 16-byte-per-lane copy into LDS.
-// Activations are split on the fly while staged.
+// Layout: the weight is split and packed ONCE on the device (occ_linear_pack_weight_bf16x3) in MFMA
+// B-fragment order,  packed[K/16][ceil(N/32)][hi | lo][lane][8 bf16]  (columns padded with zeros to a multiple
+// of 32; 4 bytes per weight like f32): the operand of a wave for (k-step, column tile, plane) is ONE coalesced
+// 1 KB global load straight into registers.  Every wave owns its own 32*NT columns, so the weights never touch
+// LDS (as a layout transposer it made the kernel LDS-bound).  Activations are split on the fly while staged.
 // Decomposition: block = 4 waves x (32*RT rows) x (128*NT columns); per 16-k chunk the activation rows are
-// split and staged once per block (double buffered, one barrier per chunk) and every wave stages its own W
-// slice into a private LDS region (48-byte row stride = conflict-free ds_read_b128); next chunk's global
-// loads in flight during the MFMAs; epilogue (bias, ReLU, residual, two-pass LayerNorm) on row-major rows
-// through an LDS transpose.
+// split and staged once per block (hi + lo planes, double buffered, one barrier per chunk, 48-byte row stride =
+// conflict-free ds_read_b128); activation loads run two chunks ahead, weight loads three (issued as one group
+// per chunk, so the in-order vmcnt wait for chunk c never drains younger prefetches); blocks walk K in a
+// rotated order (L2 channel hot-spotting); epilogue (bias, ReLU, residual, two-pass LayerNorm) on row-major
+// rows through an LDS transpose.
 #include "common.h"
 
 namespace occ {
@@ -44,19 +45,22 @@ __device__ __forceinline__ float x3_wave_sum(float v) {
   return v;
 }
 
-// (N, K) f32 -> packed[K/16][n][hi16 | lo16] bf16
+// (N, K) f32 -> packed[K/16][ceil(N/32)][plane: hi, lo][lane][8] bf16 (zero columns beyond N)
 __global__ void linear_pack_weight_bf16x3_kernel(const float* __restrict__ w,
                                                  unsigned short* __restrict__ packed, long n_elem,
                                                  int K, int N) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one (hi, lo) pair per thread
   if (idx >= n_elem) return;
-  const long n = idx / K;
-  const int k = (int)(idx % K);
-  unsigned short hi, lo;
-  x3_split(w[idx], hi, lo);
-  unsigned short* dst = packed + ((long)(k / 16) * N + n) * 32 + (k % 16);
+  const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+  const long rest = idx >> 9;
+  const int nt32 = (N + 31) / 32;
+  const int nt = (int)(rest % nt32), ks = (int)(rest / nt32);
+  const int n = nt * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
+  unsigned short hi = 0, lo = 0;
+  if (n < N) x3_split(w[(long)n * K + k], hi, lo);
+  unsigned short* dst = packed + ((rest * 2) * 64 + lane) * 8 + j;
   dst[0] = hi;
-  dst[16] = lo;
+  dst[64 * 8] = lo;
 }
 
 template <int NT, int RT, bool ADD>
@@ -67,19 +71,17 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
     float* __restrict__ out, long ldo, int M, int N) {
   constexpr int BM = 32 * RT, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
-  constexpr int A_BYTES = BM * kXLD, W_BYTES = WR * kXLD;            // one plane (hi or lo)
-  // LDS: the activation chunk (hi + lo planes) is split and staged ONCE per block (double buffered, one
-  // barrier per chunk) and read by all four waves; every wave keeps a private region for its weight slice
-  constexpr int STAGE_BYTES = 2 * (2 * A_BYTES) + 4 * (2 * W_BYTES), OUT_BYTES = 32 * OLD * 4;
+  constexpr int A_BYTES = BM * kXLD;                                 // one plane (hi or lo)
+  // LDS: only the activation chunk (hi + lo planes), split and staged ONCE per block (double buffered, one
+  // barrier per chunk) and read by all four waves
+  constexpr int STAGE_BYTES = 2 * (2 * A_BYTES), OUT_BYTES = 32 * OLD * 4;
   __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kb = lane >> 5;
-  char* sWh = lds + 4 * A_BYTES + wave * 2 * W_BYTES;
-  char* sWl = sWh + W_BYTES;
   const long m0 = (long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int nw0 = n0 + wave * WR;
   const int K = K1 + K2;
+  const int NT32 = (N + 31) / 32;
 
   f32x16 acc[RT][NT];
 #pragma unroll
@@ -89,24 +91,23 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
-  // A: thread -> (row = tid/4, 4 k = tid%4) of the block's rows (threads beyond BM rows idle in staging);
-  // W: lane -> (row = lane/4 + 16*it, 16-byte piece = lane%4) of the wave's slice.  All loads unconditional
-  // (clamped indices, 0/1-scaled addend alias) and held in named registers — see linear_mfma.hip.
-  const int arow = tid >> 2, sp = tid & 3, srow = lane >> 2;
+  // A: thread -> (row = tid/4, 4 k = tid%4) of the block's rows (threads beyond BM rows idle in staging).
+  // All loads unconditional (clamped indices, 0/1-scaled addend alias), named registers — see linear_mfma.hip.
+  const int arow = tid >> 2, sp = tid & 3;
   const bool a_live = arow < BM;
   long am = m0 + (a_live ? arow : 0);
   if (am >= M) am = (long)M - 1;
-  long wofs[2 * NT];   // uint4 index of this lane's piece in chunk 0
-#pragma unroll
-  for (int it = 0; it < 2 * NT; ++it) {
-    const int n = nw0 + srow + 16 * it;
-    wofs[it] = (long)(n < N ? n : N - 1) * 4 + sp;
-  }
-  float4 va;
-  float4 vd = make_float4(0.f, 0.f, 0.f, 0.f);     // addend (ADD only)
-  uint4 vw0, vw1, vw2, vw3;                        // W rows it = 0..3 (it >= 2 only for NT == 2)
-  float addscale = 0.f;
-#define OCC_X3_ISSUE(K0)                                                                          \
+  // this wave's column tiles in the packed weight (clamped: a wave past the last tile recomputes it, its
+  // columns are masked in the epilogue); uint4 index of (tile, plane hi, lane), the lo plane is +64
+  static_assert(NT <= 2, "weight register budget");
+  const int nt0 = min((n0 + wave * WR) / 32, NT32 - 1), nt1 = min((n0 + wave * WR) / 32 + (NT - 1), NT32 - 1);
+  const long wl0 = (long)nt0 * 128 + lane, wl1 = (long)nt1 * 128 + lane;
+  // two activation sets (two chunks ahead), three weight sets (the set of chunk c+2 is requested while the
+  // MFMAs of chunk c still read theirs)
+  float4 va_0, va_1, vd_0 = make_float4(0.f, 0.f, 0.f, 0.f), vd_1 = vd_0;
+  float as_0 = 0.f, as_1 = 0.f;                    // 1 when the chunk carries the addend (ADD only)
+  uint4 wh0_0, wl0_0, wh1_0, wl1_0, wh0_1, wl0_1, wh1_1, wl1_1, wh0_2, wl0_2, wh1_2, wl1_2;
+#define OCC_X3_ISSUE_A(S, K0)                                                                     \
   {                                                                                               \
     const int k0_ = (K0);                                                                         \
     const bool seg2 = k0_ >= K1;                                                                  \
@@ -114,69 +115,73 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
     const long lda = seg2 ? lda2 : lda1;                                                          \
     const bool add = seg2 && a2add != nullptr;                                                    \
     const float* addb = add ? a2add + (k0_ - K1) + sp * 4 : ab;                                   \
-    addscale = add ? 1.f : 0.f;                                                                   \
-    va = *reinterpret_cast<const float4*>(ab + am * lda);                                         \
-    if (ADD) vd = *reinterpret_cast<const float4*>(addb + am * lda); /* compile-time */           \
-    const long kc4 = (long)(k0_ / 16) * N * 4; /* chunk-major packed weights */                   \
-    vw0 = wp[wofs[0] + kc4];                                                                      \
-    vw1 = wp[wofs[1] + kc4];                                                                      \
-    if (NT == 2) {                                                                                \
-      vw2 = wp[wofs[2 * NT - 2] + kc4];                                                           \
-      vw3 = wp[wofs[2 * NT - 1] + kc4];                                                           \
+    as_##S = add ? 1.f : 0.f;                                                                     \
+    va_##S = *reinterpret_cast<const float4*>(ab + am * lda);                                     \
+    if (ADD) vd_##S = *reinterpret_cast<const float4*>(addb + am * lda); /* compile-time */       \
+  }
+#define OCC_X3_ISSUE_W(S, K0)                                                                     \
+  {                                                                                               \
+    const long kc = (long)((K0) / 16) * NT32 * 128;                                               \
+    wh0_##S = wp[kc + wl0]; wl0_##S = wp[kc + wl0 + 64];                                          \
+    if (NT > 1) { wh1_##S = wp[kc + wl1]; wl1_##S = wp[kc + wl1 + 64]; }                          \
+  }
+  // one 16-k chunk: A registers of set SA split into LDS buffer BUF, barrier, request chunk c+2 (A into set
+  // SA, W into set SWN), MFMAs of chunk c with the weights of set SW (small terms first)
+#define OCC_X3_STEP(SA, SW, SWN, BUF, K_NEXT)                                                     \
+  {                                                                                               \
+    char* sAh = lds + (BUF) * 2 * A_BYTES;                                                        \
+    char* sAl = sAh + A_BYTES;                                                                    \
+    if (a_live) {   /* f32 x4 (+ addend) -> 4 hi bf16 + 4 lo bf16 into the two A planes */        \
+      const float f0 = ADD ? fmaf(as_##SA, vd_##SA.x, va_##SA.x) : va_##SA.x;                     \
+      const float f1 = ADD ? fmaf(as_##SA, vd_##SA.y, va_##SA.y) : va_##SA.y;                     \
+      const float f2 = ADD ? fmaf(as_##SA, vd_##SA.z, va_##SA.z) : va_##SA.z;                     \
+      const float f3 = ADD ? fmaf(as_##SA, vd_##SA.w, va_##SA.w) : va_##SA.w;                     \
+      unsigned h01, h23, l01, l23;                                                                \
+      x3_split2(f0, f1, h01, l01); x3_split2(f2, f3, h23, l23);                                   \
+      *reinterpret_cast<uint2*>(sAh + arow * kXLD + sp * 8) = make_uint2(h01, h23);               \
+      *reinterpret_cast<uint2*>(sAl + arow * kXLD + sp * 8) = make_uint2(l01, l23);               \
+    }                                                                                             \
+    __syncthreads();   /* chunk visible to every wave; the other A buffer is free */              \
+    OCC_X3_ISSUE_A(SA, K_NEXT)                                                                    \
+    OCC_X3_ISSUE_W(SWN, K_NEXT)                                                                   \
+    bf16x8 ah[RT], al[RT];                                                                        \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
+      ah[rt] = *reinterpret_cast<const bf16x8*>(sAh + (rt * 32 + vi) * kXLD + kb * 16);           \
+      al[rt] = *reinterpret_cast<const bf16x8*>(sAl + (rt * 32 + vi) * kXLD + kb * 16);           \
+    }                                                                                             \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
+      acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], __builtin_bit_cast(bf16x8, wh0_##SW), acc[rt][0], 0, 0, 0); \
+      acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wl0_##SW), acc[rt][0], 0, 0, 0); \
+      acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wh0_##SW), acc[rt][0], 0, 0, 0); \
+      if (NT > 1) {                                                                               \
+        acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], __builtin_bit_cast(bf16x8, wh1_##SW), acc[rt][NT - 1], 0, 0, 0); \
+        acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wl1_##SW), acc[rt][NT - 1], 0, 0, 0); \
+        acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wh1_##SW), acc[rt][NT - 1], 0, 0, 0); \
+      }                                                                                           \
     }                                                                                             \
   }
-#define OCC_X3_PUT_W(V, ROW)                                                                      \
-  *reinterpret_cast<uint4*>((sp < 2 ? sWh : sWl) + (ROW) * kXLD + (sp & 1) * 16) = V;
 
   // every block walks the K chunks in a rotated order (see conv1x1_nhwc_bf16.hip): blocks launched together
   // would otherwise request the same weight chunk / same-stride activation columns at the same time
   const int NCHK = K / kXBK;
   const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)NCHK);
-  OCC_X3_ISSUE((rot % NCHK) * kXBK)
-  int buf = 0;
-  for (int ci = 0; ci < NCHK; ++ci, buf ^= 1) {
-    char* sAh = lds + buf * 2 * A_BYTES;
-    char* sAl = sAh + A_BYTES;
-    if (a_live) {   // f32 x4 (+ addend) -> 4 hi bf16 + 4 lo bf16 into the two A planes
-      const float f0 = ADD ? fmaf(addscale, vd.x, va.x) : va.x, f1 = ADD ? fmaf(addscale, vd.y, va.y) : va.y;
-      const float f2 = ADD ? fmaf(addscale, vd.z, va.z) : va.z, f3 = ADD ? fmaf(addscale, vd.w, va.w) : va.w;
-      unsigned h01, h23, l01, l23;
-      x3_split2(f0, f1, h01, l01); x3_split2(f2, f3, h23, l23);
-      *reinterpret_cast<uint2*>(sAh + arow * kXLD + sp * 8) = make_uint2(h01, h23);
-      *reinterpret_cast<uint2*>(sAl + arow * kXLD + sp * 8) = make_uint2(l01, l23);
-    }
-    OCC_X3_PUT_W(vw0, srow)
-    OCC_X3_PUT_W(vw1, srow + 16)
-    if (NT == 2) {
-      OCC_X3_PUT_W(vw2, srow + 32)
-      OCC_X3_PUT_W(vw3, srow + 48)
-    }
-    __syncthreads();   // chunk visible to every wave; the other A buffer is free for the next iteration
-    OCC_X3_ISSUE((((ci + 1 < NCHK ? ci + 1 : ci) + rot) % NCHK) * kXBK)   // unconditional prefetch
-
-    bf16x8 ah[RT], al[RT], wh[NT], wl[NT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      ah[rt] = *reinterpret_cast<const bf16x8*>(sAh + (rt * 32 + vi) * kXLD + kb * 16);
-      al[rt] = *reinterpret_cast<const bf16x8*>(sAl + (rt * 32 + vi) * kXLD + kb * 16);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      wh[t] = *reinterpret_cast<const bf16x8*>(sWh + (t * 32 + vi) * kXLD + kb * 16);
-      wl[t] = *reinterpret_cast<const bf16x8*>(sWl + (t * 32 + vi) * kXLD + kb * 16);
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {   // small terms first
-        acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], wh[t], acc[rt][t], 0, 0, 0);
-        acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], wl[t], acc[rt][t], 0, 0, 0);
-        acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], wh[t], acc[rt][t], 0, 0, 0);
-      }
+#define OCC_X3_K(CI) ((((CI) < NCHK ? (CI) : NCHK - 1) + rot) % NCHK * kXBK)   /* chunk index -> k offset */
+  OCC_X3_ISSUE_A(0, OCC_X3_K(0))
+  OCC_X3_ISSUE_W(0, OCC_X3_K(0))
+  OCC_X3_ISSUE_A(1, OCC_X3_K(1))
+  OCC_X3_ISSUE_W(1, OCC_X3_K(1))
+  for (int ci = 0; ci < NCHK; ci += 6) {
+    OCC_X3_STEP(0, 0, 2, 0, OCC_X3_K(ci + 2))
+    if (ci + 1 < NCHK) OCC_X3_STEP(1, 1, 0, 1, OCC_X3_K(ci + 3))
+    if (ci + 2 < NCHK) OCC_X3_STEP(0, 2, 1, 0, OCC_X3_K(ci + 4))
+    if (ci + 3 < NCHK) OCC_X3_STEP(1, 0, 2, 1, OCC_X3_K(ci + 5))
+    if (ci + 4 < NCHK) OCC_X3_STEP(0, 1, 0, 0, OCC_X3_K(ci + 6))
+    if (ci + 5 < NCHK) OCC_X3_STEP(1, 2, 1, 1, OCC_X3_K(ci + 7))
   }
-#undef OCC_X3_ISSUE
-#undef OCC_X3_PUT_W
+#undef OCC_X3_K
+#undef OCC_X3_STEP
+#undef OCC_X3_ISSUE_A
+#undef OCC_X3_ISSUE_W
 
   // ---- epilogue, 32 rows at a time: accumulators -> LDS row-major tile -> 8 rows per wave ------------
   const int c = lane * 4;
@@ -249,7 +254,7 @@ extern "C" int occ_linear_pack_weight_bf16x3(const float* weight, void* packed, 
     set_error("linear_pack_weight_bf16x3: K=%d is not a multiple of 16", K);
     return OCC_E_UNSUPPORTED;
   }
-  const long n = (long)N * K;
+  const long n = (long)((N + 31) / 32) * 32 * K;      // (hi, lo) pairs incl. the zero columns
   hipLaunchKernelGGL(linear_pack_weight_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), weight,
                      reinterpret_cast<unsigned short*>(packed), n, K, N);

@@ -317,14 +317,15 @@ _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight
 
 
 def linear_pack_weight_bf16x3(weight):
-    """(N, K) float32 Linear weight -> packed[K/16][n][hi16 | lo16] bf16 split (int16 storage), cached."""
+    """(N, K) float32 Linear weight -> bf16 hi/lo split in MFMA fragment order
+    packed[K/16][ceil(N/32)][hi, lo][lane][8] (int16 storage, columns zero-padded to a multiple of 32), cached."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
     hit = _PACKED_W.get(key)
     if hit is not None:
         return hit[1]
     _need_cuda_f32("weight", weight)
     N, K = weight.shape
-    packed = torch.empty(N * K * 2, dtype=torch.int16, device=weight.device)
+    packed = torch.empty((N + 31) // 32 * 32 * K * 2, dtype=torch.int16, device=weight.device)
     with torch.cuda.device(weight.device):
         rc = _lib.lib().occ_linear_pack_weight_bf16x3(ptr(weight), ptr(packed), i32(N), i32(K),
                                                       stream_ptr(weight.device))

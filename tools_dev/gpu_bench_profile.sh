@@ -15,7 +15,8 @@ trace)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_e2e -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/trace_e2e.log 2>&1)
   DB=$(find /tmp/prof_e2e -name "*.db" | head -1)
   # steady state only: the first warm-up step contains MIOpen's find (naive reference kernels)
-  python tools_dev/rocpd_summary.py $DB 60 --last-ms 100 > gpurun_out/trace_e2e_summary.txt 2>&1; head -40 gpurun_out/trace_e2e_summary.txt | cut -c1-160 ;;
+  python tools_dev/rocpd_summary.py $DB 60 --last-ms 100 > gpurun_out/trace_e2e_summary.txt 2>&1; head -40 gpurun_out/trace_e2e_summary.txt | cut -c1-160
+  for k in sca_fused conv1x1 conv3x3 linear_bf16x3 bottleneck64; do python tools_dev/rocpd_summary.py $DB --dump $k 60; done > gpurun_out/trace_e2e_dispatch.txt 2>&1 ;;
 pmc)
   i=0
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES" "TA_TA_BUSY_sum TA_BUSY_avr"; do

@@ -48,6 +48,9 @@ def parse():
                     help="folded (default): eval BN folded into the MIOpen convolutions, pure bf16 NHWC, one "
                          "HIP bias/residual/ReLU launch per convolution; autocast: stock modules under "
                          "torch.autocast(bf16), NHWC")
+    ap.add_argument("--hot-feat-format", choices=["backbone", "f32"], default="backbone",
+                    help="--scope hotpath input: 'backbone' = what the bf16 backbone plan emits (bf16 maps, NHWC "
+                         "storage); 'f32' = fp32 NCHW maps (the reference's fp32 backbone)")
     ap.add_argument("--backbone-graph", action="store_true",
                     help="replay the folded backbone plan as one hipGraph (static shapes)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
@@ -82,7 +85,8 @@ def build(cfg_path, device):
 
 
 class Stepper:
-    def __init__(self, model, geo, scope, backbone_dtype, device, seed, plan="autocast", graph=False):
+    def __init__(self, model, geo, scope, backbone_dtype, device, seed, plan="autocast", graph=False,
+                 hot_feat_format="backbone"):
         from occnet_amd import synthetic
         self.model, self.scope, self.device = model, scope, device
         self.metas = synthetic.make_img_metas(geo, batch=1, seed=seed)
@@ -99,6 +103,13 @@ class Stepper:
         else:
             self.scope = "hotpath"
             self.feats = synthetic.make_features(geo, batch=1, seed=seed, device=device)
+            if hot_feat_format == "backbone":
+                # the format the backbone plan emits: bf16, NHWC storage (B*N, h, w, C) seen as (B, N, C, h, w)
+                def nhwc(f):
+                    B, N, C, h, w = f.shape
+                    return f.reshape(B * N, C, h, w).to(torch.bfloat16).contiguous(
+                        memory_format=torch.channels_last).view(B, N, C, h, w)
+                self.feats = [nhwc(f) for f in self.feats]
 
     @torch.no_grad()
     def __call__(self):
@@ -250,7 +261,8 @@ def main():
         stepper = TrainStepper(model, geo, args.backbone_dtype, device, seed=rank, world=world)
     else:
         stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank,
-                          plan=args.backbone_plan, graph=args.backbone_graph)
+                          plan=args.backbone_plan, graph=args.backbone_graph,
+                          hot_feat_format=args.hot_feat_format)
 
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         stepper()
@@ -299,6 +311,8 @@ def main():
                 "parallelism": f"dp{world}", "hot_path_dtype": "f32",
                 "linear_precision": ext.LINEAR_PRECISION,
                 "backbone_dtype": args.backbone_dtype if stepper.scope == "e2e" else None,
+                "hot_feat_format": None if stepper.scope == "e2e" else (
+                    "bf16 NHWC (backbone plan output)" if args.hot_feat_format == "backbone" else "f32 NCHW"),
                 "config_file": os.path.relpath(args.config, ROOT),
             },
         }

@@ -223,6 +223,23 @@ int occ_dvr_render_forward_f32(const float* sigma, const float* origin, const fl
 int occ_bias_act_nhwc_bf16(void* x, const float* bias, const void* residual, int64_t rows, int C, int relu,
                            void* stream);
 
+/* SCA value projection straight off the backbone's bf16 feature maps (rows A3/A8: replaces the reference's
+ * fp32 feature flatten + embedding adds, transformer_occ.py:204-222, AND MSDeformableAttention3D.value_proj,
+ * spatial_cross_attention.py:366), all FPN levels in one launch.  For segment (= level) s, row m = g*rpg_s + i:
+ *   out[(g*out_group_rows + out_row0[s] + i)*ldo + n] = sum_k a[s][m*lda[s] + k] * W[n][k]
+ *                                                      + group_bias[s][(g % bias_groups)*N + n]
+ * n_segments <= 8 ; a[s] (rows[s], K) bf16 device pointers, lda[s] row strides ; the arrays a / lda / rows /
+ * rows_per_group / out_row0 / group_bias are HOST arrays of n_segments entries (read at launch) ;
+ * weight_packed = occ_linear_pack_weight_bf16x3(W (N, K)) (hi/lo split: products exact to 2^-17, two MFMAs per
+ * k-step) ; group_bias[s] (bias_groups, N) f32 device pointers, or group_bias == NULL — for the SCA:
+ * (cams_embeds[cam] + level_embeds[s]) . W^T + b, one row per camera ; out f32.
+ * Needs K % 32 == 0, N % 4 == 0, lda % 8 == 0, ldo % 4 == 0.
+ */
+int occ_value_proj_bf16_f32(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
+                            const int64_t* rows_per_group, const int64_t* out_row0,
+                            const float* const* group_bias, int bias_groups, const void* weight_packed,
+                            float* out, int64_t ldo, int K, int N, int64_t out_group_rows, void* stream);
+
 /* Stem tail in one pass: out = max_pool2d(relu(y + bias), kernel 3, stride 2, padding 1) on NHWC bf16
  * (outside the hand-written hot path).  y (batch, H, W, C) bf16 raw convolution output ; bias (C) f32 ;
  * out (batch, (H-1)/2+1, (W-1)/2+1, C) bf16.  Needs C % 8 == 0.

@@ -1,0 +1,213 @@
+// SCA value projection straight off the backbone's bf16 NHWC feature maps:
+//
+//   value[cam, start_l + i, :] = (feat_l[cam, i, :] + cams_embeds[cam] + level_embeds[l]) . W^T + b
+//                              =  feat_l[cam, i, :] . W^T  +  gbias[l][cam, :]
+//
+// with gbias = (cams_embeds + level_embeds[l]) . W^T + b precomputed per (level, camera) — the projection is
+// linear, so the reference's feature flatten (`transformer_occ.py:204-222`: permute + two embedding adds into a
+// (num_cam, sum hw, bs, C) fp32 tensor) and `MSDeformableAttention3D.value_proj`
+// (`spatial_cross_attention.py:366`) collapse into this one GEMM per level: the 189 MB fp32 flatten buffer is
+// never written nor read (the activation operand is the 94 MB of bf16 maps), and because the activation IS a
+// bf16 number its low split part is zero — two MFMAs per k-step (Ah.Wl + Ah.Wh) instead of bf16x3's three, with
+// the same hi/lo weight pack as occ_linear_bf16x3_f32 (product error <= 2^-17 of |a.w|).
+//
+// Structure = conv1x1_nhwc_bf16.hip: block = 4 waves x 64 rows x 128*NT columns, 32-k activation chunks staged
+// once per block in LDS (double buffered, one barrier per chunk), fragment-ordered weights global -> registers
+// one chunk ahead, K order rotated per block; epilogue through an LDS transpose: + group bias, fp32 rows written
+// at out[(g * out_group_rows + out_row0 + i) * ldo] for row m = g * rows_per_group + i (g = camera image).
+// All FPN levels go in ONE launch (segment table by value): the small levels alone are launch/ramp-bound
+// (13 us for 2 250 rows) and now overlap the large one.
+#include "common.h"
+
+namespace occ {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// one launch covers every FPN level: segment l = the (rows_l, K) pixel matrix of level l, whose groups (camera
+// images, rows_per_group_l = h_l*w_l rows each) land at out_row0_l inside the per-camera blocks of the output
+constexpr int kVpMaxSeg = 8;
+struct VpSegments {
+  const uint4* a[kVpMaxSeg];
+  const float* gbias[kVpMaxSeg];
+  long rows[kVpMaxSeg], rows_per_group[kVpMaxSeg], out_row0[kVpMaxSeg], lda8[kVpMaxSeg];
+  int first_block[kVpMaxSeg + 1];
+  int n;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void value_proj_bf16_kernel(
+    VpSegments seg, const uint4* __restrict__ wp, int bias_groups, float* __restrict__ out, long ldo, int N,
+    int K, long out_group_rows) {
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < kVpMaxSeg; ++i)
+    if (i < seg.n && (int)blockIdx.x >= seg.first_block[i]) si = i;
+  const uint4* __restrict__ a = seg.a[si];
+  const float* __restrict__ gbias = seg.gbias[si];
+  const long M = seg.rows[si], rows_per_group = seg.rows_per_group[si], out_row0 = seg.out_row0[si];
+  const long lda8 = seg.lda8[si];
+  constexpr int RT = 2, KC = 32, kLD = KC * 2 + 16, PC = KC / 8;
+  constexpr int BM = 32 * RT, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
+  constexpr int A_BYTES = BM * kLD;
+  constexpr int STAGE_BYTES = 2 * A_BYTES, OUT_BYTES = 32 * OLD * 4;
+  __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vi = lane & 31, kb = lane >> 5;
+  const long m0 = (long)((int)blockIdx.x - seg.first_block[si]) * BM;
+  const int n0 = blockIdx.y * BN;
+  const int NT32 = (N + 31) / 32;
+
+  f32x16 acc[RT][NT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
+
+  // A: thread -> (row = tid / 4, 16-byte piece = tid % 4) of the 64 x 32 chunk; unconditional clamped loads
+  static_assert(BM * PC == 256 && NT <= 2, "one activation piece per thread");
+  const int arow = tid / PC, apiece = tid % PC;
+  long am = m0 + arow;
+  if (am >= M) am = M - 1;
+  const long aofs = am * lda8 + apiece;
+  const int adst = arow * kLD + apiece * 16;
+  // this wave's column tiles in the packed weight (hi plane; the lo plane is +64 uint4)
+  const int nt0 = min((n0 + wave * WR) / 32, NT32 - 1), nt1 = min((n0 + wave * WR) / 32 + (NT - 1), NT32 - 1);
+  const long wl0 = (long)nt0 * 128 + lane, wl1 = (long)nt1 * 128 + lane;
+  // two activation sets (chunks c+1, c+2 in flight), two weight sets (chunk c in use, c+1 in flight).  (Requesting
+  // the block's whole 64 x K activation tile up front — 8 chunk registers — was measured: not faster.)
+  uint4 va_0, va_1;
+  uint4 ha0_0, la0_0, hb0_0, lb0_0, ha1_0, la1_0, hb1_0, lb1_0;     // {h,l}{k-step a,b}{tile}_{set}
+  uint4 ha0_1, la0_1, hb0_1, lb0_1, ha1_1, la1_1, hb1_1, lb1_1;
+#define OCC_VP_ISSUE_A(S, K0) { va_##S = a[aofs + (K0) / 8]; }
+#define OCC_VP_ISSUE_W(S, K0)                                                                     \
+  {                                                                                               \
+    const long k0 = (long)((K0) / 16) * NT32 * 128, k1 = k0 + (long)NT32 * 128;                   \
+    ha0_##S = wp[k0 + wl0]; la0_##S = wp[k0 + wl0 + 64];                                          \
+    hb0_##S = wp[k1 + wl0]; lb0_##S = wp[k1 + wl0 + 64];                                          \
+    if (NT > 1) {                                                                                 \
+      ha1_##S = wp[k0 + wl1]; la1_##S = wp[k0 + wl1 + 64];                                        \
+      hb1_##S = wp[k1 + wl1]; lb1_##S = wp[k1 + wl1 + 64];                                        \
+    }                                                                                             \
+  }
+#define OCC_VP_MFMA(RTI, T, AF, WREG) \
+  acc[RTI][T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF, __builtin_bit_cast(bf16x8, WREG), acc[RTI][T], 0, 0, 0);
+  // chunk c: activation set SA -> LDS buffer BUF, barrier, request A(c+2) into set SA and W(c+1) into the other
+  // weight set, MFMAs with weight set SW (small term first)
+#define OCC_VP_STEP(SA, BUF, SW, SWN, K_A_NEXT, K_W_NEXT)                                         \
+  {                                                                                               \
+    char* sA = lds + (BUF) * A_BYTES;                                                             \
+    *reinterpret_cast<uint4*>(sA + adst) = va_##SA;                                               \
+    __syncthreads();                                                                              \
+    OCC_VP_ISSUE_A(SA, K_A_NEXT)                                                                  \
+    OCC_VP_ISSUE_W(SWN, K_W_NEXT)                                                                 \
+    bf16x8 af[RT][2];                                                                             \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                             \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
+        af[rt][ks] = *reinterpret_cast<const bf16x8*>(sA + (rt * 32 + vi) * kLD + ks * 32 + kb * 16); \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
+      OCC_VP_MFMA(rt, 0, af[rt][0], la0_##SW) OCC_VP_MFMA(rt, 0, af[rt][0], ha0_##SW)             \
+      if (NT > 1) { OCC_VP_MFMA(rt, NT - 1, af[rt][0], la1_##SW) OCC_VP_MFMA(rt, NT - 1, af[rt][0], ha1_##SW) } \
+    }                                                                                             \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
+      OCC_VP_MFMA(rt, 0, af[rt][1], lb0_##SW) OCC_VP_MFMA(rt, 0, af[rt][1], hb0_##SW)             \
+      if (NT > 1) { OCC_VP_MFMA(rt, NT - 1, af[rt][1], lb1_##SW) OCC_VP_MFMA(rt, NT - 1, af[rt][1], hb1_##SW) } \
+    }                                                                                             \
+  }
+  const int NCHK = K / KC;
+  const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)NCHK);
+#define OCC_VP_K(CI) ((((CI) < NCHK ? (CI) : NCHK - 1) + rot) % NCHK * KC)
+  OCC_VP_ISSUE_A(0, OCC_VP_K(0))
+  OCC_VP_ISSUE_W(0, OCC_VP_K(0))
+  OCC_VP_ISSUE_A(1, OCC_VP_K(1))
+  for (int ci = 0; ci < NCHK; ci += 2) {
+    OCC_VP_STEP(0, 0, 0, 1, OCC_VP_K(ci + 2), OCC_VP_K(ci + 1))
+    if (ci + 1 < NCHK) OCC_VP_STEP(1, 1, 1, 0, OCC_VP_K(ci + 3), OCC_VP_K(ci + 2))
+  }
+#undef OCC_VP_K
+#undef OCC_VP_STEP
+#undef OCC_VP_MFMA
+#undef OCC_VP_ISSUE_W
+#undef OCC_VP_ISSUE_A
+
+  // ---- epilogue, 32 rows at a time through an LDS transpose: + group bias, fp32 rows ---------------------
+  const int c = lane * 4;
+  const bool col_live = c < BN && n0 + c < N;
+  float* sO = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sO[((r & 3) + 8 * (r >> 2) + 4 * kb) * OLD + (wave * NT + t) * 32 + vi] = acc[rt][t][r];
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;
+      const long m = m0 + rt * 32 + row;
+      if (m < M && col_live) {
+        const long g = m / rows_per_group, i = m - g * rows_per_group;
+        float4 v = *reinterpret_cast<const float4*>(sO + row * OLD + c);
+        if (gbias != nullptr) {
+          const float4 b = *reinterpret_cast<const float4*>(gbias + (g % bias_groups) * N + n0 + c);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        *reinterpret_cast<float4*>(out + (g * out_group_rows + out_row0 + i) * ldo + n0 + c) = v;
+      }
+    }
+  }
+}
+
+}  // namespace occ
+
+extern "C" int occ_value_proj_bf16_f32(int n_segments, const void* const* a, const int64_t* lda,
+                                       const int64_t* rows, const int64_t* rows_per_group,
+                                       const int64_t* out_row0, const float* const* group_bias,
+                                       int bias_groups, const void* weight_packed, float* out, int64_t ldo,
+                                       int K, int N, int64_t out_group_rows, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(a && lda && rows && rows_per_group && out_row0 && weight_packed && out,
+                "value_proj_bf16: null pointer argument");
+  OCC_CHECK_ARG(n_segments > 0 && n_segments <= kVpMaxSeg, "value_proj_bf16: 1..%d segments", kVpMaxSeg);
+  OCC_CHECK_ARG(K > 0 && N > 0 && out_group_rows >= 0 && ldo >= N, "value_proj_bf16: bad dimension");
+  OCC_CHECK_ARG(!group_bias || bias_groups > 0, "value_proj_bf16: bias_groups must be positive");
+  if (K % 32 || N % 4 || ldo % 4) {
+    set_error("value_proj_bf16: no kernel for K=%d N=%d (need K %% 32 == 0, N %% 4 == 0, 16-byte aligned rows)",
+              K, N);
+    return OCC_E_UNSUPPORTED;
+  }
+  VpSegments seg;
+  long blocks = 0;
+  for (int i = 0; i < kVpMaxSeg; ++i) {
+    const int j = i < n_segments ? i : n_segments - 1;       // unused slots alias the last segment
+    OCC_CHECK_ARG(a[j] && rows[j] > 0 && rows_per_group[j] > 0 && out_row0[j] >= 0 && lda[j] >= K,
+                  "value_proj_bf16: bad segment %d", j);
+    if (lda[j] % 8) {
+      set_error("value_proj_bf16: segment %d row stride %ld is not 16-byte aligned", j, (long)lda[j]);
+      return OCC_E_UNSUPPORTED;
+    }
+    seg.a[i] = reinterpret_cast<const uint4*>(a[j]);
+    seg.gbias[i] = group_bias ? group_bias[j] : nullptr;
+    seg.rows[i] = rows[j];
+    seg.rows_per_group[i] = rows_per_group[j];
+    seg.out_row0[i] = out_row0[j];
+    seg.lda8[i] = lda[j] / 8;
+    seg.first_block[i] = (int)blocks;
+    if (i < n_segments) blocks += (rows[j] + 63) / 64;
+  }
+  seg.first_block[kVpMaxSeg] = (int)blocks;
+  seg.n = n_segments;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define OCC_VP_LAUNCH(NTT, BNN)                                                                     \
+  hipLaunchKernelGGL((value_proj_bf16_kernel<NTT>), dim3((unsigned)blocks, (unsigned)((N + BNN - 1) / BNN)), \
+                     dim3(256), 0, st, seg, reinterpret_cast<const uint4*>(weight_packed), bias_groups, out, \
+                     (long)ldo, N, K, (long)out_group_rows)
+  if (N <= 128) OCC_VP_LAUNCH(1, 128); else OCC_VP_LAUNCH(2, 256);
+#undef OCC_VP_LAUNCH
+  OCC_CHECK_LAUNCH("value_proj_bf16");
+  return OCC_OK;
+}

@@ -9,6 +9,8 @@ the C ABI (include/occnet_amd.h) of libocc_amd.so.
 
 The remaining functions expose the fused MI355X kernels (no counterpart in mmcv._ext).
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -336,6 +338,52 @@ def linear_pack_weight_bf16x3(weight):
     # another tensor, so (data_ptr, version) identifies the contents
     _PACKED_W[key] = (weight, packed)
     return packed
+
+
+def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_rows, out_row0):
+    """For every segment s (FPN level) and row m = g*rows_per_group[s] + i of a_list[s]:
+        out[g*out_group_rows + out_row0[s] + i] = a_list[s][m] @ weight.T + group_bias[s][g % G]   (fp32 out),
+    all segments in one launch.  a_list[s] (M_s, K) bf16 with unit column stride (an NHWC feature map seen as
+    pixels x channels); weight (N, K) fp32 Linear weight (packed hi/lo once, cached); group_bias (S, G, N) fp32
+    contiguous or None; out fp32 2-D (rows, N); rows_per_group / out_row0: one int per segment."""
+    if isinstance(a_list, torch.Tensor):
+        a_list, rows_per_group, out_row0 = [a_list], [rows_per_group], [out_row0]
+        if group_bias is not None:
+            group_bias = group_bias.unsqueeze(0)
+    S = len(a_list)
+    _need_cuda_f32("out", out)
+    if out.dim() != 2 or out.stride(1) != 1:
+        raise OccAmdError("value_proj_bf16: out must be a 2-D fp32 matrix with unit column stride")
+    N, K = weight.shape
+    if out.shape[1] != N or len(rows_per_group) != S or len(out_row0) != S:
+        raise OccAmdError("value_proj_bf16: inconsistent shapes")
+    for a, rpg, r0 in zip(a_list, rows_per_group, out_row0):
+        if not (a.is_cuda and a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1
+                and a.shape[1] == K):
+            raise OccAmdUnsupported("value_proj_bf16: every a must be a (M, K) bfloat16 device matrix with unit "
+                                    "column stride")
+        groups = (a.shape[0] + rpg - 1) // rpg
+        if (groups - 1) * out_group_rows + r0 + min(rpg, a.shape[0]) > out.shape[0]:
+            raise OccAmdError("value_proj_bf16: output rows out of range")
+    G = 0
+    gb_ptrs = None
+    if group_bias is not None:
+        _need_cuda_f32("group_bias", group_bias)
+        if group_bias.dim() != 3 or group_bias.shape[0] != S or group_bias.shape[2] != N \
+                or not group_bias.is_contiguous():
+            raise OccAmdError("value_proj_bf16: group_bias must be a contiguous (S, G, N) tensor")
+        G = group_bias.shape[1]
+        gb_ptrs = (ctypes.c_void_p * S)(*[group_bias[s].data_ptr() for s in range(S)])
+    packed = linear_pack_weight_bf16x3(weight)
+    arr64 = lambda v: (ctypes.c_int64 * S)(*[int(x) for x in v])
+    a_ptrs = (ctypes.c_void_p * S)(*[a.data_ptr() for a in a_list])
+    with torch.cuda.device(out.device):
+        rc = _lib.lib().occ_value_proj_bf16_f32(
+            i32(S), a_ptrs, arr64([a.stride(0) for a in a_list]), arr64([a.shape[0] for a in a_list]),
+            arr64(rows_per_group), arr64(out_row0), gb_ptrs, i32(G), ptr(packed), ptr(out), i64(out.stride(0)),
+            i32(K), i32(N), i64(out_group_rows), stream_ptr(out.device))
+    _lib.check(rc, "value_proj_bf16")
+    return out
 
 
 def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, ln=None,

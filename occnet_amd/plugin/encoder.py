@@ -210,6 +210,8 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     norm_index += 1
                     i += 1
                 else:
+                    if hasattr(value, 'materialize'):    # LazyFeatures -> the reference-shaped fp32 tensor
+                        key = value = value.materialize()
                     query = attn(
                         query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
                         key_pos=key_pos, reference_points=ref_3d,

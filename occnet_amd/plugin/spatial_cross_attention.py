@@ -211,10 +211,14 @@ class SpatialCrossAttention(BaseModule):
         da = self.deformable_attention
         if not isinstance(da, MSDeformableAttention3D):
             return None
-        num_cams, l, bs, _ = value.shape
         try:
-            v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
-            v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
+            if hasattr(value, 'project'):      # LazyFeatures: bf16 NHWC maps, projected level by level
+                bs, l = value.bs, value.total
+                v = value.project(da.value_proj)
+            else:
+                num_cams, l, bs, _ = value.shape
+                v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
+                v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
             v = v.view(bs * self.num_cams, l, da.num_heads, -1)
             w, b = da._qcat.get((da.sampling_offsets, da.attention_weights))
             lin = ext.linear(query.contiguous(), w, b)

@@ -42,6 +42,67 @@ def rotate_bev_nearest(bev, angle_deg, center):
                          align_corners=False)[0]
 
 
+class LazyFeatures:
+    """The SCA `value` input kept as what the backbone emitted — bf16 NHWC FPN maps — plus the (level, camera)
+    embedding table, instead of the reference's flattened fp32 tensor (`transformer_occ.py:204-222`).
+    `project(value_proj)` runs the projection straight off the maps (ext.value_proj_bf16: the embeddings become
+    a per-(level, camera) bias because the projection is linear), so the 189 MB fp32 flatten buffer is neither
+    written nor read; `materialize()` builds the reference-shaped tensor for consumers without that kernel."""
+
+    def __init__(self, owner, mlvl_feats):
+        self.owner = owner
+        self.mlvl_feats = mlvl_feats
+        self.bs, self.num_cam, self.c = mlvl_feats[0].shape[:3]
+        self.hw = [(f.shape[3], f.shape[4]) for f in mlvl_feats]
+        self.total = sum(h * w for h, w in self.hw)
+        dev = mlvl_feats[0].device
+        self.spatial_shapes = torch.as_tensor(self.hw, dtype=torch.long, device=dev)
+        starts = [0]
+        for h, w in self.hw[:-1]:
+            starts.append(starts[-1] + h * w)
+        self.starts = starts
+        self.level_start_index = torch.as_tensor(starts, dtype=torch.long, device=dev)
+        # (bs*num_cam*h*w, C) pixel-major views of the NHWC maps
+        self.rows = [f.permute(0, 1, 3, 4, 2).reshape(-1, self.c) for f in mlvl_feats]
+        self._flat = None
+
+    @staticmethod
+    def eligible(mlvl_feats):
+        if torch.is_grad_enabled() or not mlvl_feats:
+            return False
+        c = mlvl_feats[0].shape[2]
+        return all(f.is_cuda and f.dtype == torch.bfloat16 and f.dim() == 5 and f.shape[2] == c and c % 32 == 0
+                   and f.permute(0, 1, 3, 4, 2).is_contiguous() for f in mlvl_feats)
+
+    def embeds(self):
+        """(L, num_cam, C) fp32: level_embeds[l] (+ cams_embeds[cam])."""
+        o = self.owner
+        e = o.level_embeds[:len(self.hw), None, :].float()
+        if o.use_cams_embeds:
+            return (e + o.cams_embeds[None, :, :].float()).contiguous()
+        return e.expand(-1, self.num_cam, -1).contiguous()
+
+    def materialize(self):
+        """The reference-shaped (num_cam, sum hw, bs, C) fp32 tensor."""
+        if self._flat is None:
+            flat, _, _ = self.owner.flatten_features(self.mlvl_feats)
+            self._flat = flat.view(self.bs, self.num_cam, flat.shape[1], flat.shape[2]).permute(1, 2, 0, 3)
+        return self._flat
+
+    def project(self, value_proj):
+        """value_proj(feat + embeds) for every camera pixel -> (bs*num_cam, sum hw, N) fp32."""
+        w, b = value_proj.weight, value_proj.bias
+        n = w.shape[0]
+        emb = self.embeds()                                                     # (L, cam, C)
+        gb = emb.view(-1, self.c) @ w.t().float()
+        if b is not None:
+            gb = gb + b.float()
+        gb = gb.view(len(self.hw), self.num_cam, n)
+        out = torch.empty((self.bs * self.num_cam * self.total, n), dtype=torch.float32, device=w.device)
+        ext.value_proj_bf16(self.rows, w, gb.contiguous(), out, rows_per_group=[h * wd for h, wd in self.hw],
+                            out_group_rows=self.total, out_row0=self.starts)
+        return out.view(self.bs * self.num_cam, self.total, n)
+
 @TRANSFORMER.register_module()
 class TransformerOcc(BaseModule):
 
@@ -94,6 +155,7 @@ class TransformerOcc(BaseModule):
         self.init_layers()
         self.rotate_center = rotate_center
         self.use_fused_decoder = True     # flip to force the stock torch (MIOpen) decoder
+        self.use_lazy_features = True     # bf16 NHWC maps go straight into the SCA value projection
         # autograd path only: dtype the MIOpen Conv3d decoder runs in under torch.autocast (None = fp32 as the
         # reference).  MIOpen's fp32 Conv3d backward costs 196 ms per step at 200x200x16, bf16 7 ms.
         self.decoder_autocast_dtype = None
@@ -167,9 +229,14 @@ class TransformerOcc(BaseModule):
                     tmp = prev_bev[:, i].reshape(bev_h, bev_w, -1).permute(2, 0, 1)
                     tmp = rotate_bev_nearest(tmp, float(rotation_angle), self.rotate_center)
                     prev_bev[:, i] = tmp.permute(1, 2, 0).reshape(bev_h * bev_w, -1)
-        flat, spatial_shapes, level_start_index = self.flatten_features(mlvl_feats)
-        # reference axis order (num_cam, sum hw, bs, C) as a view of the (bs*num_cam, sum hw, C) buffer
-        feat_flatten = flat.view(bs, num_cam, flat.shape[1], flat.shape[2]).permute(1, 2, 0, 3)
+        if self.use_lazy_features and LazyFeatures.eligible(mlvl_feats):
+            # bf16 NHWC maps straight into the SCA value projection (no fp32 flatten buffer)
+            feat_flatten = LazyFeatures(self, mlvl_feats)
+            spatial_shapes, level_start_index = feat_flatten.spatial_shapes, feat_flatten.level_start_index
+        else:
+            flat, spatial_shapes, level_start_index = self.flatten_features(mlvl_feats)
+            # reference axis order (num_cam, sum hw, bs, C) as a view of the (bs*num_cam, sum hw, C) buffer
+            feat_flatten = flat.view(bs, num_cam, flat.shape[1], flat.shape[2]).permute(1, 2, 0, 3)
         return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w,
                             bev_pos=bev_pos, spatial_shapes=spatial_shapes,
                             level_start_index=level_start_index, prev_bev=prev_bev, **kwargs)

@@ -115,3 +115,55 @@ def test_linear_unsupported_and_errors():
         ext.linear(torch.randn(8, 64), torch.randn(16, 64).cuda())
     with pytest.raises(OccAmdError):             # weight shape mismatch
         ext.linear(torch.randn(8, 64).cuda(), torch.randn(16, 32).cuda())
+
+
+@pytest.mark.parametrize("G,rpg,K,N,ogr,row0,nbias", [
+    (3, 50, 256, 256, 120, 7, 3),      # groups land at out_row0 inside longer per-camera blocks
+    (6, 375, 256, 256, 400, 25, 6),    # smallest FPN level of the base config
+    (4, 33, 64, 128, 40, 0, 2),        # bias table shorter than the group count (batch > 1: g % num_cam)
+    (1, 200, 96, 192, 200, 0, 1),      # 3 K chunks, 6 column tiles
+    (2, 70, 32, 36, 70, 0, 0),         # one chunk, ragged columns, no bias
+])
+def test_value_proj_bf16_matches_torch(G, rpg, K, N, ogr, row0, nbias):
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(G * 100 + K + N)
+    a = torch.randn(G * rpg, K, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    gb = torch.randn(nbias, N, generator=g).cuda() if nbias else None
+    out = torch.full(((G - 1) * ogr + row0 + rpg + 5, N), float('nan'), device='cuda')
+    ext.value_proj_bf16(a, w, gb, out, rows_per_group=rpg, out_group_rows=ogr, out_row0=row0)
+    want = a.double() @ w.double().t()
+    worst = 0.0
+    for gi in range(G):
+        ref = want[gi * rpg:(gi + 1) * rpg] + (gb[gi % nbias].double() if nbias else 0.0)
+        got = out[gi * ogr + row0: gi * ogr + row0 + rpg].double()
+        worst = max(worst, float((got - ref).abs().max()))
+    print(f"value_proj_bf16 G={G} rpg={rpg} K={K} N={N}: max diff {worst:.3e}")
+    assert worst < 3e-5
+    # rows outside the groups' windows are untouched
+    mask = torch.ones(out.shape[0], dtype=torch.bool, device='cuda')
+    for gi in range(G):
+        mask[gi * ogr + row0: gi * ogr + row0 + rpg] = False
+    assert torch.isnan(out[mask]).all() and not torch.isnan(out[~mask]).any()
+
+
+def test_value_proj_bf16_multi_segment_single_launch():
+    """Four 'levels' of different sizes into per-camera blocks of one output, one launch."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(11)
+    cams, K, N = 3, 64, 256
+    hws = [130, 37, 9, 2]
+    starts = [0, 130, 167, 176]
+    total = sum(hws)
+    a_list = [torch.randn(cams * hw, K, generator=g).cuda().to(torch.bfloat16) for hw in hws]
+    w = (torch.randn(N, K, generator=g) / 8).cuda()
+    gb = torch.randn(len(hws), cams, N, generator=g).cuda()
+    out = torch.full((cams * total, N), float('nan'), device='cuda')
+    ext.value_proj_bf16(a_list, w, gb, out, rows_per_group=hws, out_group_rows=total, out_row0=starts)
+    assert not torch.isnan(out).any()
+    o = out.view(cams, total, N).double()
+    for l, hw in enumerate(hws):
+        ref = (a_list[l].double() @ w.double().t()).view(cams, hw, N) + gb[l].double()[:, None, :]
+        d = float((o[:, starts[l]:starts[l] + hw] - ref).abs().max())
+        print(f"level {l} ({hw} px): max diff {d:.3e}")
+        assert d < 3e-5

@@ -78,6 +78,37 @@ def test_head_forward_matches_oracle(batch):
     assert agree > 0.999
 
 
+@pytest.mark.parametrize("batch", [1, 2])
+def test_bf16_nhwc_features_take_the_direct_value_projection(batch, monkeypatch):
+    """Backbone-format input (bf16 NHWC maps): the SCA value projection runs straight off the maps
+    (ext.value_proj_bf16, embeddings folded into a per-(level, camera) bias) — same result as the oracle on
+    the same (bf16-representable) feature values."""
+    from occnet_amd import ext
+    g = small_cfg()
+    prod, ora = build_pair(g, seed=3)
+    feats = [f.to(torch.bfloat16).float() for f in synthetic.make_features(g, batch=batch, seed=3)]
+    metas = _metas(g, batch=batch)
+    calls = []
+    real = ext.value_proj_bf16
+    monkeypatch.setattr(ext, 'value_proj_bf16', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def nhwc(f):
+        B, N, C, h, w = f.shape
+        return f.cuda().reshape(B * N, C, h, w).to(torch.bfloat16).contiguous(
+            memory_format=torch.channels_last).view(B, N, C, h, w)
+    with torch.no_grad():
+        out_o = ora(feats, metas, prev_bev=None)
+        out_p = prod([nhwc(f) for f in feats], metas, prev_bev=None)
+        n_direct = len(calls)
+        prod.transformer.use_lazy_features = False
+        out_f = prod([nhwc(f) for f in feats], metas, prev_bev=None)      # flatten path on the same maps
+    assert n_direct == g['num_layers'] and len(calls) == n_direct      # one launch per layer, all levels
+    for k in ('bev_embed', 'occ', 'flow'):
+        d, d2 = maxdiff(out_p[k], out_o[k]), maxdiff(out_p[k], out_f[k].cpu())
+        print(f"bs={batch} {k}: direct vs oracle {d:.3e}, direct vs flatten path {d2:.3e}")
+        assert d < TOL and d2 < TOL
+
+
 def test_head_forward_with_history_bev():
     g = small_cfg()
     prod, ora, out_p, out_o = _run_pair(g, batch=1, prev=True)

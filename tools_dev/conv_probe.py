@@ -51,5 +51,27 @@ def main(which):
                   f"{mb / us:5.2f} TB/s")
 
 
+def vp():
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(256, 256, generator=g) / 16).cuda()
+    gb = torch.randn(6, 256, generator=g).cuda()
+    total = 23200 + 5800 + 1450 + 375
+    out = torch.empty(6 * total, 256, device='cuda')
+    hws = (23200, 5800, 1450, 375)
+    a_list = [torch.randn(6 * hw, 256, generator=g).cuda().to(torch.bfloat16) for hw in hws]
+    gb4 = gb.unsqueeze(0).repeat(4, 1, 1).contiguous()
+    starts = [0, 23200, 29000, 30450]
+    us = timeit(lambda: ext.value_proj_bf16(a_list, w, gb4, out, rows_per_group=list(hws), out_group_rows=total,
+                                            out_row0=starts))
+    mb = 6 * total * 256 * (2 + 4) / 1e6
+    print(f"value_proj_bf16 all levels M={6 * total}: {us:7.1f} us  {mb / us:5.2f} TB/s")
+    x = torch.randn(6 * total, 256, generator=g).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    us = timeit(lambda: ext.linear(x, w, b))
+    print(f"linear bf16x3 f32 in M={6 * total}: {us:7.1f} us")
+
+
 if __name__ == '__main__':
+    if 'vp' in sys.argv[1:]:
+        vp()
     main(sys.argv[1:] or ['c3', 'c1'])

@@ -17,6 +17,12 @@
 // at out[(g * out_group_rows + out_row0 + i) * ldo] for row m = g * rows_per_group + i (g = camera image).
 // All FPN levels go in ONE launch (segment table by value): the small levels alone are launch/ramp-bound
 // (13 us for 2 250 rows) and now overlap the large one.
+// Ablation on the base shape (184 950 x 256 -> 256, 64-row blocks, 104 us): without the weight loads 77 us,
+// without the MFMAs 61 us, without the stores or without the activation loads 84 us each — the weight re-read
+// per block through L1/TA (256 KB per block against 32 KB of activations) and the poorly overlapped MFMA burst
+// are what separates it from the 39 us of a plain bf16 -> fp32 widening copy of the same tensors; 128-row blocks
+// halve the former (102 us).  Pinning the prefetch with sched_barrier and an 8-chunk activation prefetch were
+// measured: no gain.
 #include "common.h"
 
 namespace occ {
@@ -35,8 +41,8 @@ struct VpSegments {
   int n;
 };
 
-template <int NT>
-__global__ __launch_bounds__(256) void value_proj_bf16_kernel(
+template <int NT, int RT>
+__global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
     VpSegments seg, const uint4* __restrict__ wp, int bias_groups, float* __restrict__ out, long ldo, int N,
     int K, long out_group_rows) {
   int si = 0;
@@ -47,14 +53,14 @@ __global__ __launch_bounds__(256) void value_proj_bf16_kernel(
   const float* __restrict__ gbias = seg.gbias[si];
   const long M = seg.rows[si], rows_per_group = seg.rows_per_group[si], out_row0 = seg.out_row0[si];
   const long lda8 = seg.lda8[si];
-  constexpr int RT = 2, KC = 32, kLD = KC * 2 + 16, PC = KC / 8;
+  constexpr int KC = 32, kLD = KC * 2 + 16, PC = KC / 8;
   constexpr int BM = 32 * RT, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
   constexpr int A_BYTES = BM * kLD;
   constexpr int STAGE_BYTES = 2 * A_BYTES, OUT_BYTES = 32 * OLD * 4;
   __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kb = lane >> 5;
-  const long m0 = (long)((int)blockIdx.x - seg.first_block[si]) * BM;
+  const long m0 = (long)((int)blockIdx.x - seg.first_block[si]) * BM;     // first_block counts BM-row blocks
   const int n0 = blockIdx.y * BN;
   const int NT32 = (N + 31) / 32;
 
@@ -67,21 +73,23 @@ __global__ __launch_bounds__(256) void value_proj_bf16_kernel(
       for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
   // A: thread -> (row = tid / 4, 16-byte piece = tid % 4) of the 64 x 32 chunk; unconditional clamped loads
-  static_assert(BM * PC == 256 && NT <= 2, "one activation piece per thread");
-  const int arow = tid / PC, apiece = tid % PC;
-  long am = m0 + arow;
+  constexpr int AP = BM * PC / 256;                  // activation pieces per thread per chunk (1 or 2)
+  static_assert((AP == 1 || AP == 2) && NT <= 2, "staging register budget");
+  const int arow = tid / PC, apiece = tid % PC;      // second piece (AP == 2): row + 64
+  long am = m0 + arow, am2 = m0 + arow + 64;
   if (am >= M) am = M - 1;
-  const long aofs = am * lda8 + apiece;
+  if (am2 >= M) am2 = M - 1;
+  const long aofs = am * lda8 + apiece, aofs2 = am2 * lda8 + apiece;
   const int adst = arow * kLD + apiece * 16;
   // this wave's column tiles in the packed weight (hi plane; the lo plane is +64 uint4)
   const int nt0 = min((n0 + wave * WR) / 32, NT32 - 1), nt1 = min((n0 + wave * WR) / 32 + (NT - 1), NT32 - 1);
   const long wl0 = (long)nt0 * 128 + lane, wl1 = (long)nt1 * 128 + lane;
   // two activation sets (chunks c+1, c+2 in flight), two weight sets (chunk c in use, c+1 in flight).  (Requesting
   // the block's whole 64 x K activation tile up front — 8 chunk registers — was measured: not faster.)
-  uint4 va_0, va_1;
+  uint4 va_0, va_1, vb_0, vb_1;      // vb: the second 64 rows (RT == 4)
   uint4 ha0_0, la0_0, hb0_0, lb0_0, ha1_0, la1_0, hb1_0, lb1_0;     // {h,l}{k-step a,b}{tile}_{set}
   uint4 ha0_1, la0_1, hb0_1, lb0_1, ha1_1, la1_1, hb1_1, lb1_1;
-#define OCC_VP_ISSUE_A(S, K0) { va_##S = a[aofs + (K0) / 8]; }
+#define OCC_VP_ISSUE_A(S, K0) { va_##S = a[aofs + (K0) / 8]; if (AP > 1) vb_##S = a[aofs2 + (K0) / 8]; }
 #define OCC_VP_ISSUE_W(S, K0)                                                                     \
   {                                                                                               \
     const long k0 = (long)((K0) / 16) * NT32 * 128, k1 = k0 + (long)NT32 * 128;                   \
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(256) void value_proj_bf16_kernel(
   {                                                                                               \
     char* sA = lds + (BUF) * A_BYTES;                                                             \
     *reinterpret_cast<uint4*>(sA + adst) = va_##SA;                                               \
+    if (AP > 1) *reinterpret_cast<uint4*>(sA + adst + 64 * kLD) = vb_##SA;                        \
     __syncthreads();                                                                              \
     OCC_VP_ISSUE_A(SA, K_A_NEXT)                                                                  \
     OCC_VP_ISSUE_W(SWN, K_W_NEXT)                                                                 \
@@ -180,6 +189,12 @@ extern "C" int occ_value_proj_bf16_f32(int n_segments, const void* const* a, con
               K, N);
     return OCC_E_UNSUPPORTED;
   }
+  // 128-row blocks (four row tiles per wave: the wave's weight fragments, which stream through L1 per block —
+  // 256 KB per block at K = N = 256 against 32-64 KB of activations — are reused twice as often) whenever that
+  // still gives every CU two blocks
+  long total_rows = 0;
+  for (int i = 0; i < n_segments; ++i) total_rows += rows[i];
+  const int bm = (total_rows / 128) * ((N + 255) / 256) >= 2L * 256 ? 128 : 64;
   VpSegments seg;
   long blocks = 0;
   for (int i = 0; i < kVpMaxSeg; ++i) {
@@ -197,17 +212,19 @@ extern "C" int occ_value_proj_bf16_f32(int n_segments, const void* const* a, con
     seg.out_row0[i] = out_row0[j];
     seg.lda8[i] = lda[j] / 8;
     seg.first_block[i] = (int)blocks;
-    if (i < n_segments) blocks += (rows[j] + 63) / 64;
+    if (i < n_segments) blocks += (rows[j] + bm - 1) / bm;
   }
   seg.first_block[kVpMaxSeg] = (int)blocks;
   seg.n = n_segments;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define OCC_VP_LAUNCH(NTT, BNN)                                                                     \
-  hipLaunchKernelGGL((value_proj_bf16_kernel<NTT>), dim3((unsigned)blocks, (unsigned)((N + BNN - 1) / BNN)), \
+#define OCC_VP_LAUNCH_(NTT, BNN, RTT)                                                               \
+  hipLaunchKernelGGL((value_proj_bf16_kernel<NTT, RTT>), dim3((unsigned)blocks, (unsigned)((N + BNN - 1) / BNN)), \
                      dim3(256), 0, st, seg, reinterpret_cast<const uint4*>(weight_packed), bias_groups, out, \
                      (long)ldo, N, K, (long)out_group_rows)
+#define OCC_VP_LAUNCH(NTT, BNN) do { if (bm == 128) OCC_VP_LAUNCH_(NTT, BNN, 4); else OCC_VP_LAUNCH_(NTT, BNN, 2); } while (0)
   if (N <= 128) OCC_VP_LAUNCH(1, 128); else OCC_VP_LAUNCH(2, 256);
 #undef OCC_VP_LAUNCH
+#undef OCC_VP_LAUNCH_
   OCC_CHECK_LAUNCH("value_proj_bf16");
   return OCC_OK;
 }

@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--hot-feat-format", choices=["backbone", "f32"], default="backbone",
                     help="--scope hotpath input: 'backbone' = what the bf16 backbone plan emits (bf16 maps, NHWC "
                          "storage); 'f32' = fp32 NCHW maps (the reference's fp32 backbone)")
+    ap.add_argument("--per-step", action="store_true", help="also print every timed step's GPU time (stderr)")
     ap.add_argument("--backbone-graph", action="store_true",
                     help="replay the folded backbone plan as one hipGraph (static shapes)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
@@ -274,9 +275,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_events = []
     for _ in range(args.steps):
+        if args.per_step:       # GPU-side time of every step (events on the current stream; no host sync)
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
         stepper()
+        if args.per_step:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            step_events.append((e0, e1))
     torch.cuda.synchronize()
+    if args.per_step and rank == 0:
+        ms = [a.elapsed_time(b) for a, b in step_events]
+        print("per-step GPU ms: " + " ".join(f"{m:.2f}" for m in ms), file=sys.stderr)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0

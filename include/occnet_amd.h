@@ -240,6 +240,15 @@ int occ_value_proj_bf16_f32(int n_segments, const void* const* a, const int64_t*
                             const float* const* group_bias, int bias_groups, const void* weight_packed,
                             float* out, int64_t ldo, int K, int N, int64_t out_group_rows, void* stream);
 
+/* ResNet stem in one launch (outside the hand-written hot path):
+ *   out = max_pool2d(relu(conv2d(x, W 7x7, stride 2, pad 3) + bias), kernel 3, stride 2, pad 1)
+ * x (batch, 3, H, W) f32 NCHW (rounded to bf16 while staged) ; weight_frag = occ_mfma_pack_b_frag_bf16 of the
+ * (64, 224) matrix W2[co][ky*32 + kx*4 + c] = W[co][c][ky][kx] (zero at kx = 7 and c = 3) ; bias (64) f32 ;
+ * out (batch, Hp, Wp, 64) bf16 NHWC with Hc = (H-1)/2+1, Hp = (Hc-1)/2+1 (same for W).
+ */
+int occ_stem_conv7x7_pool_f32_bf16(const float* x, const void* weight_frag, const float* bias, void* out,
+                                   int batch, int H, int W, void* stream);
+
 /* Stem tail in one pass: out = max_pool2d(relu(y + bias), kernel 3, stride 2, padding 1) on NHWC bf16
  * (outside the hand-written hot path).  y (batch, H, W, C) bf16 raw convolution output ; bias (C) f32 ;
  * out (batch, (H-1)/2+1, (W-1)/2+1, C) bf16.  Needs C % 8 == 0.

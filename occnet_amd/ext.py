@@ -503,6 +503,37 @@ def bias_act_nhwc_(x, bias, residual=None, relu=True):
     return x
 
 
+def stem_pack_weight(weight):
+    """(64, 3, 7, 7) stem weight (BatchNorm folded) -> the fragment-ordered (64, 224) operand of stem_conv7x7_pool:
+    column ky*32 + kx*4 + c holds weight[:, c, ky, kx]; the pad columns (kx = 7, c = 3) are zero."""
+    if tuple(weight.shape) != (64, 3, 7, 7):
+        raise OccAmdUnsupported("stem_pack_weight: expected a (64, 3, 7, 7) weight")
+    w2 = torch.zeros(64, 7, 8, 4, dtype=torch.float32, device=weight.device)
+    w2[:, :, :7, :3] = weight.float().permute(0, 2, 3, 1)
+    return mfma_pack_b_frag(w2.reshape(64, 224))
+
+
+def stem_conv7x7_pool(x, weight_frag, bias):
+    """max_pool2d(relu(conv2d(x, W, stride 2, padding 3) + bias), 3, 2, 1) in one launch.
+    x (N, 3, H, W) fp32 contiguous (NCHW); weight_frag from stem_pack_weight; bias (64) fp32
+    -> (N, 64, Hp, Wp) channels_last bf16."""
+    _need_cuda_f32("x", x)
+    _need_cuda_f32("bias", bias)
+    if x.dim() != 4 or x.shape[1] != 3 or not x.is_contiguous():
+        raise OccAmdUnsupported("stem_conv7x7_pool: x must be a contiguous (N, 3, H, W) fp32 tensor")
+    if weight_frag.numel() != 64 * 224 or bias.numel() != 64:
+        raise OccAmdError("stem_conv7x7_pool: inconsistent shapes")
+    N, _, H, W = x.shape
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    out = torch.empty((N, 64, Hp, Wp), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().occ_stem_conv7x7_pool_f32_bf16(ptr(x), ptr(weight_frag), ptr(bias), ptr(out), i32(N),
+                                                       i32(H), i32(W), stream_ptr(x.device))
+    _lib.check(rc, "stem_conv7x7_pool")
+    return out
+
+
 def bias_relu_maxpool_nhwc(y, bias):
     """max_pool2d(relu(y + bias), 3, stride 2, padding 1) in one launch on a channels_last bf16 activation
     (the ResNet stem's tail).  y (N, C, H, W) channels_last bf16 raw convolution output; bias (C) f32."""

@@ -210,6 +210,18 @@ class FusedInferenceBackbone(nn.Module):
             return self._add(w, b, conv)
 
         self.stem = fold(backbone.conv1, backbone.bn1)
+        # whole stem (7x7/s2 convolution + bias + ReLU + 3x3/s2 max pooling) as one kernel reading the fp32 NCHW
+        # images directly
+        c1, mp = backbone.conv1, backbone.maxpool
+        pool_ok = (mp.kernel_size, mp.stride, mp.padding) in ((3, 2, 1), ((3, 3), (2, 2), (1, 1)))
+        sw = getattr(self, f'w{self.stem}')
+        self._stem_fused = (self.hip_tail and sw.is_cuda and tuple(sw.shape) == (64, 3, 7, 7) and pool_ok
+                            and tuple(c1.stride) == (2, 2) and tuple(c1.padding) == (3, 3)
+                            and tuple(c1.dilation) == (1, 1) and c1.groups == 1
+                            and getattr(mp, 'dilation', 1) in (1, (1, 1)) and not getattr(mp, 'ceil_mode', False))
+        if self._stem_fused:
+            from .. import ext
+            self.register_buffer('stem_frag', ext.stem_pack_weight(sw), persistent=False)
         self.stages = []
         for name in backbone.res_layers:
             blocks = []
@@ -328,8 +340,12 @@ class FusedInferenceBackbone(nn.Module):
         return st['out']
 
     def _forward_eager(self, x):
-        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
         sw = getattr(self, f'w{self.stem}')
+        if getattr(self, '_stem_fused', False) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous():
+            from .. import ext
+            x = ext.stem_conv7x7_pool(x, self.stem_frag, getattr(self, f'b{self.stem}'))
+            return self._forward_stages(x)
+        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
         if self.hip_tail and sw.shape[0] % 8 == 0 and x.is_cuda:
             # stem tail (bias + ReLU + 3x3/s2 max pooling) as one pass over the raw convolution output
             from .. import ext
@@ -342,6 +358,9 @@ class FusedInferenceBackbone(nn.Module):
                                  kernel_size=3, stride=2, padding=1)
         else:
             x = F.max_pool2d(self._conv(self.stem, x, relu=True), kernel_size=3, stride=2, padding=1)
+        return self._forward_stages(x)
+
+    def _forward_stages(self, x):
         feats = []
         for si, blocks in enumerate(self.stages):
             for bi, (c1, c2, c3, ds) in enumerate(blocks):

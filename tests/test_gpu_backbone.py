@@ -77,6 +77,28 @@ def test_conv3x3_nhwc_matches_torch(N, C, Cout, H, W, relu, stride):
     assert d <= scale * 2 ** -8 + 1e-5          # one bf16 rounding of the f32-accumulated result
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 37, 53), (1, 928 // 8, 1600 // 8), (1, 9, 7)])
+def test_stem_conv7x7_pool_matches_torch(N, H, W):
+    """Whole stem in one kernel vs torch on the same bf16-rounded operands (fp32 accumulation, one rounding of the
+    convolution output)."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(H * W)
+    x = (torch.randn(N, 3, H, W, generator=g) * 50.0).cuda()
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 12.0).cuda()
+    b = torch.randn(64, generator=g).cuda()
+    r = lambda t: t.to(torch.bfloat16).float()
+    got = ext.stem_conv7x7_pool(x, ext.stem_pack_weight(w), b)
+    F = torch.nn.functional
+    conv = r(F.conv2d(r(x), r(w), b, stride=2, padding=3).relu())
+    want = F.max_pool2d(conv, 3, 2, 1)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    d = float((got.float() - want).abs().max())
+    scale = float(want.abs().max())
+    print(f"stem {N}x3x{H}x{W}: max diff {d:.3e} (scale {scale:.1f})")
+    assert d <= scale * 2 ** -8 + 1e-5          # a bf16 rounding flip of the f32-accumulated value
+    assert float((got.float() - want).abs().mean()) <= scale * 2 ** -13
+
+
 def test_bias_relu_maxpool_matches_torch():
     from occnet_amd import ext
     g = torch.Generator().manual_seed(3)

@@ -49,6 +49,8 @@ class LazyFeatures:
     a per-(level, camera) bias because the projection is linear), so the 189 MB fp32 flatten buffer is neither
     written nor read; `materialize()` builds the reference-shaped tensor for consumers without that kernel."""
 
+    _shape_cache = {}
+
     def __init__(self, owner, mlvl_feats):
         self.owner = owner
         self.mlvl_feats = mlvl_feats
@@ -56,12 +58,21 @@ class LazyFeatures:
         self.hw = [(f.shape[3], f.shape[4]) for f in mlvl_feats]
         self.total = sum(h * w for h, w in self.hw)
         dev = mlvl_feats[0].device
-        self.spatial_shapes = torch.as_tensor(self.hw, dtype=torch.long, device=dev)
         starts = [0]
         for h, w in self.hw[:-1]:
             starts.append(starts[-1] + h * w)
         self.starts = starts
-        self.level_start_index = torch.as_tensor(starts, dtype=torch.long, device=dev)
+        # the two index tensors are constant per feature geometry: uploaded once (a pageable host-to-device copy
+        # per step stalls the launch queue)
+        key = (tuple(self.hw), str(dev))
+        hit = self._shape_cache.get(key)
+        if hit is None:
+            hit = (torch.as_tensor(self.hw, dtype=torch.long, device=dev),
+                   torch.as_tensor(starts, dtype=torch.long, device=dev))
+            if len(self._shape_cache) > 16:
+                self._shape_cache.clear()
+            self._shape_cache[key] = hit
+        self.spatial_shapes, self.level_start_index = hit
         # (bs*num_cam*h*w, C) pixel-major views of the NHWC maps
         self.rows = [f.permute(0, 1, 3, 4, 2).reshape(-1, self.c) for f in mlvl_feats]
         self._flat = None
@@ -93,13 +104,22 @@ class LazyFeatures:
         """value_proj(feat + embeds) for every camera pixel -> (bs*num_cam, sum hw, N) fp32."""
         w, b = value_proj.weight, value_proj.bias
         n = w.shape[0]
-        emb = self.embeds()                                                     # (L, cam, C)
-        gb = emb.view(-1, self.c) @ w.t().float()
-        if b is not None:
-            gb = gb + b.float()
-        gb = gb.view(len(self.hw), self.num_cam, n)
+        # per-(level, camera) bias = (cams_embeds + level_embeds) . W^T + b: constant while the parameters are,
+        # cached on the projection module (the entry holds the parameters, so the keys stay unambiguous)
+        o = self.owner
+        srcs = (w, b, o.level_embeds, o.cams_embeds if o.use_cams_embeds else None)
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs) + (len(self.hw),)
+        hit = getattr(value_proj, '_occ_group_bias', None)
+        if hit is None or hit[0] != key:
+            emb = self.embeds()                                                 # (L, cam, C)
+            gb = emb.view(-1, self.c) @ w.t().float()
+            if b is not None:
+                gb = gb + b.float()
+            hit = (key, gb.view(len(self.hw), self.num_cam, n).contiguous(), srcs)
+            value_proj._occ_group_bias = hit
+        gb = hit[1]
         out = torch.empty((self.bs * self.num_cam * self.total, n), dtype=torch.float32, device=w.device)
-        ext.value_proj_bf16(self.rows, w, gb.contiguous(), out, rows_per_group=[h * wd for h, wd in self.hw],
+        ext.value_proj_bf16(self.rows, w, gb, out, rows_per_group=[h * wd for h, wd in self.hw],
                             out_group_rows=self.total, out_row0=self.starts)
         return out.view(self.bs * self.num_cam, self.total, n)
 

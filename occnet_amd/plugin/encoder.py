@@ -314,14 +314,37 @@ class BEVFormerEncoder(TransformerLayerSequence):
         read from img_metas[0] for the whole batch, like the reference (:94, :133-134)."""
         _require_device(reference_points, 'BEVFormerEncoder.point_sampling')
         dev = reference_points.device
-        lidar2img = np.asarray([m['lidar2img'] for m in img_metas])
-        lidar2img = torch.as_tensor(lidar2img, dtype=torch.float32).to(dev).contiguous()
-        ego2lidar = torch.as_tensor(np.asarray(img_metas[0]['ego2lidar']), dtype=torch.float32
-                                    ).to(dev).contiguous()
+        lidar2img, ego2lidar = self._upload_matrices(
+            np.asarray([m['lidar2img'] for m in img_metas], dtype=np.float32),
+            np.asarray(img_metas[0]['ego2lidar'], dtype=np.float32), dev)
         img_h, img_w = img_metas[0]['img_shape'][0][0], img_metas[0]['img_shape'][0][1]
         ref_cam, mask, vis = ext.point_sampling(reference_points.float().contiguous(), lidar2img,
                                                 ego2lidar, pc_range, img_h, img_w)
         return (ref_cam, mask, vis) if return_vis else (ref_cam, mask)
+
+    def _upload_matrices(self, lidar2img, ego2lidar, dev):
+        """The per-sample camera matrices in ONE asynchronous host-to-device copy out of a small ring of pinned
+        staging buffers (two pageable copies per step each stalled the launch queue).  A slot is reused only
+        after the copy that read it has completed."""
+        n1, n2 = lidar2img.size, ego2lidar.size
+        ring = getattr(self, '_mat_ring', None)
+        if ring is None or ring['n'] != n1 + n2 or ring['dev'] != dev:
+            ring = dict(n=n1 + n2, dev=dev, i=0,
+                        host=[torch.empty(n1 + n2, dtype=torch.float32).pin_memory() for _ in range(4)],
+                        done=[None] * 4)
+            self._mat_ring = ring
+        i = ring['i']
+        ring['i'] = (i + 1) % 4
+        if ring['done'][i] is not None:
+            ring['done'][i].synchronize()
+        h = ring['host'][i]
+        h[:n1].copy_(torch.from_numpy(lidar2img.reshape(-1)))
+        h[n1:].copy_(torch.from_numpy(ego2lidar.reshape(-1)))
+        d = h.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring['done'][i] = ev
+        return d[:n1].view(lidar2img.shape), d[n1:].view(ego2lidar.shape)
 
     def _query_major_pos(self, bev_pos):
         """(nq, bs, C) positional encoding -> contiguous (bs, nq, C).  The head hands out the same

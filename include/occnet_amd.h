@@ -262,10 +262,12 @@ int occ_bias_relu_maxpool_nhwc_bf16(const void* y, const float* bias, void* out,
  *   x (batch, Hin, Win, Cin) bf16 ; weight = occ_mfma_pack_b_frag_bf16 of the (Cout, Cin) matrix (MFMA
  *   B-fragment order, read straight from global memory) ; bias (Cout) f32 ; residual / out
  *   (batch, Hout, Wout, Cout) bf16 with Hout = (Hin-1)/stride + 1.  Needs Cin % 32 == 0, Cout % 32 == 0.
+ *   residual_upsample2 != 0: residual is (batch, Hout/2, Wout/2, Cout) and is added nearest-upsampled x2 (the FPN
+ *   top-down path: lateral conv + F.interpolate(coarser, nearest) in one launch; Hout, Wout even).
  */
 int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const float* bias, const void* residual,
                           void* out, int batch, int Hin, int Win, int Cin, int Cout, int stride, int relu,
-                          void* stream);
+                          int residual_upsample2, void* stream);
 
 /* Backbone 3x3 pad-1 convolution, stride 1 or 2, on NHWC bf16 with bias (+ ReLU) fused (outside the
  * hand-written hot path).  x (batch, H, W, Cin) bf16 ; weight packed by occ_conv3x3_pack_weight_bf16 from

@@ -29,7 +29,7 @@ template <int NT, int RT>
 __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ w, const float* __restrict__ bias,
     const unsigned short* __restrict__ residual, unsigned short* __restrict__ out, long M, int N, int K,
-    int Hin, int Win, int Hout, int Wout, int stride, int relu) {
+    int Hin, int Win, int Hout, int Wout, int stride, int relu, int res_up) {
   constexpr int KC = 32, kCLD = KC * 2 + 16, PC = KC / 8;           // 80-byte LDS rows, 4 pieces of 16 B
   constexpr int BM = 32 * RT, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
   constexpr int AP = BM * PC / 256;                                 // A pieces per thread per chunk
@@ -167,7 +167,16 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
       long m = m0 + rt * 32 + wave * 8 + rr;
       if (m >= M) m = M - 1;
       rv[rr] = make_uint2(0u, 0u);
-      if (residual != nullptr && col_live) rv[rr] = *reinterpret_cast<const uint2*>(residual + m * N + n0 + c);
+      if (residual != nullptr && col_live) {
+        long rrow = m;
+        if (res_up) {   // residual = a map of half the resolution, nearest-upsampled x2 (FPN top-down path)
+          const long hw = (long)Hout * Wout;
+          const long n = m / hw, rem = m - n * hw;
+          const int yo = (int)(rem / Wout), xo = (int)(rem - (long)yo * Wout);
+          rrow = (n * (Hout >> 1) + (yo >> 1)) * (Wout >> 1) + (xo >> 1);
+        }
+        rv[rr] = *reinterpret_cast<const uint2*>(residual + rrow * N + n0 + c);
+      }
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
@@ -194,7 +203,8 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_bf16_kernel(
 
 extern "C" int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const float* bias,
                                      const void* residual, void* out, int batch, int Hin, int Win,
-                                     int Cin, int Cout, int stride, int relu, void* stream) {
+                                     int Cin, int Cout, int stride, int relu, int residual_upsample2,
+                                     void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(x && weight && bias && out, "conv1x1_nhwc_bf16: null pointer argument");
   OCC_CHECK_ARG(batch > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && stride > 0,
@@ -205,6 +215,8 @@ extern "C" int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const fl
     return OCC_E_UNSUPPORTED;
   }
   const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
+  OCC_CHECK_ARG(!residual_upsample2 || (residual && Hout % 2 == 0 && Wout % 2 == 0),
+                "conv1x1_nhwc_bf16: an upsampled residual needs even output sizes (exact x2 nearest upsampling)");
   const long M = (long)batch * Hout * Wout;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define OCC_C1_LAUNCH(NTT, RTT, BNN)                                                                \
@@ -213,7 +225,8 @@ extern "C" int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const fl
                      dim3(256), 0, st, reinterpret_cast<const uint4*>(x),                           \
                      reinterpret_cast<const uint4*>(weight), bias,                                  \
                      reinterpret_cast<const unsigned short*>(residual),                             \
-                     reinterpret_cast<unsigned short*>(out), M, Cout, Cin, Hin, Win, Hout, Wout, stride, relu)
+                     reinterpret_cast<unsigned short*>(out), M, Cout, Cin, Hin, Win, Hout, Wout, stride, relu,  \
+                     residual_upsample2)
   // 64-row blocks (128-row blocks were measured on the ResNet-50 shapes and are not faster)
   if (Cout <= 128) OCC_C1_LAUNCH(1, 2, 128); else OCC_C1_LAUNCH(2, 2, 256);
 #undef OCC_C1_LAUNCH

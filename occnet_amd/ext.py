@@ -562,10 +562,11 @@ def conv1x1_pack_weight(weight2d):
     return mfma_pack_b_frag(weight2d.float().contiguous())
 
 
-def conv1x1_nhwc(x, weight_frag, bias, residual=None, relu=False, stride=1):
+def conv1x1_nhwc(x, weight_frag, bias, residual=None, relu=False, stride=1, residual_upsample2=False):
     """1x1 convolution + bias (+ residual) (+ ReLU) on a channels_last bf16 activation, one launch.
     x (N, Cin, H, W) channels_last bf16; weight_frag = conv1x1_pack_weight((Cout, Cin) matrix); bias (Cout) f32;
-    residual (N, Cout, Ho, Wo) channels_last bf16 or None -> (N, Cout, Ho, Wo) channels_last bf16."""
+    residual (N, Cout, Ho, Wo) channels_last bf16 or None -> (N, Cout, Ho, Wo) channels_last bf16.
+    residual_upsample2: residual is (N, Cout, Ho/2, Wo/2) and is added nearest-upsampled x2 (FPN top-down)."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)):
         raise OccAmdUnsupported("conv1x1_nhwc: x must be a channels_last bfloat16 device tensor")
@@ -579,13 +580,17 @@ def conv1x1_nhwc(x, weight_frag, bias, residual=None, relu=False, stride=1):
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
     out = torch.empty((N, Cout, Ho, Wo), dtype=torch.bfloat16, device=x.device,
                       memory_format=torch.channels_last)
-    if residual is not None and not (residual.dtype == torch.bfloat16 and residual.shape == out.shape and
+    want = (N, Cout, Ho // 2, Wo // 2) if residual_upsample2 else tuple(out.shape)
+    if residual_upsample2 and (residual is None or Ho % 2 or Wo % 2):
+        raise OccAmdUnsupported("conv1x1_nhwc: an upsampled residual needs even output sizes")
+    if residual is not None and not (residual.dtype == torch.bfloat16 and tuple(residual.shape) == want and
                                      residual.is_contiguous(memory_format=torch.channels_last)):
         raise OccAmdUnsupported("conv1x1_nhwc: residual must match the output (channels_last bfloat16)")
     with torch.cuda.device(x.device):
         rc = _lib.lib().occ_conv1x1_nhwc_bf16(ptr(x), ptr(weight_frag), ptr(bias), ptr(residual), ptr(out),
                                               i32(N), i32(H), i32(W), i32(Cin), i32(Cout), i32(s),
-                                              i32(1 if relu else 0), stream_ptr(x.device))
+                                              i32(1 if relu else 0), i32(1 if residual_upsample2 else 0),
+                                              stream_ptr(x.device))
     _lib.check(rc, "conv1x1_nhwc")
     return out
 

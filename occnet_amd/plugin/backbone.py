@@ -378,12 +378,22 @@ class FusedInferenceBackbone(nn.Module):
                 feats.append(x)
         nk = self.neck
         inputs = feats
-        lat = [self._conv(self.laterals[i], inputs[i + nk.start_level])
-               for i in range(len(self.laterals))]
-        n = len(lat)
-        for i in range(n - 1, 0, -1):
-            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:],
-                                                    **nk.upsample_cfg)
+        n = len(self.laterals)
+        lat = [None] * n
+        nearest = nk.upsample_cfg.get('mode', 'nearest') == 'nearest' and 'scale_factor' not in nk.upsample_cfg
+        for i in range(n - 1, -1, -1):      # top-down: lateral 1x1 conv + nearest x2 upsample of the coarser level
+            xin = inputs[i + nk.start_level]
+            li = self.laterals[i]
+            up = lat[i + 1] if i + 1 < n else None
+            if up is not None and nearest and self._gemm.get(li) and xin.shape[2] == 2 * up.shape[2] \
+                    and xin.shape[3] == 2 * up.shape[3] and xin.is_contiguous(memory_format=torch.channels_last):
+                from .. import ext       # one launch: the upsampled coarser lateral is the GEMM's residual
+                lat[i] = ext.conv1x1_nhwc(xin, getattr(self, f'm{li}'), getattr(self, f'b{li}'), residual=up,
+                                          relu=False, residual_upsample2=True)
+                continue
+            lat[i] = self._conv(li, xin)
+            if up is not None:
+                lat[i] = lat[i] + F.interpolate(up, size=lat[i].shape[2:], **nk.upsample_cfg)
         outs = [self._conv(self.fpn[i], lat[i]) for i in range(n)]
         if nk.num_outs > n:
             if not nk.add_extra_convs:

@@ -52,6 +52,27 @@ def test_conv1x1_nhwc_matches_torch(N, Cin, Cout, H, W, stride, res, relu):
     assert d <= scale * 2 ** -8 + 1e-6          # one bf16 rounding of the f32-accumulated result
 
 
+def test_conv1x1_upsampled_residual_matches_torch():
+    """FPN top-down step in one launch: lateral 1x1 conv + nearest x2 upsampling of the coarser lateral."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(5)
+    cl = lambda t: t.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    for (N, Cin, Cout, H, W) in [(2, 64, 256, 6, 10), (1, 512, 256, 58, 100)]:
+        x = cl(torch.randn(N, Cin, H, W, generator=g))
+        r = cl(torch.randn(N, Cout, H // 2, W // 2, generator=g))
+        w = (torch.randn(Cout, Cin, generator=g) / Cin ** 0.5).cuda().to(torch.bfloat16)
+        b = torch.randn(Cout, generator=g).cuda()
+        got = ext.conv1x1_nhwc(x, ext.conv1x1_pack_weight(w), b, residual=r, relu=False, residual_upsample2=True)
+        F = torch.nn.functional
+        want = F.conv2d(x.float(), w.float().view(Cout, Cin, 1, 1), b) + F.interpolate(r.float(), size=(H, W))
+        d, scale = float((got.float() - want).abs().max()), float(want.abs().max())
+        print(f"conv1x1+up2 {Cin}->{Cout} {H}x{W}: max diff {d:.3e} (scale {scale:.2f})")
+        assert d <= scale * 2 ** -8 + 1e-6
+    with pytest.raises(ext.OccAmdUnsupported):
+        ext.conv1x1_nhwc(cl(torch.randn(1, 32, 5, 6)), ext.conv1x1_pack_weight(torch.randn(32, 32).cuda()),
+                         torch.zeros(32).cuda(), residual=cl(torch.randn(1, 32, 2, 3)), residual_upsample2=True)
+
+
 @pytest.mark.parametrize("N,C,Cout,H,W,relu,stride", [
     (2, 128, 128, 9, 21, True, 1), (1, 256, 256, 16, 32, False, 1), (1, 512, 512, 5, 7, True, 1),
     (3, 64, 256, 8, 16, True, 1), (1, 32, 128, 1, 1, False, 1), (1, 256, 128, 29, 50, True, 1),

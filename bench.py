@@ -359,12 +359,19 @@ def main():
                 vox = head.bev_h * head.bev_w * tr.pillar_h
                 fl = [2.0 * vox * 27 * tr.middle_dims * tr.out_dim, 2.0 * vox * 27 * tr.out_dim * tr.out_dim]
                 ms = [sum(conv[0::2]) / (len(conv) // 2), sum(conv[1::2]) / (len(conv) // 2)]
+                # bf16x3 (default): 3 bf16 MFMAs per product -> priced against the dense bf16 peak with 3x the
+                # algorithmic flops; f32: v_mfma_f32_32x32x2_f32 against the f32 peak
+                x3 = ext.CONV3D_PRECISION == "bf16x3" and tr.middle_dims % 16 == 0 and tr.out_dim % 16 == 0
+                peak, mult = (2500.0, 3.0) if x3 else (157.3, 1.0)
                 out["mfma_kernels"] = {
-                    "peak_tflops_f32": 157.3,
+                    "peak_tflops_f32": 157.3, "peak_tflops_bf16": 2500.0,
+                    "conv3d_precision": "bf16x3" if x3 else "f32",
                     "conv3d_lifter": {"launch_ms": ms[0], "tflops": fl[0] / ms[0] / 1e9,
-                                      "frac": fl[0] / ms[0] / 1e9 / 157.3},
+                                      "mfma_tflops": mult * fl[0] / ms[0] / 1e9,
+                                      "frac": mult * fl[0] / ms[0] / 1e9 / peak},
                     "conv3d_2": {"launch_ms": ms[1], "tflops": fl[1] / ms[1] / 1e9,
-                                 "frac": fl[1] / ms[1] / 1e9 / 157.3},
+                                 "mfma_tflops": mult * fl[1] / ms[1] / 1e9,
+                                 "frac": mult * fl[1] / ms[1] / 1e9 / peak},
                 }
                 hd = times.get("occ_heads", [])
                 if hd:

@@ -153,6 +153,17 @@ int occ_conv3d_bn_relu_f32(const float* in, const float* w_packed, const float* 
                            int Cout, int in_layout, int64_t out_stride_b, int64_t out_stride_y,
                            int64_t out_stride_x, int relu, void* stream);
 
+/* bf16x3 variant of the two calls above (the default decoder kernel): operands split into hi + lo bf16,
+ * a.w ~= al.wh + ah.wl + ah.wh accumulated in f32 by v_mfma_f32_32x32x16_bf16 (product error <= 2^-16; 5.3x less
+ * matrix-pipe time than the exact-f32 instruction).  Same arguments; packed = 2 * Cout*Cin*27 16-bit words
+ * ([phase][tap][hi, lo][k half][co][8]); needs Cout == 32, Cin % 16 == 0, Z in {4, 8, 16, 32}.
+ */
+int occ_conv3d_pack_weight_bf16x3(const float* weight, void* packed, int Cin, int Cout, void* stream);
+int occ_conv3d_bn_relu_bf16x3_f32(const float* in, const void* w_packed, const float* scale, const float* shift,
+                                  float* out, int B, int Z, int Y, int X, int Cin, int Cout, int in_layout,
+                                  int64_t out_stride_b, int64_t out_stride_y, int64_t out_stride_x, int relu,
+                                  void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Occupancy heads on every voxel feature row:
  *   occ  = Linear(hidden, num_classes)( Softplus( Linear(C, hidden)(feat) ) )     (predicter)

@@ -196,6 +196,214 @@ __global__ void conv3d_pack_weight_kernel(const float* __restrict__ w, float* __
   packed[idx] = w[((long)co * Cin + ci) * 27 + t];
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16x3 variant (default): same decomposition, but the K contraction runs on the bf16 matrix cores with every
+// f32 operand split into hi + lo bf16 (x = hi + lo to 16 mantissa bits) and  a.w ~= al.wh + ah.wl + ah.wh
+// accumulated in f32 — three 32-cycle v_mfma_f32_32x32x16_bf16 per tap and 16 channels instead of eight 64-cycle
+// v_mfma_f32_32x32x2_f32: 5.3x less matrix-pipe time at a product error <= 2^-16 (the same trade as
+// linear_bf16x3.hip; gfx950 has no xf32 instruction).  CH = 16 channels per phase; a halo voxel slot holds
+// [16 hi | 16 lo] bf16 + 16 B pad = the same 80 bytes as the f32 kernel's 16 + 4 floats, so the LDS geometry and
+// its conflict-free ds_read_b128 pattern carry over; lanes 0-31 / 32-63 supply channels 0-7 / 8-15 of a voxel.
+// Weights: packed[phase][tap][hi, lo][k half][co][8] bf16 — one 16-byte load per lane, plane and tap.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ void conv3d_pack_weight_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed,
+                                                 int Cin) {
+  const int n = 32 * Cin * 27;                                 // one (hi, lo) pair per thread
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  int r = idx;
+  const int j = r % 8; r /= 8;
+  const int co = r % 32; r /= 32;
+  const int kh = r % 2; r /= 2;
+  const int t = r % 27;
+  const int p = r / 27;
+  const int ci = p * 16 + kh * 8 + j;
+  const float x = w[((long)co * Cin + ci) * 27 + t];
+  const unsigned short hi = bf16_rne(x);
+  const unsigned short lo = bf16_rne(x - __uint_as_float((unsigned)hi << 16));
+  const long base = (((long)(p * 27 + t) * 2) * 2 + kh) * 32 * 8 + co * 8 + j;     // plane 0 (hi)
+  packed[base] = hi;
+  packed[base + 2 * 32 * 8] = lo;                                                    // plane 1 (lo)
+}
+
+template <int Z, int TY, int TX, int LAYOUT>
+__global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(
+    const float* __restrict__ in, const uint4* __restrict__ wp, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int Y, int X, int Cin, long out_sb,
+    long out_sy, long out_sx, int relu, int tiles_x, int tiles_y) {
+  constexpr int CH = 16;
+  using G = ConvGeom<Z, CH, TY, TX>;
+  constexpr int VSB = G::VS * 4, PSB = G::PS * 4, HX = G::HX, HY = G::HY, NACC = G::NACC;   // bytes
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int tx_i = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty_i = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty_i * TY, x0 = tx_i * TX;
+  const float* inb = in + (long)b * Y * X * Z * Cin;
+
+  // z-halo slots (z = -1 and z = Z) of every halo pillar stay zero for all phases
+  for (int i = tid; i < HY * HX * 2 * (VSB / 16); i += 256) {
+    const int pil = i / (2 * (VSB / 16)), rem = i % (2 * (VSB / 16));
+    const int part = rem % (VSB / 16);
+    *reinterpret_cast<uint4*>(ldsb + pil * PSB + (rem >= VSB / 16 ? (Z + 1) * VSB : 0) + part * 16) =
+        make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  const int vi = lane & 31, kh = lane >> 5;
+  int abase[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int rt = wave * NACC + a;
+    const int ty = rt / G::TXG, txg = rt % G::TXG;
+    const int px = txg * G::PX + vi / Z, z = vi % Z;
+    abase[a] = (ty * HX + px) * PSB + z * VSB + kh * 16;       // tap (0,0,0) = halo corner (-1,-1,-1), hi plane
+  }
+
+  const int nph = Cin / CH;
+  for (int p = 0; p < nph; ++p) {
+    if (p) __syncthreads();  // every wave is done reading the previous phase's halo
+    // ---- stage 16 channels of the halo, split into hi / lo bf16 -------------------------------------
+    if (LAYOUT == 0) {
+      constexpr int PARTS = CH / 4, ITEMS = HY * HX * Z * PARTS, ITERS = (ITEMS + 255) / 256;
+      float4 v[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int part = idx % PARTS, z = (idx / PARTS) % Z, pil = idx / (PARTS * Z);
+        const int gy = y0 + pil / HX - 1, gx = x0 + pil % HX - 1;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < ITEMS && gy >= 0 && gy < Y && gx >= 0 && gx < X)
+          v[it] = *reinterpret_cast<const float4*>(inb + (((long)gy * X + gx) * Z + z) * Cin +
+                                                   p * CH + part * 4);
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int part = idx % PARTS, z = (idx / PARTS) % Z, pil = idx / (PARTS * Z);
+        if (idx < ITEMS) {
+          const unsigned h01 = pack_bf16x2_rne(v[it].x, v[it].y), h23 = pack_bf16x2_rne(v[it].z, v[it].w);
+          const unsigned l01 = pack_bf16x2_rne(v[it].x - __uint_as_float(h01 << 16),
+                                               v[it].y - __uint_as_float(h01 & 0xffff0000u));
+          const unsigned l23 = pack_bf16x2_rne(v[it].z - __uint_as_float(h23 << 16),
+                                               v[it].w - __uint_as_float(h23 & 0xffff0000u));
+          char* d = ldsb + pil * PSB + (z + 1) * VSB + part * 8;
+          *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(d + 32) = make_uint2(l01, l23);
+        }
+      }
+    } else {
+      constexpr int Z4 = Z / 4, ITEMS = HY * HX * CH * Z4, ITERS = (ITEMS + 255) / 256;
+      float4 v[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int z4 = idx % Z4, ci = (idx / Z4) % CH, pil = idx / (Z4 * CH);
+        const int gy = y0 + pil / HX - 1, gx = x0 + pil % HX - 1;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < ITEMS && gy >= 0 && gy < Y && gx >= 0 && gx < X)
+          v[it] = *reinterpret_cast<const float4*>(inb + ((long)gy * X + gx) * Z * Cin +
+                                                   (long)(p * CH + ci) * Z + z4 * 4);
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int z4 = idx % Z4, ci = (idx / Z4) % CH, pil = idx / (Z4 * CH);
+        if (idx < ITEMS) {
+          const float f[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+          char* d = ldsb + pil * PSB + (z4 * 4 + 1) * VSB + ci * 2;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned short hi = bf16_rne(f[q]);
+            const unsigned short lo = bf16_rne(f[q] - __uint_as_float((unsigned)hi << 16));
+            *reinterpret_cast<unsigned short*>(d + q * VSB) = hi;
+            *reinterpret_cast<unsigned short*>(d + q * VSB + 32) = lo;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 27 taps x NACC accumulators x 3 MFMAs (small terms first) ----------------------------------
+    const uint4* wq = wp + ((long)p * 27 * 2 * 2 + kh) * 32 + vi;      // + (t*2 + plane) * 64
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+      const int toff = (ky * HX + kx) * PSB + kz * VSB;
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[(t * 2 + 0) * 64]);
+      const bf16x8 wl = __builtin_bit_cast(bf16x8, wq[(t * 2 + 1) * 64]);
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff + 32);
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[a], 0, 0, 0);
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[a], 0, 0, 0);
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[a], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: BN(eval) + ReLU, one 128-byte row per voxel ---------------------------------------
+  const float sc = scale[vi], sh = shift[vi];
+  float* outb = out + (long)b * out_sb;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int rt = wave * NACC + a;
+    const int ty = rt / G::TXG, txg = rt % G::TXG;
+    const int gy = y0 + ty;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const int gx = x0 + txg * G::PX + row / Z, z = row % Z;
+      float v = fmaf(acc[a][r], sc, sh);
+      if (relu) v = fmaxf(v, 0.f);
+      if (gy < Y && gx < X) outb[gy * out_sy + gx * out_sx + z * 32 + vi] = v;
+    }
+  }
+}
+
+template <int Z, int TY, int TX>
+static int launch_conv_x3(const float* in, const void* wp, const float* scale, const float* shift,
+                          float* out, int B, int Y, int X, int Cin, long out_sb, long out_sy,
+                          long out_sx, int relu, int layout, hipStream_t st) {
+  using G = ConvGeom<Z, 16, TY, TX>;
+  const int tiles_x = (X + TX - 1) / TX, tiles_y = (Y + TY - 1) / TY;
+  const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+  const dim3 grid((unsigned)((long)B * tiles_x * tiles_y));
+  const uint4* w4 = reinterpret_cast<const uint4*>(wp);
+  hipError_t e;
+  if (layout == 0) {
+    auto k = conv3d_bf16x3_kernel<Z, TY, TX, 0>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(k, grid, dim3(256), lds, st, in, w4, scale, shift, out, Y, X, Cin, out_sb,
+                         out_sy, out_sx, relu, tiles_x, tiles_y);
+  } else {
+    auto k = conv3d_bf16x3_kernel<Z, TY, TX, 1>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(k, grid, dim3(256), lds, st, in, w4, scale, shift, out, Y, X, Cin, out_sb,
+                         out_sy, out_sx, relu, tiles_x, tiles_y);
+  }
+  if (e != hipSuccess) {
+    set_error("conv3d_bn_relu_bf16x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return OCC_E_LAUNCH;
+  }
+  OCC_CHECK_LAUNCH("conv3d_bn_relu_bf16x3");
+  return OCC_OK;
+}
+
 template <int Z, int CH, int TY, int TX>
 static int launch_conv(const float* in, const float* wp, const float* scale, const float* shift,
                        float* out, int B, int Y, int X, int Cin, long out_sb, long out_sy,
@@ -283,5 +491,51 @@ extern "C" int occ_conv3d_bn_relu_f32(const float* in, const float* w_packed, co
   OCC_CONV_CASE(4, 8, 2, 16)
 #undef OCC_CONV_CASE
   set_error("conv3d_bn_relu: no MFMA kernel for Z=%d CH=%d", Z, CH);
+  return OCC_E_UNSUPPORTED;
+}
+
+extern "C" int occ_conv3d_pack_weight_bf16x3(const float* weight, void* packed, int Cin, int Cout,
+                                             void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(weight && packed, "conv3d_pack_weight_bf16x3: null pointer argument");
+  if (Cout != 32 || Cin <= 0 || Cin % 16) {
+    set_error("conv3d_pack_weight_bf16x3: no kernel for Cin=%d Cout=%d (need Cout=32, Cin %% 16 == 0)", Cin, Cout);
+    return OCC_E_UNSUPPORTED;
+  }
+  const int n = 32 * Cin * 27;
+  hipLaunchKernelGGL(conv3d_pack_weight_bf16x3_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), weight, reinterpret_cast<unsigned short*>(packed), Cin);
+  OCC_CHECK_LAUNCH("conv3d_pack_weight_bf16x3");
+  return OCC_OK;
+}
+
+extern "C" int occ_conv3d_bn_relu_bf16x3_f32(const float* in, const void* w_packed, const float* scale,
+                                             const float* shift, float* out, int B, int Z, int Y, int X,
+                                             int Cin, int Cout, int in_layout, int64_t out_stride_b,
+                                             int64_t out_stride_y, int64_t out_stride_x, int relu,
+                                             void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(in && w_packed && scale && shift && out, "conv3d_bn_relu_bf16x3: null pointer argument");
+  OCC_CHECK_ARG(B > 0 && Z > 0 && Y > 0 && X > 0 && Cin > 0 && Cout > 0,
+                "conv3d_bn_relu_bf16x3: bad dimension (B=%d Z=%d Y=%d X=%d Cin=%d Cout=%d)", B, Z, Y, X, Cin,
+                Cout);
+  OCC_CHECK_ARG(in_layout == 0 || in_layout == 1, "conv3d_bn_relu_bf16x3: in_layout must be 0 or 1");
+  OCC_CHECK_ARG((long)Y * X * Z * (Cin > Cout ? Cin : Cout) < (1L << 31),
+                "conv3d_bn_relu_bf16x3: one batch entry exceeds 2^31 elements");
+  if (Cout != 32 || Cin % 16 || !(Z == 4 || Z == 8 || Z == 16 || Z == 32)) {
+    set_error("conv3d_bn_relu_bf16x3: no kernel for Z=%d Cin=%d Cout=%d", Z, Cin, Cout);
+    return OCC_E_UNSUPPORTED;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define OCC_CONV_CASE(ZZ, TTY, TTX)                                                                \
+  if (Z == ZZ)                                                                                     \
+    return launch_conv_x3<ZZ, TTY, TTX>(in, w_packed, scale, shift, out, B, Y, X, Cin,             \
+                                        (long)out_stride_b, (long)out_stride_y,                    \
+                                        (long)out_stride_x, relu, in_layout, st);
+  OCC_CONV_CASE(16, 2, 8)
+  OCC_CONV_CASE(32, 2, 4)
+  OCC_CONV_CASE(8, 2, 16)
+  OCC_CONV_CASE(4, 2, 16)
+#undef OCC_CONV_CASE
   return OCC_E_UNSUPPORTED;
 }

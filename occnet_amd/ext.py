@@ -10,6 +10,7 @@ the C ABI (include/occnet_amd.h) of libocc_amd.so.
 The remaining functions expose the fused MI355X kernels (no counterpart in mmcv._ext).
 """
 import ctypes
+import os
 
 import torch
 
@@ -224,12 +225,24 @@ def conv3d_channel_block(cin):
     return int(_lib.lib().occ_conv3d_channel_block(i32(int(cin))))
 
 
-def conv3d_pack_weight(weight):
-    """torch Conv3d weight (Cout, Cin, 3, 3, 3) f32 -> packed MFMA B-fragment order (flat tensor)."""
+CONV3D_PRECISION = os.environ.get("OCC_CONV3D_PRECISION", "bf16x3")   # 'bf16x3' (default) or 'f32'
+
+
+def conv3d_pack_weight(weight, precision=None):
+    """torch Conv3d weight (Cout, Cin, 3, 3, 3) f32 -> packed MFMA B-fragment order (flat tensor): float32 for
+    the exact-f32 kernel, int16 (bf16 hi/lo planes) for the bf16x3 kernel (Cin % 16 == 0, else f32)."""
     _need_cuda_f32("weight", weight)
     if weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3):
         raise OccAmdError("conv3d_pack_weight: expected a (Cout, Cin, 3, 3, 3) weight")
     cout, cin = weight.shape[:2]
+    precision = precision or CONV3D_PRECISION
+    if precision == 'bf16x3' and cin % 16 == 0:
+        packed = torch.empty(weight.numel() * 2, dtype=torch.int16, device=weight.device)
+        with torch.cuda.device(weight.device):
+            rc = _lib.lib().occ_conv3d_pack_weight_bf16x3(ptr(weight), ptr(packed), i32(cin), i32(cout),
+                                                          stream_ptr(weight.device))
+        _lib.check(rc, "conv3d_pack_weight")
+        return packed
     packed = torch.empty(weight.numel(), dtype=torch.float32, device=weight.device)
     with torch.cuda.device(weight.device):
         rc = _lib.lib().occ_conv3d_pack_weight_f32(ptr(weight), ptr(packed), i32(cin), i32(cout),
@@ -240,15 +253,19 @@ def conv3d_pack_weight(weight):
 
 def conv3d_bn_relu(x, w_packed, scale, shift, Z, Y, X, cin, cout, in_layout, out_xy_major=False,
                    relu=True):
-    """Lifter/Conv3d(k3,p1)+BN(eval)+ReLU on the f32 matrix cores.
+    """Lifter/Conv3d(k3,p1)+BN(eval)+ReLU on the matrix cores; the kernel (exact f32, or bf16x3: operands split
+    into hi + lo bf16, f32 accumulation) follows the dtype of `w_packed` (conv3d_pack_weight).
 
     x: in_layout 0 -> (B, Y, X, Z, cin); in_layout 1 -> (B, Y*X, cin*Z) BEV embedding (lifter view).
     -> (B, Y, X, Z, cout), or (B, X, Y, Z, cout) with out_xy_major (the reference's
     permute(0,4,3,2,1) order, transformer_occ.py:308)."""
-    for n, t in (("x", x), ("w_packed", w_packed), ("scale", scale), ("shift", shift)):
+    for n, t in (("x", x), ("scale", scale), ("shift", shift)):
         _need_cuda_f32(n, t)
+    x3 = w_packed.dtype == torch.int16
+    if not (w_packed.is_cuda and w_packed.is_contiguous() and (x3 or w_packed.dtype == torch.float32)):
+        raise OccAmdError("conv3d_bn_relu: w_packed must come from conv3d_pack_weight")
     B = x.shape[0]
-    if x.numel() != B * Y * X * Z * cin or w_packed.numel() != cout * cin * 27 \
+    if x.numel() != B * Y * X * Z * cin or w_packed.numel() != cout * cin * 27 * (2 if x3 else 1) \
             or scale.numel() != cout or shift.numel() != cout:
         raise OccAmdError("conv3d_bn_relu: inconsistent shapes")
     if out_xy_major:
@@ -257,11 +274,11 @@ def conv3d_bn_relu(x, w_packed, scale, shift, Z, Y, X, cin, cout, in_layout, out
     else:
         out = torch.empty((B, Y, X, Z, cout), dtype=torch.float32, device=x.device)
         sy, sx = X * Z * cout, Z * cout
+    fn = _lib.lib().occ_conv3d_bn_relu_bf16x3_f32 if x3 else _lib.lib().occ_conv3d_bn_relu_f32
     with torch.cuda.device(x.device), _timed('conv3d_bn_relu'):
-        rc = _lib.lib().occ_conv3d_bn_relu_f32(
-            ptr(x), ptr(w_packed), ptr(scale), ptr(shift), ptr(out), i32(B), i32(Z), i32(Y), i32(X),
-            i32(cin), i32(cout), i32(int(in_layout)), i64(Y * X * Z * cout), i64(sy), i64(sx),
-            i32(1 if relu else 0), stream_ptr(x.device))
+        rc = fn(ptr(x), ptr(w_packed), ptr(scale), ptr(shift), ptr(out), i32(B), i32(Z), i32(Y), i32(X),
+                i32(cin), i32(cout), i32(int(in_layout)), i64(Y * X * Z * cout), i64(sy), i64(sx),
+                i32(1 if relu else 0), stream_ptr(x.device))
     _lib.check(rc, "conv3d_bn_relu")
     return out
 

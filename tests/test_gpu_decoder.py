@@ -32,7 +32,8 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("name,B,Z,Y,X,Cin", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 @pytest.mark.parametrize("layout", [0, 1])
-def test_conv3d_bn_relu_matches_oracle(name, B, Z, Y, X, Cin, layout):
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_conv3d_bn_relu_matches_oracle(name, B, Z, Y, X, Cin, layout, precision):
     from occnet_amd import ext
     g = torch.Generator().manual_seed(20 + layout)
     cout = 32
@@ -46,7 +47,9 @@ def test_conv3d_bn_relu_matches_oracle(name, B, Z, Y, X, Cin, layout):
         xin = x.permute(0, 3, 4, 1, 2).reshape(B, Y * X, Cin * Z).contiguous()   # BEV embedding
         assert torch.equal(odec.lifter(xin, Z, Y, X), x)           # the lifter view is exactly this
     scale, shift = _fold(bn)
-    wp = ext.conv3d_pack_weight(w.cuda())
+    wp = ext.conv3d_pack_weight(w.cuda(), precision=precision)
+    x3 = wp.dtype == torch.int16            # Cin % 16 != 0 keeps the exact-f32 kernel
+    assert x3 == (precision == "bf16x3" and Cin % 16 == 0)
     for xy_major in (False, True):
         out = ext.conv3d_bn_relu(xin.cuda(), wp, scale.cuda(), shift.cuda(), Z, Y, X, Cin, cout,
                                  in_layout=layout, out_xy_major=xy_major)
@@ -54,9 +57,10 @@ def test_conv3d_bn_relu_matches_oracle(name, B, Z, Y, X, Cin, layout):
         got = out.cpu().double()
         want = ref.permute(0, 4, 3, 2, 1) if xy_major else ref.permute(0, 3, 4, 2, 1)
         d = float((got - want).abs().max())
-        print(f"{name} layout={layout} xy_major={xy_major}: max|hip - oracle(f64)| = {d:.3e}")
+        print(f"{name} layout={layout} {precision} xy_major={xy_major}: max|hip - oracle(f64)| = {d:.3e}")
         assert got.shape == want.shape
-        assert d < 2e-5
+        # exact f32: summation-order noise; bf16x3: 2^-16 per product over K = 27*Cin terms (bound 1e-3)
+        assert d < (1e-4 if x3 else 2e-5)
 
 
 def test_conv3d_linearity_full_size():
@@ -67,7 +71,7 @@ def test_conv3d_linearity_full_size():
     Z, Y, X, C = 16, 200, 200, 32
     x = torch.randn(1, Y, X, Z, C, generator=g).cuda()
     w = torch.randn(C, C, 3, 3, 3, generator=g) * 0.05
-    wp = ext.conv3d_pack_weight(w.cuda())
+    wp = ext.conv3d_pack_weight(w.cuda())          # default precision (bf16x3)
     one, zero = torch.ones(C).cuda(), torch.zeros(C).cuda()
     f = lambda t: ext.conv3d_bn_relu(t, wp, one, zero, Z, Y, X, C, C, in_layout=0, relu=False)
     o1, o2 = f(x), f(x * 2.0)
@@ -78,7 +82,7 @@ def test_conv3d_linearity_full_size():
     got = o1[:, ys, xs].cpu().double().permute(0, 4, 3, 1, 2)
     d = float((got - ref).abs().max())
     print(f"full-size crop: max|hip - oracle(f64)| = {d:.3e}")
-    assert d < 5e-5
+    assert d < 1e-4        # bf16x3 products (default precision)
 
 
 @pytest.mark.parametrize("n_rows,ncls", [(1, 17), (31, 17), (32, 17), (1000, 17), (4099, 18), (77, 3)])

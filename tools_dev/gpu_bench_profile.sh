@@ -3,7 +3,7 @@
 # to keep into profiles/).   usage: gpurun -- 'bash tools_dev/gpu_bench_profile.sh [bench|trace|pmc|train ...]'
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export TMPDIR=/tmp
-KR="sca_fused|tsa_fused|conv3d_mfma|occ_heads|linear_bf16x3|linear_mfma"
+KR="sca_fused|tsa_fused|conv3d_mfma|conv3d_bf16x3|occ_heads|linear_bf16x3|linear_mfma|value_proj"
 for what in "${@:-bench trace}"; do
 case $what in
 bench)
@@ -24,6 +24,27 @@ pmc)
     (cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv --kernel-include-regex "$KR" -d /tmp/pmc_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --scope hotpath --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/gpurun_out/pmc_$i.log 2>&1)
     f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/pmc_${i}_counters.csv
   done
-  python tools_dev/pmc_summary.py gpurun_out/pmc_*_counters.csv > gpurun_out/pmc_summary.txt; tail -50 gpurun_out/pmc_summary.txt ;;
+  python tools_dev/pmc_summary.py gpurun_out/pmc_*_counters.csv > gpurun_out/pmc_summary.txt
+  python - > gpurun_out/pmc_derived.txt <<'PY'
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for path in sorted(glob.glob('gpurun_out/pmc_[0-9]*_counters.csv')):
+    for row in csv.DictReader(open(path)):
+        k = row['Kernel_Name'].split('(')[0].replace('void ', '')
+        a = acc[k][row['Counter_Name']]; a[0] += 1; a[1] += float(row['Counter_Value'])
+print("# derived per-kernel means (rocprofv3 --pmc, one counter set per pass; bench.py --scope hotpath)")
+print("# MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES/32 * 1024); TA = TA_BUSY_avr / (SQ_BUSY_CYCLES/32);")
+print("# L2hit = TCC_HIT/(TCC_HIT+TCC_MISS); L2missMB = TCC_MISS*128/1e6; LDScf = SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE;")
+print("# FETCH/WRITE_SIZE as reported (KB on gfx950 after the guide's x2 correction is NOT applied here)")
+print(f"{'kernel':44s} {'n':>4s} {'kcyc':>8s} {'Mfma':>6s} {'TA':>6s} {'L2hit':>6s} {'L2missMB':>9s} {'LDScf':>6s} {'FETCH':>10s} {'WRITE':>10s}")
+for k, c in sorted(acc.items()):
+    m = lambda n: c[n][1] / c[n][0] if n in c and c[n][0] else float('nan')
+    dur = m('SQ_BUSY_CYCLES') / 32
+    hit, miss = m('TCC_HIT_sum'), m('TCC_MISS_sum')
+    print(f"{k[:44]:44s} {c['SQ_BUSY_CYCLES'][0]:4d} {dur/1e3:8.1f} {m('SQ_VALU_MFMA_BUSY_CYCLES')/(dur*1024):6.3f} "
+          f"{m('TA_BUSY_avr')/dur:6.3f} {hit/(hit+miss):6.3f} {miss*128/1e6:9.1f} "
+          f"{m('SQ_LDS_BANK_CONFLICT')/m('SQ_LDS_IDX_ACTIVE'):6.3f} {m('FETCH_SIZE'):10.0f} {m('WRITE_SIZE'):10.0f}")
+PY
+  cat gpurun_out/pmc_derived.txt ;;
 esac
 done

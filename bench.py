@@ -261,6 +261,8 @@ def main():
     if args.mode == "train":
         stepper = TrainStepper(model, geo, args.backbone_dtype, device, seed=rank, world=world)
     else:
+        if args.scope == "e2e" and getattr(model, "img_backbone", None) is None:
+            args.scope = "hotpath"          # feature-input config (no image backbone): only the hot path exists
         stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank,
                           plan=args.backbone_plan, graph=args.backbone_graph,
                           hot_feat_format=args.hot_feat_format)

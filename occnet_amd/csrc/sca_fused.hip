@@ -19,8 +19,10 @@ namespace occ {
 
 constexpr int kScaWaves = 4;
 
+// three waves per SIMD: unconstrained, hipcc spends 172 VGPRs (two waves per SIMD); at <= 168 a third wave fits
+// and the TA-bound gather runs 10 % faster (0.316 -> 0.285 ms); four waves need spills and are slower (0.308 ms)
 template <int L, int P>
-__global__ __launch_bounds__(256) void sca_fused_kernel(
+__global__ __launch_bounds__(256, 3) void sca_fused_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lstart, const float* __restrict__ offs, long offs_stride,
     const float* __restrict__ logits, long logits_stride, const float* __restrict__ ref_cam,

@@ -182,13 +182,17 @@ class FPN(BaseModule):
 
 
 class FusedInferenceBackbone(nn.Module):
-    """Inference-time execution plan for ResNet + FPN on stock PyTorch-ROCm / MIOpen ops: eval-mode
-    BatchNorm folded into the preceding convolution (`fuse_conv_bn_weights`), in one dtype and
-    channels_last (NHWC) memory; `fused_ops=True` additionally issues convolution + bias (+ residual) +
-    ReLU as MIOpen's fused forward (`torch.miopen_convolution_relu` / `_add_relu`) — measured on MI355X /
-    ROCm 7.2 this falls back to MIOpen's naive bf16 NHWC kernel (1.7 s per forward), so it is off by default so the FPN outputs are already in the (Cam, H, W, C) layout
-    the gather kernels want.  Built from the live modules' parameters (it owns folded COPIES: rebuild
-    after changing weights); no custom kernels — the backbone stays outside the hand-written scope."""
+    """Inference-time execution plan for ResNet + FPN: eval-mode BatchNorm folded into the preceding
+    convolution (`fuse_conv_bn_weights`), bf16, channels_last (NHWC) memory end to end, so the FPN outputs are
+    already in the (Cam, H, W, C) layout the hot path reads.  With `hip_tail` (bf16, default) every layer of the
+    configs' ResNet-50 + FPN runs on this repository's kernels: whole stem (ext.stem_conv7x7_pool), whole
+    64-mid-channel bottlenecks (ext.bottleneck64_nhwc), 1x1 / 3x3 convolutions with bias, residual and ReLU fused
+    (ext.conv1x1_nhwc incl. the FPN top-down step, ext.conv3x3_nhwc); convolutions of other shapes fall back to
+    MIOpen + one fused bias/residual/ReLU launch.  `hip_tail=False` keeps stock torch ops (any dtype);
+    `fused_ops=True` would issue MIOpen's fused conv+bias+ReLU — measured on MI355X / ROCm 7.2 that falls back to
+    MIOpen's naive bf16 NHWC kernel (1.7 s per forward), so it is off.  Built from the live modules' parameters
+    (it owns folded COPIES: rebuild after changing weights).  The backbone is outside SURVEY.md §8's hand-written
+    scope; these kernels exist because end-to-end samples/s (images -> voxels) is the headline metric."""
 
     def __init__(self, backbone, neck, dtype=torch.bfloat16, fused_ops=False, hip_tail=True,
                  fused_bottleneck=True):

@@ -37,6 +37,43 @@ def test_argument_validation_without_gpu():
     assert rc == -1
 
 
+def test_backbone_and_projection_entry_points_validate_without_gpu():
+    """The newer entry points reject bad arguments / unsupported shapes before any launch."""
+    lib = _lib.lib()
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    i64 = ctypes.c_int64
+    assert lib.occ_conv1x1_nhwc_bf16(null, p, p, null, p, 1, 4, 4, 32, 32, 1, 0, 0, null) == -1
+    assert lib.occ_conv1x1_nhwc_bf16(p, p, p, null, p, 1, 4, 4, 48, 32, 1, 0, 0, null) == -3      # Cin % 32
+    assert lib.occ_conv1x1_nhwc_bf16(p, p, p, null, p, 1, 4, 4, 32, 40, 1, 0, 0, null) == -3      # Cout % 32
+    assert lib.occ_conv1x1_nhwc_bf16(p, p, p, p, p, 1, 5, 4, 32, 32, 1, 0, 1, null) == -1         # odd size, up2
+    assert b'upsampled residual' in lib.occ_last_error()
+    assert lib.occ_conv3x3_nhwc_bf16(p, p, p, p, 1, 4, 4, 32, 128, 3, 1, null) == -3              # stride 3
+    assert lib.occ_conv3x3_nhwc_bf16(p, p, p, p, 1, 4, 4, 32, 64, 1, 1, null) == -3               # Cout % 128
+    assert lib.occ_bottleneck64_nhwc_bf16(p, p, p, p, p, p, p, p, 1, 4, 4, 128, 0, null) == -3    # Cin 128
+    assert lib.occ_bottleneck64_nhwc_bf16(p, p, p, p, p, p, p, p, 1, 4, 4, 64, 0, null) == -3     # 64 needs ds
+    assert lib.occ_mfma_pack_b_frag_bf16(p, p, 48, 16, null) == -3                                # N % 32
+    assert lib.occ_stem_conv7x7_pool_f32_bf16(p, p, p, null, 1, 8, 8, null) == -1
+    assert lib.occ_bias_relu_maxpool_nhwc_bf16(p, p, p, 1, 4, 4, 12, null) == -3                  # C % 8
+    assert lib.occ_conv3d_pack_weight_bf16x3(p, p, 24, 32, null) == -3                            # Cin % 16
+    assert lib.occ_conv3d_bn_relu_bf16x3_f32(p, p, p, p, p, 1, 6, 4, 4, 32, 32, 0, i64(1), i64(1), i64(1), 1,
+                                             null) == -3                                          # Z = 6
+    # value projection: segment table checks
+    ptrs = (ctypes.c_void_p * 1)(ctypes.addressof(buf))
+    one = (ctypes.c_int64 * 1)(64)
+    zero = (ctypes.c_int64 * 1)(0)
+    args = lambda n, lda, K, N: (n, ptrs, lda, one, one, zero, null, 0, p, p, i64(256), K, N, i64(64), null)
+    assert lib.occ_value_proj_bf16_f32(*args(0, one, 64, 256)) == -1                              # no segments
+    assert lib.occ_value_proj_bf16_f32(*args(9, one, 64, 256)) == -1                              # > 8 segments
+    assert lib.occ_value_proj_bf16_f32(*args(1, one, 48, 256)) == -3                              # K % 32
+    assert lib.occ_value_proj_bf16_f32(*args(1, (ctypes.c_int64 * 1)(32), 64, 256)) == -1         # lda < K
+    with pytest.raises(_lib.OccAmdUnsupported):
+        ext.conv1x1_pack_weight(torch.zeros(8, 32))
+    with pytest.raises(_lib.OccAmdUnsupported):
+        ext.stem_pack_weight(torch.zeros(64, 3, 3, 3))
+
+
 def test_product_refuses_host_tensors():
     v = torch.zeros(1, 4, 8, 32)
     shapes = torch.tensor([[2, 2]])

@@ -340,8 +340,7 @@ def _rows2d(name, t, k=None):
 # Precision of the MFMA Linear kernel: 'f32' = v_mfma_f32_32x32x2_f32 (exact fp32, bitwise an fmaf
 # chain), 'bf16x3' = three bf16 MFMAs on hi/lo-split operands with f32 accumulation (relative error of a
 # product <= 2^-16; 2-3x faster).  The default can be overridden with OCC_LINEAR_PRECISION.
-import os as _os
-LINEAR_PRECISION = _os.environ.get("OCC_LINEAR_PRECISION", "bf16x3")
+LINEAR_PRECISION = os.environ.get("OCC_LINEAR_PRECISION", "bf16x3")
 _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight (small LRU)
 
 

@@ -1,6 +1,5 @@
 """The golden cases shared by oracle/gen_golden.py (writer, runs the reference's own files) and the
 tests (readers).  Geometries are small enough that fixtures stay well under 1 MB each."""
-import numpy as np
 import torch
 
 from occnet_amd import synthetic

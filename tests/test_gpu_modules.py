@@ -1,7 +1,5 @@
 """-m gpu: the MI355X modules (fused HIP path through the C ABI) vs the CPU oracle, same weights,
 same seeded inputs.  Tolerance: north_star's 1e-3 (fp32); observed differences are printed."""
-import copy
-
 import numpy as np
 import pytest
 import torch

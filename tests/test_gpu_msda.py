@@ -2,7 +2,6 @@
 import ctypes
 import os
 
-import numpy as np
 import pytest
 import torch
 

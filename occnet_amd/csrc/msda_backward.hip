@@ -6,13 +6,29 @@
 //   grad_loc_x     = W * sum_c top_c * attn * (hh*(v2-v1) + lh*(v4-v3))      (only in-range corners)
 //   grad_loc_y     = H * sum_c top_c * attn * (hw*(v3-v1) + lw*(v4-v2))
 //   grad_value[k] += top_c * attn * w_k                                     (atomic, in-range corners)
-// The three grad tensors arrive pre-zeroed (the caller's contract); grad_value is accumulated with
-// atomics, the other two are overwritten (each sample has exactly one writer), as mmcv does.
+// The three grad tensors arrive pre-zeroed (the caller's contract); grad_value is accumulated, the other two
+// are overwritten (each sample has exactly one writer), as mmcv does.
+//
+// grad_value without floating-point atomics (D == 32, default).  gfx950 retires float atomic adds at ~82 G/s
+// device-wide, in global memory and in LDS alike, whatever the access pattern (tools_dev/bwd_probe.py): the
+// 1.8 G dword atomics of one SCA launch cost 21 ms while everything else in the kernel costs 0.6 ms.  So the
+// scatter becomes a counting sort + owner-computes gather:
+//   1. the per-sample kernel (atomics compiled out) writes grad_loc / grad_attn and flags the items whose output
+//      gradient is non-zero;
+//   2. every value map is cut into BINS of 32 consecutive pixels; a sample contributes one "row item" per bilinear
+//      row (left + right corner weights, already multiplied by the attention weight) to the bin of its left
+//      pixel (two items when the pair straddles a bin edge).  COUNT (integer atomics, one per item, 60x fewer
+//      than the float adds) -> exclusive SCAN -> FILL writes the items (12 bytes: query, pixel in bin, two
+//      weights) bin by bin;
+//   3. REPLAY: one wave owns one bin: 32 pixels x 32 channels accumulators in LDS, private per half-wave (lane =
+//      channel, the two half-waves take alternate items), plain read-add-write — no atomics, no conflicts; the
+//      bin is then added to grad_value by its only owner.
 //
 // Decomposition (D == 32): 8 lanes x 4 channels per (b,q,m) item, 8 items per wave — the forward's
 // layout, so a corner is one 128-byte row per group; the channel sums are 3-step DPP/shuffle
 // reductions inside the 8-lane group.  Other D: one thread per (item, channel), mmcv's own shape,
 // with the channel sums reduced through LDS.
+#include <cstdlib>
 #include "common.h"
 
 namespace occ {
@@ -24,12 +40,13 @@ __device__ __forceinline__ float group8_sum(float v) {
   return v;
 }
 
+template <bool VALUE_ATOMICS>
 __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lstart, const float* __restrict__ loc,
     const float* __restrict__ attn, const float* __restrict__ grad_out,
     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
-    int S, int M, int L, int Lq, int P, long n_items) {
+    unsigned char* __restrict__ nzflag, int S, int M, int L, int Lq, int P, long n_items) {
   constexpr int D = 32;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long item = gid >> 3;
@@ -47,6 +64,7 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
   const bool nz = top.x != 0.f || top.y != 0.f || top.z != 0.f || top.w != 0.f;
   const unsigned long long any = __ballot(nz);
   if (((any >> (threadIdx.x & 56)) & 0xffull) == 0ull) return;
+  if (!VALUE_ATOMICS && c4 == 0) nzflag[item] = 1;     // the binning kernels skip the other items
   const int LP = L * P;
   for (int s = 0; s < LP; ++s) {
     const int l = s / P;
@@ -79,10 +97,12 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
         g_attn += tx[k] * (w1 * a1[k] + w2 * a2[k] + w3 * a3[k] + w4 * a4[k]);
         g_x += ta * (hh * (a2[k] - a1[k]) + lh * (a4[k] - a3[k]));
         g_y += ta * (hw * (a3[k] - a1[k]) + lw * (a4[k] - a2[k]));
-        if (t_ok && l_ok) unsafeAtomicAdd(gvb + base + k, ta * w1);
-        if (t_ok && r_ok) unsafeAtomicAdd(gvb + base + row_stride + k, ta * w2);
-        if (b_ok && l_ok) unsafeAtomicAdd(gvb + base + (long)W * row_stride + k, ta * w3);
-        if (b_ok && r_ok) unsafeAtomicAdd(gvb + base + (long)(W + 1) * row_stride + k, ta * w4);
+        if (VALUE_ATOMICS) {
+          if (t_ok && l_ok) unsafeAtomicAdd(gvb + base + k, ta * w1);
+          if (t_ok && r_ok) unsafeAtomicAdd(gvb + base + row_stride + k, ta * w2);
+          if (b_ok && l_ok) unsafeAtomicAdd(gvb + base + (long)W * row_stride + k, ta * w3);
+          if (b_ok && r_ok) unsafeAtomicAdd(gvb + base + (long)(W + 1) * row_stride + k, ta * w4);
+        }
       }
       g_x *= (float)W;
       g_y *= (float)H;
@@ -95,6 +115,195 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
       grad_loc[si * 2] = g_x;
       grad_loc[si * 2 + 1] = g_y;
     }
+  }
+}
+
+// ---- counting sort of the bilinear row items into 32-pixel bins + owner-computes replay (file header) ------
+constexpr int kBinPix = 32;
+
+struct BwdItem { int qpl; float w0, w1; };            // (query << 5 | pixel in bin), left / right corner weight
+
+// counter[gbin] += 1 for every lane with `valid`, aggregated inside the wave: lanes that target the same bin are
+// served by ONE atomic of their leader (up to 4 rounds = 4 distinct bins, the rest individually).  The coarse FPN
+// levels put the samples of thousands of queries into a few dozen bins: one atomic per lane made those counters
+// the bottleneck of the whole backward (count + fill: 12.7 of 16.4 ms).  Returns the lane's slot (FILL only).
+template <bool FILL>
+__device__ __forceinline__ int bwd_agg_add(int* __restrict__ counter, bool valid, int gbin, int lane) {
+  int slot = 0;
+  unsigned long long rem = __ballot(valid);
+#pragma unroll 1
+  for (int round = 0; round < 4 && rem; ++round) {
+    const int leader = __builtin_ctzll(rem);
+    const int b0 = __builtin_amdgcn_readlane(gbin, leader);
+    const unsigned long long same = __ballot(valid && gbin == b0) & rem;
+    int base = 0;
+    if (lane == leader) {
+      if (FILL) base = atomicAdd(counter + b0, (int)__builtin_popcountll(same));
+      else atomicAdd(counter + b0, (int)__builtin_popcountll(same));
+    }
+    if (FILL) {
+      base = __builtin_amdgcn_readlane(base, leader);
+      if ((same >> lane) & 1ull) slot = base + (int)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+    }
+    rem &= ~same;
+  }
+  if ((rem >> lane) & 1ull) {
+    if (FILL) slot = atomicAdd(counter + gbin, 1);
+    else atomicAdd(counter + gbin, 1);
+  }
+  return slot;
+}
+
+// FILL == false: count the items per bin; FILL == true: write them at cursor[bin]++.  One thread = one sample,
+// ordered (b, m, l, q, p) so that a wave holds 64 consecutive (query, point) pairs of ONE (batch, head, level):
+// neighbouring queries sample neighbouring pixels, i.e. mostly the same few bins.
+template <bool FILL>
+__global__ __launch_bounds__(256) void msda_bwd_bin_kernel(
+    const int64_t* __restrict__ shapes, const float* __restrict__ loc, const float* __restrict__ attn,
+    const unsigned char* __restrict__ nzflag, int* __restrict__ counter, BwdItem* __restrict__ items, int M,
+    int L, int Lq, int P, int bins_per_bm, long n_samples) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const long qp_n = (long)Lq * P;
+  const bool in_grid = gid < n_samples;
+  const long g = in_grid ? gid : n_samples - 1;
+  const long qp = g % qp_n;
+  long rest = g / qp_n;
+  const int l = (int)(rest % L); rest /= L;
+  const int m = (int)(rest % M);
+  const long b = rest / M;
+  const int q = (int)(qp / P), p = (int)(qp - (long)q * P);
+  const long item = (b * Lq + q) * M + m;             // (b, q, m)
+  const long si = (item * L + l) * P + p;
+  int binoff = 0, H = 0, W = 0;
+  for (int i = 0; i <= l; ++i) {
+    H = (int)shapes[2 * i]; W = (int)shapes[2 * i + 1];
+    if (i < l) binoff += (H * W + kBinPix - 1) / kBinPix;
+  }
+  const unsigned char fl = nzflag[item];
+  const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
+  const float a = attn[si];
+  const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
+  const bool ok = in_grid && fl != 0 && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h_low = (int)hf, w_low = (int)wf;
+  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+  const bool l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+  const bool both = l_ok && r_ok;
+  const int gbase = (int)((b * M + m) * (long)bins_per_bm) + binoff;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {                       // top row, bottom row (wave-uniform control flow)
+    const int hy = h_low + r;
+    const bool valid = ok && hy >= 0 && hy <= H - 1;
+    const float wy = (r ? lh : hh) * a;
+    const float wl = l_ok ? wy * hw : 0.f, wr = r_ok ? wy * lw : 0.f;
+    // left pixel (or the right one when the left is outside the map) decides the bin
+    const int pl = hy * W + (l_ok ? w_low : w_low + 1);
+    const int bin = valid ? pl / kBinPix : 0, in = pl - bin * kBinPix;
+    const bool split = valid && both && in == kBinPix - 1;   // the pair straddles a bin edge: two single items
+    const float i0 = l_ok ? wl : wr, i1 = (both && !split) ? wr : 0.f;
+    const int slot = bwd_agg_add<FILL>(counter, valid, gbase + bin, lane);
+    if (FILL && valid) items[slot] = BwdItem{(q << 5) | in, i0, i1};
+    if (split) {                                      // 1 in 32: plain atomics
+      if (FILL) {
+        const int slot2 = atomicAdd(counter + gbase + bin + 1, 1);
+        items[slot2] = BwdItem{(q << 5) | 0, wr, 0.f};
+      } else {
+        atomicAdd(counter + gbase + bin + 1, 1);
+      }
+    }
+  }
+}
+
+// exclusive prefix sum of counts[0..n) into counts (in place) and cursor; counts[n] = total.  One block.
+__global__ __launch_bounds__(1024) void msda_bwd_scan_kernel(int* __restrict__ counts, int* __restrict__ cursor,
+                                                             int n) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = tid * per, hi = min(lo + per, n);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += counts[i];
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {                // Hillis-Steele inclusive scan of the partials
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = tid ? part[tid - 1] : 0;
+  for (int i = lo; i < hi; ++i) {
+    const int c = counts[i];
+    counts[i] = run;
+    cursor[i] = run;
+    run += c;
+  }
+  if (tid == 1023) counts[n] = part[1023];
+}
+
+// one wave = one bin: offsets[bin] .. offsets[bin + 1] items -> 32 pixels x 32 channels, added to grad_value
+__global__ __launch_bounds__(256) void msda_bwd_replay_kernel(
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lstart, const int* __restrict__ offsets,
+    const BwdItem* __restrict__ items, const float* __restrict__ grad_out, float* __restrict__ grad_value, int S,
+    int M, int L, int Lq, int bins_per_bm, long n_bins) {
+  constexpr int D = 32;
+  __shared__ float acc_s[4][2][(kBinPix + 1) * D];     // per wave, per half-wave; +1 pixel: the w1 lane of pixel 31
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ch = lane & 31;
+  const long bin_g = (long)blockIdx.x * 4 + wave;
+  if (bin_g >= n_bins) return;                         // whole waves leave; no block-level barrier below
+  float* acc = acc_s[wave][half];
+#pragma unroll
+  for (int i = 0; i <= kBinPix; ++i) acc[i * D + ch] = 0.f;
+  const long bm = bin_g / bins_per_bm;
+  int bl = (int)(bin_g - bm * bins_per_bm);
+  const int m = (int)(bm % M);
+  const long b = bm / M;
+  int l = 0, HW = 0;
+  for (; l < L; ++l) {
+    HW = (int)shapes[2 * l] * (int)shapes[2 * l + 1];
+    const int nb = (HW + kBinPix - 1) / kBinPix;
+    if (bl < nb) break;
+    bl -= nb;
+  }
+  if (l >= L) return;                                  // slack bins of the upper bound
+  const int beg = offsets[bin_g], end = offsets[bin_g + 1];
+  const float* go = grad_out + (b * Lq * (long)M + m) * D + ch;        // + q * M * D
+  for (int base = beg; base < end; base += 16) {       // 8 items per half-wave per step, loads first
+    int qpl[8];
+    float w0[8], w1[8], g[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + 2 * u + half;
+      const BwdItem it = items[idx < end ? idx : beg];
+      qpl[u] = idx < end ? it.qpl : -1;
+      w0[u] = it.w0; w1[u] = it.w1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) g[u] = go[(long)(qpl[u] < 0 ? 0 : qpl[u] >> 5) * M * D];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (qpl[u] >= 0) {
+        const int pl = qpl[u] & 31;
+        acc[pl * D + ch] += g[u] * w0[u];
+        acc[(pl + 1) * D + ch] += g[u] * w1[u];        // w1 == 0 for single items (pixel 32 is a dummy row)
+      }
+    }
+  }
+  // both halves' partial sums -> grad_value (this wave is the bin's only writer)
+  wave_lds_sync();
+  const int p0 = bl * kBinPix, np = min(kBinPix, HW - p0);
+  const long st = lstart[l];
+  const float* a0 = acc_s[wave][0];
+  const float* a1 = acc_s[wave][1];
+  for (int i = lane; i < np * 8; i += 64) {
+    const int px = i >> 3, c4 = i & 7;
+    const float4 u0 = *reinterpret_cast<const float4*>(a0 + px * D + c4 * 4);
+    const float4 u1 = *reinterpret_cast<const float4*>(a1 + px * D + c4 * 4);
+    float4* dst = reinterpret_cast<float4*>(grad_value + ((b * S + st + p0 + px) * M + m) * D + c4 * 4);
+    float4 o = *dst;
+    o.x += u0.x + u1.x; o.y += u0.y + u1.y; o.z += u0.z + u1.z; o.w += u0.w + u1.w;
+    *dst = o;
   }
 }
 
@@ -192,10 +401,47 @@ extern "C" int occ_ms_deform_attn_backward_f32(
   const long n_items = (long)B * Lq * M;
   if (D == 32) {
     const long threads = n_items * 8;
-    hipLaunchKernelGGL(msda_bwd_d32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st,
-                       value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                       grad_output, grad_value, grad_sampling_loc, grad_attn_weight, S, M, L, Lq, P,
-                       n_items);
+    const dim3 grid1((unsigned)((threads + 255) / 256));
+    // atomic-free grad_value (file header): per-sample gradients + flags, count, scan, fill, replay
+    static const bool use_atomics = getenv("OCC_MSDA_BWD_ATOMICS") != nullptr;
+    const int bins_per_bm = S / kBinPix + L + 1;                        // >= sum_l ceil(H_l*W_l / 32)
+    const long n_bins = (long)B * M * bins_per_bm;
+    const long n_samples = n_items * L * P;
+    const long max_items = 4 * n_samples;                               // 2 rows x (1 or 2 items)
+    char* ws = nullptr;
+    const size_t off_cnt = ((size_t)n_items + 255) & ~(size_t)255;
+    const size_t off_cur = off_cnt + (((size_t)(n_bins + 1) * 4 + 255) & ~(size_t)255);
+    const size_t off_items = off_cur + (((size_t)(n_bins + 1) * 4 + 255) & ~(size_t)255);
+    const size_t ws_bytes = off_items + (size_t)max_items * sizeof(BwdItem);
+    hipError_t e = hipErrorUnknown;
+    if (!use_atomics && Lq < (1 << 26) && n_bins < (1L << 30) && max_items < (1L << 31))
+      e = hipMallocAsync(reinterpret_cast<void**>(&ws), ws_bytes, st);
+    if (e == hipSuccess) e = hipMemsetAsync(ws, 0, off_cur, st);        // flags + counts
+    if (e == hipSuccess) {
+      unsigned char* flags = reinterpret_cast<unsigned char*>(ws);
+      int* counts = reinterpret_cast<int*>(ws + off_cnt);
+      int* cursor = reinterpret_cast<int*>(ws + off_cur);
+      BwdItem* items = reinterpret_cast<BwdItem*>(ws + off_items);
+      const dim3 grid_s((unsigned)((n_samples + 255) / 256));
+      hipLaunchKernelGGL(msda_bwd_d32_kernel<false>, grid1, dim3(256), 0, st, value, spatial_shapes,
+                         level_start_index, sampling_loc, attn_weight, grad_output, grad_value,
+                         grad_sampling_loc, grad_attn_weight, flags, S, M, L, Lq, P, n_items);
+      hipLaunchKernelGGL(msda_bwd_bin_kernel<false>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
+                         attn_weight, flags, counts, items, M, L, Lq, P, bins_per_bm, n_samples);
+      hipLaunchKernelGGL(msda_bwd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, cursor, (int)n_bins);
+      hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
+                         attn_weight, flags, cursor, items, M, L, Lq, P, bins_per_bm, n_samples);
+      hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)((n_bins + 3) / 4)), dim3(256), 0, st,
+                         spatial_shapes, level_start_index, counts, items, grad_output, grad_value, S, M, L, Lq,
+                         bins_per_bm, n_bins);
+      (void)hipFreeAsync(ws, st);
+    } else {
+      if (ws) (void)hipFreeAsync(ws, st);
+      (void)hipGetLastError();
+      hipLaunchKernelGGL(msda_bwd_d32_kernel<true>, grid1, dim3(256), 0, st, value, spatial_shapes,
+                         level_start_index, sampling_loc, attn_weight, grad_output, grad_value,
+                         grad_sampling_loc, grad_attn_weight, nullptr, S, M, L, Lq, P, n_items);
+    }
   } else {
     const int per_block = 256 / D > 0 ? 256 / D : 1;
     const int threads = per_block * D;

@@ -17,9 +17,9 @@
 //      gradient is non-zero;
 //   2. every value map is cut into BINS of 32 consecutive pixels; a sample contributes one "row item" per bilinear
 //      row (left + right corner weights, already multiplied by the attention weight) to the bin of its left
-//      pixel (two items when the pair straddles a bin edge).  COUNT (integer atomics, one per item, 60x fewer
-//      than the float adds) -> exclusive SCAN -> FILL writes the items (12 bytes: query, pixel in bin, two
-//      weights) bin by bin;
+//      pixel (two items when the pair straddles a bin edge).  COUNT (integer atomics, aggregated inside the wave:
+//      threads are ordered (batch, head, level, query, point), so a wave's 64 samples mostly share a few bins)
+//      -> exclusive SCAN -> FILL writes the items (12 bytes: query, pixel in bin, two weights) bin by bin;
 //   3. REPLAY: one wave owns one bin: 32 pixels x 32 channels accumulators in LDS, private per half-wave (lane =
 //      channel, the two half-waves take alternate items), plain read-add-write — no atomics, no conflicts; the
 //      bin is then added to grad_value by its only owner.

@@ -20,9 +20,9 @@
 //      pixel (two items when the pair straddles a bin edge).  COUNT (integer atomics, aggregated inside the wave:
 //      threads are ordered (batch, head, level, query, point), so a wave's 64 samples mostly share a few bins)
 //      -> exclusive SCAN -> FILL writes the items (12 bytes: query, pixel in bin, two weights) bin by bin;
-//   3. REPLAY: one wave owns one bin: 32 pixels x 32 channels accumulators in LDS, private per half-wave (lane =
-//      channel, the two half-waves take alternate items), plain read-add-write — no atomics, no conflicts; the
-//      bin is then added to grad_value by its only owner.
+//   3. REPLAY: one block owns one bin: 32 pixels x 32 channels accumulators in LDS, private per half-wave (lane =
+//      channel, the items dealt round-robin to the 8 half-waves), plain read-add-write — no atomics, no
+//      conflicts; the 8 copies are summed and added to grad_value by the bin's only owner.
 //
 // Decomposition (D == 32): 8 lanes x 4 channels per (b,q,m) item, 8 items per wave — the forward's
 // layout, so a corner is one 128-byte row per group; the channel sums are 3-step DPP/shuffle
@@ -242,17 +242,22 @@ __global__ __launch_bounds__(1024) void msda_bwd_scan_kernel(int* __restrict__ c
   if (tid == 1023) counts[n] = part[1023];
 }
 
-// one wave = one bin: offsets[bin] .. offsets[bin + 1] items -> 32 pixels x 32 channels, added to grad_value
+// one block = one bin: its items offsets[bin] .. offsets[bin + 1] are dealt to the block's 8 half-waves, each with
+// a private 32 pixels x 32 channels accumulator in LDS (lane = channel; plain read-add-write, no conflicts); the 8
+// copies are summed and added to grad_value by the block, the bin's only writer.  (One WAVE per bin left the hot
+// bins of the coarse FPN levels — thousands of items — on a single wave: 24 ms of a training step.)
 __global__ __launch_bounds__(256) void msda_bwd_replay_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lstart, const int* __restrict__ offsets,
     const BwdItem* __restrict__ items, const float* __restrict__ grad_out, float* __restrict__ grad_value, int S,
     int M, int L, int Lq, int bins_per_bm, long n_bins) {
   constexpr int D = 32;
-  __shared__ float acc_s[4][2][(kBinPix + 1) * D];     // per wave, per half-wave; +1 pixel: the w1 lane of pixel 31
+  __shared__ float acc_s[8][(kBinPix + 1) * D];        // per half-wave; +1 pixel: the w1 lane of pixel 31
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ch = lane & 31;
-  const long bin_g = (long)blockIdx.x * 4 + wave;
-  if (bin_g >= n_bins) return;                         // whole waves leave; no block-level barrier below
-  float* acc = acc_s[wave][half];
+  const long bin_g = blockIdx.x;
+  const int beg = offsets[bin_g], end = offsets[bin_g + 1];
+  if (beg == end) return;                              // block-uniform: nothing to add
+  const int hw = wave * 2 + half;
+  float* acc = acc_s[hw];
 #pragma unroll
   for (int i = 0; i <= kBinPix; ++i) acc[i * D + ch] = 0.f;
   const long bm = bin_g / bins_per_bm;
@@ -266,15 +271,14 @@ __global__ __launch_bounds__(256) void msda_bwd_replay_kernel(
     if (bl < nb) break;
     bl -= nb;
   }
-  if (l >= L) return;                                  // slack bins of the upper bound
-  const int beg = offsets[bin_g], end = offsets[bin_g + 1];
+  if (l >= L) return;                                  // slack bins of the upper bound (never filled)
   const float* go = grad_out + (b * Lq * (long)M + m) * D + ch;        // + q * M * D
-  for (int base = beg; base < end; base += 16) {       // 8 items per half-wave per step, loads first
+  for (int base = beg; base < end; base += 64) {       // 8 items per half-wave per step, loads first
     int qpl[8];
     float w0[8], w1[8], g[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int idx = base + 2 * u + half;
+      const int idx = base + hw + 8 * u;
       const BwdItem it = items[idx < end ? idx : beg];
       qpl[u] = idx < end ? it.qpl : -1;
       w0[u] = it.w0; w1[u] = it.w1;
@@ -290,19 +294,21 @@ __global__ __launch_bounds__(256) void msda_bwd_replay_kernel(
       }
     }
   }
-  // both halves' partial sums -> grad_value (this wave is the bin's only writer)
-  wave_lds_sync();
+  __syncthreads();
+  // the 8 partial sums -> grad_value
   const int p0 = bl * kBinPix, np = min(kBinPix, HW - p0);
   const long st = lstart[l];
-  const float* a0 = acc_s[wave][0];
-  const float* a1 = acc_s[wave][1];
-  for (int i = lane; i < np * 8; i += 64) {
+  for (int i = tid; i < np * 8; i += 256) {
     const int px = i >> 3, c4 = i & 7;
-    const float4 u0 = *reinterpret_cast<const float4*>(a0 + px * D + c4 * 4);
-    const float4 u1 = *reinterpret_cast<const float4*>(a1 + px * D + c4 * 4);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(acc_s[k] + px * D + c4 * 4);
+      sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
+    }
     float4* dst = reinterpret_cast<float4*>(grad_value + ((b * S + st + p0 + px) * M + m) * D + c4 * 4);
     float4 o = *dst;
-    o.x += u0.x + u1.x; o.y += u0.y + u1.y; o.z += u0.z + u1.z; o.w += u0.w + u1.w;
+    o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += sum.w;
     *dst = o;
   }
 }
@@ -431,7 +437,7 @@ extern "C" int occ_ms_deform_attn_backward_f32(
       hipLaunchKernelGGL(msda_bwd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, cursor, (int)n_bins);
       hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
                          attn_weight, flags, cursor, items, M, L, Lq, P, bins_per_bm, n_samples);
-      hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)((n_bins + 3) / 4)), dim3(256), 0, st,
+      hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)n_bins), dim3(256), 0, st,
                          spatial_shapes, level_start_index, counts, items, grad_output, grad_value, S, M, L, Lq,
                          bins_per_bm, n_bins);
       (void)hipFreeAsync(ws, st);

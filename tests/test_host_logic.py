@@ -108,3 +108,41 @@ def test_gloo_world2_plumbing():
         assert r[2] == 2.0                      # max over ranks
         assert abs(r[3] - 2 * 4 / 2.0) < 1e-9   # all ranks' units / max time
         assert r[4] == [1.5] * 5
+
+
+def test_folded_backbone_plan_on_cpu_matches_modules():
+    """The BatchNorm fold and the plan's control flow (stem, bottlenecks with/without projection, FPN top-down,
+    extra levels) on stock torch ops: fp32 on the CPU the folded plan equals the modules to rounding."""
+    from occnet_amd.plugin.backbone import FPN, FusedInferenceBackbone, ResNet
+    torch.manual_seed(0)
+    bb = ResNet(depth=50, num_stages=4, out_indices=(1, 2, 3), frozen_stages=1, norm_eval=True).eval()
+    bb.init_weights()
+    g = torch.Generator().manual_seed(1)
+    for m in bb.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.75)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    nk = FPN(in_channels=[512, 1024, 2048], out_channels=256, start_level=0, add_extra_convs='on_output',
+             num_outs=4, relu_before_extra_convs=True).eval()
+    x = torch.randn(1, 3, 64, 96, generator=g)
+    with torch.no_grad():
+        ref = nk(bb(x))
+        plan = FusedInferenceBackbone(bb, nk, dtype=torch.float32, hip_tail=True)   # fp32: hip_tail switches off
+        assert not plan.hip_tail and not plan._bneck and not plan._stem_fused
+        out = plan(x)
+    assert len(out) == len(ref) == 4
+    for a, b in zip(ref, out):
+        assert a.shape == b.shape
+        rel = float((a - b).abs().max() / a.abs().max())
+        assert rel < 2e-5, rel
+
+
+def test_lazy_features_only_for_backbone_format_inputs():
+    from occnet_amd.plugin.transformer_occ import LazyFeatures
+    f32 = [torch.zeros(1, 6, 256, 4, 5)]
+    bf16 = [torch.zeros(1, 6, 256, 4, 5, dtype=torch.bfloat16)]
+    with torch.no_grad():
+        assert not LazyFeatures.eligible(f32) and not LazyFeatures.eligible(bf16)     # host tensors: never
+    assert not LazyFeatures.eligible([])

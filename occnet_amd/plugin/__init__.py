@@ -9,6 +9,8 @@ from .backbone import FPN, ResNet  # noqa: F401
 from .bevformer_occ import BEVFormerOcc  # noqa: F401
 from .bevformer_occ_head import BEVFormerOccHead  # noqa: F401
 from .config import Config, ConfigDict, import_plugin  # noqa: F401
+from .detection_names import (CustomMSDeformableAttention, DetectionTransformerDecoder,  # noqa: F401
+                              LearnedPositionalEncoding3D, PerceptionTransformer)
 from .encoder import BEVFormerEncoder, BEVFormerLayer, MyCustomBaseTransformerLayer  # noqa: F401
 from .functions import (MultiScaleDeformableAttnFunction_fp16,  # noqa: F401
                         MultiScaleDeformableAttnFunction_fp32)

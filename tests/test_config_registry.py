@@ -11,7 +11,9 @@ from occnet_amd.plugin import (ATTENTION, DETECTORS, HEADS, POSITIONAL_ENCODING,
                                import_plugin)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_CFG = '/root/reference/projects/configs/bevformer'
+VENDORED = os.path.join(ROOT, 'projects', 'configs')          # byte-identical copies of the reference's configs
+REF_CFG = os.path.join(VENDORED, 'bevformer')
+REF_TREE = '/root/reference/projects/configs'                 # only in the build container
 
 
 def test_registry_surface():
@@ -23,6 +25,38 @@ def test_registry_surface():
     for n in ('TemporalSelfAttention', 'SpatialCrossAttention', 'MSDeformableAttention3D'):
         assert n in ATTENTION
     assert 'LearnedPositionalEncoding' in POSITIONAL_ENCODING
+    # detection-branch names §8(b) lists (no occ config builds them)
+    assert 'PerceptionTransformer' in TRANSFORMER
+    assert 'DetectionTransformerDecoder' in TRANSFORMER_LAYER_SEQUENCE
+    assert 'CustomMSDeformableAttention' in ATTENTION
+    assert 'LearnedPositionalEncoding3D' in POSITIONAL_ENCODING
+
+
+def test_vendored_configs_are_byte_identical():
+    """projects/configs holds the reference's five config files unmodified: checksums match SHA256SUMS (taken
+    from the reference tree) and, where the reference tree exists, the files themselves."""
+    import hashlib
+    with open(os.path.join(VENDORED, 'SHA256SUMS')) as f:
+        sums = dict(reversed(l.split()) for l in f if l.strip())
+    assert len(sums) == 5
+    for rel, want in sums.items():
+        with open(os.path.join(VENDORED, rel), 'rb') as f:
+            data = f.read()
+        assert hashlib.sha256(data).hexdigest() == want, rel
+        ref = os.path.join(REF_TREE, rel)
+        if os.path.exists(ref):
+            with open(ref, 'rb') as f:
+                assert f.read() == data, rel
+
+
+def test_learned_positional_encoding_3d_shape():
+    from occnet_amd.plugin import build_positional_encoding
+    pe = build_positional_encoding(dict(type='LearnedPositionalEncoding3D', num_feats=4, row_num_embed=5,
+                                        col_num_embed=6, height_num_embed=3))
+    pos = pe(torch.zeros(2, 3, 5, 6))
+    assert pos.shape == (2, 12, 3, 5, 6)
+    assert torch.equal(pos[0, :4, 1, 2, :].T, pe.col_embed.weight)          # x block varies along w only
+    assert torch.equal(pos[1, 8:, :, 4, 5].T, pe.height_embed.weight)
 
 
 def test_plugin_import_convention():
@@ -32,7 +66,6 @@ def test_plugin_import_convention():
     assert hasattr(mod, 'BEVFormerOcc')
 
 
-@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason='reference tree not present (GPU box)')
 @pytest.mark.parametrize('name', ['bevformer_base_occ.py', 'bevformer_base_occ_test.py',
                                   'bevformer_base_occ_w_lightwheel.py'])
 def test_reference_configs_load_unchanged(name):

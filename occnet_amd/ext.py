@@ -14,7 +14,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, cache_epoch
 from ._lib import OccAmdError, OccAmdUnsupported, f32, i32, i64, ptr, stream_ptr
 
 
@@ -347,7 +347,7 @@ _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight
 def linear_pack_weight_bf16x3(weight):
     """(N, K) float32 Linear weight -> bf16 hi/lo split in MFMA fragment order
     packed[K/16][ceil(N/32)][hi, lo][lane][8] (int16 storage, columns zero-padded to a multiple of 32), cached."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device), cache_epoch())
     hit = _PACKED_W.get(key)
     if hit is not None:
         return hit[1]

@@ -8,7 +8,9 @@ train_cfg / test_cfg is injected into the head's config.
 """
 import torch
 
+from .. import cache_epoch
 from .bricks import BaseModule
+from .grid_mask import GridMask
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
@@ -37,10 +39,16 @@ class BEVFormerOcc(BaseModule):
         if img_neck is not None:
             self.img_neck = build_neck(img_neck)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
-        # GridMask is a train-time image augmentation (reference models/utils/grid_mask.py): outside
-        # the forward hot path, accepted and not applied.
+        # train-time image augmentation, applied in extract_img_feat when use_grid_mask (reference :52-53,81-82)
+        self.grid_mask = GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=1, prob=0.7)
         self.use_grid_mask = use_grid_mask
         self.fp16_enabled = False
+        # mixed-precision knob of THIS implementation (the reference is fp32 throughout): when set (e.g.
+        # torch.bfloat16) the stock ResNet/FPN modules of the training / autograd path run under torch.autocast
+        # and the FPN maps are handed to the fp32 hot path as float32.  It lives inside the detector so that
+        # a DDP-wrapped model is driven through DDP.forward (the reducer must see the forward).
+        self.backbone_autocast_dtype = None
+        self.pretrained = pretrained
         self.video_test_mode = video_test_mode
         self.prev_frame_info = {'prev_bev': None, 'scene_token': None, 'prev_pos': 0, 'prev_angle': 0}
 
@@ -63,13 +71,22 @@ class BEVFormerOcc(BaseModule):
             img = img.reshape(B * N, C, H, W)
         plan = getattr(self, '_inference_backbone', None)
         if plan is not None and not self.training and not torch.is_grad_enabled():
-            img_feats = plan(img)       # BN-folded, NHWC, MIOpen fused conv+bias+ReLU (stock ops)
+            if plan.built_epoch != cache_epoch():     # parameters were reloaded / trained since the fold
+                self.enable_fused_backbone(**self._inference_backbone_args)
+                plan = self._inference_backbone
+            img_feats = plan(img)       # BN-folded, NHWC, own bf16 kernels
         else:
-            img_feats = self.img_backbone(img)
-            if isinstance(img_feats, dict):
-                img_feats = list(img_feats.values())
-            if self.with_img_neck:
-                img_feats = self.img_neck(img_feats)
+            if self.use_grid_mask:
+                img = self.grid_mask(img)
+            ac = self.backbone_autocast_dtype
+            with torch.autocast(img.device.type, dtype=ac or torch.bfloat16, enabled=ac is not None):
+                img_feats = self.img_backbone(img)
+                if isinstance(img_feats, dict):
+                    img_feats = list(img_feats.values())
+                if self.with_img_neck:
+                    img_feats = self.img_neck(img_feats)
+            if ac is not None:
+                img_feats = [f.float() for f in img_feats]
         out = []
         for f in img_feats:
             BN, C, H, W = f.size()
@@ -86,16 +103,35 @@ class BEVFormerOcc(BaseModule):
         weights; pass dtype=None to disable."""
         from .backbone import FusedInferenceBackbone
         object.__setattr__(self, '_inference_backbone', None)
+        object.__setattr__(self, '_inference_backbone_args', dict(
+            dtype=dtype, fused_ops=fused_ops, hip_tail=hip_tail, use_graph=use_graph,
+            fused_bottleneck=fused_bottleneck))
         if dtype is not None:
             plan = FusedInferenceBackbone(self.img_backbone, self.img_neck, dtype=dtype,
                                           fused_ops=fused_ops, hip_tail=hip_tail,
                                           fused_bottleneck=fused_bottleneck)
             plan.use_graph = use_graph
+            plan.built_epoch = cache_epoch()
             object.__setattr__(self, '_inference_backbone', plan)   # not a sub-module: owns copies
         return self
 
     def extract_feat(self, img, img_metas=None, len_queue=None):
         return self.extract_img_feat(img, img_metas, len_queue=len_queue)
+
+    def load_checkpoint(self, path_or_state, strict=False, map_location='cpu'):
+        """Load an mmcv-format checkpoint ({'state_dict': ..., 'meta': ...}, what the reference's
+        `load_checkpoint(model, ckpt, map_location='cpu')` reads, tools/test.py:213) or a bare state_dict; a
+        'module.' prefix (saved from a DDP wrapper) is stripped.  Every derived-weight cache is invalidated.
+        -> (missing_keys, unexpected_keys)."""
+        from .. import invalidate_caches
+        ckpt = path_or_state
+        if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, '__fspath__'):
+            ckpt = torch.load(ckpt, map_location=map_location, weights_only=False)
+        sd = ckpt.get('state_dict', ckpt) if isinstance(ckpt, dict) else ckpt
+        sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}
+        res = self.load_state_dict(sd, strict=strict)
+        invalidate_caches(self)
+        return list(res.missing_keys), list(res.unexpected_keys)
 
     def forward_pts_train(self, pts_feats, gt_bboxes_3d, gt_labels_3d, voxel_semantics, voxel_flow,
                           mask_camera, img_metas, gt_bboxes_ignore=None, prev_bev=None):

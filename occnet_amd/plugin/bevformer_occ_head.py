@@ -8,6 +8,7 @@ test_cfg through **kwargs and reading kwargs['num_classes'] —, `bev_embedding`
 import torch
 import torch.nn as nn
 
+from .. import cache_epoch
 from .bricks import BaseModule
 from .registry import HEADS, build_loss, build_positional_encoding, build_transformer
 
@@ -52,7 +53,7 @@ class BEVFormerOccHead(BaseModule):
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in pe.parameters())
         key = None
         if not needs_grad:
-            key = (bs, str(device), dtype) + tuple((p.data_ptr(), p._version) for p in pe.parameters())
+            key = (bs, str(device), dtype, cache_epoch()) + tuple((p.data_ptr(), p._version) for p in pe.parameters())
             if getattr(self, '_pos_key', None) == key:
                 return self._pos_val
         bev_mask = torch.zeros((bs, self.bev_h, self.bev_w), device=device).to(dtype)

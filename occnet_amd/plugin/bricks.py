@@ -11,6 +11,11 @@ from .registry import (ACTIVATION_LAYERS, CONV_LAYERS, FEEDFORWARD_NETWORK, LOSS
                        POSITIONAL_ENCODING, build_from_cfg)
 
 
+def _bump_cache_epoch(*_):
+    import occnet_amd
+    occnet_amd._CACHE_EPOCH += 1
+
+
 class BaseModule(nn.Module):
     """mmcv.runner.BaseModule call shape: BaseModule(init_cfg) + init_weights()."""
 
@@ -18,6 +23,14 @@ class BaseModule(nn.Module):
         super().__init__()
         self._is_init = False
         self.init_cfg = init_cfg
+        # parameters rewritten through load_state_dict (param.data.copy_: no _version bump) or a mode change
+        # (training updates, BatchNorm statistics) make every derived-weight cache stale: bump the epoch
+        self.register_load_state_dict_post_hook(_bump_cache_epoch)
+
+    def train(self, mode=True):
+        if mode != self.training:
+            _bump_cache_epoch()
+        return super().train(mode)
 
     def init_weights(self):
         for m in self.children():

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ext
+from .. import cache_epoch, ext
 from ..synthetic import bev_tile_order
 from .bricks import BaseModule, ModuleList, build_norm_layer
 from .registry import (TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_attention,
@@ -351,7 +351,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         tensor while its embedding tables are unchanged (inference): keep the transposed copy."""
         if torch.is_grad_enabled() and bev_pos.requires_grad:
             return bev_pos.permute(1, 0, 2).contiguous()
-        key = (bev_pos.data_ptr(), bev_pos._version, tuple(bev_pos.shape), tuple(bev_pos.stride()))
+        key = (bev_pos.data_ptr(), bev_pos._version, tuple(bev_pos.shape), tuple(bev_pos.stride()), cache_epoch())
         if getattr(self, '_pos_key', None) != key:
             # keep `bev_pos` referenced: its address cannot be recycled while this entry is live
             self._pos_key, self._pos_src, self._pos_qm = key, bev_pos, bev_pos.permute(1, 0, 2).contiguous()

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ext
+from .. import cache_epoch, ext
 from .._lib import OccAmdError, OccAmdUnsupported
 from .bricks import BaseModule, constant_init, xavier_init
 from .functions import MultiScaleDeformableAttnFunction_fp32
@@ -43,7 +43,7 @@ class _CatLinearCache:
 
     def get(self, linears):
         key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version)
-                    for l in linears)
+                    for l in linears) + (cache_epoch(),)
         if key != self._key:
             self._w = torch.cat([l.weight.detach() for l in linears], 0).contiguous()
             self._b = torch.cat([l.bias.detach() for l in linears], 0).contiguous()

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ext
+from .. import cache_epoch, ext
 from .._lib import OccAmdUnsupported
 from .bricks import BaseModule, constant_init, xavier_init
 from .functions import MultiScaleDeformableAttnFunction_fp32
@@ -90,7 +90,7 @@ class TemporalSelfAttention(BaseModule):
     def _folded_query_weights(self, w, b, query_pos):
         c = self.embed_dims
         key = (w.data_ptr(), w._version, b.data_ptr(), b._version, query_pos.data_ptr(),
-               query_pos._version, tuple(query_pos.shape))
+               query_pos._version, tuple(query_pos.shape), cache_epoch())
         if getattr(self, '_fold_key', None) != key:
             w_sum = (w[:, :c] + w[:, c:]).contiguous()
             pos_term = ext.linear(query_pos.contiguous(), w[:, c:].contiguous(), b)

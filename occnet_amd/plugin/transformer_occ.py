@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import ext
+from .. import cache_epoch, ext
 from .._lib import OccAmdUnsupported
 from .bricks import BaseModule, ConvModule
 from .registry import TRANSFORMER, build_transformer_layer_sequence
@@ -108,7 +108,7 @@ class LazyFeatures:
         # cached on the projection module (the entry holds the parameters, so the keys stay unambiguous)
         o = self.owner
         srcs = (w, b, o.level_embeds, o.cams_embeds if o.use_cams_embeds else None)
-        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs) + (len(self.hw),)
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs) + (len(self.hw), cache_epoch())
         hit = getattr(value_proj, '_occ_group_bias', None)
         if hit is None or hit[0] != key:
             emb = self.embeds()                                                 # (L, cam, C)
@@ -271,7 +271,7 @@ class TransformerOcc(BaseModule):
             ts += [m.conv.weight, m.norm.weight, m.norm.bias, m.norm.running_mean, m.norm.running_var]
             if m.conv.bias is not None:
                 ts.append(m.conv.bias)
-        key = tuple((t.data_ptr(), t._version) for t in ts)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (cache_epoch(),)
         if key != self._dec_key:
             pack = []
             with torch.no_grad():

@@ -33,8 +33,12 @@ def wrap_ddp(model, device):
     from torch.nn.parallel import DistributedDataParallel as DDP
     if not (dist.is_available() and dist.is_initialized()):
         return model
-    return DDP(model, device_ids=[device.index], broadcast_buffers=False,
-               find_unused_parameters=False)
+    ddp = DDP(model, device_ids=[device.index] if device.type == 'cuda' else None, broadcast_buffers=False,
+              find_unused_parameters=False)
+    # the constructor broadcasts rank 0's parameters into the others through .data (no _version bump)
+    from . import invalidate_caches
+    invalidate_caches()
+    return ddp
 
 
 def synthetic_targets(bev_h, bev_w, pillar_h, num_classes=18, batch=1, seed=0, device='cpu'):
@@ -53,24 +57,15 @@ def train_step(model, optimizer, img, img_metas, voxel_semantics, voxel_flow, ma
     call .item() on the values only when logging)."""
     net = model.module if hasattr(model, 'module') else model
     optimizer.zero_grad(set_to_none=True)
-    if autocast_backbone:
-        # the stock MIOpen backbone may run in bf16; the hand-written hot path stays fp32
-        with torch.autocast('cuda', dtype=torch.bfloat16):
-            feats = net.extract_feat(img=img, img_metas=img_metas)
-        feats = [f.float() for f in feats]
-        losses = _head_losses(model, feats, img_metas, voxel_semantics, voxel_flow, mask_camera)
-    else:
-        losses = model(return_loss=True, img_metas=img_metas, img=img, voxel_semantics=voxel_semantics,
-                       voxel_flow=voxel_flow, mask_camera=mask_camera)
+    # the stock MIOpen backbone may run in bf16 (the hand-written hot path stays fp32): a detector attribute,
+    # so that the WHOLE step goes through model(...) — i.e. through DDP.forward, which arms the reducer; a
+    # forward that bypasses the wrapper leaves the gradients un-reduced (each rank would diverge silently)
+    net.backbone_autocast_dtype = torch.bfloat16 if autocast_backbone else None
+    losses = model(return_loss=True, img_metas=img_metas, img=img, voxel_semantics=voxel_semantics,
+                   voxel_flow=voxel_flow, mask_camera=mask_camera)
     loss = sum(losses.values())
     loss.backward()          # DDP all-reduces the gradient buckets here (overlapped with backward)
     params = [p for p in net.parameters() if p.grad is not None]
     torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2)
     optimizer.step()
     return losses
-
-
-def _head_losses(model, feats, img_metas, voxel_semantics, voxel_flow, mask_camera):
-    net = model.module if hasattr(model, 'module') else model
-    return net.forward_pts_train(feats, None, None, voxel_semantics, voxel_flow, mask_camera,
-                                 img_metas)

@@ -110,6 +110,149 @@ def test_gloo_world2_plumbing():
         assert r[4] == [1.5] * 5
 
 
+class _ToyDetector(torch.nn.Module):
+    """Stands in for BEVFormerOcc in the DDP wiring test: same forward(return_loss=True, **kw) call shape,
+    same `backbone_autocast_dtype` knob, a 'backbone' and a 'head' parameter group."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.img_backbone = torch.nn.Linear(6, 5)
+        self.pts_bbox_head = torch.nn.Linear(5, 3)
+        self.backbone_autocast_dtype = None
+        self.saw_autocast = []
+
+    def forward(self, return_loss=True, img=None, img_metas=None, voxel_semantics=None, voxel_flow=None,
+                mask_camera=None):
+        ac = self.backbone_autocast_dtype
+        self.saw_autocast.append(ac)
+        with torch.autocast('cpu', dtype=ac or torch.bfloat16, enabled=ac is not None):
+            f = self.img_backbone(img)
+        out = self.pts_bbox_head(f.float())
+        return dict(loss_occ=(out - voxel_flow).pow(2).mean(), loss_flow=out.abs().mean() * 0.25)
+
+
+def _ddp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from occnet_amd.train import make_optimizer, train_step, wrap_ddp
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        res = {}
+        for autocast in (False, True):
+            net = _ToyDetector()
+            ddp = wrap_ddp(net, torch.device('cpu'))
+            assert ddp is not net                           # really wrapped
+            opt = make_optimizer(ddp, lr=0.0)               # lr 0: parameters stay put, grads are what we check
+            g = torch.Generator().manual_seed(100 + rank)   # every rank its own sample
+            img, tgt = torch.randn(4, 6, generator=g), torch.randn(4, 3, generator=g)
+            train_step(ddp, opt, img, None, None, tgt, None, max_norm=1e9, autocast_backbone=autocast)
+            grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+            # the same sample through the bare module: the rank-local gradient DDP must have averaged
+            ref = _ToyDetector()
+            ref.backbone_autocast_dtype = torch.bfloat16 if autocast else None
+            sum(ref(img=img, voxel_flow=tgt).values()).backward()
+            local = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+            res[autocast] = (grads.tolist(), local.tolist(), [str(a) for a in net.saw_autocast])
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_step_goes_through_ddp_forward_world2():
+    """train_step must drive the DDP wrapper's forward for BOTH autocast settings, or the
+    reducer is never armed and every rank keeps its local gradient.  Two gloo ranks, different samples:
+    after one step the gradients are identical on both ranks and equal the mean of the rank-local ones."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for autocast in (False, True):
+        g0, l0, seen0 = res[0][autocast]
+        g1, l1, _ = res[1][autocast]
+        assert seen0 == ['torch.bfloat16' if autocast else 'None']
+        assert g0 == g1                                                 # all-reduced: bitwise the same
+        mean = [(a + b) / 2 for a, b in zip(l0, l1)]
+        assert max(abs(a - b) for a, b in zip(g0, mean)) < (2e-3 if autocast else 1e-6)
+        assert max(abs(a - b) for a, b in zip(l0, l1)) > 1e-3           # the local gradients did differ
+
+
+def test_cache_epoch_invalidation():
+    """derived-weight caches also key on an epoch that load_state_dict, a train()/eval()
+    change and invalidate_caches() bump (writes through param.data do not touch tensor._version)."""
+    import occnet_amd
+    from occnet_amd.plugin.spatial_cross_attention import _CatLinearCache
+    from occnet_amd.plugin.bricks import BaseModule
+
+    class M(BaseModule):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(3, 2), torch.nn.Linear(3, 4)
+
+    m = M()
+    cache = _CatLinearCache()
+    w0, _ = cache.get((m.a, m.b))
+    assert cache.get((m.a, m.b))[0] is w0                       # hit
+    m.a.weight.data.mul_(2.0)                                   # invisible to _version ...
+    assert cache.get((m.a, m.b))[0] is w0                       # ... so still (stale) a hit,
+    occnet_amd.invalidate_caches()                              # until the owner says so
+    w1, _ = cache.get((m.a, m.b))
+    assert w1 is not w0 and torch.equal(w1[:2], m.a.weight)
+    e = occnet_amd.cache_epoch()
+    m.load_state_dict(m.state_dict())                           # post hook
+    assert occnet_amd.cache_epoch() > e
+    e = occnet_amd.cache_epoch()
+    m.train(False)
+    assert occnet_amd.cache_epoch() > e                         # mode change (trained weights, BN statistics)
+    e = occnet_amd.cache_epoch()
+    m.train(False)
+    assert occnet_amd.cache_epoch() == e                        # no change, no bump
+
+
+def test_grid_mask_follows_reference_rng_and_geometry():
+    """GridMask(True, True, rotate=1, ratio=0.5, mode=1, prob=0.7) as BEVFormerOcc builds it (reference
+    bevformer_occ.py:52-53): eval -> identity; train -> kept pixels form the complement of a square lattice of
+    (d - l)-wide holes, drawn from numpy's global RNG in the reference's order."""
+    import numpy as np
+    from occnet_amd.plugin.grid_mask import GridMask
+    gm = GridMask(True, True, rotate=1, offset=False, ratio=0.5, mode=1, prob=0.7)
+    x = torch.ones(2, 3, 40, 64)
+    gm.eval()
+    assert gm(x) is x
+    gm.train()
+    np.random.seed(3)
+    outs = [gm(x) for _ in range(40)]
+    n_kept = sum(o is x for o in outs)
+    assert 3 <= n_kept <= 25                                                    # prob 0.7 of being applied
+    np.random.seed(11)
+    while True:
+        y = gm(x)
+        if y is not x:
+            break
+    np.random.seed(11)
+    while np.random.rand() > gm.prob:
+        pass
+    h, w = 40, 64
+    d = np.random.randint(2, h)
+    l = min(max(int(d * 0.5 + 0.5), 1), d - 1)
+    st_h, st_w = np.random.randint(d), np.random.randint(d)
+    rows = np.zeros(60, bool)
+    cols = np.zeros(96, bool)
+    for i in range(60 // d):
+        rows[d * i + st_h:min(d * i + st_h + l, 60)] = True
+    for i in range(96 // d):
+        cols[d * i + st_w:min(d * i + st_w + l, 96)] = True
+    keep = (rows[:, None] | cols[None, :])[10:50, 16:80]                       # mode 1: 1 - (1-rows)(1-cols)
+    assert torch.equal(y[1, 2], torch.from_numpy(keep.astype(np.float32)))
+
+
 def test_folded_backbone_plan_on_cpu_matches_modules():
     """The BatchNorm fold and the plan's control flow (stem, bottlenecks with/without projection, FPN top-down,
     extra levels) on stock torch ops: fp32 on the CPU the folded plan equals the modules to rounding."""

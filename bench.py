@@ -15,8 +15,21 @@ line.  Extra objects on that line:
                (N_in*d*e_v + R*S*12 + R*256*e_v, with R and N_in counted on device for
                the very inputs being timed) / mean launch duration from HIP events recorded on the
                launch stream inside the timed region, against 8 TB/s HBM.
-  cpu_baseline the CPU oracle (restated reference path, torch fp32, all host cores) on a bounded
-               sample of the same workload, rank 0 at N=1 only.
+               The figure counts cache-served bytes, so it is reported next to the PHYSICAL numbers:
+               `traffic` = HBM bytes per launch from rocprofv3 PMC (profiles/sca_gather_traffic.json),
+               `frac` = frac_hbm = traffic / launch time / 8 TB/s, `frac_l1` = bytes pulled through the
+               texture-addresser / L1 path (in-map corner rows x row bytes) / launch time / 39.3 TB/s
+               (256 CU x 64 B/clk x 2.4 GHz), `compulsory_bytes` = every input read once + output written
+               once.  `bound` is what the PMC counters say limits the kernel.
+  cpu_baseline the CPU oracle (restated reference path, torch fp32) on a bounded sample of the same
+               workload, rank 0 at N=1 only: thread-count sweep on one camera's share of the SCA
+               deformable-attention call (1 warm-up + 3 runs, median), per-op seconds (A1 SCA call, A2 TSA
+               call, A9 decoder) and one encoder layer + the rest of the path at the best thread count,
+               scaled to the layer count.  The same oracle outputs are used to CHECK the HIP path at full
+               size (`parity_max_abs_diff`, bound 1e-3): a 1-layer head with the oracle's weights on the GPU.
+
+`python bench.py --gpus N` with no torchrun environment re-executes itself under torch.distributed.run with N
+ranks (the reference's tools/dist_train.sh:9-11 role); under torchrun it reads RANK/LOCAL_RANK/WORLD_SIZE.
 """
 import argparse
 import json
@@ -33,6 +46,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (guides/MI355X_MICROARCH.md)
+L1_PEAK = 256 * 64 * 2.4e9   # B/s through the texture-addresser / vector-L1 path: 256 CU x 64 B/clk x 2.4 GHz
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    sys.stdout.flush()
+    os.execvp(sys.executable, cmd)
 
 
 def parse():
@@ -60,6 +89,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="plumbing only (runs without a GPU, gloo): spawn/rank env/barrier/MAX-reduce and the "
+                         "one-JSON-line contract of the N-rank launch, no model")
     return ap.parse_args()
 
 
@@ -179,10 +211,23 @@ def gather_stats(model, stepper):
     return [tuple(int(v) for v in st.cpu().tolist()) for st in stats], da
 
 
-def cpu_baseline(cfg, geo):
-    """Oracle (oracle/model.py, torch fp32, all host cores) on a bounded sample: ONE of the encoder
-    layers plus everything outside the layer stack (feature flatten, reference points, lifter,
-    Conv3d decoder, heads), backbone excluded; scaled to the full layer count."""
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def cpu_baseline(cfg, geo, device=None, thread_counts=None):
+    """The CPU oracle (oracle/model.py = the restated reference path, torch fp32; `kind: "port"`) on a bounded
+    sample of the bench workload, backbone excluded (the oracle starts at the FPN maps).
+
+    1. one encoder layer (of `n_layers`) + everything outside the layer stack (feature flatten, reference points,
+       lifter, Conv3d decoder, heads) at a moderate thread count, recording the inputs of the two deformable-
+       attention calls (A1 = SCA use, A2 = TSA use, SURVEY.md §8a) and the decoder (A9);
+    2. thread sweep (SURVEY.md §8d; 1 warm-up + 3 runs, median) on ONE camera's share of the A1 call;
+    3. A1 (all cameras), A2 and A9 at the best thread count: 1 warm-up + 3 runs, median -> per_op_seconds;
+    4. the pass of step 1 again at the best thread count -> `value` (scaled to n_layers);
+    5. with `device`: the same 1-layer head on the HIP path with the oracle's weights and inputs ->
+       parity_max_abs_diff (full base geometry: 40 000 queries x 6 cameras x 30 825 keys)."""
     import copy
     import oracle.model as om
     from occnet_amd import synthetic
@@ -197,40 +242,167 @@ def cpu_baseline(cfg, geo):
     torch.manual_seed(0)
     ora = om.BEVFormerOccHead(**hc).eval()
     ora.init_weights()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():    # query-dependent sampling pattern, as in build()
+        for n, p in ora.named_parameters():
+            if n.endswith("sampling_offsets.weight") or n.endswith("attention_weights.weight"):
+                p.add_(torch.randn(p.shape, generator=g) * 0.02)
     feats = synthetic.make_features(geo, batch=1, seed=0)
     metas = synthetic.make_img_metas(geo, batch=1, seed=0)
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    layer = ora.transformer.encoder.layers[0]
-    t_layer = [0.0]
-    orig = layer.forward
+    if thread_counts is None:
+        thread_counts = sorted({t for t in (8, 32, 64, cores) if t <= cores})
 
-    def timed(*a, **k):
-        t0 = time.perf_counter()
-        out = orig(*a, **k)
-        t_layer[0] += time.perf_counter() - t0
-        return out
-    layer.forward = timed
+    layer = ora.transformer.encoder.layers[0]
+    decoder = ora.transformer.decoder
+    rec = {}
+
+    def run_once():
+        """One pass; returns (outputs, seconds total, seconds in the layer) and records op inputs/timings."""
+        t = {"layer": 0.0, "msda": [], "dec": 0.0}
+        calls = []
+        orig_layer, orig_msda, orig_dec = layer.forward, om.multi_scale_deformable_attn_pytorch, decoder.forward
+
+        def layer_fwd(*a, **k):
+            t0 = time.perf_counter()
+            out = orig_layer(*a, **k)
+            t["layer"] += time.perf_counter() - t0
+            return out
+
+        def msda(*a):
+            t0 = time.perf_counter()
+            out = orig_msda(*a)
+            t["msda"].append(time.perf_counter() - t0)
+            calls.append(a)
+            return out
+
+        def dec_fwd(x):
+            rec["dec_in"] = x
+            t0 = time.perf_counter()
+            out = orig_dec(x)
+            t["dec"] += time.perf_counter() - t0
+            return out
+        layer.forward, om.multi_scale_deformable_attn_pytorch, decoder.forward = layer_fwd, msda, dec_fwd
+        try:
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                out = ora(feats, metas)
+                total = time.perf_counter() - t0
+        finally:
+            layer.forward, om.multi_scale_deformable_attn_pytorch = orig_layer, orig_msda
+            decoder.forward = orig_dec
+        rec["calls"] = calls
+        return out, total, t
+
+    def timed(fn, runs=3):
+        fn()                                    # warm-up
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return _median(ts)
+
+    t_start = time.perf_counter()
+    torch.set_num_threads(min(32, cores))
+    out, total0, t0 = run_once()
+    tsa_args, sca_args = rec["calls"][0], rec["calls"][1]      # layer order: TSA first, then SCA
+    one_cam = (sca_args[0][:1], sca_args[1], sca_args[2][:1], sca_args[3][:1])
+    sweep = {}
     with torch.no_grad():
-        t0 = time.perf_counter()
-        ora(feats, metas)
-        t_total = time.perf_counter() - t0
-    t_rest = t_total - t_layer[0]
-    t_sample = t_layer[0] * n_layers + t_rest
-    return {
-        "value": 1.0 / t_sample, "unit": "samples/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle hot path (FPN features -> voxels, backbone excluded): 1 of {n_layers} "
-                   f"encoder layers timed ({t_layer[0]:.2f} s) x{n_layers} + rest of the path "
-                   f"({t_rest:.2f} s), one sample, torch fp32 CPU"),
+        for nt in thread_counts:
+            torch.set_num_threads(nt)
+            sweep[nt] = timed(lambda: om.multi_scale_deformable_attn_pytorch(*one_cam))
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        per_op = {
+            "A1_sca_deform_attn_call": timed(lambda: om.multi_scale_deformable_attn_pytorch(*sca_args)),
+            "A2_tsa_deform_attn_call": timed(lambda: om.multi_scale_deformable_attn_pytorch(*tsa_args)),
+            "A9_conv3d_decoder": timed(lambda: decoder(rec["dec_in"])),
+        }
+    out, total, t = run_once()
+    t_rest = total - t["layer"]
+    t_sample = t["layer"] * n_layers + t_rest
+    res = {
+        "value": 1.0 / t_sample, "unit": "samples/s", "cores": best, "kind": "port",
+        "host_cores_available": cores,
+        "sample": (f"oracle hot path (FPN features -> voxels, backbone excluded), one sample, torch fp32 CPU, "
+                   f"{best} threads (best of the sweep): 1 of {n_layers} encoder layers timed "
+                   f"({t['layer']:.2f} s) x{n_layers} + rest of the path ({t_rest:.2f} s)"),
         "seconds_per_sample": t_sample,
+        "thread_sweep_seconds_A1_one_camera": {str(k): v for k, v in sweep.items()},
+        "per_op_seconds": per_op,
+        "per_op_note": "1 warm-up + 3 runs, median, at the best thread count; A1/A2 = the two "
+                       "multi_scale_deformable_attn_pytorch calls of one layer, A9 = 2x(Conv3d+BN3d+ReLU)",
+        "first_pass_seconds_at_32_threads": total0,
+        "baseline_wall_seconds": None,
     }
+    if device is not None:
+        res.update(_bench_parity(hc, ora, feats, metas, out, device))
+    res["baseline_wall_seconds"] = time.perf_counter() - t_start
+    return res
+
+
+def _bench_parity(head_cfg, ora, feats, metas, out_o, device):
+    """The HIP path at FULL base geometry against the oracle pass the baseline just timed: a 1-layer head built
+    from the same config, loaded with the oracle's weights, same fp32 features (north star: <= 1e-3)."""
+    from occnet_amd.plugin import build_head
+    cfgp = json.loads(json.dumps(head_cfg))
+    cfgp["type"] = "BEVFormerOccHead"
+    cfgp["transformer"]["encoder"]["transformerlayers"]["operation_order"] = tuple(
+        cfgp["transformer"]["encoder"]["transformerlayers"]["operation_order"])
+    prod = build_head(cfgp)
+    prod.load_state_dict(ora.state_dict(), strict=True)
+    prod = prod.to(device).eval()
+    with torch.no_grad():
+        out_p = prod([f.to(device) for f in feats], metas)
+    torch.cuda.synchronize()
+    diffs = {k: float((out_p[k].detach().cpu().double() - out_o[k].double()).abs().max())
+             for k in ("bev_embed", "occ", "flow")}
+    worst = max(diffs.values())
+    if not worst < 1e-3:
+        raise AssertionError(f"bench parity check failed: HIP path differs from the oracle by {diffs}")
+    return {"parity_max_abs_diff": diffs, "parity_bound": 1e-3,
+            "parity_case": "1 encoder layer + lifter + Conv3d decoder + heads, full base geometry, fp32 features"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                   # does not return: re-exec under torch.distributed.run
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}",
+              file=sys.stderr)
+
+    if args.launcher_selftest:
+        # the N-rank launch contract without a model: process group (gloo: no GPU needed), barrier, K timed
+        # "steps", barrier, MAX over ranks, ONE JSON line from rank 0
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.001 * (rank + 1))
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:
+            print(json.dumps({"metric": "launcher selftest (no model)", "value": world * args.steps / elapsed,
+                              "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                              "config": {"workload": "launcher selftest", "parallelism": f"dp{world}"}}),
+                  flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     if args.cpu_baseline_only:
         from occnet_amd.plugin import Config
@@ -314,9 +486,11 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            # hot path: fp32 storage and accumulation everywhere; Conv3d/heads exact-f32 MFMA; encoder Linears
-            # per ext.LINEAR_PRECISION (bf16x3 = hi/lo-split bf16 MFMA, 16 mantissa bits); backbone bf16
-            "dtype": "f32" if ext.LINEAR_PRECISION == "f32" else "f32 (Linear operands bf16x3-split)",
+            # hot path: fp32 storage and accumulation everywhere; encoder Linears / Conv3d per
+            # ext.LINEAR_PRECISION / CONV3D_PRECISION (bf16x3 = hi/lo-split bf16 MFMA, 16 mantissa bits);
+            # the image backbone (ResNet-50 + FPN, ~45 % of the step) runs in --backbone-dtype
+            "dtype": (("f32 hot path" if ext.LINEAR_PRECISION == "f32" else "f32 hot path (GEMM operands bf16x3-split)")
+                      + (f" + {args.backbone_dtype} backbone" if stepper.scope == "e2e" else "")),
             "data": "synthetic",
             "config": {
                 "workload": ("bevformer_base_occ forward: 6x(3x928x1600) images -> ResNet-50+FPN -> "
@@ -338,21 +512,45 @@ def main():
             M, D = da.num_heads, da.embed_dims // da.num_heads
             S = M * da.num_levels * da.num_points
             n_layers = len(stats)
-            b_alg = [n_in * D * 4 + rows * S * 12 + rows * M * D * 4 for rows, n_in in stats]
+            ev = ext.SCA_VALUE_BYTES                       # bytes per value element (4 = f32, 2 = f16 opt-in)
+            row_b = D * ev
+            b_alg = [n_in * row_b + rows * S * 12 + rows * M * D * 4 for rows, n_in in stats]
             mean_ms = sum(sca) / len(sca)
             mean_bytes = sum(b_alg) / n_layers
-            achieved = mean_bytes / (mean_ms * 1e-3)
-            traffic = None
+            sec = mean_ms * 1e-3
+            # bytes the kernel pulls through the texture-addresser / L1 path per launch: one row per in-map corner
+            # (out-of-map corners are never requested: buffer loads with an out-of-range offset)
+            l1_bytes = sum(n_in * row_b for _, n_in in stats) / n_layers
+            nq = model.pts_bbox_head.bev_h * model.pts_bbox_head.bev_w
+            ncam = model.pts_bbox_head.transformer.num_cams
+            s_keys = sum(h * w for h, w in geo["feat_shapes"])
+            # every input once + the output once: projected value maps, the query Linears' (offsets | logits) rows,
+            # ref_cam, visibility words, the slots written
+            compulsory = (ncam * s_keys * M * D * ev + nq * (S * 3) * 4 + ncam * nq * geo["num_points_in_pillar"] * 8
+                          + nq * 4 + nq * M * D * 4)
+            traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "sca_gather_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    tj = json.load(f)
+                if tj.get("kernel_variant") == ext.SCA_VARIANT:      # measured on the kernel that just ran
+                    traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
             out["roofline"] = {
-                "kernel": "sca_fused_kernel<4,8> (fused SCA deformable gather, fp32 values)",
-                "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": traffic,
-                "algorithmic_bytes_per_launch": mean_bytes, "launch_ms": mean_ms,
-                "launches_timed": len(sca), "rows_R": [r for r, _ in stats],
+                "kernel": f"{ext.SCA_VARIANT} (fused SCA deformable gather, {'f32' if ev == 4 else 'f16'} values)",
+                # rocprofv3 PMC (profiles/): texture addresser busy most of the launch, L2 hit ~0.8, HBM-side
+                # traffic a fraction of peak -> the binding resource is the L1/TA row-gather path, not HBM
+                "bound": "l1/ta",
+                "achieved": (traffic / sec / 1e9) if traffic else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": (traffic / sec / HBM_PEAK) if traffic else None,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "frac_hbm": (traffic / sec / HBM_PEAK) if traffic else None,
+                "frac_l1": l1_bytes / sec / L1_PEAK, "l1_bytes_per_launch": l1_bytes, "l1_peak_gbps": L1_PEAK / 1e9,
+                "compulsory_bytes": compulsory,
+                "compulsory_frac_hbm": compulsory / sec / HBM_PEAK,
+                "traffic_over_compulsory": (traffic / compulsory) if traffic else None,
+                "algorithmic_bytes_per_launch": mean_bytes, "algorithmic_gbps": mean_bytes / sec / 1e9,
+                "algorithmic_over_hbm_peak": mean_bytes / sec / HBM_PEAK,
+                "launch_ms": mean_ms, "launches_timed": len(sca), "rows_R": [r for r, _ in stats],
                 "n_in_corners": [n for _, n in stats],
             }
             tsa = times.get("tsa_fused_forward", [])
@@ -392,7 +590,9 @@ def main():
                         out["mfma_kernels"]["linear_tflops"] = sum(fl) / (sum(lin) * 1e-3) / 1e12
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, geo)
+                out["cpu_baseline"] = cpu_baseline(cfg, geo, device=device)
+            except AssertionError:
+                raise                # a parity failure is not a measurement: fail loudly
             except Exception as e:  # the baseline must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -153,6 +153,11 @@ def point_sampling(ref_3d, lidar2img, ego2lidar, pc_range, img_h, img_w):
     return ref_cam, mask.view(torch.bool), vis
 
 
+# which SCA gather kernel runs (bench.py's roofline names it and only trusts a PMC traffic file measured on it)
+SCA_VARIANT = "sca_fused_kernel<4,8>"
+SCA_VALUE_BYTES = 4
+
+
 def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, ref_cam, vis_bits,
                       num_heads, num_levels, num_points, order=None, stats=None):
     """Fused SCA gather.  value (B*NC, S, M, D); offs (B, Nq, M*L*P*2) / logits (B, Nq, M*L*P) may

@@ -289,3 +289,25 @@ def test_lazy_features_only_for_backbone_format_inputs():
     with torch.no_grad():
         assert not LazyFeatures.eligible(f32) and not LazyFeatures.eligible(bf16)     # host tensors: never
     assert not LazyFeatures.eligible([])
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start 2 ranks itself (the reference's
+    tools/dist_train.sh:9-11 role) and rank 0 must print ONE JSON line with n_gpus = 2.
+    --launcher-selftest exercises exactly the launch / rank-env / barrier / MAX-reduce code of the real run
+    (gloo, no model), so it runs without a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4',
+                          '--warmup', '1', '--launcher-selftest'], env=env, capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 4 and out['config']['parallelism'] == 'dp2'
+    # whole-job value = all ranks' steps / max-over-ranks time; rank 1 sleeps 2 ms per step
+    assert out['ms_per_step'] >= 2.0
+    assert abs(out['value'] - 2 * 4 / (out['ms_per_step'] * 4e-3)) / out['value'] < 1e-6

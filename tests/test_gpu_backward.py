@@ -83,3 +83,53 @@ def test_autograd_function_round_trip():
     for got, ref in ((v.grad, gv_ref), (l.grad, gl_ref), (a.grad, ga_ref)):
         scale = max(1.0, float(ref.abs().max()))
         assert float((got.cpu().double() - ref).abs().max()) / scale < 1e-4
+
+
+def test_integration_3a_seam_reference_call_shape():
+    """INTEGRATION.md §3a, executed: the reference obtains its operator with
+    `from mmcv.utils import ext_loader; ext_module = ext_loader.load_ext('_ext', ['ms_deform_attn_backward',
+    'ms_deform_attn_forward'])` (multi_scale_deformable_attn_function.py:8-12) and calls it as written at
+    :118-124 (forward: five positional tensors + `im2col_step=` keyword) and :146-160 (backward: zeros_like grad
+    buffers, `grad_output.contiguous()`, writes in place, returns None).  With `mmcv.utils.ext_loader` resolved
+    to `occnet_amd.ext_loader` — the 2-line swap — that exact call sequence must run on the HIP library and
+    match the oracle.  (The call sequence below restates those reference lines; the reference file itself
+    cannot travel to the GPU box.)"""
+    import sys
+    import types
+    from occnet_amd import ext_loader as occ_loader
+    saved = {k: sys.modules.get(k) for k in ('mmcv', 'mmcv.utils')}
+    mmcv = types.ModuleType('mmcv')
+    mmcv.utils = types.ModuleType('mmcv.utils')
+    mmcv.utils.ext_loader = occ_loader
+    sys.modules['mmcv'], sys.modules['mmcv.utils'] = mmcv, mmcv.utils
+    try:
+        from mmcv.utils import ext_loader                                            # reference :8
+        ext_module = ext_loader.load_ext('_ext', ['ms_deform_attn_backward', 'ms_deform_attn_forward'])  # :11-12
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    shapes = [[12, 20], [6, 10], [3, 5], [2, 3]]
+    value, shapes_t, start, loc, attn = _inputs(2, shapes, 8, 32, 96, 8, seed=21, adversarial=False)
+    loc = _interior(loc, shapes)
+    value, shapes_t, start, loc, attn = (t.cuda() for t in (value, shapes_t, start, loc, attn))
+    im2col_step = 64
+    output = ext_module.ms_deform_attn_forward(value, shapes_t, start, loc, attn, im2col_step=im2col_step)
+    ref = omsda.multi_scale_deformable_attn_pytorch(value.cpu().double(), shapes_t.cpu(), loc.cpu().double(),
+                                                    attn.cpu().double())
+    assert float((output.cpu().double() - ref).abs().max()) < 1e-5
+    grad_output = torch.randn(output.shape, generator=torch.Generator().manual_seed(22)).cuda().t().t()
+    grad_value = torch.zeros_like(value)                                             # reference :146-148
+    grad_sampling_loc = torch.zeros_like(loc)
+    grad_attn_weight = torch.zeros_like(attn)
+    ret = ext_module.ms_deform_attn_backward(value, shapes_t, start, loc, attn, grad_output.contiguous(),
+                                             grad_value, grad_sampling_loc, grad_attn_weight,
+                                             im2col_step=im2col_step)               # :150-160
+    assert ret is None
+    gv_r, gl_r, ga_r = omsda.msda_backward_autograd(value.cpu().double(), shapes_t.cpu(), loc.cpu().double(),
+                                                    attn.cpu().double(), grad_output.cpu().double())
+    for got, want in ((grad_value, gv_r), (grad_sampling_loc, gl_r), (grad_attn_weight, ga_r)):
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got.cpu().double() - want).abs().max()) / scale < 1e-4

@@ -334,7 +334,7 @@ def cpu_baseline(cfg, geo, device=None, thread_counts=None):
         "per_op_seconds": per_op,
         "per_op_note": "1 warm-up + 3 runs, median, at the best thread count; A1/A2 = the two "
                        "multi_scale_deformable_attn_pytorch calls of one layer, A9 = 2x(Conv3d+BN3d+ReLU)",
-        "first_pass_seconds_at_32_threads": total0,
+        "first_pass_seconds": total0, "first_pass_threads": min(32, cores),
         "baseline_wall_seconds": None,
     }
     if device is not None:

@@ -120,7 +120,7 @@ def test_integration_3a_seam_reference_call_shape():
     ref = omsda.multi_scale_deformable_attn_pytorch(value.cpu().double(), shapes_t.cpu(), loc.cpu().double(),
                                                     attn.cpu().double())
     assert float((output.cpu().double() - ref).abs().max()) < 1e-5
-    grad_output = torch.randn(output.shape, generator=torch.Generator().manual_seed(22)).cuda().t().t()
+    grad_output = torch.randn(output.shape, generator=torch.Generator().manual_seed(22)).cuda()
     grad_value = torch.zeros_like(value)                                             # reference :146-148
     grad_sampling_loc = torch.zeros_like(loc)
     grad_attn_weight = torch.zeros_like(attn)

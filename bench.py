@@ -533,10 +533,10 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("kernel_variant") == ext.SCA_VARIANT:      # measured on the kernel that just ran
+                if tj.get("kernel_variant") == ext.sca_variant_name():      # measured on the kernel that just ran
                     traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
             out["roofline"] = {
-                "kernel": f"{ext.SCA_VARIANT} (fused SCA deformable gather, {'f32' if ev == 4 else 'f16'} values)",
+                "kernel": f"{ext.sca_variant_name()} (fused SCA deformable gather, {'f32' if ev == 4 else 'f16'} values)",
                 # rocprofv3 PMC (profiles/): texture addresser busy most of the launch, L2 hit ~0.8, HBM-side
                 # traffic a fraction of peak -> the binding resource is the L1/TA row-gather path, not HBM
                 "bound": "l1/ta",

@@ -100,6 +100,22 @@ int occ_sca_fused_forward_f32(const float* value, const int64_t* spatial_shapes,
                               int L, int P, int Z, int Nq, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused spatial cross-attention gather, HEAD-MAJOR decomposition (csrc/sca_head.hip): same arguments, semantics
+ * and reference lines as occ_sca_fused_forward_f32 — a block works on ONE attention head (= one XCD's L2 holds one
+ * head's slice of the value maps), a wave on 8 neighbouring queries, out-of-map corners are not requested (buffer
+ * loads with an out-of-range offset), and for variant >= 2 the coarsest level's map of (camera, head) is staged
+ * in LDS (stage_pix = H*W of the last level; needs stage_pix*128 B <= 64 KB, else variant 1 is taken).
+ *   variant 1: 4 waves x 8 queries, every level through buffer loads
+ *   variant 2: 8 waves x 16 queries, last level from LDS      variant 3: 6 waves x 16 queries, last level from LDS
+ */
+int occ_sca_head_forward_f32(const float* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start_index, const float* offs, int64_t offs_stride,
+                             const float* logits, int64_t logits_stride, const float* ref_cam,
+                             const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats,
+                             int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq, int stage_pix,
+                             int variant, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused temporal self-attention gather over the 2-deep BEV queue (single level):
  *   out[b,q,:] = 0.5 * sum_{t in {0,1}} MSDA( value[b*2+t], softmax_p(logits[b,q,m,t,:]),
  *                                            ref_2d[b*2+t,q] + offs[b,q,m,t,p]/(W,H) )

@@ -153,16 +153,26 @@ def point_sampling(ref_3d, lidar2img, ego2lidar, pc_range, img_h, img_w):
     return ref_cam, mask.view(torch.bool), vis
 
 
-# which SCA gather kernel runs (bench.py's roofline names it and only trusts a PMC traffic file measured on it)
-SCA_VARIANT = "sca_fused_kernel<4,8>"
+# Which SCA gather kernel runs: 0 = query-major (round 1, csrc/sca_fused.hip), 1..3 = head-major
+# (csrc/sca_head.hip: 1 = no LDS staging, 2 / 3 = coarsest level staged in LDS with 8 / 6 waves per block).
+# bench.py's roofline names the kernel and only trusts a PMC traffic file measured on the same variant.
+SCA_KERNEL = int(os.environ.get("OCC_SCA_KERNEL", "3"))
 SCA_VALUE_BYTES = 4
+_SCA_NAMES = {0: "sca_fused_kernel<4,8> (query-major)", 1: "sca_head_kernel<4,8,4,1,false> (head-major)",
+              2: "sca_head_kernel<4,8,8,2,true> (head-major, coarsest level in LDS)",
+              3: "sca_head_kernel<4,8,6,2,true> (head-major, coarsest level in LDS)"}
+
+
+def sca_variant_name(kernel=None):
+    return _SCA_NAMES[SCA_KERNEL if kernel is None else kernel]
 
 
 def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, ref_cam, vis_bits,
-                      num_heads, num_levels, num_points, order=None, stats=None):
+                      num_heads, num_levels, num_points, order=None, stats=None, kernel=None, stage_pix=None):
     """Fused SCA gather.  value (B*NC, S, M, D); offs (B, Nq, M*L*P*2) / logits (B, Nq, M*L*P) may
     be column slices of one wider Linear output (last dim contiguous); ref_cam (NC,B,Nq,Z,2);
-    vis_bits (B,Nq) int32.  -> slots (B, Nq, M*D)."""
+    vis_bits (B,Nq) int32.  -> slots (B, Nq, M*D).  kernel: see SCA_KERNEL; stage_pix = H*W of the last level
+    (computed from spatial_shapes — one host sync — when not given)."""
     _need_cuda_f32("value", value)
     _need_cuda_f32("ref_cam", ref_cam)
     _need_cuda_f32("offs", offs, contiguous=False)
@@ -182,13 +192,31 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
         raise OccAmdError("sca_fused_forward: vis_bits must be contiguous int32 (B,Nq)")
     if order is not None and (order.dtype != torch.int32 or order.numel() != Nq):
         raise OccAmdError("sca_fused_forward: order must be int32 (Nq)")
+    kernel = SCA_KERNEL if kernel is None else int(kernel)
     slots = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
     with torch.cuda.device(value.device), _timed('sca_fused_forward'):
-        rc = _lib.lib().occ_sca_fused_forward_f32(
-            ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
-            i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
-            ptr(order), ptr(slots), ptr(stats), i32(B), i32(NC), i32(S), i32(M), i32(D), i32(L),
-            i32(P), i32(Z), i32(Nq), stream_ptr(value.device))
+        if kernel == 0:
+            rc = _lib.lib().occ_sca_fused_forward_f32(
+                ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
+                i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
+                ptr(order), ptr(slots), ptr(stats), i32(B), i32(NC), i32(S), i32(M), i32(D), i32(L),
+                i32(P), i32(Z), i32(Nq), stream_ptr(value.device))
+        else:
+            if stage_pix is None:
+                # H*W of the last level: from the host copy the plugin attaches to the shapes tensor, else one
+                # device->host read
+                hw = getattr(spatial_shapes, '_occ_hw', None)
+                if kernel < 2:
+                    stage_pix = 0
+                elif hw is not None:
+                    stage_pix = int(hw[-1][0]) * int(hw[-1][1])
+                else:
+                    stage_pix = S - int(level_start_index[-1])
+            rc = _lib.lib().occ_sca_head_forward_f32(
+                ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
+                i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
+                ptr(order), ptr(slots), ptr(stats), i32(B), i32(NC), i32(S), i32(M), i32(D), i32(L),
+                i32(P), i32(Z), i32(Nq), i32(int(stage_pix)), i32(kernel), stream_ptr(value.device))
     _lib.check(rc, "sca_fused_forward")
     return slots
 

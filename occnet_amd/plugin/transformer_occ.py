@@ -69,6 +69,7 @@ class LazyFeatures:
         if hit is None:
             hit = (torch.as_tensor(self.hw, dtype=torch.long, device=dev),
                    torch.as_tensor(starts, dtype=torch.long, device=dev))
+            hit[0]._occ_hw = tuple(self.hw)        # host copy of the shapes travels with the tensor object
             if len(self._shape_cache) > 16:
                 self._shape_cache.clear()
             self._shape_cache[key] = hit
@@ -221,6 +222,7 @@ class TransformerOcc(BaseModule):
             start += h * w
         dev = mlvl_feats[0].device
         spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=dev)
+        spatial_shapes._occ_hw = tuple(tuple(int(v) for v in hw) for hw in shapes)
         starts = [0]
         for h, w in shapes[:-1]:
             starts.append(starts[-1] + h * w)

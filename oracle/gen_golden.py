@@ -21,7 +21,59 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
-from tests.golden_cases import CASES, case_inputs, checksum  # noqa: E402
+from tests.golden_cases import CASES, METRIC_SEEDS, case_inputs, checksum, metric_scene  # noqa: E402
+
+
+def metric_golden():
+    """RayIoU / mAVE / OccScore fixtures from the reference's own ray_metrics.py (process_one_sample :89-143,
+    calc_metrics :146-197, main :200-257) and tools/ray_iou/metric.py (calc_metrics :6-81), both executed in place
+    with the reference's ray-casting kernel compiled for the host (oracle/build_ref.py)."""
+    import contextlib
+    import io
+    from oracle import refshim
+    ns = refshim.install_metrics()
+    print('reference metric files executed:')
+    for f in ns.files:
+        print('  ', f)
+    rm = ns.ray_metrics
+    scenes = [metric_scene(s) for s in METRIC_SEEDS]
+    lidar_rays = torch.from_numpy(rm.generate_lidar_rays())
+    arrays = {'lidar_rays': lidar_rays.numpy()}
+    pcd_pred_list, pcd_gt_list = [], []
+    with ns.on_host():
+        for i, (sp, sg, fp, fg, org) in enumerate(scenes):
+            pcd_pred = rm.process_one_sample(sp, lidar_rays, org, fp)          # unmasked: every ray of every origin
+            pcd_gt = rm.process_one_sample(sg, lidar_rays, org, fg)
+            arrays[f'pcd_pred_{i}'], arrays[f'pcd_gt_{i}'] = pcd_pred, pcd_gt
+            valid = pcd_gt[:, 0].astype(np.int32) != len(rm.occ_class_names) - 1
+            pcd_pred_list.append(pcd_pred[valid])
+            pcd_gt_list.append(pcd_gt[valid])
+        with np.errstate(divide='ignore', invalid='ignore'):
+            iou_list, ave_list = rm.calc_metrics(pcd_pred_list, pcd_gt_list)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                rm.main([s[0].reshape(-1) for s in scenes], [s[1].reshape(-1) for s in scenes],
+                        [s[2].reshape(-1) for s in scenes], [s[3].reshape(-1) for s in scenes],
+                        [s[4] for s in scenes])
+            score_line = [l for l in buf.getvalue().splitlines() if 'Occ score' in l][-1]
+            occ_score = float(score_line.split(':')[-1])
+            # tools/ray_iou/metric.py on the per-ray (class, distance, flow) lists of a submission file
+            m_iou, m_ave = ns.metric.calc_metrics(
+                [p[:, 0] for p in arrays_lists(arrays, 'pcd_pred')], [p[:, 1] for p in arrays_lists(arrays, 'pcd_pred')],
+                [p[:, 2:4] for p in arrays_lists(arrays, 'pcd_pred')], [p[:, 0] for p in arrays_lists(arrays, 'pcd_gt')],
+                [p[:, 1] for p in arrays_lists(arrays, 'pcd_gt')], [p[:, 2:4] for p in arrays_lists(arrays, 'pcd_gt')])
+    arrays.update(iou=np.stack(iou_list), ave=np.asarray(ave_list), occ_score=np.float64(occ_score),
+                  miou=np.float64(np.nanmean(iou_list)), mave=np.float64(np.nanmean(ave_list)),
+                  metric_py_iou=np.stack(m_iou), metric_py_ave=np.asarray(m_ave))
+    arrays.pop('lidar_rays')
+    path = os.path.join(OUT, 'ray_metrics.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'ray_metrics: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); RayIoU {arrays["miou"]:.4f} '
+          f'mAVE {arrays["mave"]:.4f} OccScore {occ_score:.4f}')
+
+
+def arrays_lists(arrays, prefix):
+    return [arrays[f'{prefix}_{i}'] for i in range(len(METRIC_SEEDS))]
 
 
 def main():
@@ -66,4 +118,6 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if '--metrics-only' not in sys.argv:
+        main()
+    metric_golden()

@@ -2,7 +2,9 @@
 
 Literal restatement of projects/mmdet3d_plugin/datasets/ray_metrics.py: `process_one_sample` (:89-143)
 driving the plain-C ray caster (oracle/dvr_ref.c) and `calc_metrics` (:146-197) with the reference's
-per-class Python loops.  Parity unpinned by reference-owned vectors (the reference has none)."""
+per-class Python loops.  PINNED: tests/golden/ray_metrics.npz holds the outputs of the reference's own file run in
+place (oracle/refshim.install_metrics + oracle/build_ref.py) — tests/test_ray_metrics_golden.py checks this
+restatement against them bit for bit, and oracle/dvr_ref.c against the reference's kernel body."""
 import ctypes
 import os
 

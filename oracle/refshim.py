@@ -198,3 +198,89 @@ def install():
         TransformerOcc=trf.TransformerOcc, BEVFormerOccHead=head.BEVFormerOccHead,
         build_head=lambda cfg: build_from_cfg(cfg, HEADS),
         files=[m.__file__ for m in (sca, tsa, enc, trf, head)])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The reference's METRIC code, executed from where it lies.
+#   projects/mmdet3d_plugin/datasets/ray_metrics.py JIT-compiles its CUDA ray caster at import
+#   (`dvr = load("dvr", sources=[...dvr.cpp, ...dvr.cu])`, :12), imports prettytable and moves tensors with
+#   .cuda() (:117-120); tools/ray_iou/metric.py is plain numpy.  With
+#     torch.utils.cpp_extension.load -> an object whose render_forward() runs the reference's OWN kernel body
+#                                       compiled for the host (oracle/_ref/libdvr_reference.so, oracle/build_ref.py),
+#     prettytable                    -> a 10-line stand-in,
+#     Tensor.cuda                    -> identity (while a reference function runs)
+#   both files run unmodified; oracle/gen_golden.py records their outputs.
+def _reference_dvr(lib_name='libdvr_reference.so'):
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref', lib_name)
+    if not os.path.exists(so):
+        from oracle import build_ref
+        build_ref.build(verbose=False)
+    lib = ctypes.CDLL(so)
+
+    def render_forward(sigma, origin, points, tindex, grid=None, phase_name="test"):
+        sigma, origin, points, tindex = (t.detach().cpu().contiguous().float()
+                                         for t in (sigma, origin, points, tindex))
+        N, T, Z, Y, X = sigma.shape
+        assert grid is None or [int(v) for v in grid] == [T, Z, Y, X]
+        M = points.shape[1]
+        pred, gt, coord = torch.empty(N, M), torch.empty(N, M), torch.empty(N, M, 3)
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        lib.dvr_render_forward_reference(p(sigma), p(origin), p(points), p(tindex), p(pred), p(gt), p(coord),
+                                         N, T, Z, Y, X, M, points.shape[2], 1 if phase_name == "train" else 0)
+        return pred, gt, coord
+    return types.SimpleNamespace(render_forward=render_forward)
+
+
+class _cpu_cuda:
+    """`tensor.cuda()` is the identity while the reference's metric functions run on this GPU-less host."""
+
+    def __enter__(self):
+        self._orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        self._ec = torch.cuda.empty_cache
+        torch.cuda.empty_cache = lambda: None
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda = self._orig
+        torch.cuda.empty_cache = self._ec
+        return False
+
+
+def install_metrics():
+    """-> namespace(ray_metrics=<reference module>, metric=<reference module>, on_host=<context manager>,
+    files=[...]) with both reference files executed in place."""
+    import importlib.util
+    import torch.utils.cpp_extension as cpp_ext
+
+    class PrettyTable:
+        def __init__(self, field_names=None):
+            self.field_names, self.rows, self.float_format = field_names, [], ''
+
+        def add_row(self, row, divider=False):
+            self.rows.append(list(row))
+
+        def __str__(self):
+            return '\n'.join(' | '.join(f'{v:.3f}' if isinstance(v, float) else str(v) for v in r)
+                             for r in [self.field_names] + self.rows)
+    saved_load, saved_pt = cpp_ext.load, sys.modules.get('prettytable')
+    cpp_ext.load = lambda name, sources=None, **kw: _reference_dvr()
+    _mod('prettytable', PrettyTable=PrettyTable)
+    try:
+        mods = {}
+        for name, rel in (('ref_ray_metrics', 'projects/mmdet3d_plugin/datasets/ray_metrics.py'),
+                          ('ref_ray_iou_metric', 'tools/ray_iou/metric.py')):
+            path = os.path.join(REF_ROOT, rel)
+            spec = importlib.util.spec_from_file_location(name, path)
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+            assert m.__file__.startswith(REF_ROOT)
+            mods[name] = m
+    finally:
+        cpp_ext.load = saved_load
+        if saved_pt is None:
+            sys.modules.pop('prettytable', None)
+        else:
+            sys.modules['prettytable'] = saved_pt
+    return types.SimpleNamespace(ray_metrics=mods['ref_ray_metrics'], metric=mods['ref_ray_iou_metric'],
+                                 on_host=_cpu_cuda, files=[m.__file__ for m in mods.values()])

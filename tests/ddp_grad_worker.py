@@ -45,13 +45,21 @@ def main():
     sem, flow, mask = synthetic_targets(head.bev_h, head.bev_w, head.transformer.pillar_h,
                                         num_classes=head.num_classes, seed=rank, device=device)
     out = {}
+    import numpy as np
+
+    def reseed():       # the same dropout masks (torch RNG) and GridMask draw (numpy RNG) in both passes
+        torch.manual_seed(1000 + rank)
+        torch.cuda.manual_seed(1000 + rank)
+        np.random.seed(1000 + rank)
     for autocast in (False, True):
+        reseed()
         train_step(ddp, opt, img, metas, sem, flow, mask, max_norm=1e9, autocast_backbone=autocast)
         g = torch.cat([p.grad.detach().float().reshape(-1) for p in model.parameters() if p.grad is not None])
         digest = torch.stack([g.double().sum(), g.double().abs().sum(), (g.double() ** 2).sum()])
         # the same sample WITHOUT the wrapper: the rank-local gradient
         model.zero_grad(set_to_none=True)
         model.backbone_autocast_dtype = torch.bfloat16 if autocast else None
+        reseed()
         losses = model(return_loss=True, img_metas=metas, img=img, voxel_semantics=sem, voxel_flow=flow,
                        mask_camera=mask)
         sum(losses.values()).backward()

@@ -37,3 +37,42 @@ def case_inputs(case):
 
 def checksum(tensors):
     return float(sum(t.detach().double().abs().sum() for t in tensors))
+
+
+# ---- RayIoU / mAVE / OccScore -----------------------------------------------------------
+METRIC_SEEDS = (41, 42)
+
+
+def metric_scene(seed):
+    """A seeded synthetic occupancy scene at the metric's hard-coded size (ray_metrics.py:209-212 reshapes to
+    [200, 200, 16]): -> (sem_pred, sem_gt uint8 (200,200,16), flow_pred, flow_gt float32 (200,200,16,2),
+    lidar_origins float tensor (1, T, 3)).  Ground plane + boxes of several classes; the prediction shifts /
+    relabels / drops some of them so every term of the score (per-class IoU at 1/2/4 m, flow error of true
+    positives, free rays) is exercised."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(seed)
+    FREE = 16
+    gt = np.full((200, 200, 16), FREE, np.uint8)
+    gt[:, :, 0:2] = 10                                       # driveable surface
+    gt[:, :60, 0:2] = 12                                     # sidewalk strip
+    gt[:, 185:, 0:12] = 14                                   # a wall (manmade)
+    pred = gt.copy()
+    fgt = np.zeros((200, 200, 16, 2), np.float32)
+    fpred = np.zeros_like(fgt)
+    for i in range(28):
+        cls = int(rng.choice([0, 1, 3, 5, 6, 7, 8, 9, 15]))
+        sx, sy, sz = (int(v) for v in rng.integers(2, 9, 3))
+        x0, y0 = int(rng.integers(40, 160 - sx)), int(rng.integers(40, 160 - sy))
+        gt[x0:x0 + sx, y0:y0 + sy, 2:2 + sz] = cls
+        vel = rng.normal(scale=2.0, size=2).astype(np.float32) if cls < 8 else np.zeros(2, np.float32)
+        fgt[x0:x0 + sx, y0:y0 + sy, 2:2 + sz] = vel
+        mode = i % 4
+        if mode == 3:
+            continue                                         # missed object
+        dx, dy = (int(v) for v in rng.integers(-4, 5, 2)) if mode == 1 else (0, 0)
+        pcls = int(rng.choice([0, 1, 7])) if mode == 2 else cls
+        pred[x0 + dx:x0 + dx + sx, y0 + dy:y0 + dy + sy, 2:2 + sz] = pcls
+        fpred[x0 + dx:x0 + dx + sx, y0 + dy:y0 + dy + sy, 2:2 + sz] = vel + rng.normal(scale=0.4, size=2)
+    origins = torch.tensor([[[0.9858, 0.0, 1.8402], [2.4, -0.7, 1.84]]], dtype=torch.float32)
+    return pred, gt, fpred, fgt, origins

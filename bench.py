@@ -512,7 +512,7 @@ def main():
             M, D = da.num_heads, da.embed_dims // da.num_heads
             S = M * da.num_levels * da.num_points
             n_layers = len(stats)
-            ev = ext.SCA_VALUE_BYTES                       # bytes per value element (4 = f32, 2 = f16 opt-in)
+            ev = ext.sca_value_bytes()                       # bytes per value element (4 = f32, 2 = f16 opt-in)
             row_b = D * ev
             b_alg = [n_in * row_b + rows * S * 12 + rows * M * D * 4 for rows, n_in in stats]
             mean_ms = sum(sca) / len(sca)

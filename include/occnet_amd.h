@@ -115,6 +115,15 @@ int occ_sca_head_forward_f32(const float* value, const int64_t* spatial_shapes,
                              int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq, int stage_pix,
                              int variant, void* stream);
 
+/* Opt-in fp16 VALUE maps for the gather above (SURVEY.md §8d's e_v = 2 variant): value (B*NC, S, M, D) fp16 as
+ * written by occ_value_proj_bf16_f16; sampling arithmetic and accumulation stay fp32.  Not the default: the value
+ * elements are rounded to 11 significant bits (measured effect in DESIGN.md §3). */
+int occ_sca_head_forward_f16v(const void* value_f16, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const float* offs, int64_t offs_stride,
+                              const float* logits, int64_t logits_stride, const float* ref_cam,
+                              const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats,
+                              int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused temporal self-attention gather over the 2-deep BEV queue (single level):
  *   out[b,q,:] = 0.5 * sum_{t in {0,1}} MSDA( value[b*2+t], softmax_p(logits[b,q,m,t,:]),
@@ -196,6 +205,14 @@ int occ_occ_heads_f32(const float* feat, const float* w1_occ, const float* b1_oc
                       const float* b1_flow, const float* w2_flow, const float* b2_flow,
                       float* occ_out, float* flow_out, int64_t n_rows, int C, int hidden,
                       int num_classes, void* stream);
+/* same + the decoded class per voxel, occ_cls[row] = argmax_c occ[row, c] (first index on ties) as int64 — the
+ * reference's get_occ, P/bevformer/dense_heads/bevformer_occ_head.py:210-212 (softmax(-1).argmax(-1); softmax is
+ * monotonic) — written by the same pass; occ_cls_out may be NULL. */
+int occ_occ_heads_decode_f32(const float* feat, const float* w1_occ, const float* b1_occ, const float* w2_occ,
+                             const float* b2_occ, const float* w1_flow, const float* b1_flow,
+                             const float* w2_flow, const float* b2_flow, float* occ_out, float* flow_out,
+                             int64_t* occ_cls_out, int64_t n_rows, int C, int hidden, int num_classes,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * nn.Linear on the f32 matrix cores (exact f32) with the encoder's elementwise tail fused:
@@ -229,6 +246,14 @@ int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2
                           const float* residual, int64_t ldres, const float* ln_gamma,
                           const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N,
                           void* stream);
+
+/* Round-2 variant of occ_linear_bf16x3_f32 (same arguments, same packed weights, same arithmetic): 160-row blocks,
+ * 32-k chunks, weights staged once per block in LDS (csrc/linear_x3s.hip).  Needs K1 % 32 == 0 and K2 % 32 == 0;
+ * OCC_E_UNSUPPORTED otherwise (the caller then takes occ_linear_bf16x3_f32). */
+int occ_linear_bf16x3s_f32(const float* a1, int64_t lda1, int K1, const float* a2, const float* a2_add,
+                           int64_t lda2, int K2, const void* weight_packed, const float* bias, int act,
+                           const float* residual, int64_t ldres, const float* ln_gamma, const float* ln_beta,
+                           float ln_eps, float* out, int64_t ldo, int M, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ray casting through an occupancy grid (RayIoU metric) — replaces the reference's `dvr.render_forward`
@@ -269,6 +294,11 @@ int occ_value_proj_bf16_f32(int n_segments, const void* const* a, const int64_t*
                             const int64_t* rows_per_group, const int64_t* out_row0,
                             const float* const* group_bias, int bias_groups, const void* weight_packed,
                             float* out, int64_t ldo, int K, int N, int64_t out_group_rows, void* stream);
+/* same with the output written as fp16 (ldo in fp16 elements): feeds occ_sca_head_forward_f16v */
+int occ_value_proj_bf16_f16(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
+                            const int64_t* rows_per_group, const int64_t* out_row0,
+                            const float* const* group_bias, int bias_groups, const void* weight_packed,
+                            void* out, int64_t ldo, int K, int N, int64_t out_group_rows, void* stream);
 
 /* ResNet stem in one launch (outside the hand-written hot path):
  *   out = max_pool2d(relu(conv2d(x, W 7x7, stride 2, pad 3) + bias), kernel 3, stride 2, pad 1)

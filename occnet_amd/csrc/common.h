@@ -135,4 +135,91 @@ __device__ __forceinline__ float4 gather_samples(const float* __restrict__ vb,
   return acc;
 }
 
+constexpr unsigned kOobOffset = 0x7fffff00u;   // byte offset no value map reaches: the buffer load returns 0
+
+struct __attribute__((aligned(16))) SampleParamB {   // like SampleParam, offsets in BYTES (global) or LDS bytes
+  float w[4];
+  unsigned o[4];
+};
+
+// bilinear_setup (common.h) with byte offsets: corner k of pixel (h, w) -> (lvl_pix0 + h*W + w) * pix_bytes;
+// corners outside the map (and every corner of a sample that fails the admission test, or when !live) get
+// `dead` (weight 0).  Returns the number of corners inside the map.
+__device__ __forceinline__ int bilinear_setup_b(float loc_x, float loc_y, float attn, int H, int W, int lvl_pix0,
+                                                unsigned pix_bytes, unsigned dead, bool live, SampleParamB& sp) {
+  sp.w[0] = sp.w[1] = sp.w[2] = sp.w[3] = 0.f;
+  sp.o[0] = sp.o[1] = sp.o[2] = sp.o[3] = dead;
+  const float h_im = loc_y * (float)H - 0.5f;
+  const float w_im = loc_x * (float)W - 0.5f;
+  int n_in = 0;
+  if (live && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h_low = (int)hf, w_low = (int)wf;
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = h_im - hf, lw = w_im - wf;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const bool t = h_low >= 0, b = h_high <= H - 1, l = w_low >= 0, r = w_high <= W - 1;
+    const int base = lvl_pix0 + h_low * W + w_low;
+    if (t && l) { sp.w[0] = hh * hw * attn; sp.o[0] = (unsigned)base * pix_bytes; ++n_in; }
+    if (t && r) { sp.w[1] = hh * lw * attn; sp.o[1] = (unsigned)(base + 1) * pix_bytes; ++n_in; }
+    if (b && l) { sp.w[2] = lh * hw * attn; sp.o[2] = (unsigned)(base + W) * pix_bytes; ++n_in; }
+    if (b && r) { sp.w[3] = lh * lw * attn; sp.o[3] = (unsigned)(base + W + 1) * pix_bytes; ++n_in; }
+  }
+  return n_in;
+}
+
+typedef unsigned occ_u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor over `bytes` bytes at `base`, built from PROVABLY wave-uniform words: anything derived from
+// threadIdx — even the wave id — is divergent to hipcc, which then wraps every buffer load in a waterfall loop
+// (v_readfirstlane x4, compare, s_and_saveexec, loop) that serialises the loads.  `base` must really be the same
+// for all lanes of the wave.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* p = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0));
+}
+
+__device__ __forceinline__ void fma4(float4& acc, float w, const float4& v) {
+  acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
+  acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+}
+
+// gather_samples with BUFFER loads: offsets in bytes relative to the descriptor's base (this lane's 16 bytes of a
+// row at + lane_off), out-of-map corners carry kOobOffset -> the hardware returns 0 and requests nothing.
+template <int UNROLL>
+__device__ __forceinline__ float4 gather_samples_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
+                                                     const SampleParamB* sp, int ns, float4 acc) {
+  int s = 0;
+  for (; s + UNROLL <= ns; s += UNROLL) {
+    float4 v[UNROLL][4];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const occ_u32x4 o = *reinterpret_cast<const occ_u32x4*>(sp[s + u].o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[u][k] = buf_load16(rsrc, o[k] + lane_off);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const float4 w = *reinterpret_cast<const float4*>(sp[s + u].w);
+      fma4(acc, w.x, v[u][0]); fma4(acc, w.y, v[u][1]); fma4(acc, w.z, v[u][2]); fma4(acc, w.w, v[u][3]);
+    }
+  }
+  for (; s < ns; ++s) {
+    const occ_u32x4 o = *reinterpret_cast<const occ_u32x4*>(sp[s].o);
+    const float4 w = *reinterpret_cast<const float4*>(sp[s].w);
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = buf_load16(rsrc, o[k] + lane_off);
+    fma4(acc, w.x, v[0]); fma4(acc, w.y, v[1]); fma4(acc, w.z, v[2]); fma4(acc, w.w, v[3]);
+  }
+  return acc;
+}
+
 }  // namespace occ

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void occ_heads_kernel(
     const float* __restrict__ feat, const float* __restrict__ w1o, const float* __restrict__ b1o,
     const float* __restrict__ w2o, const float* __restrict__ b2o, const float* __restrict__ w1f,
     const float* __restrict__ b1f, const float* __restrict__ w2f, const float* __restrict__ b2f,
-    float* __restrict__ occ, float* __restrict__ flow, long n_rows, int ncls) {
+    float* __restrict__ occ, float* __restrict__ flow, long long* __restrict__ occ_cls, long n_rows, int ncls) {
   constexpr int C = 32, HID = 64;
   __shared__ float w2s[65 * 64];                    // [step (a*16+r), bias step 64][lane]
   __shared__ float osm[kHeadWaves][32 * 33];        // per-wave output transpose
@@ -131,17 +131,28 @@ __global__ __launch_bounds__(256) void occ_heads_kernel(
     const long valid = n_rows - row0 < 32 ? n_rows - row0 : 32;
     for (int e = lane; e < valid * ncls; e += 64) occ[row0 * ncls + e] = sm[(e / ncls) * 33 + e % ncls];
     if (lane < valid * 2) flow[row0 * 2 + lane] = sm[(lane >> 1) * 33 + ncls + (lane & 1)];
+    // decode (reference bevformer_occ_head.py:210-212: softmax(-1).argmax(-1)): softmax is monotonic, so the class
+    // is the argmax of the logits, first index on ties as torch.argmax resolves them
+    if (occ_cls != nullptr && lane < valid) {
+      float best = sm[lane * 33];
+      int arg = 0;
+      for (int ch = 1; ch < ncls; ++ch) {
+        const float x = sm[lane * 33 + ch];
+        if (x > best) { best = x; arg = ch; }
+      }
+      occ_cls[row0 + lane] = arg;
+    }
     wave_lds_sync();
   }
 }
 
 }  // namespace occ
 
-extern "C" int occ_occ_heads_f32(const float* feat, const float* w1_occ, const float* b1_occ,
-                                 const float* w2_occ, const float* b2_occ, const float* w1_flow,
-                                 const float* b1_flow, const float* w2_flow, const float* b2_flow,
-                                 float* occ_out, float* flow_out, int64_t n_rows, int C, int hidden,
-                                 int num_classes, void* stream) {
+extern "C" int occ_occ_heads_decode_f32(const float* feat, const float* w1_occ, const float* b1_occ,
+                                        const float* w2_occ, const float* b2_occ, const float* w1_flow,
+                                        const float* b1_flow, const float* w2_flow, const float* b2_flow,
+                                        float* occ_out, float* flow_out, int64_t* occ_cls_out, int64_t n_rows,
+                                        int C, int hidden, int num_classes, void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(feat && w1_occ && b1_occ && w2_occ && b2_occ && w1_flow && b1_flow && w2_flow &&
                     b2_flow && occ_out && flow_out,
@@ -156,8 +167,17 @@ extern "C" int occ_occ_heads_f32(const float* feat, const float* w1_occ, const f
   if (blocks > 256 * 4) blocks = 256 * 4;   // persistent waves: W fragments are loaded once per wave
   hipLaunchKernelGGL(occ_heads_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), feat, w1_occ, b1_occ, w2_occ, b2_occ,
-                     w1_flow, b1_flow, w2_flow, b2_flow, occ_out, flow_out, (long)n_rows,
-                     num_classes);
+                     w1_flow, b1_flow, w2_flow, b2_flow, occ_out, flow_out,
+                     reinterpret_cast<long long*>(occ_cls_out), (long)n_rows, num_classes);
   OCC_CHECK_LAUNCH("occ_heads");
   return OCC_OK;
+}
+
+extern "C" int occ_occ_heads_f32(const float* feat, const float* w1_occ, const float* b1_occ,
+                                 const float* w2_occ, const float* b2_occ, const float* w1_flow,
+                                 const float* b1_flow, const float* w2_flow, const float* b2_flow,
+                                 float* occ_out, float* flow_out, int64_t n_rows, int C, int hidden,
+                                 int num_classes, void* stream) {
+  return occ_occ_heads_decode_f32(feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow,
+                                  occ_out, flow_out, nullptr, n_rows, C, hidden, num_classes, stream);
 }

@@ -33,7 +33,11 @@ __global__ __launch_bounds__(256, 3) void sca_fused_kernel(
   constexpr int K = M * LP / 64;  // samples resolved per lane
   static_assert(LP >= 8 && LP <= 32 && (LP & (LP - 1)) == 0, "L*P must be a power of two in [8,32]");
   constexpr int LPp = LP + 1;
-  __shared__ __attribute__((aligned(16))) SampleParam smem[kScaWaves * M * LPp];
+  __shared__ __attribute__((aligned(16))) SampleParamB smem[kScaWaves * M * LPp];
+  // the camera-independent per-sample terms (softmax weight, normalised offset) wait in LDS, not in registers:
+  // live across the gather they push the kernel over the 168 VGPRs of three waves per SIMD (10 scratch spills =
+  // 100 MB of extra writes per launch)
+  __shared__ __attribute__((aligned(16))) float pre[kScaWaves][3][K][64];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256, 3) void sca_fused_kernel(
   const int b = (int)(wg / Nq);
   const int r = (int)(wg - (long)b * Nq);
   const int q = order ? order[r] : r;
-  SampleParam* sp = smem + wave * M * LPp;
+  SampleParamB* sp = smem + wave * M * LPp;
 
   constexpr int row_stride = M * D;
   const uint32_t vis = vis_bits[q];                       // batch 0's mask picks the cameras
@@ -51,14 +55,15 @@ __global__ __launch_bounds__(256, 3) void sca_fused_kernel(
 
   // ---- camera-independent part: softmax(logits) and offsets / (W_l, H_l) ------------------
   float aw[K], ox[K], oy[K];
-  int lvH[K], lvW[K], lvS[K];
+  // sample index s = (lane + 64 k) % LP does not depend on k (64 % LP == 0): one level per lane
+  static_assert(64 % LP == 0, "the lane's level must not depend on k");
+  const int lane_l = (lane % LP) / P;
+  const int lvH = (int)shapes[2 * lane_l], lvW = (int)shapes[2 * lane_l + 1], lvS = (int)lstart[lane_l];
   const float* lrow = logits + ((long)b * Nq + q) * logits_stride;
   const float* orow = offs + ((long)b * Nq + q) * offs_stride;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int idx = lane + 64 * k;  // = m*LP + s
-    const int s = idx % LP;
-    const int l = s / P;
     float x = lrow[idx];
     float mx = x;
 #pragma unroll
@@ -68,11 +73,12 @@ __global__ __launch_bounds__(256, 3) void sca_fused_kernel(
 #pragma unroll
     for (int d = LP / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
     aw[k] = e / sum;
-    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-    lvH[k] = H; lvW[k] = W; lvS[k] = (int)lstart[l];
     const float2 o = *reinterpret_cast<const float2*>(orow + 2 * idx);
-    ox[k] = o.x / (float)W;
-    oy[k] = o.y / (float)H;
+    ox[k] = o.x / (float)lvW;
+    oy[k] = o.y / (float)lvH;
+    pre[wave][0][k][lane] = aw[k];
+    pre[wave][1][k][lane] = ox[k];
+    pre[wave][2][k][lane] = oy[k];
   }
 
   const int g = lane >> 3, c4 = lane & 7;
@@ -88,14 +94,18 @@ __global__ __launch_bounds__(256, 3) void sca_fused_kernel(
       const int m = idx / LP, s = idx % LP;
       const int z = (s % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
       const float2 rxy = *reinterpret_cast<const float2*>(rp + 2 * z);
-      SampleParam p;
-      n_in += bilinear_setup(rxy.x + ox[k], rxy.y + oy[k], aw[k], lvH[k], lvW[k], lvS[k],
-                             row_stride, p);
+      SampleParamB p;
+      const float aw_k = pre[wave][0][k][lane], ox_k = pre[wave][1][k][lane], oy_k = pre[wave][2][k][lane];
+      n_in += bilinear_setup_b(rxy.x + ox_k, rxy.y + oy_k, aw_k, lvH, lvW, lvS,
+                               (unsigned)row_stride * 4u, kOobOffset, true, p);
       sp[m * LPp + s] = p;
     }
     wave_lds_sync();
-    const float* vb = value + ((long)b * NC + c) * S * row_stride + g * D + c4 * 4;
-    acc = gather_samples<4>(vb, sp + g * LPp, LP, acc);
+    // corners outside their map carry an out-of-range byte offset: the buffer load returns 0 without a request
+    // (round 1 issued a dummy load of row 0 for them: 9 % of the rows through the texture path, and 0 * Inf)
+    const __amdgpu_buffer_rsrc_t rsrc =
+        uniform_rsrc(value + ((long)b * NC + c) * S * row_stride, (unsigned)S * row_stride * 4u);
+    acc = gather_samples_buf<4>(rsrc, (unsigned)(g * D + c4 * 4) * 4u, sp + g * LPp, LP, acc);
     wave_lds_sync();  // WAR: next camera rewrites the LDS slab
     ++n_rows;
   }
@@ -148,7 +158,7 @@ extern "C" int occ_sca_fused_forward_f32(const float* value, const int64_t* spat
   OCC_CHECK_ARG(P % Z == 0, "sca_fused_forward: num_points(%d) must be a multiple of Z(%d)", P, Z);
   OCC_CHECK_ARG(offs_stride >= (int64_t)M * L * P * 2 && logits_stride >= (int64_t)M * L * P,
                 "sca_fused_forward: row strides smaller than a row");
-  OCC_CHECK_ARG((long)S * M * D < (1L << 31), "sca_fused_forward: value batch entry too large");
+  OCC_CHECK_ARG((long)S * M * D * 4 < (long)kOobOffset, "sca_fused_forward: value batch entry too large");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (M != 8 || D != 32) {
     set_error("sca_fused_forward: no fused kernel for M=%d D=%d", M, D);

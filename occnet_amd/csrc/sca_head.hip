@@ -26,54 +26,11 @@
 // Arithmetic per sample is unchanged (common.h: mmcv's ms_deformable_im2col), so are the camera order of the
 // accumulation and the divide by the visible-camera count; only the f32 summation order inside a query differs
 // from the query-major kernel (samples are accumulated level by level here as well).
+#include <hip/hip_fp16.h>
 #include <type_traits>
 #include "common.h"
 
 namespace occ {
-
-constexpr unsigned kOobOffset = 0x7fffff00u;   // byte offset no value map reaches: the buffer load returns 0
-
-struct __attribute__((aligned(16))) SampleParamB {   // like SampleParam, offsets in BYTES (global) or LDS bytes
-  float w[4];
-  unsigned o[4];
-};
-
-// bilinear_setup (common.h) with byte offsets: corner k of pixel (h, w) -> (lvl_pix0 + h*W + w) * pix_bytes;
-// corners outside the map (and every corner of a sample that fails the admission test, or when !live) get
-// `dead` (weight 0).  Returns the number of corners inside the map.
-__device__ __forceinline__ int bilinear_setup_b(float loc_x, float loc_y, float attn, int H, int W, int lvl_pix0,
-                                                unsigned pix_bytes, unsigned dead, bool live, SampleParamB& sp) {
-  sp.w[0] = sp.w[1] = sp.w[2] = sp.w[3] = 0.f;
-  sp.o[0] = sp.o[1] = sp.o[2] = sp.o[3] = dead;
-  const float h_im = loc_y * (float)H - 0.5f;
-  const float w_im = loc_x * (float)W - 0.5f;
-  int n_in = 0;
-  if (live && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    const int h_low = (int)hf, w_low = (int)wf;
-    const int h_high = h_low + 1, w_high = w_low + 1;
-    const float lh = h_im - hf, lw = w_im - wf;
-    const float hh = 1.f - lh, hw = 1.f - lw;
-    const bool t = h_low >= 0, b = h_high <= H - 1, l = w_low >= 0, r = w_high <= W - 1;
-    const int base = lvl_pix0 + h_low * W + w_low;
-    if (t && l) { sp.w[0] = hh * hw * attn; sp.o[0] = (unsigned)base * pix_bytes; ++n_in; }
-    if (t && r) { sp.w[1] = hh * lw * attn; sp.o[1] = (unsigned)(base + 1) * pix_bytes; ++n_in; }
-    if (b && l) { sp.w[2] = lh * hw * attn; sp.o[2] = (unsigned)(base + W) * pix_bytes; ++n_in; }
-    if (b && r) { sp.w[3] = lh * lw * attn; sp.o[3] = (unsigned)(base + W + 1) * pix_bytes; ++n_in; }
-  }
-  return n_in;
-}
-
-typedef unsigned occ_u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0));
-}
-
-__device__ __forceinline__ void fma4(float4& acc, float w, const float4& v) {
-  acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y);
-  acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
-}
 
 // NW waves per block, OPW octets (8 queries) per wave; STAGE: last level through LDS (camera-outer block loop)
 template <int L, int P, int NW, int OPW, bool STAGE>
@@ -147,8 +104,7 @@ __global__ __launch_bounds__(NW * 64, (NW * 64 >= 512) ? 4 : 3) void sca_head_ke
   for (int c = 0; c < NC; ++c) {
     if (!((cams >> c) & 1u)) continue;            // block-uniform (STAGE) / wave-uniform
     const float* vmap = value + ((long)b * NC + c) * S * (M * D) + m * D;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(vmap), 0, (int)((unsigned)S * ROW_B - (unsigned)(m * D * 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(vmap, (unsigned)S * ROW_B - (unsigned)(m * D * 4));
     if (STAGE) {
       __syncthreads();                            // every wave is done with the previous camera's map
       const unsigned pix0 = (unsigned)Ss[L - 1];
@@ -276,6 +232,128 @@ __global__ __launch_bounds__(NW * 64, (NW * 64 >= 512) ? 4 : 3) void sca_head_ke
   }
 }
 
+// ---- opt-in: fp16 value maps (SURVEY.md §8d's e_v = 2 variant) ---------------------------------------------------
+// The exact kernels above are bound by the bytes they pull through the texture-addresser / L1 path (64 B/clk/CU);
+// with the projected value stored as fp16 a bilinear corner of a head is one 64-byte row: 4 lanes x 16 bytes.  The
+// 8 lanes of a query group split into two half-groups that take samples 0-3 / 4-7 of a chunk at the same time —
+// 16 row loads per lane and chunk instead of 32 — each lane accumulating 8 channels in fp32 (v_fma_mix); the two
+// halves are added with one shuffle at the end.  Sampling arithmetic (locations, weights, softmax) stays fp32; the
+// only change to the result is the rounding of the value elements to 11 significant bits (measured end to end in
+// tests/test_gpu_modules.py::test_sca_fp16_values_*), so this path is NOT the default.
+template <int L, int P>
+__global__ __launch_bounds__(256, 4) void sca_head_h_kernel(
+    const __half* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lstart,
+    const float* __restrict__ offs, long offs_stride, const float* __restrict__ logits, long logits_stride,
+    const float* __restrict__ ref_cam, const uint32_t* __restrict__ vis_bits, const int32_t* __restrict__ order,
+    float* __restrict__ slots, unsigned long long* __restrict__ stats, int B, int NC, int S, int Z, int Nq) {
+  constexpr int M = 8, D = 32, LP = L * P, NCH = LP / 8, NW = 4;
+  static_assert(P == 4 || P == 8, "a chunk of 8 samples spans at most two levels");
+  constexpr unsigned ROW_B = M * D * 2;
+  constexpr int GRP_B = 9 * 32, PAR_B = 8 * GRP_B;
+  __shared__ __attribute__((aligned(16))) char par_all[NW * PAR_B];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* par = par_all + wave * PAR_B;
+  const int qi = lane >> 3, li = lane & 7, hg = li >> 2, c8 = li & 3;
+  const int m = blockIdx.x & 7, chunk = blockIdx.x >> 3, b = blockIdx.y;
+  int Hs[L], Ws[L], Ss[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    Hs[l] = (int)shapes[2 * l]; Ws[l] = (int)shapes[2 * l + 1]; Ss[l] = (int)lstart[l];
+  }
+  const long r = ((long)chunk * NW + wave) * 8 + qi;
+  const bool ok = r < Nq;
+  const int q = ok ? (order ? order[r] : (int)r) : 0;
+  const uint32_t vq = ok ? vis_bits[q] : 0u;
+  const uint32_t cnt = ok ? (uint32_t)__builtin_popcount(vis_bits[(long)b * Nq + q]) : 0u;
+  uint32_t cams = vq;
+#pragma unroll
+  for (int d = 32; d >= 8; d >>= 1) cams |= __shfl_xor(cams, d);
+  cams = __builtin_amdgcn_readfirstlane(cams);
+  const float* lrow = logits + ((long)b * Nq + q) * logits_stride + m * LP;
+  const float* orow = offs + ((long)b * Nq + q) * offs_stride + (long)m * LP * 2;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) mx = fmaxf(mx, lrow[8 * j + li]);
+  mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) sum += expf(lrow[8 * j + li] - mx);
+  sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  unsigned n_in = 0, n_rows = 0;
+  const char* gp = par + qi * GRP_B + hg * 4 * 32;        // this half-group's four samples of a chunk
+  for (int c = 0; c < NC; ++c) {
+    if (!((cams >> c) & 1u)) continue;                    // wave-uniform
+    const bool live = (vq >> c) & 1u;
+    const __half* vmap = value + ((long)b * NC + c) * S * (M * D) + m * D;
+    const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(vmap, (unsigned)S * ROW_B - (unsigned)(m * D * 2));
+    const float* rp = ref_cam + (((long)c * B + b) * Nq + q) * Z * 2;
+    if (m == 0 && li == 0 && live) ++n_rows;
+#pragma unroll 1
+    for (int j = 0; j < NCH; ++j) {
+      const int s = 8 * j + li;
+      const int l = s / P;
+      int H = Hs[0], W = Ws[0], st = Ss[0];
+#pragma unroll
+      for (int t = 1; t < L; ++t)
+        if (l == t) { H = Hs[t]; W = Ws[t]; st = Ss[t]; }
+      const int z = (s % P) % Z;
+      const float2 of = *reinterpret_cast<const float2*>(orow + 2 * s);
+      const float2 rxy = *reinterpret_cast<const float2*>(rp + 2 * z);
+      const float aw = expf(lrow[s] - mx) / sum;
+      SampleParamB sp;
+      n_in += bilinear_setup_b(rxy.x + of.x / (float)W, rxy.y + of.y / (float)H, aw, H, W, st, ROW_B, kOobOffset,
+                               live, sp);
+      *reinterpret_cast<SampleParamB*>(par + qi * GRP_B + li * 32) = sp;
+      wave_lds_sync();
+      occ_u32x4 v[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const occ_u32x4 o4 = *reinterpret_cast<const occ_u32x4*>(gp + u * 32 + 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[u][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o4[k] + (unsigned)c8 * 16u), 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 w4 = *reinterpret_cast<const float4*>(gp + u * 32);
+        const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __half2 h2 = __builtin_bit_cast(__half2, v[u][k][e]);
+            acc[2 * e] = fmaf(ww[k], __low2float(h2), acc[2 * e]);
+            acc[2 * e + 1] = fmaf(ww[k], __high2float(h2), acc[2 * e + 1]);
+          }
+      }
+      wave_lds_sync();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], 4);     // the two half-groups' samples
+  if (ok && hg == 0) {
+    const float inv = (float)(cnt > 0 ? cnt : 1u);
+    float* dst = slots + ((long)b * Nq + q) * (M * D) + m * D + c8 * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0] / inv, acc[1] / inv, acc[2] / inv, acc[3] / inv);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4] / inv, acc[5] / inv, acc[6] / inv, acc[7] / inv);
+  }
+  if (stats) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      n_in += __shfl_xor(n_in, d);
+      n_rows += __shfl_xor(n_rows, d);
+    }
+    if (lane == 0) {
+      if (n_rows) atomicAdd(&stats[0], (unsigned long long)n_rows);
+      if (n_in) atomicAdd(&stats[1], (unsigned long long)n_in);
+    }
+  }
+}
+
 template <int L, int P, int NW, int OPW, bool STAGE>
 static int launch_sca_head(const float* value, const int64_t* shapes, const int64_t* lstart, const float* offs,
                            long offs_stride, const float* logits, long logits_stride, const float* ref_cam,
@@ -341,5 +419,45 @@ extern "C" int occ_sca_head_forward_f32(const float* value, const int64_t* spati
   if (L == 1 && P == 8) return launch_sca_head<1, 8, 4, 1, false>(OCC_SCAH_ARGS, 0, st);
 #undef OCC_SCAH_ARGS
   set_error("sca_head_forward: no fused kernel for L=%d P=%d", L, P);
+  return OCC_E_UNSUPPORTED;
+}
+
+// fp16 value maps (opt-in, see sca_head_h_kernel): value (B*NC, S, M, D) __half; everything else as above.
+extern "C" int occ_sca_head_forward_f16v(const void* value_f16, const int64_t* spatial_shapes,
+                                         const int64_t* level_start_index, const float* offs, int64_t offs_stride,
+                                         const float* logits, int64_t logits_stride, const float* ref_cam,
+                                         const uint32_t* vis_bits, const int32_t* order, float* slots,
+                                         uint64_t* stats, int B, int NC, int S, int M, int D, int L, int P, int Z,
+                                         int Nq, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(value_f16 && spatial_shapes && level_start_index && offs && logits && ref_cam && vis_bits && slots,
+                "sca_head_forward_f16v: null pointer argument");
+  OCC_CHECK_ARG(B > 0 && B < 65536 && NC > 0 && NC <= 32 && S > 0 && Nq > 0 && Z > 0 && L > 0 && P > 0,
+                "sca_head_forward_f16v: bad dimension");
+  OCC_CHECK_ARG(P % Z == 0, "sca_head_forward_f16v: num_points(%d) must be a multiple of Z(%d)", P, Z);
+  OCC_CHECK_ARG(offs_stride >= (int64_t)M * L * P * 2 && logits_stride >= (int64_t)M * L * P,
+                "sca_head_forward_f16v: row strides smaller than a row");
+  OCC_CHECK_ARG((long)S * M * D * 2 < (long)kOobOffset, "sca_head_forward_f16v: value batch entry too large");
+  if (M != 8 || D != 32) {
+    set_error("sca_head_forward_f16v: no fused kernel for M=%d D=%d", M, D);
+    return OCC_E_UNSUPPORTED;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((Nq + 31) / 32) * 8, (unsigned)B);
+#define OCC_SCAHH(LL, PP)                                                                                       \
+  if (L == LL && P == PP) {                                                                                     \
+    hipLaunchKernelGGL((sca_head_h_kernel<LL, PP>), grid, dim3(256), 0, st,                                     \
+                       reinterpret_cast<const __half*>(value_f16), spatial_shapes, level_start_index, offs,     \
+                       (long)offs_stride, logits, (long)logits_stride, ref_cam, vis_bits, order, slots,         \
+                       reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq);                          \
+    OCC_CHECK_LAUNCH("sca_head_forward_f16v");                                                                  \
+    return OCC_OK;                                                                                              \
+  }
+  OCC_SCAHH(4, 8)
+  OCC_SCAHH(4, 4)
+  OCC_SCAHH(2, 8)
+  OCC_SCAHH(1, 8)
+#undef OCC_SCAHH
+  set_error("sca_head_forward_f16v: no fused kernel for L=%d P=%d", L, P);
   return OCC_E_UNSUPPORTED;
 }

@@ -23,6 +23,7 @@
 // are what separates it from the 39 us of a plain bf16 -> fp32 widening copy of the same tensors; 128-row blocks
 // halve the former (102 us).  Pinning the prefetch with sched_barrier and an 8-chunk activation prefetch were
 // measured: no gain.
+#include <hip/hip_fp16.h>
 #include "common.h"
 
 namespace occ {
@@ -41,10 +42,12 @@ struct VpSegments {
   int n;
 };
 
-template <int NT, int RT>
+// OUTH: the projected value is written as fp16 (opt-in fp16-value mode of the SCA gather) instead of fp32
+template <int NT, int RT, bool OUTH>
 __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
-    VpSegments seg, const uint4* __restrict__ wp, int bias_groups, float* __restrict__ out, long ldo, int N,
+    VpSegments seg, const uint4* __restrict__ wp, int bias_groups, void* __restrict__ out_, long ldo, int N,
     int K, long out_group_rows) {
+  float* __restrict__ out = reinterpret_cast<float*>(out_);
   int si = 0;
 #pragma unroll
   for (int i = 1; i < kVpMaxSeg; ++i)
@@ -165,7 +168,14 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
           const float4 b = *reinterpret_cast<const float4*>(gbias + (g % bias_groups) * N + n0 + c);
           v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
-        *reinterpret_cast<float4*>(out + (g * out_group_rows + out_row0 + i) * ldo + n0 + c) = v;
+        const long eo = (g * out_group_rows + out_row0 + i) * ldo + n0 + c;
+        if (OUTH) {
+          const __half2 h01 = __floats2half2_rn(v.x, v.y), h23 = __floats2half2_rn(v.z, v.w);
+          *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(out_) + eo) =
+              make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+        } else {
+          *reinterpret_cast<float4*>(out + eo) = v;
+        }
       }
     }
   }
@@ -173,11 +183,11 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
 
 }  // namespace occ
 
-extern "C" int occ_value_proj_bf16_f32(int n_segments, const void* const* a, const int64_t* lda,
-                                       const int64_t* rows, const int64_t* rows_per_group,
-                                       const int64_t* out_row0, const float* const* group_bias,
-                                       int bias_groups, const void* weight_packed, float* out, int64_t ldo,
-                                       int K, int N, int64_t out_group_rows, void* stream) {
+static int value_proj_bf16_launch(int n_segments, const void* const* a, const int64_t* lda,
+                                  const int64_t* rows, const int64_t* rows_per_group,
+                                  const int64_t* out_row0, const float* const* group_bias,
+                                  int bias_groups, const void* weight_packed, void* out, int64_t ldo,
+                                  int K, int N, int64_t out_group_rows, bool out_f16, void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(a && lda && rows && rows_per_group && out_row0 && weight_packed && out,
                 "value_proj_bf16: null pointer argument");
@@ -217,14 +227,35 @@ extern "C" int occ_value_proj_bf16_f32(int n_segments, const void* const* a, con
   seg.first_block[kVpMaxSeg] = (int)blocks;
   seg.n = n_segments;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define OCC_VP_LAUNCH_(NTT, BNN, RTT)                                                               \
-  hipLaunchKernelGGL((value_proj_bf16_kernel<NTT, RTT>), dim3((unsigned)blocks, (unsigned)((N + BNN - 1) / BNN)), \
+#define OCC_VP_LAUNCH__(NTT, BNN, RTT, HH)                                                          \
+  hipLaunchKernelGGL((value_proj_bf16_kernel<NTT, RTT, HH>), dim3((unsigned)blocks, (unsigned)((N + BNN - 1) / BNN)), \
                      dim3(256), 0, st, seg, reinterpret_cast<const uint4*>(weight_packed), bias_groups, out, \
                      (long)ldo, N, K, (long)out_group_rows)
+#define OCC_VP_LAUNCH_(NTT, BNN, RTT) do { if (out_f16) OCC_VP_LAUNCH__(NTT, BNN, RTT, true); else OCC_VP_LAUNCH__(NTT, BNN, RTT, false); } while (0)
 #define OCC_VP_LAUNCH(NTT, BNN) do { if (bm == 128) OCC_VP_LAUNCH_(NTT, BNN, 4); else OCC_VP_LAUNCH_(NTT, BNN, 2); } while (0)
   if (N <= 128) OCC_VP_LAUNCH(1, 128); else OCC_VP_LAUNCH(2, 256);
 #undef OCC_VP_LAUNCH
 #undef OCC_VP_LAUNCH_
+#undef OCC_VP_LAUNCH__
   OCC_CHECK_LAUNCH("value_proj_bf16");
   return OCC_OK;
+}
+
+extern "C" int occ_value_proj_bf16_f32(int n_segments, const void* const* a, const int64_t* lda,
+                                       const int64_t* rows, const int64_t* rows_per_group,
+                                       const int64_t* out_row0, const float* const* group_bias,
+                                       int bias_groups, const void* weight_packed, float* out, int64_t ldo,
+                                       int K, int N, int64_t out_group_rows, void* stream) {
+  return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
+                                weight_packed, out, ldo, K, N, out_group_rows, false, stream);
+}
+
+// same, output written as fp16 (ldo in fp16 elements): the opt-in fp16-value mode of the SCA gather
+extern "C" int occ_value_proj_bf16_f16(int n_segments, const void* const* a, const int64_t* lda,
+                                       const int64_t* rows, const int64_t* rows_per_group,
+                                       const int64_t* out_row0, const float* const* group_bias,
+                                       int bias_groups, const void* weight_packed, void* out, int64_t ldo,
+                                       int K, int N, int64_t out_group_rows, void* stream) {
+  return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
+                                weight_packed, out, ldo, K, N, out_group_rows, true, stream);
 }

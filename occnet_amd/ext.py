@@ -156,15 +156,23 @@ def point_sampling(ref_3d, lidar2img, ego2lidar, pc_range, img_h, img_w):
 # Which SCA gather kernel runs: 0 = query-major (round 1, csrc/sca_fused.hip), 1..3 = head-major
 # (csrc/sca_head.hip: 1 = no LDS staging, 2 / 3 = coarsest level staged in LDS with 8 / 6 waves per block).
 # bench.py's roofline names the kernel and only trusts a PMC traffic file measured on the same variant.
-SCA_KERNEL = int(os.environ.get("OCC_SCA_KERNEL", "3"))
-SCA_VALUE_BYTES = 4
+SCA_KERNEL = int(os.environ.get("OCC_SCA_KERNEL", "0"))
+# OCC_SCA_VALUES=f16 (opt-in): the projected value maps are stored as fp16 and gathered by sca_head_h_kernel — half
+# the bytes through the texture path; the value elements are rounded to 11 significant bits (not the default)
+SCA_VALUES = os.environ.get("OCC_SCA_VALUES", "f32")
 _SCA_NAMES = {0: "sca_fused_kernel<4,8> (query-major)", 1: "sca_head_kernel<4,8,4,1,false> (head-major)",
               2: "sca_head_kernel<4,8,8,2,true> (head-major, coarsest level in LDS)",
               3: "sca_head_kernel<4,8,6,2,true> (head-major, coarsest level in LDS)"}
 
 
 def sca_variant_name(kernel=None):
+    if kernel is None and SCA_VALUES == "f16":
+        return "sca_head_h_kernel<4,8> (head-major, fp16 values)"
     return _SCA_NAMES[SCA_KERNEL if kernel is None else kernel]
+
+
+def sca_value_bytes():
+    return 2 if SCA_VALUES == "f16" else 4
 
 
 def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, ref_cam, vis_bits,
@@ -173,7 +181,12 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
     be column slices of one wider Linear output (last dim contiguous); ref_cam (NC,B,Nq,Z,2);
     vis_bits (B,Nq) int32.  -> slots (B, Nq, M*D).  kernel: see SCA_KERNEL; stage_pix = H*W of the last level
     (computed from spatial_shapes — one host sync — when not given)."""
-    _need_cuda_f32("value", value)
+    half = value.dtype == torch.float16
+    if half:
+        if not (value.is_cuda and value.is_contiguous()):
+            raise OccAmdError("sca_fused_forward: fp16 value must be a contiguous device tensor")
+    else:
+        _need_cuda_f32("value", value)
     _need_cuda_f32("ref_cam", ref_cam)
     _need_cuda_f32("offs", offs, contiguous=False)
     _need_cuda_f32("logits", logits, contiguous=False)
@@ -195,7 +208,13 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
     kernel = SCA_KERNEL if kernel is None else int(kernel)
     slots = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
     with torch.cuda.device(value.device), _timed('sca_fused_forward'):
-        if kernel == 0:
+        if half:
+            rc = _lib.lib().occ_sca_head_forward_f16v(
+                ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
+                i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
+                ptr(order), ptr(slots), ptr(stats), i32(B), i32(NC), i32(S), i32(M), i32(D), i32(L),
+                i32(P), i32(Z), i32(Nq), stream_ptr(value.device))
+        elif kernel == 0:
             rc = _lib.lib().occ_sca_fused_forward_f32(
                 ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
                 i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
@@ -326,8 +345,9 @@ def conv3d_bn_relu(x, w_packed, scale, shift, Z, Y, X, cin, cout, in_layout, out
     return out
 
 
-def occ_heads(feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow):
-    """feat (..., C) -> occ (..., num_classes), flow (..., 2): both decoder MLP heads in one kernel."""
+def occ_heads(feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow, decode=False):
+    """feat (..., C) -> occ (..., num_classes), flow (..., 2): both decoder MLP heads in one kernel.  With `decode`
+    the same pass also writes argmax_c occ (int64, first index on ties): -> (occ, flow, occ_cls)."""
     ts = (feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow)
     for n, t in zip(("feat", "w1_occ", "b1_occ", "w2_occ", "b2_occ", "w1_flow", "b1_flow", "w2_flow",
                      "b2_flow"), ts):
@@ -342,13 +362,14 @@ def occ_heads(feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b
     n_rows = feat.numel() // C
     occ = torch.empty(feat.shape[:-1] + (ncls,), dtype=torch.float32, device=feat.device)
     flow = torch.empty(feat.shape[:-1] + (2,), dtype=torch.float32, device=feat.device)
+    cls = torch.empty(feat.shape[:-1], dtype=torch.int64, device=feat.device) if decode else None
     with torch.cuda.device(feat.device), _timed('occ_heads'):
-        rc = _lib.lib().occ_occ_heads_f32(
+        rc = _lib.lib().occ_occ_heads_decode_f32(
             ptr(feat), ptr(w1_occ), ptr(b1_occ), ptr(w2_occ), ptr(b2_occ), ptr(w1_flow), ptr(b1_flow),
-            ptr(w2_flow), ptr(b2_flow), ptr(occ), ptr(flow), i64(n_rows), i32(C), i32(hidden),
+            ptr(w2_flow), ptr(b2_flow), ptr(occ), ptr(flow), ptr(cls), i64(n_rows), i32(C), i32(hidden),
             i32(ncls), stream_ptr(feat.device))
     _lib.check(rc, "occ_heads")
-    return occ, flow
+    return (occ, flow, cls) if decode else (occ, flow)
 
 
 def _rows2d(name, t, k=None):
@@ -374,6 +395,8 @@ def _rows2d(name, t, k=None):
 # chain), 'bf16x3' = three bf16 MFMAs on hi/lo-split operands with f32 accumulation (relative error of a
 # product <= 2^-16; 2-3x faster).  The default can be overridden with OCC_LINEAR_PRECISION.
 LINEAR_PRECISION = os.environ.get("OCC_LINEAR_PRECISION", "bf16x3")
+# bf16x3 kernel: 'x3s' (round 2: 160-row blocks, LDS-shared weights; default) or 'x3' (round 1: 64-row blocks)
+LINEAR_KERNEL = os.environ.get("OCC_LINEAR_KERNEL", "x3s")
 _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight (small LRU)
 
 
@@ -410,9 +433,11 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
         if group_bias is not None:
             group_bias = group_bias.unsqueeze(0)
     S = len(a_list)
-    _need_cuda_f32("out", out)
-    if out.dim() != 2 or out.stride(1) != 1:
-        raise OccAmdError("value_proj_bf16: out must be a 2-D fp32 matrix with unit column stride")
+    out_half = out.dtype == torch.float16
+    if not out_half:
+        _need_cuda_f32("out", out)
+    if not out.is_cuda or out.dim() != 2 or out.stride(1) != 1:
+        raise OccAmdError("value_proj_bf16: out must be a 2-D fp32 (or fp16) device matrix with unit column stride")
     N, K = weight.shape
     if out.shape[1] != N or len(rows_per_group) != S or len(out_row0) != S:
         raise OccAmdError("value_proj_bf16: inconsistent shapes")
@@ -436,8 +461,9 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
     packed = linear_pack_weight_bf16x3(weight)
     arr64 = lambda v: (ctypes.c_int64 * S)(*[int(x) for x in v])
     a_ptrs = (ctypes.c_void_p * S)(*[a.data_ptr() for a in a_list])
-    with torch.cuda.device(out.device):
-        rc = _lib.lib().occ_value_proj_bf16_f32(
+    fn = _lib.lib().occ_value_proj_bf16_f16 if out_half else _lib.lib().occ_value_proj_bf16_f32
+    with torch.cuda.device(out.device), _timed('value_proj'):
+        rc = fn(
             i32(S), a_ptrs, arr64([a.stride(0) for a in a_list]), arr64([a.shape[0] for a in a_list]),
             arr64(rows_per_group), arr64(out_row0), gb_ptrs, i32(G), ptr(packed), ptr(out), i64(out.stride(0)),
             i32(K), i32(N), i64(out_group_rows), stream_ptr(out.device))
@@ -497,7 +523,12 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
     if not weight.is_contiguous():
         raise OccAmdError("linear: weight must be contiguous")
     wdev = linear_pack_weight_bf16x3(weight) if precision == "bf16x3" and (K1 + K2) % 16 == 0 else weight
-    fn = _lib.lib().occ_linear_bf16x3_f32 if wdev is not weight else _lib.lib().occ_linear_f32
+    if wdev is weight:
+        fn = _lib.lib().occ_linear_f32
+    elif LINEAR_KERNEL == "x3s" and K1 % 32 == 0 and K2 % 32 == 0:
+        fn = _lib.lib().occ_linear_bf16x3s_f32
+    else:
+        fn = _lib.lib().occ_linear_bf16x3_f32
     out = torch.empty(a.shape[:-1] + (N,), dtype=torch.float32, device=a.device)
     if _TIMING is not None and (_TIMING_ONLY is None or 'linear' in _TIMING_ONLY):
         _TIMING.setdefault('linear_flops', []).append(2.0 * M * N * (K1 + K2))

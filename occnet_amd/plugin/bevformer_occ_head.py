@@ -106,5 +106,9 @@ class BEVFormerOccHead(BaseModule):
 
     def get_occ(self, preds_dicts, img_metas=None, rescale=False):
         """-> (class index per voxel (B, W, H, Z) int64, flow (B, W, H, Z, 2))."""
-        occ_score = preds_dicts['occ'].float().softmax(-1).argmax(-1)
+        occ = preds_dicts['occ']
+        cls = getattr(occ, '_occ_cls', None)          # written by the fused heads kernel for THIS logits tensor
+        if cls is not None and cls.shape == occ.shape[:-1] and cls.device == occ.device:
+            return cls, preds_dicts['flow']
+        occ_score = occ.float().softmax(-1).argmax(-1)
         return occ_score, preds_dicts['flow']

@@ -11,6 +11,7 @@ SpatialCrossAttention layer would otherwise rebuild with nonzero(); the encoder 
 hands it (plus a cache-friendly query processing order) to all layers through kwargs.
 """
 import copy
+import os
 import warnings
 
 import numpy as np
@@ -362,9 +363,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
         """Query processing order of the gather kernels: 8x8 BEV tiles; `flat` = plain tile order (head-major SCA
         kernels: a block = 8-query rows of consecutive tiles, the XCD is picked by the head), else the tile list
         is additionally dealt over the 8 XCDs in 4-query blocks (query-major kernels)."""
-        key = (bev_h, bev_w, str(device), flat)
+        sweep = os.environ.get("OCC_BEV_SWEEP", "raster")
+        key = (bev_h, bev_w, str(device), flat, sweep)
         if key not in self._order_cache:
-            order = bev_tile_order(bev_h, bev_w, n_xcd=1) if flat else bev_tile_order(bev_h, bev_w)
+            order = bev_tile_order(bev_h, bev_w, n_xcd=1 if flat else 8, sweep=sweep)
             self._order_cache[key] = torch.from_numpy(order).to(device)
         return self._order_cache[key]
 

@@ -102,7 +102,8 @@ class LazyFeatures:
         return self._flat
 
     def project(self, value_proj):
-        """value_proj(feat + embeds) for every camera pixel -> (bs*num_cam, sum hw, N) fp32."""
+        """value_proj(feat + embeds) for every camera pixel -> (bs*num_cam, sum hw, N) fp32 (fp16 in the opt-in
+        OCC_SCA_VALUES=f16 mode)."""
         w, b = value_proj.weight, value_proj.bias
         n = w.shape[0]
         # per-(level, camera) bias = (cams_embeds + level_embeds) . W^T + b: constant while the parameters are,
@@ -119,7 +120,8 @@ class LazyFeatures:
             hit = (key, gb.view(len(self.hw), self.num_cam, n).contiguous(), srcs)
             value_proj._occ_group_bias = hit
         gb = hit[1]
-        out = torch.empty((self.bs * self.num_cam * self.total, n), dtype=torch.float32, device=w.device)
+        out = torch.empty((self.bs * self.num_cam * self.total, n), device=w.device,
+                          dtype=torch.float16 if ext.SCA_VALUES == "f16" else torch.float32)
         ext.value_proj_bf16(self.rows, w, gb, out, rows_per_group=[h * wd for h, wd in self.hw],
                             out_group_rows=self.total, out_row0=self.starts)
         return out.view(self.bs * self.num_cam, self.total, n)
@@ -319,8 +321,12 @@ class TransformerOcc(BaseModule):
         x = ext.conv3d_bn_relu(x, w2, s2, t2, Z, bev_h, bev_w, self.out_dim, self.out_dim,
                                in_layout=0, out_xy_major=True)
         p, f = self.predicter, self.flow_predicter
-        return ext.occ_heads(x, p[0].weight, p[0].bias, p[2].weight, p[2].bias,
-                             f[0].weight, f[0].bias, f[2].weight, f[2].bias)
+        occ, flow, cls = ext.occ_heads(x, p[0].weight, p[0].bias, p[2].weight, p[2].bias,
+                                       f[0].weight, f[0].bias, f[2].weight, f[2].bias, decode=True)
+        # the decoded classes ride on the logits tensor OBJECT (BEVFormerOccHead.get_occ picks them up): the
+        # reference's softmax(-1).argmax(-1) would re-read the 43 MB of logits in two more launches
+        occ._occ_cls = cls
+        return occ, flow
 
     def forward(self, mlvl_feats, bev_queries, object_query_embed, bev_h, bev_w,
                 grid_length=[0.512, 0.512], bev_pos=None, reg_branches=None, cls_branches=None,

@@ -104,6 +104,25 @@ def test_occ_heads_match_oracle(n_rows, ncls):
     assert d1 < 2e-5 and d2 < 2e-5
     d_typ = float((occ[1:].cpu().double() - occ_ref[1:]).abs().max()) if n_rows > 1 else 0.0
     assert d_typ < 5e-5
+    # fused decode: the class written by the same pass is exactly the reference's softmax(-1).argmax(-1)
+    # (bevformer_occ_head.py:210-212) of the logits the kernel wrote, and the logits are bit-identical with or
+    # without it
+    occ2, flow2, cls = ext.occ_heads(feat.cuda(), *[t.cuda() for t in ws], decode=True)
+    assert torch.equal(occ2, occ) and torch.equal(flow2, flow)
+    assert cls.dtype == torch.int64 and cls.shape == (n_rows,)
+    assert torch.equal(cls, occ.softmax(-1).argmax(-1))
+
+
+def test_fused_decode_ties_take_the_first_index():
+    """Equal logits: torch.argmax (and therefore the reference's decode) returns the first maximal index."""
+    from occnet_amd import ext
+    z = lambda *s: torch.zeros(*s)
+    feat = torch.randn(64, 32, generator=torch.Generator().manual_seed(2))
+    b2 = torch.tensor([0.5, 2.0, 2.0, -1.0, 2.0])                 # classes 1, 2, 4 tie for every voxel
+    occ, flow, cls = ext.occ_heads(feat.cuda(), z(64, 32).cuda(), z(64).cuda(), z(5, 64).cuda(), b2.cuda(),
+                                   z(64, 32).cuda(), z(64).cuda(), z(2, 64).cuda(), z(2).cuda(), decode=True)
+    assert torch.equal(cls.cpu(), torch.ones(64, dtype=torch.int64))
+    assert torch.equal(cls, occ.softmax(-1).argmax(-1))
 
 
 def test_unsupported_shapes_raise_unsupported():

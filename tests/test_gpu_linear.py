@@ -25,13 +25,21 @@ CASES = [
     ("two_seg_noadd",  33,   32,  64,  36,  False, None,  False,  True,     False),
     ("k16_chunks",     50,   48,  16,  64,  True,  None,  True,   False,    False),
     ("one_row",        1,    256, 0,   256, True,  None,  False,  True,     True),
+    # 160-row blocks of the round-2 kernel: exact multiple, ragged tail, rows 128..159 of a block, > 1 column block
+    ("m160",           160,  256, 0,   256, True,  None,  False,  True,     True),
+    ("m481_tail",      481,  256, 256, 192, True,  None,  True,   False,    False),
+    ("m130_n768",      130,  256, 0,   768, True,  'relu', False, False,    False),
+    ("k512_n260",      200,  512, 0,   260, True,  None,  False,  True,     False),
 ]
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3/x3"])
 @pytest.mark.parametrize("name,M,K1,K2,N,bias,act,addend,residual,ln", CASES, ids=[c[0] for c in CASES])
-def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, ln, precision):
+def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, ln, precision, monkeypatch):
     from occnet_amd import ext
+    # "bf16x3" = the default kernel (round 2: x3s; shapes with K % 32 != 0 fall to x3), "bf16x3/x3" = round-1 kernel
+    monkeypatch.setattr(ext, "LINEAR_KERNEL", "x3" if precision.endswith("/x3") else "x3s")
+    precision = precision.split("/")[0]
     g = torch.Generator().manual_seed(50)
     a = _mk(g, M, K1)
     a2 = _mk(g, M, K2) if K2 else None

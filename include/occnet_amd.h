@@ -256,6 +256,21 @@ int occ_linear_bf16x3s_f32(const float* a1, int64_t lda1, int K1, const float* a
                            float ln_eps, float* out, int64_t ldo, int M, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The encoder's feed-forward block + its LayerNorm as ONE kernel (csrc/ffn_fused.hip):
+ *     out = LayerNorm( x + W2 . relu(W1 . x + b1) + b2 )
+ * = mmcv FFN (Linear, ReLU, Linear, + identity) and the `norm` that follows it in the layer's operation_order
+ * (P/bevformer/modules/encoder.py:377-404; custom_base_transformer_layer.py:74-99).  bf16x3 arithmetic as
+ * occ_linear_bf16x3_f32; the 512-wide hidden activations never leave the registers.
+ *   w1 (hidden, C), w2 (C, hidden) f32 torch Linear layouts -> packed: 8*C*hidden bytes (both matrices, bf16 hi + lo, MFMA fragment
+ *   order, W2 with the k order the hidden registers come in).  Kernel exists for C = 256, hidden = 512.
+ *   x (M, C) f32 rows of stride ldx; ln_gamma / ln_beta both NULL = no LayerNorm; out (M, C) rows of stride ldo.
+ */
+int occ_ffn_pack_weights_bf16x3(const float* w1, const float* w2, void* packed, int C, int hidden, void* stream);
+int occ_ffn_fused_bf16x3_f32(const float* x, int64_t ldx, const void* packed, const float* b1, const float* b2,
+                             const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int64_t ldo,
+                             int M, int C, int hidden, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Ray casting through an occupancy grid (RayIoU metric) — replaces the reference's `dvr.render_forward`
  * (tools/ray_iou/lib/dvr/dvr.cpp:68-72 binding, dvr.cu:70-388), called at
  * projects/mmdet3d_plugin/datasets/ray_metrics.py:116-123.
@@ -308,6 +323,13 @@ int occ_value_proj_bf16_f16(int n_segments, const void* const* a, const int64_t*
  */
 int occ_stem_conv7x7_pool_f32_bf16(const float* x, const void* weight_frag, const float* bias, void* out,
                                    int batch, int H, int W, void* stream);
+/* The same stem fed with the RAW camera images: x (batch, Hs, Ws, 3) uint8 HWC; the pipeline's
+ * NormalizeMultiviewImage ((x[to_rgb ? 2-c : c] - mean[c]) / std[c], float32) and PadMultiViewImage (zeros to
+ * H x W) — reference P/datasets/pipelines/transform_3d.py:31-45,82-94 — run while the input tile is staged.
+ * mean, std: 3 HOST floats each (network channel order). */
+int occ_stem_conv7x7_pool_u8_bf16(const uint8_t* x, const void* weight_frag, const float* bias, void* out,
+                                  int batch, int Hs, int Ws, int H, int W, const float* mean,
+                                  const float* std, int to_rgb, void* stream);
 
 /* Stem tail in one pass: out = max_pool2d(relu(y + bias), kernel 3, stride 2, padding 1) on NHWC bf16
  * (outside the hand-written hot path).  y (batch, H, W, C) bf16 raw convolution output ; bias (C) f32 ;

@@ -309,13 +309,17 @@ __global__ __launch_bounds__(256, 4) void sca_head_h_kernel(
                                live, sp);
       *reinterpret_cast<SampleParamB*>(par + qi * GRP_B + li * 32) = sp;
       wave_lds_sync();
-      occ_u32x4 v[4][4];
+      // (bit_cast, not an assignment: the builtin returns a GCC vector, and hipcc converts that to an ext_vector
+      // by splatting element 0 — the loads shrink to one dword each, silently)
+      typedef _Float16 occ_h8 __attribute__((ext_vector_type(8)));
+      occ_h8 v[4][4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const occ_u32x4 o4 = *reinterpret_cast<const occ_u32x4*>(gp + u * 32 + 16);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          v[u][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o4[k] + (unsigned)c8 * 16u), 0, 0);
+          v[u][k] = __builtin_bit_cast(
+              occ_h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o4[k] + (unsigned)c8 * 16u), 0, 0));
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -324,11 +328,7 @@ __global__ __launch_bounds__(256, 4) void sca_head_h_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const __half2 h2 = __builtin_bit_cast(__half2, v[u][k][e]);
-            acc[2 * e] = fmaf(ww[k], __low2float(h2), acc[2 * e]);
-            acc[2 * e + 1] = fmaf(ww[k], __high2float(h2), acc[2 * e + 1]);
-          }
+          for (int e = 0; e < 8; ++e) acc[e] = fmaf(ww[k], (float)v[u][k][e], acc[e]);
       }
       wave_lds_sync();
     }

@@ -31,9 +31,17 @@ constexpr int kStNC = kStC * kStC;             // 289 conv pixels
 constexpr int kStMS = 144;                     // conv pixel slot: 64 bf16 + 16 B pad
 constexpr int kStConv = 320 * kStMS;           // 10 row tiles of 32 slots
 
+// U8 (the input side of the path): x is the RAW camera image, uint8 HWC (N, Hs, Ws, 3), and the
+// pipeline's NormalizeMultiviewImage ((x[to_rgb ? 2 - c : c] - mean[c]) / std[c], float32) and PadMultiViewImage
+// (zeros to H x W = the next multiple of 32; reference P/datasets/pipelines/transform_3d.py:31-45,82-94) happen
+// while the tile is staged: the 107 MB fp32 tensor of the six images is never built, 26 MB of uint8 cross PCIe
+struct StemNorm { float mean[3], std[3]; int Hs, Ws, to_rgb; };
+
+template <bool U8>
 __global__ __launch_bounds__(256, 2) void stem_conv7x7_pool_kernel(
-    const float* __restrict__ x, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
-    uint4* __restrict__ out, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_x, int tiles_y) {
+    const void* __restrict__ x_, const uint4* __restrict__ wfrag, const float* __restrict__ bias,
+    uint4* __restrict__ out, int H, int W, int Hc, int Wc, int Hp, int Wp, int tiles_x, int tiles_y,
+    StemNorm nrm) {
   __shared__ __attribute__((aligned(16))) char lds[kStIn + kStConv];
   char* const sIn = lds;
   char* const sCv = lds + kStIn;
@@ -59,7 +67,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_pool_kernel(
   // ---- stage the input tile: 4 x 39 x 40 bf16 items (channel-major for coalesced plane reads) ---------
   {
     const long plane = (long)H * W;
-    const float* xi = x + (long)img * 3 * plane;
+    const float* xi = reinterpret_cast<const float*>(x_) + (long)img * 3 * plane;
+    const unsigned char* xu = reinterpret_cast<const unsigned char*>(x_) + (long)img * nrm.Hs * nrm.Ws * 3;
     constexpr int ITEMS = 4 * kStI * kStIW;                    // 6 240
     constexpr int NJ = (ITEMS + 255) / 256;                    // 25 per thread
     // all loads first (unconditional, clamped), then the conversions and LDS stores: a load inside the
@@ -71,7 +80,15 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_pool_kernel(
       const int c = idx / (kStI * kStIW), r = idx % (kStI * kStIW);
       const int ly = r / kStIW, lx = r % kStIW;
       const int cc = c < 3 ? c : 0, cy = min(max(iy0 + ly, 0), H - 1), cx = min(max(ix0 + lx, 0), W - 1);
-      v[j] = xi[cc * plane + (long)cy * W + cx];
+      if (U8) {
+        const int sy = min(cy, nrm.Hs - 1), sx = min(cx, nrm.Ws - 1), sc = nrm.to_rgb ? 2 - cc : cc;
+        const float raw = (float)xu[((long)sy * nrm.Ws + sx) * 3 + sc];
+        const float mu = cc == 0 ? nrm.mean[0] : (cc == 1 ? nrm.mean[1] : nrm.mean[2]);
+        const float sd = cc == 0 ? nrm.std[0] : (cc == 1 ? nrm.std[1] : nrm.std[2]);
+        v[j] = (cy < nrm.Hs && cx < nrm.Ws) ? (raw - mu) / sd : 0.f;       // bottom / right pad: normalised zeros
+      } else {
+        v[j] = xi[cc * plane + (long)cy * W + cx];
+      }
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -172,9 +189,32 @@ extern "C" int occ_stem_conv7x7_pool_f32_bf16(const float* x, const void* weight
   const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1;        // floor((H + 6 - 7) / 2) + 1
   const int Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;      // floor((Hc + 2 - 3) / 2) + 1
   const int tiles_x = (Wp + kStP - 1) / kStP, tiles_y = (Hp + kStP - 1) / kStP;
-  hipLaunchKernelGGL(stem_conv7x7_pool_kernel, dim3((unsigned)((long)batch * tiles_x * tiles_y)), dim3(256), 0,
+  hipLaunchKernelGGL(stem_conv7x7_pool_kernel<false>, dim3((unsigned)((long)batch * tiles_x * tiles_y)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<const uint4*>(weight_frag), bias,
-                     reinterpret_cast<uint4*>(out), H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y);
+                     reinterpret_cast<uint4*>(out), H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y, StemNorm{});
   OCC_CHECK_LAUNCH("stem_conv7x7_pool");
+  return OCC_OK;
+}
+
+// Raw camera images in: x (batch, Hs, Ws, 3) uint8 HWC; the stem sees (x[to_rgb ? 2-c : c] - mean[c]) / std[c]
+// zero-padded bottom/right to H x W (H >= Hs, W >= Ws) — NormalizeMultiviewImage + PadMultiViewImage fused into
+// the tile staging.  mean / std: 3 host floats each, in the network's channel order.
+extern "C" int occ_stem_conv7x7_pool_u8_bf16(const uint8_t* x, const void* weight_frag, const float* bias,
+                                             void* out, int batch, int Hs, int Ws, int H, int W,
+                                             const float* mean, const float* std, int to_rgb, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(x && weight_frag && bias && out && mean && std, "stem_conv7x7_pool_u8: null pointer argument");
+  OCC_CHECK_ARG(batch > 0 && Hs > 0 && Ws > 0 && H >= Hs && W >= Ws, "stem_conv7x7_pool_u8: bad dimension");
+  OCC_CHECK_ARG(std[0] != 0.f && std[1] != 0.f && std[2] != 0.f, "stem_conv7x7_pool_u8: zero std");
+  const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1;
+  const int Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
+  const int tiles_x = (Wp + kStP - 1) / kStP, tiles_y = (Hp + kStP - 1) / kStP;
+  StemNorm nrm;
+  for (int c = 0; c < 3; ++c) { nrm.mean[c] = mean[c]; nrm.std[c] = std[c]; }
+  nrm.Hs = Hs; nrm.Ws = Ws; nrm.to_rgb = to_rgb ? 1 : 0;
+  hipLaunchKernelGGL(stem_conv7x7_pool_kernel<true>, dim3((unsigned)((long)batch * tiles_x * tiles_y)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<const uint4*>(weight_frag), bias,
+                     reinterpret_cast<uint4*>(out), H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y, nrm);
+  OCC_CHECK_LAUNCH("stem_conv7x7_pool_u8");
   return OCC_OK;
 }

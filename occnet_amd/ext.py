@@ -395,8 +395,13 @@ def _rows2d(name, t, k=None):
 # chain), 'bf16x3' = three bf16 MFMAs on hi/lo-split operands with f32 accumulation (relative error of a
 # product <= 2^-16; 2-3x faster).  The default can be overridden with OCC_LINEAR_PRECISION.
 LINEAR_PRECISION = os.environ.get("OCC_LINEAR_PRECISION", "bf16x3")
-# bf16x3 kernel: 'x3s' (round 2: 160-row blocks, LDS-shared weights; default) or 'x3' (round 1: 64-row blocks)
-LINEAR_KERNEL = os.environ.get("OCC_LINEAR_KERNEL", "x3s")
+# bf16x3 kernel: 'x3' (64-row blocks, weights global -> registers; default) or 'x3s' (round-2 experiment: 160-row
+# blocks, 32-k chunks, weights staged once per block in LDS — measured 0-25 % SLOWER on the encoder's shapes, both
+# kernels sit at ~3 TB/s of activation traffic: profiles/r02_linear_probe.txt)
+LINEAR_KERNEL = os.environ.get("OCC_LINEAR_KERNEL", "x3")
+# the encoder's FFN + LayerNorm as one kernel (csrc/ffn_fused.hip), OCC_FFN_FUSED=1; default: two Linear launches
+# (default off: measured 137 us against 111 us for the two launches on 40 000 rows — profiles/r02_linear_probe.txt)
+FFN_FUSED = os.environ.get("OCC_FFN_FUSED", "0") == "1"
 _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight (small LRU)
 
 
@@ -540,6 +545,53 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
     return out
 
 
+_PACKED_FFN = {}        # (w1 ptr/version, w2 ptr/version, epoch) -> packed stream
+
+
+def ffn_fused(x, w1, b1, w2, b2, ln=None):
+    """LayerNorm(x + relu(x @ w1^T + b1) @ w2^T + b2) in ONE launch (csrc/ffn_fused.hip; hidden activations stay
+    in registers).  x (..., 256) fp32 with uniformly strided rows; w1 (512, 256), w2 (256, 512) Linear weights;
+    ln = (gamma, beta, eps) | nn.LayerNorm | None.  Raises OccAmdUnsupported for other sizes."""
+    x_, M, C, ldx = _rows2d("x", x)
+    for n, t in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2)):
+        _need_cuda_f32(n, t)
+    hidden = w1.shape[0]
+    if tuple(w1.shape) != (hidden, C) or tuple(w2.shape) != (C, hidden) or b1.numel() != hidden or b2.numel() != C:
+        raise OccAmdError("ffn_fused: inconsistent weight shapes")
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        if isinstance(ln, torch.nn.LayerNorm):
+            if tuple(ln.normalized_shape) != (C,) or ln.weight is None or ln.bias is None:
+                raise OccAmdUnsupported("ffn_fused: LayerNorm must be affine over the C features")
+            g, b, eps = ln.weight, ln.bias, ln.eps
+        else:
+            g, b, eps = ln
+        _need_cuda_f32("ln_gamma", g)
+        _need_cuda_f32("ln_beta", b)
+    key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version, str(w1.device), cache_epoch())
+    hit = _PACKED_FFN.get(key)
+    if hit is None:
+        packed = torch.empty(8 * C * hidden, dtype=torch.uint8, device=w1.device)   # two matrices x (hi + lo) bf16
+        with torch.cuda.device(w1.device):
+            rc = _lib.lib().occ_ffn_pack_weights_bf16x3(ptr(w1.contiguous()), ptr(w2.contiguous()), ptr(packed),
+                                                        i32(C), i32(hidden), stream_ptr(w1.device))
+        _lib.check(rc, "ffn_pack_weights")
+        if len(_PACKED_FFN) >= 64:
+            _PACKED_FFN.pop(next(iter(_PACKED_FFN)))
+        hit = (packed, w1, w2)              # the weights stay referenced: their addresses cannot be recycled
+        _PACKED_FFN[key] = hit
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if _TIMING is not None and (_TIMING_ONLY is None or 'linear' in _TIMING_ONLY):
+        _TIMING.setdefault('linear_flops', []).append(4.0 * M * C * hidden)
+    with torch.cuda.device(x.device), _timed('linear'):
+        rc = _lib.lib().occ_ffn_fused_bf16x3_f32(ptr(x_), i64(ldx), ptr(hit[0]), ptr(b1), ptr(b2), ptr(g), ptr(b),
+                                                 f32(float(eps)), ptr(out), i64(C), i32(M), i32(C), i32(hidden),
+                                                 stream_ptr(x.device))
+    _lib.check(rc, "ffn_fused")
+    return out
+
+
 def dvr_render_forward(sigma, origin, points, tindex, grid=None, phase_name="test"):
     """Same call shape as the reference's `dvr.render_forward(sigma, origin, points, tindex, grid,
     phase_name)` (tools/ray_iou/lib/dvr/dvr.cpp:68-72; used at ray_metrics.py:116-123):
@@ -622,6 +674,33 @@ def stem_conv7x7_pool(x, weight_frag, bias):
                                                        i32(H), i32(W), stream_ptr(x.device))
     _lib.check(rc, "stem_conv7x7_pool")
     return out
+
+
+def stem_conv7x7_pool_u8(x_u8, weight_frag, bias, mean, std, to_rgb=False, size_divisor=32):
+    """The stem fed with RAW camera images: x_u8 (N, Hs, Ws, 3) uint8 HWC on the device.  NormalizeMultiviewImage
+    ((x[to_rgb ? 2-c : c] - mean[c]) / std[c]) and PadMultiViewImage (zeros to the next multiple of `size_divisor`;
+    reference transform_3d.py:31-45,82-94) are applied while the input tile is staged.
+    -> (N, 64, Hp, Wp) channels_last bf16, and the padded (H, W)."""
+    if not (x_u8.is_cuda and x_u8.dtype == torch.uint8 and x_u8.dim() == 4 and x_u8.shape[-1] == 3
+            and x_u8.is_contiguous()):
+        raise OccAmdUnsupported("stem_conv7x7_pool_u8: x must be a contiguous (N, H, W, 3) uint8 device tensor")
+    _need_cuda_f32("bias", bias)
+    if weight_frag.numel() != 64 * 224 or bias.numel() != 64:
+        raise OccAmdError("stem_conv7x7_pool_u8: inconsistent shapes")
+    N, Hs, Ws, _ = x_u8.shape
+    d = int(size_divisor)
+    H, W = (Hs + d - 1) // d * d, (Ws + d - 1) // d * d
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    out = torch.empty((N, 64, Hp, Wp), dtype=torch.bfloat16, device=x_u8.device, memory_format=torch.channels_last)
+    mean_c = (f32 * 3)(*[float(v) for v in mean])
+    std_c = (f32 * 3)(*[float(v) for v in std])
+    with torch.cuda.device(x_u8.device):
+        rc = _lib.lib().occ_stem_conv7x7_pool_u8_bf16(ptr(x_u8), ptr(weight_frag), ptr(bias), ptr(out), i32(N),
+                                                      i32(Hs), i32(Ws), i32(H), i32(W), mean_c, std_c,
+                                                      i32(1 if to_rgb else 0), stream_ptr(x_u8.device))
+    _lib.check(rc, "stem_conv7x7_pool_u8")
+    return out, (H, W)
 
 
 def bias_relu_maxpool_nhwc(y, bias):

@@ -343,6 +343,17 @@ class FusedInferenceBackbone(nn.Module):
         st['graph'].replay()
         return st['out']
 
+    def forward_u8(self, x_u8, mean, std, to_rgb=False, size_divisor=32):
+        """Raw camera images in: x_u8 (N, Hs, Ws, 3) uint8 HWC on the device; normalise + pad happen inside the stem
+        kernel (ext.stem_conv7x7_pool_u8).  -> (FPN maps, padded (H, W)).  Needs the fused HIP stem."""
+        from .. import ext
+        from .._lib import OccAmdUnsupported
+        if not getattr(self, '_stem_fused', False):
+            raise OccAmdUnsupported("forward_u8 needs the fused stem kernel (bf16 plan, 7x7/s2 stem + 3x3/s2 pool)")
+        x, hw = ext.stem_conv7x7_pool_u8(x_u8, self.stem_frag, getattr(self, f'b{self.stem}'), mean, std,
+                                         to_rgb=to_rgb, size_divisor=size_divisor)
+        return self._forward_stages(x), hw
+
     def _forward_eager(self, x):
         sw = getattr(self, f'w{self.stem}')
         if getattr(self, '_stem_fused', False) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous():

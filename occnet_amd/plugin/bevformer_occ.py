@@ -118,6 +118,35 @@ class BEVFormerOcc(BaseModule):
     def extract_feat(self, img, img_metas=None, len_queue=None):
         return self.extract_img_feat(img, img_metas, len_queue=len_queue)
 
+    def extract_feat_u8(self, img_u8, img_norm_cfg, size_divisor=32):
+        """Device-side input path: img_u8 (B, N, Hs, Ws, 3) uint8 HWC raw camera images on
+        the device.  NormalizeMultiviewImage(**img_norm_cfg) + PadMultiViewImage(size_divisor) + the layout
+        change of DefaultFormatBundle3D (reference transform_3d.py:31-45,82-94) run inside the stem kernel of
+        the inference plan, or as torch device ops without it.  -> (list of (B, N, C, h, w) maps, padded (H, W))."""
+        B, N, Hs, Ws, _ = img_u8.shape
+        mean, std = img_norm_cfg['mean'], img_norm_cfg['std']
+        to_rgb = bool(img_norm_cfg.get('to_rgb', True))
+        plan = getattr(self, '_inference_backbone', None)
+        if plan is not None and not self.training and getattr(plan, '_stem_fused', False):
+            if plan.built_epoch != cache_epoch():
+                self.enable_fused_backbone(**self._inference_backbone_args)
+                plan = self._inference_backbone
+            feats, hw = plan.forward_u8(img_u8.reshape(B * N, Hs, Ws, 3), mean, std, to_rgb, size_divisor)
+        else:
+            x = img_u8.reshape(B * N, Hs, Ws, 3).float()
+            if to_rgb:
+                x = x.flip(-1)
+            x = (x - x.new_tensor(mean)) / x.new_tensor(std)
+            d = int(size_divisor)
+            H, W = (Hs + d - 1) // d * d, (Ws + d - 1) // d * d
+            x = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (0, W - Ws, 0, H - Hs))
+            return self.extract_img_feat(x.reshape(B, N, 3, H, W).contiguous()), (H, W)
+        out = []
+        for f in feats:
+            BN, C, H, W = f.size()
+            out.append(f.view(B, N, C, H, W))
+        return out, hw
+
     def load_checkpoint(self, path_or_state, strict=False, map_location='cpu'):
         """Load an mmcv-format checkpoint ({'state_dict': ..., 'meta': ...}, what the reference's
         `load_checkpoint(model, ckpt, map_location='cpu')` reads, tools/test.py:213) or a bare state_dict; a

@@ -128,8 +128,13 @@ class FFN(BaseModule):
         if not (self.num_fcs == 2 and self.add_identity and isinstance(self.layers[0][1], nn.ReLU)
                 and isinstance(self.dropout_layer, nn.Identity)):
             return None
+        fc1, fc2 = self.layers[0][0], self.layers[1]
+        if identity is None and ext.LINEAR_PRECISION == "bf16x3" and ext.FFN_FUSED:
+            try:    # one launch, hidden activations in registers (embed 256 / hidden 512; else the two-launch form)
+                return ext.ffn_fused(x.contiguous(), fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln=post_norm)
+            except OccAmdUnsupported:
+                pass
         try:
-            fc1, fc2 = self.layers[0][0], self.layers[1]
             h = ext.linear(x.contiguous(), fc1.weight, fc1.bias, act='relu')
             return ext.linear(h, fc2.weight, fc2.bias,
                               residual=(x if identity is None else identity).contiguous(), ln=post_norm)

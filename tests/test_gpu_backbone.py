@@ -228,3 +228,63 @@ def test_folded_plan_matches_fp32_modules():
                 rel = float((a - b.float()).abs().max() / a.abs().max())
                 print(f"hip_tail={hip_tail} level {tuple(a.shape)}: max rel diff {rel:.3e}")
                 assert rel < 0.06       # bf16 through 53 convolutions
+
+
+@pytest.mark.parametrize("N,Hs,Ws,to_rgb,std", [(2, 37, 50, False, (1.0, 1.0, 1.0)),
+                                                (1, 64, 96, True, (58.395, 57.12, 57.375)),
+                                                (3, 900 // 10, 1600 // 10, False, (1.0, 1.0, 1.0))])
+def test_stem_u8_input_equals_normalise_pad_then_stem(N, Hs, Ws, to_rgb, std):
+    """SURVEY.md §8f N4, device side: the stem fed with raw uint8 HWC camera images (NormalizeMultiviewImage +
+    PadMultiViewImage fused into the tile staging; reference transform_3d.py:31-45,82-94) is BIT-IDENTICAL to the
+    stem run on the float tensor the host pipeline (occnet_amd/io.py = the pipeline's numpy restatement) builds."""
+    import numpy as np
+    from occnet_amd import ext, io
+    rng = np.random.default_rng(N * 1000 + Hs)
+    raw = [rng.integers(0, 256, (Hs, Ws, 3), dtype=np.uint8) for _ in range(N)]
+    mean = (103.530, 116.280, 123.675)
+    normed, _ = io.normalize_multiview(raw, mean, std, to_rgb=to_rgb)
+    padded, meta = io.pad_multiview(normed, size_divisor=32)
+    x = io.to_batch(padded)[0].cuda().contiguous()                      # (N, 3, H, W) fp32
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.05).cuda()
+    b = torch.randn(64, generator=g).cuda()
+    frag = ext.stem_pack_weight(w)
+    want = ext.stem_conv7x7_pool(x, frag, b)
+    got, hw = ext.stem_conv7x7_pool_u8(torch.from_numpy(np.stack(raw)).cuda(), frag, b, mean, std, to_rgb=to_rgb)
+    assert hw == tuple(x.shape[2:]) and got.shape == want.shape
+    assert torch.equal(got, want)
+
+
+def test_detector_u8_path_equals_float_path():
+    """BEVFormerOcc.extract_feat_u8 (raw images -> FPN maps on the inference plan) == extract_feat on the
+    host-normalised / padded float tensor."""
+    import numpy as np
+    import os
+    from occnet_amd import io
+    from occnet_amd.plugin import Config, build_model, import_plugin
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs', 'occ_base_200x200x16.py'))
+    import_plugin(cfg)
+    torch.manual_seed(0)
+    model = build_model(cfg.model)
+    model.init_weights()
+    model = model.cuda().eval()
+    model.enable_fused_backbone(dtype=torch.bfloat16)
+    rng = np.random.default_rng(5)
+    raw = [rng.integers(0, 256, (90, 160, 3), dtype=np.uint8) for _ in range(6)]
+    ncfg = dict(mean=[103.530, 116.280, 123.675], std=[1.0, 1.0, 1.0], to_rgb=False)
+    normed, _ = io.normalize_multiview(raw, **ncfg)
+    padded, _ = io.pad_multiview(normed, size_divisor=32)
+    with torch.no_grad():
+        want = model.extract_feat(img=io.to_batch(padded).cuda())
+        got, hw = model.extract_feat_u8(torch.from_numpy(np.stack(raw))[None].cuda(), ncfg)
+    assert hw == (96, 160)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # without the plan: torch device ops for normalise / pad, stock modules -> same maps up to bf16-vs-fp32 backbone
+    model.enable_fused_backbone(dtype=None)
+    with torch.no_grad():
+        ref = model.extract_feat(img=io.to_batch(padded).cuda())
+        alt, _ = model.extract_feat_u8(torch.from_numpy(np.stack(raw))[None].cuda(), ncfg)
+    for a, b in zip(alt, ref):       # same fp32 modules; MIOpen may pick another algorithm for the other memory layout
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())

@@ -33,12 +33,12 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3/x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3/x3s"])
 @pytest.mark.parametrize("name,M,K1,K2,N,bias,act,addend,residual,ln", CASES, ids=[c[0] for c in CASES])
 def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, ln, precision, monkeypatch):
     from occnet_amd import ext
-    # "bf16x3" = the default kernel (round 2: x3s; shapes with K % 32 != 0 fall to x3), "bf16x3/x3" = round-1 kernel
-    monkeypatch.setattr(ext, "LINEAR_KERNEL", "x3" if precision.endswith("/x3") else "x3s")
+    # "bf16x3" = the default kernel (x3), "bf16x3/x3s" = the LDS-shared-weights variant (K % 32 != 0 falls to x3)
+    monkeypatch.setattr(ext, "LINEAR_KERNEL", "x3s" if precision.endswith("/x3s") else "x3")
     precision = precision.split("/")[0]
     g = torch.Generator().manual_seed(50)
     a = _mk(g, M, K1)
@@ -175,3 +175,43 @@ def test_value_proj_bf16_multi_segment_single_launch():
         d = float((o[:, starts[l]:starts[l] + hw] - ref).abs().max())
         print(f"level {l} ({hw} px): max diff {d:.3e}")
         assert d < 3e-5
+
+
+@pytest.mark.parametrize("M,ln", [(1, True), (31, True), (128, True), (129, False), (1000, True), (4099, True)])
+def test_ffn_fused_matches_oracle(M, ln):
+    """csrc/ffn_fused.hip: LayerNorm(x + W2 relu(W1 x + b1) + b2) in one launch vs the float64 oracle chain
+    (mmcv FFN + nn.LayerNorm; reference encoder.py:377-404), ragged row counts."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(70 + M)
+    x = _mk(g, M, 256)
+    w1, b1 = _mk(g, 512, 256, scale=1 / 16), _mk(g, 512, scale=0.1)
+    w2, b2 = _mk(g, 256, 512, scale=(1 / 512) ** 0.5), _mk(g, 256, scale=0.1)
+    lnp = (torch.rand(256, generator=g) + 0.5, _mk(g, 256, scale=0.1), 1e-5) if ln else None
+    h = odense.linear_chain(x.double(), w1.double(), b1.double(), act='relu')
+    ref = odense.linear_chain(h, w2.double(), b2.double(), residual=x.double(),
+                              ln=None if lnp is None else (lnp[0].double(), lnp[1].double(), lnp[2]))
+    out = ext.ffn_fused(x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(),
+                        ln=None if lnp is None else (lnp[0].cuda(), lnp[1].cuda(), lnp[2]))
+    torch.cuda.synchronize()
+    d = float((out.cpu().double() - ref).abs().max())
+    print(f"ffn_fused M={M} ln={ln}: max|hip - oracle(f64)| = {d:.3e}")
+    assert out.shape == (M, 256) and d < 2e-4
+    # and against the two-launch form it replaces (same arithmetic, different summation order)
+    two = ext.linear(ext.linear(x.cuda(), w1.cuda(), b1.cuda(), act='relu'), w2.cuda(), b2.cuda(),
+                     residual=x.cuda(), ln=None if lnp is None else (lnp[0].cuda(), lnp[1].cuda(), lnp[2]))
+    assert float((out - two).abs().max()) < 1e-4
+
+
+def test_ffn_fused_asymmetric_weights_catch_layout_mistakes():
+    """Structured weights: W1 picks input feature (u mod 256) for hidden unit u, W2 sums hidden units with
+    distinct power-of-two-ish weights — any mistake in the fragment / permuted-k layout changes the result."""
+    from occnet_amd import ext
+    M = 64
+    x = (torch.arange(M * 256, dtype=torch.float32).reshape(M, 256) % 97) / 32.0 + 0.25       # positive: ReLU passes
+    w1 = torch.zeros(512, 256)
+    w1[torch.arange(512), (torch.arange(512) * 7) % 256] = 1.0
+    w2 = ((torch.arange(256 * 512, dtype=torch.float32).reshape(256, 512) % 13) - 6.0) / 8.0
+    b1, b2 = torch.zeros(512), torch.zeros(256)
+    ref = x.double() + torch.relu(x.double() @ w1.double().T) @ w2.double().T
+    out = ext.ffn_fused(x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())

@@ -43,3 +43,26 @@ for name, K1, K2, N, act, resln in SHAPES:
         line += f"  {kern}: {ms[len(ms) // 2] * 1e3:7.1f} us ({fl / ms[len(ms) // 2] / 1e9:6.1f} TF f32-eq)"
     line += f"  maxdiff {float((outs['x3'] - outs['x3s']).abs().max()):.2e}"
     print(line, flush=True)
+
+# fused FFN vs the two launches it replaces
+w1 = (torch.randn(512, 256, generator=g) / 16).to(dev); b1 = torch.randn(512, generator=g).to(dev)
+w2 = (torch.randn(256, 512, generator=g) / 22).to(dev); b2 = torch.randn(256, generator=g).to(dev)
+xx = torch.randn(M, 256, generator=g).to(dev)
+ln = (torch.ones(256, device=dev), torch.zeros(256, device=dev), 1e-5)
+ext.LINEAR_KERNEL = "x3"
+def two():
+    return ext.linear(ext.linear(xx, w1, b1, act='relu'), w2, b2, residual=xx, ln=ln)
+def one():
+    return ext.ffn_fused(xx, w1, b1, w2, b2, ln=ln)
+for name, fn in (("ffn two launches", two), ("ffn fused", one)):
+    for _ in range(5):
+        o = fn()
+    evs = []
+    for _ in range(30):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); o = fn(); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    print(f"{name:30s} {ms[len(ms) // 2] * 1e3:7.1f} us", flush=True)
+print("maxdiff fused vs two:", float((one() - two()).abs().max()))

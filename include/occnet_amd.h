@@ -207,12 +207,14 @@ int occ_occ_heads_f32(const float* feat, const float* w1_occ, const float* b1_oc
                       int num_classes, void* stream);
 /* same + the decoded class per voxel, occ_cls[row] = argmax_c occ[row, c] (first index on ties) as int64 — the
  * reference's get_occ, P/bevformer/dense_heads/bevformer_occ_head.py:210-212 (softmax(-1).argmax(-1); softmax is
- * monotonic) — written by the same pass; occ_cls_out may be NULL. */
+ * monotonic) — written by the same pass; occ_cls_out may be NULL.  exact_f32 != 0: the f32 matrix instruction
+ * (occ_occ_heads_f32's kernel); 0: bf16x3 arithmetic (hi/lo-split operands on the bf16 MFMA, f32 accumulation,
+ * product error <= 2^-16) — 5x less matrix-pipe time. */
 int occ_occ_heads_decode_f32(const float* feat, const float* w1_occ, const float* b1_occ, const float* w2_occ,
                              const float* b2_occ, const float* w1_flow, const float* b1_flow,
                              const float* w2_flow, const float* b2_flow, float* occ_out, float* flow_out,
                              int64_t* occ_cls_out, int64_t n_rows, int C, int hidden, int num_classes,
-                             void* stream);
+                             int exact_f32, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * nn.Linear on the f32 matrix cores (exact f32) with the encoder's elementwise tail fused:

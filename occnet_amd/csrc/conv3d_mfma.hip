@@ -341,14 +341,20 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(
       const int toff = (ky * HX + kx) * PSB + kz * VSB;
       const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[(t * 2 + 0) * 64]);
       const bf16x8 wl = __builtin_bit_cast(bf16x8, wq[(t * 2 + 1) * 64]);
+      // term-major over the NACC accumulators: three MFMAs on ONE accumulator back to back wait out the 64-cycle
+      // result latency (issue: 32 cycles)
+      bf16x8 ah[NACC], al[NACC];
 #pragma unroll
       for (int a = 0; a < NACC; ++a) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff + 32);
-        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[a], 0, 0, 0);
-        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[a], 0, 0, 0);
-        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[a], 0, 0, 0);
+        ah[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff);
+        al[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff + 32);
       }
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], wh, acc[a], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], wl, acc[a], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], wh, acc[a], 0, 0, 0);
     }
   }
 

@@ -149,15 +149,19 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
       ah[rt] = *reinterpret_cast<const bf16x8*>(sAh + (rt * 32 + vi) * kXLD + kb * 16);           \
       al[rt] = *reinterpret_cast<const bf16x8*>(sAl + (rt * 32 + vi) * kXLD + kb * 16);           \
     }                                                                                             \
+    /* term-major order (small terms first): back-to-back MFMAs on ONE accumulator wait out the 64-cycle result  \
+       latency (issue: 32); walking the RT*NT tiles per term keeps the pipe fed */                               \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
       acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], __builtin_bit_cast(bf16x8, wh0_##SW), acc[rt][0], 0, 0, 0); \
+      if (NT > 1) acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], __builtin_bit_cast(bf16x8, wh1_##SW), acc[rt][NT - 1], 0, 0, 0); \
+    }                                                                                             \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
       acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wl0_##SW), acc[rt][0], 0, 0, 0); \
+      if (NT > 1) acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wl1_##SW), acc[rt][NT - 1], 0, 0, 0); \
+    }                                                                                             \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
       acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wh0_##SW), acc[rt][0], 0, 0, 0); \
-      if (NT > 1) {                                                                               \
-        acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], __builtin_bit_cast(bf16x8, wh1_##SW), acc[rt][NT - 1], 0, 0, 0); \
-        acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wl1_##SW), acc[rt][NT - 1], 0, 0, 0); \
-        acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wh1_##SW), acc[rt][NT - 1], 0, 0, 0); \
-      }                                                                                           \
+      if (NT > 1) acc[rt][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], __builtin_bit_cast(bf16x8, wh1_##SW), acc[rt][NT - 1], 0, 0, 0); \
     }                                                                                             \
   }
 

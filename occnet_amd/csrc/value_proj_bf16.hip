@@ -119,14 +119,16 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                             \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
         af[rt][ks] = *reinterpret_cast<const bf16x8*>(sA + (rt * 32 + vi) * kLD + ks * 32 + kb * 16); \
+    /* term-major order: two MFMAs on ONE accumulator back to back wait out the 64-cycle result latency (issue  \
+       is 32 cycles); walking all tiles per term puts RT*NT instructions between them */                         \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
-      OCC_VP_MFMA(rt, 0, af[rt][0], la0_##SW) OCC_VP_MFMA(rt, 0, af[rt][0], ha0_##SW)             \
-      if (NT > 1) { OCC_VP_MFMA(rt, NT - 1, af[rt][0], la1_##SW) OCC_VP_MFMA(rt, NT - 1, af[rt][0], ha1_##SW) } \
-    }                                                                                             \
+      OCC_VP_MFMA(rt, 0, af[rt][0], la0_##SW) if (NT > 1) { OCC_VP_MFMA(rt, NT - 1, af[rt][0], la1_##SW) } }   \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
-      OCC_VP_MFMA(rt, 0, af[rt][1], lb0_##SW) OCC_VP_MFMA(rt, 0, af[rt][1], hb0_##SW)             \
-      if (NT > 1) { OCC_VP_MFMA(rt, NT - 1, af[rt][1], lb1_##SW) OCC_VP_MFMA(rt, NT - 1, af[rt][1], hb1_##SW) } \
-    }                                                                                             \
+      OCC_VP_MFMA(rt, 0, af[rt][0], ha0_##SW) if (NT > 1) { OCC_VP_MFMA(rt, NT - 1, af[rt][0], ha1_##SW) } }   \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
+      OCC_VP_MFMA(rt, 0, af[rt][1], lb0_##SW) if (NT > 1) { OCC_VP_MFMA(rt, NT - 1, af[rt][1], lb1_##SW) } }   \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                           \
+      OCC_VP_MFMA(rt, 0, af[rt][1], hb0_##SW) if (NT > 1) { OCC_VP_MFMA(rt, NT - 1, af[rt][1], hb1_##SW) } }   \
   }
   const int NCHK = K / KC;
   const int rot = (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)NCHK);

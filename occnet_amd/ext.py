@@ -345,7 +345,11 @@ def conv3d_bn_relu(x, w_packed, scale, shift, Z, Y, X, cin, cout, in_layout, out
     return out
 
 
-def occ_heads(feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow, decode=False):
+HEADS_PRECISION = os.environ.get("OCC_HEADS_PRECISION", "bf16x3")    # 'bf16x3' (default) or 'f32'
+
+
+def occ_heads(feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow, decode=False,
+              precision=None):
     """feat (..., C) -> occ (..., num_classes), flow (..., 2): both decoder MLP heads in one kernel.  With `decode`
     the same pass also writes argmax_c occ (int64, first index on ties): -> (occ, flow, occ_cls)."""
     ts = (feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow)
@@ -367,7 +371,7 @@ def occ_heads(feat, w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b
         rc = _lib.lib().occ_occ_heads_decode_f32(
             ptr(feat), ptr(w1_occ), ptr(b1_occ), ptr(w2_occ), ptr(b2_occ), ptr(w1_flow), ptr(b1_flow),
             ptr(w2_flow), ptr(b2_flow), ptr(occ), ptr(flow), ptr(cls), i64(n_rows), i32(C), i32(hidden),
-            i32(ncls), stream_ptr(feat.device))
+            i32(ncls), i32(1 if (precision or HEADS_PRECISION) == "f32" else 0), stream_ptr(feat.device))
     _lib.check(rc, "occ_heads")
     return (occ, flow, cls) if decode else (occ, flow)
 

@@ -242,8 +242,17 @@ class SpatialCrossAttention(BaseModule):
         bs, num_query, _ = query.size()
         D = reference_points_cam.size(3)
         slots = torch.zeros_like(query)
-        # visible-query lists come from batch element 0's mask (reference :138-140)
-        indexes = [m[0].sum(-1).nonzero().squeeze(-1) for m in bev_mask]
+        # visible-query lists come from batch element 0's mask (reference :138-140).  nonzero() is a host sync: the
+        # lists are built once per mask TENSOR (the encoder hands the same bev_mask to every layer) instead of once
+        # per layer and camera
+        cached = getattr(bev_mask, '_occ_indexes', None)
+        if cached is None:
+            cached = [m[0].sum(-1).nonzero().squeeze(-1) for m in bev_mask]
+            try:
+                bev_mask._occ_indexes = cached
+            except AttributeError:
+                pass
+        indexes = cached
         max_len = max(len(each) for each in indexes)
         queries_rebatch = query.new_zeros([bs, self.num_cams, max_len, self.embed_dims])
         reference_points_rebatch = reference_points_cam.new_zeros([bs, self.num_cams, max_len, D, 2])

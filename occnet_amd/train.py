@@ -25,7 +25,9 @@ def make_optimizer(model, lr=2e-4, weight_decay=0.01, backbone_lr_mult=0.1):
     groups = [dict(params=rest, lr=lr)]
     if backbone:
         groups.append(dict(params=backbone, lr=lr * backbone_lr_mult))
-    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
+    # fused: one multi-tensor kernel per parameter group instead of a dozen foreach launches per step
+    fused = all(p.is_cuda for g in groups for p in g['params'])
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=fused)
 
 
 def wrap_ddp(model, device):

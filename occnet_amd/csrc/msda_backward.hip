@@ -387,11 +387,44 @@ __global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
 
 }  // namespace occ
 
-extern "C" int occ_ms_deform_attn_backward_f32(
+namespace occ {
+struct BwdWsLayout { size_t off_cnt, off_cur, off_items, bytes; long n_bins, n_samples, max_items; int bins_per_bm; bool ok; };
+static BwdWsLayout bwd_ws_layout(int B, int S, int M, int L, int Lq, int P) {
+  BwdWsLayout w;
+  const long n_items = (long)B * Lq * M;
+  w.bins_per_bm = S / kBinPix + L + 1;                                // >= sum_l ceil(H_l*W_l / 32)
+  w.n_bins = (long)B * M * w.bins_per_bm;
+  w.n_samples = n_items * L * P;
+  w.max_items = 4 * w.n_samples;                                      // 2 rows x (1 or 2 items)
+  w.off_cnt = ((size_t)n_items + 255) & ~(size_t)255;
+  w.off_cur = w.off_cnt + (((size_t)(w.n_bins + 1) * 4 + 255) & ~(size_t)255);
+  w.off_items = w.off_cur + (((size_t)(w.n_bins + 1) * 4 + 255) & ~(size_t)255);
+  w.bytes = w.off_items + (size_t)w.max_items * sizeof(BwdItem);
+  w.ok = Lq < (1 << 26) && w.n_bins < (1L << 30) && w.max_items < (1L << 31);
+  return w;
+}
+}  // namespace occ
+
+// Bytes of scratch the atomic-free grad_value path (D == 32) needs for these shapes; 0 = that path does not apply
+// (other D, or index ranges beyond its 32-bit counters) and occ_ms_deform_attn_backward_ws_f32 ignores `workspace`.
+extern "C" int64_t occ_ms_deform_attn_backward_workspace_bytes(int B, int S, int M, int D, int L, int Lq, int P) {
+  using namespace occ;
+  if (D != 32 || B <= 0 || S <= 0 || M <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
+  const BwdWsLayout w = bwd_ws_layout(B, S, M, L, Lq, P);
+  return w.ok ? (int64_t)w.bytes : 0;
+}
+
+// ms_deform_attn_backward with CALLER-PROVIDED scratch (`workspace`, at least ..._workspace_bytes() bytes, 256-byte
+// aligned, need not be initialised): the Python operator module passes a tensor from torch's caching allocator, so
+// the ~0.7-0.9 GB per SCA call at the base config neither bypass nor compete with that pool.  workspace == NULL:
+// the library allocates with hipMallocAsync; if that fails it falls back to the float-atomic kernel (~4x slower) and
+// says so ONCE on stderr.  grad_value's summation order inside a 32-pixel bin follows integer-atomic slot order:
+// the last bits of grad_value are not reproducible run to run (as with mmcv's atomicAdd).
+extern "C" int occ_ms_deform_attn_backward_ws_f32(
     const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
     const float* sampling_loc, const float* attn_weight, const float* grad_output, float* grad_value,
     float* grad_sampling_loc, float* grad_attn_weight, int B, int S, int M, int D, int L, int Lq,
-    int P, int im2col_step, void* stream) {
+    int P, int im2col_step, void* workspace, int64_t workspace_bytes, void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight &&
                     grad_output && grad_value && grad_sampling_loc && grad_attn_weight,
@@ -410,40 +443,53 @@ extern "C" int occ_ms_deform_attn_backward_f32(
     const dim3 grid1((unsigned)((threads + 255) / 256));
     // atomic-free grad_value (file header): per-sample gradients + flags, count, scan, fill, replay
     static const bool use_atomics = getenv("OCC_MSDA_BWD_ATOMICS") != nullptr;
-    const int bins_per_bm = S / kBinPix + L + 1;                        // >= sum_l ceil(H_l*W_l / 32)
-    const long n_bins = (long)B * M * bins_per_bm;
-    const long n_samples = n_items * L * P;
-    const long max_items = 4 * n_samples;                               // 2 rows x (1 or 2 items)
+    const BwdWsLayout w = bwd_ws_layout(B, S, M, L, Lq, P);
     char* ws = nullptr;
-    const size_t off_cnt = ((size_t)n_items + 255) & ~(size_t)255;
-    const size_t off_cur = off_cnt + (((size_t)(n_bins + 1) * 4 + 255) & ~(size_t)255);
-    const size_t off_items = off_cur + (((size_t)(n_bins + 1) * 4 + 255) & ~(size_t)255);
-    const size_t ws_bytes = off_items + (size_t)max_items * sizeof(BwdItem);
+    bool own = false;
     hipError_t e = hipErrorUnknown;
-    if (!use_atomics && Lq < (1 << 26) && n_bins < (1L << 30) && max_items < (1L << 31))
-      e = hipMallocAsync(reinterpret_cast<void**>(&ws), ws_bytes, st);
-    if (e == hipSuccess) e = hipMemsetAsync(ws, 0, off_cur, st);        // flags + counts
+    if (!use_atomics && w.ok) {
+      if (workspace != nullptr) {
+        OCC_CHECK_ARG(workspace_bytes >= (int64_t)w.bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+                      "ms_deform_attn_backward: workspace too small (%ld < %ld bytes) or not 256-byte aligned",
+                      (long)workspace_bytes, (long)w.bytes);
+        ws = reinterpret_cast<char*>(workspace);
+        e = hipSuccess;
+      } else {
+        e = hipMallocAsync(reinterpret_cast<void**>(&ws), w.bytes, st);
+        own = e == hipSuccess;
+      }
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(ws, 0, w.off_cur, st);      // flags + counts
     if (e == hipSuccess) {
       unsigned char* flags = reinterpret_cast<unsigned char*>(ws);
-      int* counts = reinterpret_cast<int*>(ws + off_cnt);
-      int* cursor = reinterpret_cast<int*>(ws + off_cur);
-      BwdItem* items = reinterpret_cast<BwdItem*>(ws + off_items);
-      const dim3 grid_s((unsigned)((n_samples + 255) / 256));
+      int* counts = reinterpret_cast<int*>(ws + w.off_cnt);
+      int* cursor = reinterpret_cast<int*>(ws + w.off_cur);
+      BwdItem* items = reinterpret_cast<BwdItem*>(ws + w.off_items);
+      const dim3 grid_s((unsigned)((w.n_samples + 255) / 256));
       hipLaunchKernelGGL(msda_bwd_d32_kernel<false>, grid1, dim3(256), 0, st, value, spatial_shapes,
                          level_start_index, sampling_loc, attn_weight, grad_output, grad_value,
                          grad_sampling_loc, grad_attn_weight, flags, S, M, L, Lq, P, n_items);
       hipLaunchKernelGGL(msda_bwd_bin_kernel<false>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
-                         attn_weight, flags, counts, items, M, L, Lq, P, bins_per_bm, n_samples);
-      hipLaunchKernelGGL(msda_bwd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, cursor, (int)n_bins);
+                         attn_weight, flags, counts, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
+      hipLaunchKernelGGL(msda_bwd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, cursor, (int)w.n_bins);
       hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
-                         attn_weight, flags, cursor, items, M, L, Lq, P, bins_per_bm, n_samples);
-      hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)n_bins), dim3(256), 0, st,
+                         attn_weight, flags, cursor, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
+      hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)w.n_bins), dim3(256), 0, st,
                          spatial_shapes, level_start_index, counts, items, grad_output, grad_value, S, M, L, Lq,
-                         bins_per_bm, n_bins);
-      (void)hipFreeAsync(ws, st);
+                         w.bins_per_bm, w.n_bins);
+      if (own) (void)hipFreeAsync(ws, st);
     } else {
-      if (ws) (void)hipFreeAsync(ws, st);
+      if (own && ws) (void)hipFreeAsync(ws, st);
       (void)hipGetLastError();
+      if (!use_atomics) {
+        static bool warned = false;
+        if (!warned) {
+          warned = true;
+          fprintf(stderr, "occnet_amd: ms_deform_attn_backward: no %.2f GB of scratch for the atomic-free grad_value "
+                          "path (or shapes beyond its index range) - falling back to float atomics (~4x slower)\n",
+                  (double)w.bytes / 1e9);
+        }
+      }
       hipLaunchKernelGGL(msda_bwd_d32_kernel<true>, grid1, dim3(256), 0, st, value, spatial_shapes,
                          level_start_index, sampling_loc, attn_weight, grad_output, grad_value,
                          grad_sampling_loc, grad_attn_weight, nullptr, S, M, L, Lq, P, n_items);
@@ -459,4 +505,15 @@ extern "C" int occ_ms_deform_attn_backward_f32(
   }
   OCC_CHECK_LAUNCH("ms_deform_attn_backward");
   return OCC_OK;
+}
+
+// mmcv's exact argument list (no workspace argument): the library allocates the scratch itself.
+extern "C" int occ_ms_deform_attn_backward_f32(
+    const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+    const float* sampling_loc, const float* attn_weight, const float* grad_output, float* grad_value,
+    float* grad_sampling_loc, float* grad_attn_weight, int B, int S, int M, int D, int L, int Lq,
+    int P, int im2col_step, void* stream) {
+  return occ_ms_deform_attn_backward_ws_f32(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                            grad_output, grad_value, grad_sampling_loc, grad_attn_weight, B, S, M,
+                                            D, L, Lq, P, im2col_step, nullptr, 0, stream);
 }

@@ -122,12 +122,19 @@ def ms_deform_attn_backward(value, value_spatial_shapes, value_level_start_index
             grad_attn_weight.shape != attention_weights.shape or
             grad_output.numel() != B * Lq * M * D):
         raise OccAmdError("ms_deform_attn_backward: inconsistent shapes")
+    lib = _lib.lib()
+    lib.occ_ms_deform_attn_backward_workspace_bytes.restype = ctypes.c_int64
+    # scratch of the atomic-free grad_value path from torch's caching allocator (not hipMallocAsync behind its back);
+    # freed back to the pool when this call returns — stream-ordered, the kernels are already enqueued
+    need = int(lib.occ_ms_deform_attn_backward_workspace_bytes(i32(B), i32(S), i32(M), i32(D), i32(L), i32(Lq),
+                                                               i32(P)))
+    ws = torch.empty(need, dtype=torch.uint8, device=value.device) if need > 0 else None
     with torch.cuda.device(value.device):
-        rc = _lib.lib().occ_ms_deform_attn_backward_f32(
+        rc = lib.occ_ms_deform_attn_backward_ws_f32(
             ptr(value), ptr(value_spatial_shapes), ptr(value_level_start_index),
             ptr(sampling_locations), ptr(attention_weights), ptr(grad_output), ptr(grad_value),
             ptr(grad_sampling_loc), ptr(grad_attn_weight), i32(B), i32(S), i32(M), i32(D), i32(L),
-            i32(Lq), i32(P), i32(int(im2col_step)), stream_ptr(value.device))
+            i32(Lq), i32(P), i32(int(im2col_step)), ptr(ws), i64(need), stream_ptr(value.device))
     _lib.check(rc, "ms_deform_attn_backward")
 
 

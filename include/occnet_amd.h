@@ -262,6 +262,18 @@ int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2
                           const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N,
                           void* stream);
 
+/* Training partner of occ_linear_bf16x3_f32 (csrc/linear_wgrad.hip): weight and bias gradient of a Linear,
+ *     dw[n][k] = sum_m dy[m][n] * x[m][k]      db[n] = sum_m dy[m][n]      (db may be NULL)
+ * on the bf16 matrix cores with the same hi/lo operand split (product error <= 2^-16), f32 accumulation.
+ * The row dimension is reduced in chunks into `workspace` (occ_linear_wgrad_workspace_bytes(M, N, K) bytes, owned by
+ * the caller, 16-byte aligned) and summed in a fixed order: the result is deterministic, no float atomics.
+ * dy (M, N) with row stride lddy, x (M, K) with row stride ldx, dw (N, K) contiguous (overwritten, not accumulated).
+ * Replaces: ATen's addmm backward behind the nn.Linear call sites listed at occ_linear_f32.  The input gradient
+ * needs no entry point: dx = occ_linear_bf16x3_f32(dy, pack(W^T)). */
+int64_t occ_linear_wgrad_workspace_bytes(int M, int N, int K);
+int occ_linear_wgrad_bf16x3_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
+                                void* workspace, int64_t workspace_bytes, int M, int N, int K, void* stream);
+
 /* Round-2 variant of occ_linear_bf16x3_f32 (same arguments, same packed weights, same arithmetic): 160-row blocks,
  * 32-k chunks, weights staged once per block in LDS (csrc/linear_x3s.hip).  Needs K1 % 32 == 0 and K2 % 32 == 0;
  * OCC_E_UNSUPPORTED otherwise (the caller then takes occ_linear_bf16x3_f32). */

@@ -1,0 +1,224 @@
+// Weight / bias gradient of a Linear on the bf16 matrix cores (bf16x3 split, f32 accumulation) for gfx950.
+//
+//   dW[n][k] = sum_m dY[m][n] * X[m][k]        db[n] = sum_m dY[m][n]
+//
+// The training-side partner of linear_bf16x3.hip (reference: the autograd of the nn.Linear call sites of a
+// BEVFormerLayer — temporal_self_attention.py:197-209,266-272, spatial_cross_attention.py:334-341,173-175, mmcv FFN —
+// which the reference leaves to ATen's addmm backward).  dX needs no kernel of its own: it is
+// occ_linear_bf16x3_f32(dY, W^T).
+//
+// Shape of the problem: M = 40 000 .. 185 000 rows is the REDUCTION dimension, the output is small (N, K <= 768).
+// The reduction is split over `chunks` row ranges (grid.y); every block owns one 128 x 128 output tile of one
+// chunk, writes its partial tile, and a second kernel adds the partials in a fixed order (deterministic: no float
+// atomics — gfx950 retires them at ~82 G/s, and rank-to-rank bit equality of gradients is worth keeping).
+//
+// MFMA operand layout makes LDS unnecessary: for v_mfma_f32_32x32x16_bf16 lane l holds, of the A operand, row
+// l % 32 and the 8 reduction indices 8 * (l / 32) .. +7 — here: column n of dY and 8 consecutive rows m.  A dword
+// load per (lane, m) therefore reads two fully used 128-byte segments per wave instruction (lanes 0-31: row m,
+// lanes 32-63: row m + 8), and the 8 loaded values ARE the fragment once split into hi / lo bf16.  Same for X as
+// the B operand.  Three MFMAs per tile pair and 16 rows: dYl.Xh + dYh.Xl + dYh.Xh, term-major over the wave's four
+// independent accumulator tiles.
+#include "common.h"
+
+namespace occ {
+
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wg_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2_rne(x0, x1);
+  lo = pack_bf16x2_rne(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
+// 8 consecutive-m values of one column -> hi / lo fragments
+__device__ __forceinline__ void wg_frag(const float (&v)[8], wg_bf16x8& hi, wg_bf16x8& lo) {
+  wg_u32x4 h, l;
+  unsigned a, b;
+  wg_split2(v[0], v[1], a, b); h.x = a; l.x = b;
+  wg_split2(v[2], v[3], a, b); h.y = a; l.y = b;
+  wg_split2(v[4], v[5], a, b); h.z = a; l.z = b;
+  wg_split2(v[6], v[7], a, b); h.w = a; l.w = b;
+  hi = __builtin_bit_cast(wg_bf16x8, h);
+  lo = __builtin_bit_cast(wg_bf16x8, l);
+}
+
+// rows m .. m+15 of this wave's two dY column tiles and two X column tiles -> raw registers.  Rows are clamped to
+// M - 1 so the load is always legal; `rows_left` < 16 zeroes the rows beyond the chunk (wave-uniform branch).
+__device__ __forceinline__ void wg_load(const float* __restrict__ pa0, const float* __restrict__ pa1,
+                                        const float* __restrict__ pb0, const float* __restrict__ pb1, long lda,
+                                        long ldb, int m, int g, int M, int rows_left, float (&a0)[8],
+                                        float (&a1)[8], float (&b0)[8], float (&b1)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = m + 8 * g + j;
+    const long r = row < M ? row : M - 1;
+    a0[j] = pa0[r * lda];
+    a1[j] = pa1[r * lda];
+    b0[j] = pb0[r * ldb];
+    b1[j] = pb1[r * ldb];
+  }
+  if (rows_left < 16) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = 8 * g + j < rows_left;
+      a0[j] = ok ? a0[j] : 0.f;
+      a1[j] = ok ? a1[j] : 0.f;
+      b0[j] = ok ? b0[j] : 0.f;
+      b1[j] = ok ? b1[j] : 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void wg_step(const float (&a0)[8], const float (&a1)[8], const float (&b0)[8],
+                                        const float (&b1)[8], wg_f32x16 (&acc)[4], float& s0, float& s1) {
+  wg_bf16x8 ah0, al0, ah1, al1, bh0, bl0, bh1, bl1;
+  wg_frag(a0, ah0, al0);
+  wg_frag(a1, ah1, al1);
+  wg_frag(b0, bh0, bl0);
+  wg_frag(b1, bh1, bl1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s0 += a0[j];
+    s1 += a1[j];
+  }
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc[0], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc[1], 0, 0, 0);
+  acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh0, acc[2], 0, 0, 0);
+  acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh1, acc[3], 0, 0, 0);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl0, acc[0], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl1, acc[1], 0, 0, 0);
+  acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl0, acc[2], 0, 0, 0);
+  acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl1, acc[3], 0, 0, 0);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc[0], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc[1], 0, 0, 0);
+  acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[2], 0, 0, 0);
+  acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[3], 0, 0, 0);
+}
+
+// grid (tiles_n * tiles_k, chunks); block = 4 waves as 2 x 2 over a 128 (n) x 128 (k) tile
+__global__ __launch_bounds__(256, 2) void linear_wgrad_x3_kernel(
+    const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, float* __restrict__ part_w,
+    float* __restrict__ part_b, int M, int N, int K, int MC, int tiles_k) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, g = lane >> 5;
+  const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+  const int c = blockIdx.y;
+  const int n0 = tile_n * 128 + (wave >> 1) * 64, k0 = tile_k * 128 + (wave & 1) * 64;
+  const int m_begin = c * MC;
+  const int m_end = m_begin + MC < M ? m_begin + MC : M;
+
+  // column pointers; columns beyond N / K are clamped for the load and dropped at the store
+  const int na0 = n0 + col, na1 = n0 + 32 + col, kb0 = k0 + col, kb1 = k0 + 32 + col;
+  const float* pa0 = dy + (na0 < N ? na0 : N - 1);
+  const float* pa1 = dy + (na1 < N ? na1 : N - 1);
+  const float* pb0 = x + (kb0 < K ? kb0 : K - 1);
+  const float* pb1 = x + (kb1 < K ? kb1 : K - 1);
+
+  wg_f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float s0 = 0.f, s1 = 0.f;
+
+  float a0[8], a1[8], b0[8], b1[8], c0[8], c1[8], d0[8], d1[8];
+  int m = m_begin;
+  if (m < m_end) wg_load(pa0, pa1, pb0, pb1, lddy, ldx, m, g, M, m_end - m, a0, a1, b0, b1);
+  // two steps per iteration: the next 16 rows are requested before the current ones are consumed
+  while (m < m_end) {
+    const int m1 = m + 16;
+    if (m1 < m_end) wg_load(pa0, pa1, pb0, pb1, lddy, ldx, m1, g, M, m_end - m1, c0, c1, d0, d1);
+    wg_step(a0, a1, b0, b1, acc, s0, s1);
+    if (m1 >= m_end) break;
+    const int m2 = m1 + 16;
+    if (m2 < m_end) wg_load(pa0, pa1, pb0, pb1, lddy, ldx, m2, g, M, m_end - m2, a0, a1, b0, b1);
+    wg_step(c0, c1, d0, d1, acc, s0, s1);
+    m = m2;
+  }
+
+  // partial tile: D[i][col], i = 8 * (r / 4) + 4 * g + r % 4  (rows = n, columns = k)
+  float* pw = part_w + (long)c * N * K;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int nb = n0 + (t >> 1) * 32, kk = k0 + (t & 1) * 32 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nb + 8 * (r >> 2) + 4 * g + (r & 3);
+      if (n < N && kk < K) pw[(long)n * K + kk] = acc[t][r];
+    }
+  }
+  if (part_b && tile_k == 0 && (wave & 1) == 0) {
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    if (g == 0) {
+      if (na0 < N) part_b[(long)c * N + na0] = s0;
+      if (na1 < N) part_b[(long)c * N + na1] = s1;
+    }
+  }
+}
+
+// dW = sum_c partial[c] (fixed order), db likewise
+__global__ void linear_wgrad_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b,
+                                           float* __restrict__ dw, float* __restrict__ db, long NK, int N,
+                                           int chunks) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < NK) {
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part_w[(long)c * NK + i];
+    dw[i] = s;
+  }
+  if (db && i < N) {
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part_b[(long)c * N + i];
+    db[i] = s;
+  }
+}
+
+static void wgrad_plan(int M, int N, int K, int& tiles_n, int& tiles_k, int& chunks, int& MC) {
+  tiles_n = (N + 127) / 128;
+  tiles_k = (K + 127) / 128;
+  const int tiles = tiles_n * tiles_k;
+  int want = (640 + tiles - 1) / tiles;              // ~2.5 blocks per CU
+  const int max_chunks = (M + 63) / 64;              // at least 4 MFMA steps per block
+  if (want > max_chunks) want = max_chunks;
+  if (want < 1) want = 1;
+  MC = ((M + want - 1) / want + 15) / 16 * 16;
+  chunks = (M + MC - 1) / MC;
+}
+
+}  // namespace occ
+
+extern "C" int64_t occ_linear_wgrad_workspace_bytes(int M, int N, int K) {
+  using namespace occ;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int tn, tk, chunks, MC;
+  wgrad_plan(M, N, K, tn, tk, chunks, MC);
+  return (int64_t)chunks * ((int64_t)N * K + N) * 4;
+}
+
+extern "C" int occ_linear_wgrad_bf16x3_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw,
+                                           float* db, void* workspace, int64_t workspace_bytes, int M, int N,
+                                           int K, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(dy && x && dw && workspace, "linear_wgrad: null pointer argument");
+  OCC_CHECK_ARG(M > 0 && N > 0 && K > 0, "linear_wgrad: bad dimension (M=%d N=%d K=%d)", M, N, K);
+  OCC_CHECK_ARG(lddy >= N && ldx >= K, "linear_wgrad: row strides smaller than a row");
+  OCC_CHECK_ARG(workspace_bytes >= occ_linear_wgrad_workspace_bytes(M, N, K),
+                "linear_wgrad: workspace too small (%lld bytes, need %lld)", (long long)workspace_bytes,
+                (long long)occ_linear_wgrad_workspace_bytes(M, N, K));
+  OCC_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "linear_wgrad: workspace must be 16-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int tn, tk, chunks, MC;
+  wgrad_plan(M, N, K, tn, tk, chunks, MC);
+  float* part_w = reinterpret_cast<float*>(workspace);
+  float* part_b = part_w + (long)chunks * N * K;
+  hipLaunchKernelGGL(linear_wgrad_x3_kernel, dim3((unsigned)(tn * tk), (unsigned)chunks), dim3(256), 0, st, dy,
+                     (long)lddy, x, (long)ldx, part_w, db ? part_b : nullptr, M, N, K, MC, tk);
+  OCC_CHECK_LAUNCH("linear_wgrad");
+  const long NK = (long)N * K;
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, st, part_w,
+                     part_b, dw, db, NK, N, chunks);
+  OCC_CHECK_LAUNCH("linear_wgrad_reduce");
+  return OCC_OK;
+}

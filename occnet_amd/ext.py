@@ -556,6 +556,73 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
     return out
 
 
+def linear_wgrad(dy, x, with_bias=True):
+    """Weight / bias gradient of out = x @ W^T + b on the bf16x3 matrix-core kernel (csrc/linear_wgrad.hip):
+    dW (N, K) = dy^T @ x, db (N) = dy.sum(rows).  dy (…, N), x (…, K) float32 device tensors with the same leading
+    shape and unit column stride.  Deterministic (chunked reduction, fixed order)."""
+    dy_, M, N, lddy = _rows2d("dy", dy)
+    x_, Mx, K, ldx = _rows2d("x", x)
+    if Mx != M:
+        raise OccAmdError("linear_wgrad: dy and x differ in rows")
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy.device) if with_bias else None
+    lib = _lib.lib()
+    lib.occ_linear_wgrad_workspace_bytes.restype = ctypes.c_int64
+    nbytes = int(lib.occ_linear_wgrad_workspace_bytes(i32(M), i32(N), i32(K)))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device), _timed('linear_wgrad'):
+        rc = lib.occ_linear_wgrad_bf16x3_f32(ptr(dy_), i64(lddy), ptr(x_), i64(ldx), ptr(dw), ptr(db), ptr(ws),
+                                             i64(nbytes), i32(M), i32(N), i32(K), stream_ptr(dy.device))
+    _lib.check(rc, "linear_wgrad")
+    return dw, db
+
+
+class LinearX3Function(torch.autograd.Function):
+    """y = act(x @ W^T + b) with forward AND backward on the bf16x3 kernels: forward = linear(), dx = linear(dy, W^T),
+    dW / db = linear_wgrad().  The training-mode replacement for F.linear at the encoder's Linear call sites
+    (reference: nn.Linear + ATen autograd; temporal_self_attention.py:197-209, spatial_cross_attention.py:334-341,
+    mmcv FFN)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        out = linear(x, weight, bias, act=act, precision='bf16x3')
+        ctx.act = act
+        ctx.save_for_backward(x, weight, out if act == 'relu' else None)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x, weight, out = ctx.saved_tensors
+        gout = gout.contiguous()
+        if ctx.act == 'relu':
+            gout = gout * (out > 0)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = linear(gout, weight.t().contiguous(), None, precision='bf16x3')
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = linear_wgrad(gout, x, with_bias=ctx.has_bias)
+        return gx, gw, gb, None
+
+
+TRAIN_LINEAR = os.environ.get("OCC_TRAIN_LINEAR", "x3")      # 'x3' (own kernels) or 'torch' (F.linear + ATen autograd)
+
+
+def linear_autograd(x, weight, bias=None, act=None):
+    """F.linear(+ReLU) that is differentiable: on a float32 device tensor with supported shapes the forward and the
+    backward run on the bf16x3 kernels; anything else takes F.linear (still on the device: no CPU branch here)."""
+    ok = (TRAIN_LINEAR == "x3" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+          and weight.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0 and weight.is_contiguous()
+          and torch.is_grad_enabled() and not torch.is_autocast_enabled())
+    if ok:
+        if not (x.is_contiguous() or (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0)):
+            x = x.contiguous()
+        return LinearX3Function.apply(x, weight, bias, act)
+    y = torch.nn.functional.linear(x, weight, bias)
+    return torch.relu(y) if act == 'relu' else y
+
+
 _PACKED_FFN = {}        # (w1 ptr/version, w2 ptr/version, epoch) -> packed stream
 
 

@@ -6,6 +6,8 @@ Out of the hot path's kernel scope ("backbone/neck stay sto
 `layer{1..4}.{i}.{conv,bn}{1,2,3}`, `downsample.{0,1}`; `lateral_convs.{i}.conv`, `fpn_convs.{i}.conv`)
 so a reference checkpoint's `img_backbone.*` / `img_neck.*` keys load.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -14,8 +16,24 @@ from .bricks import BaseModule, ConvModule
 from .registry import BACKBONES, NECKS
 
 
+def conv_bn_folded(x, conv, bn):
+    """conv -> eval-mode BatchNorm as ONE convolution with autograd intact: y = conv(x, W * s) + t with
+    s = gamma / sqrt(running_var + eps), t = beta - running_mean * s.  Identical function and identical gradients for
+    W, gamma and beta (they flow through the small weight-side products), but no BatchNorm kernel ever touches the
+    activation: the reference trains its ResNet with `norm_eval=True` (projects/configs/bevformer/
+    bevformer_base_occ.py:55), and torch's eval-mode BN backward costs two passes over every activation
+    (batch_norm_backward_reduce + elementwise: 19 ms of the 137 ms training step on MI355X)."""
+    s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    w = conv.weight * s.view(-1, 1, 1, 1)
+    b = bn.bias - bn.running_mean * s
+    if conv.bias is not None:
+        b = b + conv.bias * s
+    return F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
 class Bottleneck(nn.Module):
     expansion = 4
+    fold_eval_bn = True     # class-wide switch (OCC_TRAIN_FOLD_BN=0 clears it)
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
@@ -30,11 +48,22 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if (self.fold_eval_bn and torch.is_grad_enabled() and not self.bn1.training and x.is_cuda
+                and self.bn1.affine and self.bn1.track_running_stats):
+            identity = x if self.downsample is None else conv_bn_folded(x, self.downsample[0], self.downsample[1])
+            out = self.relu(conv_bn_folded(x, self.conv1, self.bn1))
+            out = self.relu(conv_bn_folded(out, self.conv2, self.bn2))
+            out = conv_bn_folded(out, self.conv3, self.bn3)
+            return self.relu(out + identity)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
         return self.relu(out + identity)
+
+
+if os.environ.get("OCC_TRAIN_FOLD_BN", "1") == "0":
+    Bottleneck.fold_eval_bn = False
 
 
 @BACKBONES.register_module()
@@ -93,10 +122,37 @@ class ResNet(BaseModule):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    use_frozen_prefix_plan = os.environ.get("OCC_TRAIN_FROZEN_PREFIX", "1") != "0"
+
+    def _frozen_prefix(self, x):
+        """Training with frozen_stages >= 1: the stem and the frozen stages need no autograd graph, so they run on
+        the inference plan's kernels (whole stem + whole-bottleneck launches, bf16 NHWC) instead of MIOpen.
+        -> (activation after the last frozen stage, number of stages done) or (None, 0)."""
+        from .. import cache_epoch
+        n = self.frozen_stages
+        if not (self.use_frozen_prefix_plan and self.training and n >= 1 and x.is_cuda and x.dtype == torch.float32
+                and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+                and not any(i < n for i in self.out_indices)):
+            return None, 0
+        plan = getattr(self, '_prefix_plan', None)
+        if plan is None or plan.built_epoch != cache_epoch():
+            plan = FusedInferenceBackbone(self, None, dtype=torch.bfloat16, prefix_stages=n)
+            plan.built_epoch = cache_epoch()
+            object.__setattr__(self, '_prefix_plan', plan)      # not a sub-module: owns folded copies
+        if not plan._stem_fused:
+            return None, 0
+        return plan.forward_prefix(x.contiguous()), n
+
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x0, done = self._frozen_prefix(x)
+        if x0 is not None:
+            x = x0
+        else:
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         outs = []
         for i, name in enumerate(self.res_layers):
+            if i < done:
+                continue
             x = getattr(self, name)(x)
             if i in self.out_indices:
                 outs.append(x)
@@ -195,8 +251,11 @@ class FusedInferenceBackbone(nn.Module):
     scope; these kernels exist because end-to-end samples/s (images -> voxels) is the headline metric."""
 
     def __init__(self, backbone, neck, dtype=torch.bfloat16, fused_ops=False, hip_tail=True,
-                 fused_bottleneck=True):
+                 fused_bottleneck=True, prefix_stages=None):
         super().__init__()
+        # prefix_stages = k: fold only the stem and the first k stages, no neck (forward_prefix: the frozen part of
+        # a training step)
+        self.prefix_stages = prefix_stages
         # hip_tail: bias + (residual) + ReLU after each convolution as ONE in-place HIP launch
         # (occ_bias_act_nhwc_bf16) instead of PyTorch's add / add_ / relu_ launches (bf16 only)
         self.hip_tail = hip_tail and dtype == torch.bfloat16
@@ -227,7 +286,7 @@ class FusedInferenceBackbone(nn.Module):
             from .. import ext
             self.register_buffer('stem_frag', ext.stem_pack_weight(sw), persistent=False)
         self.stages = []
-        for name in backbone.res_layers:
+        for name in (backbone.res_layers if prefix_stages is None else backbone.res_layers[:prefix_stages]):
             blocks = []
             for blk in getattr(backbone, name):
                 ds = None if blk.downsample is None else fold(blk.downsample[0], blk.downsample[1])
@@ -256,6 +315,9 @@ class FusedInferenceBackbone(nn.Module):
                         self.register_buffer(f'k{si}_{bi}_{k}', pk[k], persistent=False)
                     self._bneck[(si, bi)] = (pk['cin'], pk['ds'])
         self.neck = neck
+        if neck is None:
+            self.laterals, self.fpn = [], []
+            return
         self.laterals = [self._add(m.conv.weight, m.conv.bias, m.conv) for m in neck.lateral_convs]
         self.fpn = [self._add(m.conv.weight, m.conv.bias, m.conv) for m in neck.fpn_convs]
         for m in list(neck.lateral_convs) + list(neck.fpn_convs):
@@ -375,20 +437,33 @@ class FusedInferenceBackbone(nn.Module):
             x = F.max_pool2d(self._conv(self.stem, x, relu=True), kernel_size=3, stride=2, padding=1)
         return self._forward_stages(x)
 
+    def _run_stage(self, si, x):
+        for bi, (c1, c2, c3, ds) in enumerate(self.stages[si]):
+            if (si, bi) in self._bneck and x.is_contiguous(memory_format=torch.channels_last):
+                from .. import ext
+                cin, has_ds = self._bneck[(si, bi)]
+                pk = {k: getattr(self, f'k{si}_{bi}_{k}') for k in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3')}
+                pk.update(cin=cin, ds=has_ds)
+                x = ext.bottleneck64_nhwc(x, pk)
+                continue
+            identity = x if ds is None else self._conv(ds, x)
+            y = self._conv(c2, self._conv(c1, x, relu=True), relu=True)
+            x = self._conv(c3, y, add=identity)
+        return x
+
+    @torch.no_grad()
+    def forward_prefix(self, x):
+        """x (N, 3, H, W) fp32 contiguous -> activation after the folded stages, (N, C, h, w) bf16 channels_last."""
+        from .. import ext
+        x = ext.stem_conv7x7_pool(x, self.stem_frag, getattr(self, f'b{self.stem}'))
+        for si in range(len(self.stages)):
+            x = self._run_stage(si, x)
+        return x
+
     def _forward_stages(self, x):
         feats = []
-        for si, blocks in enumerate(self.stages):
-            for bi, (c1, c2, c3, ds) in enumerate(blocks):
-                if (si, bi) in self._bneck and x.is_contiguous(memory_format=torch.channels_last):
-                    from .. import ext
-                    cin, has_ds = self._bneck[(si, bi)]
-                    pk = {k: getattr(self, f'k{si}_{bi}_{k}') for k in ('w1', 'b1', 'w2', 'b2', 'w3', 'b3')}
-                    pk.update(cin=cin, ds=has_ds)
-                    x = ext.bottleneck64_nhwc(x, pk)
-                    continue
-                identity = x if ds is None else self._conv(ds, x)
-                y = self._conv(c2, self._conv(c1, x, relu=True), relu=True)
-                x = self._conv(c3, y, add=identity)
+        for si in range(len(self.stages)):
+            x = self._run_stage(si, x)
             if si in self.out_indices:
                 feats.append(x)
         nk = self.neck

@@ -88,6 +88,20 @@ def build_norm_layer(cfg, num_features, postfix=''):
     return abbr + str(postfix), layer
 
 
+class X3Linear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) whose TRAINING forward and backward run on the bf16x3
+    matrix-core kernels (ext.LinearX3Function: forward + dx on linear_bf16x3.hip, dW / db on linear_wgrad.hip)
+    instead of ATen's fp32 library GEMMs.  Without autograd, on the host, or for shapes the kernels do not cover it
+    is F.linear."""
+
+    def forward(self, x, act=None):
+        from .. import ext
+        if x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return ext.linear_autograd(x, self.weight, self.bias, act=act)
+        y = F.linear(x, self.weight, self.bias)
+        return torch.relu(y) if act == 'relu' else y
+
+
 def build_activation_layer(cfg):
     return build_from_cfg(cfg, ACTIVATION_LAYERS)
 
@@ -110,10 +124,10 @@ class FFN(BaseModule):
         layers = []
         in_channels = embed_dims
         for _ in range(num_fcs - 1):
-            layers.append(Sequential(nn.Linear(in_channels, feedforward_channels),
+            layers.append(Sequential(X3Linear(in_channels, feedforward_channels),
                                      build_activation_layer(act_cfg), nn.Dropout(ffn_drop)))
             in_channels = feedforward_channels
-        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(X3Linear(feedforward_channels, embed_dims))
         layers.append(nn.Dropout(ffn_drop))
         self.layers = Sequential(*layers)
         self.dropout_layer = nn.Identity()
@@ -142,7 +156,13 @@ class FFN(BaseModule):
             return None
 
     def forward(self, x, identity=None):
-        out = self.layers(x)
+        if (self.num_fcs == 2 and isinstance(self.layers[0][1], nn.ReLU) and x.is_cuda
+                and torch.is_grad_enabled()):
+            # training: Linear + ReLU as one kernel (the mask for the backward is the output itself)
+            h = self.layers[0][2](self.layers[0][0](x, act='relu'))
+            out = self.layers[2](self.layers[1](h))
+        else:
+            out = self.layers(x)
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from .. import cache_epoch, ext
 from .._lib import OccAmdError, OccAmdUnsupported
-from .bricks import BaseModule, constant_init, xavier_init
+from .bricks import BaseModule, X3Linear, constant_init, xavier_init
 from .functions import MultiScaleDeformableAttnFunction_fp32
 from .registry import ATTENTION, build_attention
 
@@ -75,9 +75,9 @@ class MSDeformableAttention3D(BaseModule):
         self.num_levels = num_levels
         self.num_heads = num_heads
         self.num_points = num_points
-        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.sampling_offsets = X3Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = X3Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = X3Linear(embed_dims, embed_dims)
         self._qcat = _CatLinearCache()
         self.init_weights()
 
@@ -177,7 +177,7 @@ class SpatialCrossAttention(BaseModule):
         self.deformable_attention = build_attention(deformable_attention)
         self.embed_dims = embed_dims
         self.num_cams = num_cams
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = X3Linear(embed_dims, embed_dims)
         self.batch_first = batch_first
         self.use_fused = True          # flip to force the unfused (reference-shaped) HIP path
         self.init_weight()

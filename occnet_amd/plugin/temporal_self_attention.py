@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from .. import cache_epoch, ext
 from .._lib import OccAmdUnsupported
-from .bricks import BaseModule, constant_init, xavier_init
+from .bricks import BaseModule, X3Linear, constant_init, xavier_init
 from .functions import MultiScaleDeformableAttnFunction_fp32
 from .registry import ATTENTION
 from .spatial_cross_attention import _CatLinearCache, _require_device
@@ -50,12 +50,12 @@ class TemporalSelfAttention(BaseModule):
         self.num_heads = num_heads
         self.num_points = num_points
         self.num_bev_queue = num_bev_queue
-        self.sampling_offsets = nn.Linear(
+        self.sampling_offsets = X3Linear(
             embed_dims * num_bev_queue, num_bev_queue * num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(
+        self.attention_weights = X3Linear(
             embed_dims * num_bev_queue, num_bev_queue * num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, embed_dims)
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.value_proj = X3Linear(embed_dims, embed_dims)
+        self.output_proj = X3Linear(embed_dims, embed_dims)
         self._qcat = _CatLinearCache()
         self.use_fused = True
         self.init_weights()

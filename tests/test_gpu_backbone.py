@@ -288,3 +288,70 @@ def test_detector_u8_path_equals_float_path():
         alt, _ = model.extract_feat_u8(torch.from_numpy(np.stack(raw))[None].cuda(), ncfg)
     for a, b in zip(alt, ref):       # same fp32 modules; MIOpen may pick another algorithm for the other memory layout
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+
+
+def _train_backbone():
+    from occnet_amd.plugin.backbone import ResNet
+    torch.manual_seed(0)
+    bb = ResNet(depth=50, num_stages=4, out_indices=(1, 2, 3), frozen_stages=1, norm_eval=True)
+    bb.init_weights()
+    g = torch.Generator().manual_seed(1)
+    for m in bb.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.75)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    return bb.cuda().train(), g
+
+
+def test_training_backbone_folded_bn_matches_batchnorm_modules_fp32():
+    """norm_eval training: conv+BN as one folded convolution (conv_bn_folded) vs the conv -> BatchNorm2d modules,
+    fp32, outputs and parameter gradients (same function, different association: 1e-4 relative)."""
+    from occnet_amd.plugin.backbone import Bottleneck
+    bb, g = _train_backbone()
+    x = (torch.randn(2, 3, 64, 96, generator=g) * 50.0).cuda()
+    res = {}
+    for fold in (True, False):
+        Bottleneck.fold_eval_bn = fold
+        try:
+            bb.zero_grad(set_to_none=True)
+            outs = bb(x)
+            sum((o.float() ** 2).mean() for o in outs).backward()
+            res[fold] = ([o.detach().clone() for o in outs],
+                         {n: p.grad.detach().clone() for n, p in bb.named_parameters() if p.grad is not None})
+        finally:
+            Bottleneck.fold_eval_bn = True
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) > 100
+    assert not any(n.startswith(('conv1.', 'bn1.', 'layer1.')) for n in res[True][1])       # frozen_stages=1
+    for a, b in zip(res[True][0], res[False][0]):
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-4
+    worst = max(float((res[True][1][n] - gb).abs().max() / (gb.abs().max() + 1e-12)) for n, gb in res[False][1].items())
+    print(f"folded-BN training backbone: worst relative gradient difference {worst:.2e}")
+    assert worst < 2e-3
+
+
+def test_training_backbone_frozen_prefix_runs_on_the_plan_kernels():
+    """frozen_stages=1 under bf16 autocast: stem + layer1 on the own kernels (no autograd graph needed) vs the
+    torch modules; the trainable stages see the same activations up to bf16 rounding and still get gradients."""
+    from occnet_amd.plugin.backbone import ResNet
+    bb, g = _train_backbone()
+    x = (torch.randn(2, 3, 96, 160, generator=g) * 50.0).cuda()
+    res = {}
+    for use in (True, False):
+        ResNet.use_frozen_prefix_plan = use
+        try:
+            bb.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                outs = bb(x)
+            sum((o.float() ** 2).mean() for o in outs).backward()
+            res[use] = ([o.detach().float() for o in outs], bb.layer2[0].conv1.weight.grad.detach().clone())
+        finally:
+            ResNet.use_frozen_prefix_plan = True
+    assert getattr(bb, '_prefix_plan', None) is not None and len(bb._prefix_plan.stages) == 1
+    for a, b in zip(res[True][0], res[False][0]):
+        rel = float((a - b).abs().max() / b.abs().max())
+        print(f"frozen prefix on plan kernels, level {tuple(a.shape)}: max rel diff {rel:.3e}")
+        assert rel < 0.06
+    gr = float((res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max())
+    assert gr < 0.1

@@ -311,3 +311,28 @@ def test_bench_self_launches_n_ranks():
     # whole-job value = all ranks' steps / max-over-ranks time; rank 1 sleeps 2 ms per step
     assert out['ms_per_step'] >= 2.0
     assert abs(out['value'] - 2 * 4 / (out['ms_per_step'] * 4e-3)) / out['value'] < 1e-6
+
+
+def test_conv_bn_folded_matches_eval_batchnorm_with_gradients():
+    """Training with norm_eval=True: conv -> eval BN computed as one convolution with folded weights must give the
+    same output and the same gradients for the input, the convolution weight and the BN affine parameters."""
+    import torch.nn as nn
+    from occnet_amd.plugin.backbone import conv_bn_folded
+    torch.manual_seed(3)
+    conv = nn.Conv2d(8, 16, 3, stride=2, padding=1, bias=False).double()
+    bn = nn.BatchNorm2d(16).double()
+    with torch.no_grad():
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.normal_()
+        bn.bias.normal_()
+    bn.eval()
+    x = torch.randn(2, 8, 9, 11, dtype=torch.double, requires_grad=True)
+    go = torch.randn(2, 16, 5, 6, dtype=torch.double)
+    y_ref = bn(conv(x))
+    g_ref = torch.autograd.grad(y_ref, [x, conv.weight, bn.weight, bn.bias], go)
+    y = conv_bn_folded(x, conv, bn)
+    g = torch.autograd.grad(y, [x, conv.weight, bn.weight, bn.bias], go)
+    assert float((y - y_ref).abs().max()) < 1e-12
+    for a, b in zip(g, g_ref):
+        assert float((a - b).abs().max()) < 1e-10 * max(1.0, float(b.abs().max()))

@@ -158,20 +158,37 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_x3_kernel(
   }
 }
 
-// dW = sum_c partial[c] (fixed order), db likewise
-__global__ void linear_wgrad_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b,
-                                           float* __restrict__ dw, float* __restrict__ db, long NK, int N,
-                                           int chunks) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < NK) {
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part_w[(long)c * NK + i];
-    dw[i] = s;
+// dW = sum_c partial[c], db likewise, in a fixed order: a block owns 64 consecutive outputs, its 4 waves each add
+// every 4th chunk (4 independent loads in flight per lane), and the four wave sums are combined in wave order through
+// LDS.  (One thread per output walking all chunks serially ran at 0.7 TB/s: as long as the MFMA kernel itself.)
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ part_w,
+                                                                  const float* __restrict__ part_b,
+                                                                  float* __restrict__ dw, float* __restrict__ db,
+                                                                  long NK, int N, int chunks) {
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long n_w_blocks = (NK + 63) / 64;
+  const bool is_w = (long)blockIdx.x < n_w_blocks;
+  const float* src = is_w ? part_w : part_b;
+  const long stride = is_w ? NK : (long)N;
+  const long i = (is_w ? (long)blockIdx.x : (long)blockIdx.x - n_w_blocks) * 64 + o;
+  const bool ok = i < stride;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (ok) {
+    int c = g;
+    for (; c + 12 < chunks; c += 16) {
+      s0 += src[(long)c * stride + i];
+      s1 += src[(long)(c + 4) * stride + i];
+      s2 += src[(long)(c + 8) * stride + i];
+      s3 += src[(long)(c + 12) * stride + i];
+    }
+    for (; c < chunks; c += 4) s0 += src[(long)c * stride + i];
   }
-  if (db && i < N) {
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part_b[(long)c * N + i];
-    db[i] = s;
+  red[g][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && ok) {
+    const float r = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+    if (is_w) dw[i] = r; else db[i] = r;
   }
 }
 
@@ -179,7 +196,9 @@ static void wgrad_plan(int M, int N, int K, int& tiles_n, int& tiles_k, int& chu
   tiles_n = (N + 127) / 128;
   tiles_k = (K + 127) / 128;
   const int tiles = tiles_n * tiles_k;
-  int want = (640 + tiles - 1) / tiles;              // ~2.5 blocks per CU
+  // 512 blocks = two per CU, all resident at once (640 left a quarter-full second round); every chunk costs one
+  // N x K partial written and read back, so small outputs take what fills the chip and no more
+  int want = (512 + tiles - 1) / tiles;
   const int max_chunks = (M + 63) / 64;              // at least 4 MFMA steps per block
   if (want > max_chunks) want = max_chunks;
   if (want < 1) want = 1;
@@ -217,7 +236,8 @@ extern "C" int occ_linear_wgrad_bf16x3_f32(const float* dy, int64_t lddy, const 
                      (long)lddy, x, (long)ldx, part_w, db ? part_b : nullptr, M, N, K, MC, tk);
   OCC_CHECK_LAUNCH("linear_wgrad");
   const long NK = (long)N * K;
-  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((NK + 255) / 256)), dim3(256), 0, st, part_w,
+  const long red_blocks = (NK + 63) / 64 + (db ? (N + 63) / 64 : 0);
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)red_blocks), dim3(256), 0, st, part_w,
                      part_b, dw, db, NK, N, chunks);
   OCC_CHECK_LAUNCH("linear_wgrad_reduce");
   return OCC_OK;

@@ -29,6 +29,7 @@
 // reductions inside the 8-lane group.  Other D: one thread per (item, channel), mmcv's own shape,
 // with the channel sums reduced through LDS.
 #include <cstdlib>
+#include <string>
 #include "common.h"
 
 namespace occ {
@@ -211,6 +212,99 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(
       } else {
         atomicAdd(counter + gbase + bin + 1, 1);
       }
+    }
+  }
+}
+
+// Block-aggregated form of the two binning passes (default).  PMC on the training step (profiles/
+// r02_train_pmc_msda_bwd.txt) showed the wave-aggregated kernels above resident at < 2 waves per SIMD with 63-88 % of
+// their wave-cycles waiting: an SCA launch sends 8.7 M device-scope integer atomics, thousands of them to the SAME
+// counter of a coarse-level bin (32 pixels of the 15 x 25 map collect ~20 000 row items), and same-address
+// device-scope atomics retire one round trip at a time.  Here one 1024-thread block owns 1024 consecutive
+// (query, point) samples of ONE (batch, head, level); the level's bins (<= a few hundred) are a dense histogram in
+// LDS (ds_add is cheap and returns the sample's slot inside the block), and the block issues ONE global atomic per
+// bin it touched: ~30 per 1024 samples instead of ~600, and a hot counter sees one atomic per block (77 per SCA
+// launch instead of ~3 700).
+constexpr int kBinBlockThreads = 1024;
+
+template <bool FILL>
+__global__ __launch_bounds__(kBinBlockThreads) void msda_bwd_bin_block_kernel(
+    const int64_t* __restrict__ shapes, const float* __restrict__ loc, const float* __restrict__ attn,
+    const unsigned char* __restrict__ nzflag, int* __restrict__ counter, BwdItem* __restrict__ items, int M,
+    int L, int Lq, int P, int bins_per_bm, int blocks_per_bml) {
+  extern __shared__ int bin_lds[];                    // [nb] block histogram, then (FILL) [nb] global bases
+  const int tid = threadIdx.x;
+  const int chunk = (int)(blockIdx.x % (unsigned)blocks_per_bml);
+  long rest = blockIdx.x / (unsigned)blocks_per_bml;
+  const int l = (int)(rest % L); rest /= L;
+  const int m = (int)(rest % M);
+  const long b = rest / M;
+  int binoff = 0, H = 0, W = 0;
+  for (int i = 0; i <= l; ++i) {
+    H = (int)shapes[2 * i]; W = (int)shapes[2 * i + 1];
+    if (i < l) binoff += (H * W + kBinPix - 1) / kBinPix;
+  }
+  const int nb = (H * W + kBinPix - 1) / kBinPix;
+  int* hist = bin_lds;
+  int* gbase_of = bin_lds + nb;
+  for (int i = tid; i < nb; i += kBinBlockThreads) hist[i] = 0;
+  __syncthreads();
+
+  const long qp_n = (long)Lq * P;
+  const long qp_raw = (long)chunk * kBinBlockThreads + tid;
+  const bool in_grid = qp_raw < qp_n;
+  const long qp = in_grid ? qp_raw : qp_n - 1;
+  const int q = (int)(qp / P), p = (int)(qp - (long)q * P);
+  const long item = (b * Lq + q) * M + m;             // (b, q, m)
+  const long si = (item * L + l) * P + p;
+  const unsigned char fl = nzflag[item];
+  const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
+  const float a = attn[si];
+  const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
+  const bool ok = in_grid && fl != 0 && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h_low = (int)hf, w_low = (int)wf;
+  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+  const bool l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+  const bool both = l_ok && r_ok;
+
+  // same row items as msda_bwd_bin_kernel: per bilinear row one item at the left pixel's bin (two single items when
+  // the pair straddles a bin edge)
+  bool valid[2], split[2];
+  int bin[2], in[2], slot[2], slot2[2];
+  float i0[2], i1[2], wr_[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int hy = h_low + r;
+    valid[r] = ok && hy >= 0 && hy <= H - 1;
+    const float wy = (r ? lh : hh) * a;
+    const float wl = l_ok ? wy * hw : 0.f, wr = r_ok ? wy * lw : 0.f;
+    const int pl = hy * W + (l_ok ? w_low : w_low + 1);
+    bin[r] = valid[r] ? pl / kBinPix : 0;
+    in[r] = pl - bin[r] * kBinPix;
+    split[r] = valid[r] && both && in[r] == kBinPix - 1;
+    i0[r] = l_ok ? wl : wr;
+    i1[r] = (both && !split[r]) ? wr : 0.f;
+    wr_[r] = wr;
+    slot[r] = slot2[r] = 0;
+    if (valid[r]) slot[r] = atomicAdd(&hist[bin[r]], 1);            // LDS
+    if (split[r]) slot2[r] = atomicAdd(&hist[bin[r] + 1], 1);
+  }
+  __syncthreads();
+  int* gcnt = counter + (long)(b * M + m) * bins_per_bm + binoff;
+  for (int i = tid; i < nb; i += kBinBlockThreads) {
+    const int c = hist[i];
+    if (c > 0) {
+      if (FILL) gbase_of[i] = atomicAdd(gcnt + i, c);               // global: one per (block, touched bin)
+      else atomicAdd(gcnt + i, c);
+    }
+  }
+  if (FILL) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (valid[r]) items[gbase_of[bin[r]] + slot[r]] = BwdItem{(q << 5) | in[r], i0[r], i1[r]};
+      if (split[r]) items[gbase_of[bin[r] + 1] + slot2[r]] = BwdItem{(q << 5) | 0, wr_[r], 0.f};
     }
   }
 }
@@ -469,11 +563,32 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
       hipLaunchKernelGGL(msda_bwd_d32_kernel<false>, grid1, dim3(256), 0, st, value, spatial_shapes,
                          level_start_index, sampling_loc, attn_weight, grad_output, grad_value,
                          grad_sampling_loc, grad_attn_weight, flags, S, M, L, Lq, P, n_items);
-      hipLaunchKernelGGL(msda_bwd_bin_kernel<false>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
-                         attn_weight, flags, counts, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
+      // binning passes: block-aggregated (default) or the wave-aggregated kernels (OCC_MSDA_BWD_BIN=wave, or a
+      // level with more bins than the LDS histogram holds)
+      static const bool wave_bins = getenv("OCC_MSDA_BWD_BIN") != nullptr &&
+                                    std::string(getenv("OCC_MSDA_BWD_BIN")) == "wave";
+      const long qp_n = (long)Lq * P;
+      const long blocks_per_bml = (qp_n + kBinBlockThreads - 1) / kBinBlockThreads;
+      const long grid_b = (long)B * M * L * blocks_per_bml;
+      const size_t lds_b = (size_t)(S / kBinPix + 2) * 2 * sizeof(int);        // >= 2 * bins of the largest level
+      const bool block_bins = !wave_bins && lds_b <= 48 * 1024 && grid_b < (1L << 31);
+      if (block_bins) {
+        hipLaunchKernelGGL(msda_bwd_bin_block_kernel<false>, dim3((unsigned)grid_b), dim3(kBinBlockThreads), lds_b,
+                           st, spatial_shapes, sampling_loc, attn_weight, flags, counts, items, M, L, Lq, P,
+                           w.bins_per_bm, (int)blocks_per_bml);
+      } else {
+        hipLaunchKernelGGL(msda_bwd_bin_kernel<false>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
+                           attn_weight, flags, counts, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
+      }
       hipLaunchKernelGGL(msda_bwd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, cursor, (int)w.n_bins);
-      hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
-                         attn_weight, flags, cursor, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
+      if (block_bins) {
+        hipLaunchKernelGGL(msda_bwd_bin_block_kernel<true>, dim3((unsigned)grid_b), dim3(kBinBlockThreads), lds_b,
+                           st, spatial_shapes, sampling_loc, attn_weight, flags, cursor, items, M, L, Lq, P,
+                           w.bins_per_bm, (int)blocks_per_bml);
+      } else {
+        hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
+                           attn_weight, flags, cursor, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
+      }
       hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)w.n_bins), dim3(256), 0, st,
                          spatial_shapes, level_start_index, counts, items, grad_output, grad_value, S, M, L, Lq,
                          w.bins_per_bm, w.n_bins);

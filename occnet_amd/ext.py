@@ -560,8 +560,15 @@ def linear_wgrad(dy, x, with_bias=True):
     """Weight / bias gradient of out = x @ W^T + b on the bf16x3 matrix-core kernel (csrc/linear_wgrad.hip):
     dW (N, K) = dy^T @ x, db (N) = dy.sum(rows).  dy (…, N), x (…, K) float32 device tensors with the same leading
     shape and unit column stride.  Deterministic (chunked reduction, fixed order)."""
-    dy_, M, N, lddy = _rows2d("dy", dy)
-    x_, Mx, K, ldx = _rows2d("x", x)
+    def rows(name, t):          # dword loads: any row stride / alignment, unit column stride
+        _need_cuda_f32(name, t, contiguous=False)
+        if t.dim() == 2 and t.stride(1) == 1:
+            return t, t.shape[0], t.shape[1], t.stride(0)
+        if t.is_contiguous():
+            return t, t.numel() // t.shape[-1], t.shape[-1], t.shape[-1]
+        raise OccAmdError(f"linear_wgrad: {name} must be contiguous or a 2-D row-strided view")
+    dy_, M, N, lddy = rows("dy", dy)
+    x_, Mx, K, ldx = rows("x", x)
     if Mx != M:
         raise OccAmdError("linear_wgrad: dy and x differ in rows")
     dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
@@ -606,19 +613,48 @@ class LinearX3Function(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class LinearWgradFunction(torch.autograd.Function):
+    """y = x @ W^T + b for the shapes linear_bf16x3 does not cover (the occupancy heads' 64 -> 17 and 64 -> 2 layers:
+    N not a multiple of 16) but whose WEIGHT gradient is the expensive part: 640 000 voxels reduced into a 17 x 64
+    matrix is a 1.0-1.5 ms fp32 library GEMM plus a 1.6 ms column reduction for the bias in ATen; linear_wgrad does
+    both in one pass.  Forward and dx stay library GEMMs (thin, fast)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x, weight = ctx.saved_tensors
+        gout = gout.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gout.matmul(weight)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = linear_wgrad(gout, x if x.is_contiguous() else x.contiguous(), with_bias=ctx.has_bias)
+        return gx, gw, gb
+
+
 TRAIN_LINEAR = os.environ.get("OCC_TRAIN_LINEAR", "x3")      # 'x3' (own kernels) or 'torch' (F.linear + ATen autograd)
+TRAIN_WGRAD_ONLY = os.environ.get("OCC_TRAIN_WGRAD_ONLY", "1") != "0"   # LinearWgradFunction for the other shapes
 
 
 def linear_autograd(x, weight, bias=None, act=None):
     """F.linear(+ReLU) that is differentiable: on a float32 device tensor with supported shapes the forward and the
-    backward run on the bf16x3 kernels; anything else takes F.linear (still on the device: no CPU branch here)."""
-    ok = (TRAIN_LINEAR == "x3" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
-          and weight.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0 and weight.is_contiguous()
-          and torch.is_grad_enabled() and not torch.is_autocast_enabled())
-    if ok:
+    backward run on the bf16x3 kernels; shapes the forward kernel does not cover keep the library forward and take
+    only the weight/bias gradient kernel (many rows); anything else is F.linear (still on the device: no CPU
+    branch here)."""
+    dev_ok = (TRAIN_LINEAR == "x3" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+              and weight.is_contiguous() and torch.is_grad_enabled() and not torch.is_autocast_enabled())
+    if dev_ok and weight.shape[1] % 16 == 0 and weight.shape[0] % 16 == 0:
         if not (x.is_contiguous() or (x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0)):
             x = x.contiguous()
         return LinearX3Function.apply(x, weight, bias, act)
+    if dev_ok and TRAIN_WGRAD_ONLY and act is None and x.numel() // x.shape[-1] >= 4096:
+        return LinearWgradFunction.apply(x, weight, bias)
     y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if act == 'relu' else y
 

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import cache_epoch
 from .bricks import BaseModule, ConvModule
 from .registry import BACKBONES, NECKS
 
@@ -23,9 +24,19 @@ def conv_bn_folded(x, conv, bn):
     activation: the reference trains its ResNet with `norm_eval=True` (projects/configs/bevformer/
     bevformer_base_occ.py:55), and torch's eval-mode BN backward costs two passes over every activation
     (batch_norm_backward_reduce + elementwise: 19 ms of the 137 ms training step on MI355X)."""
-    s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    # the statistics are frozen (eval mode): 1/sqrt(var + eps) and mean/sqrt(var + eps) are constants, cached per
+    # BatchNorm until a buffer is written (three small launches per convolution instead of six, fewer in backward)
+    key = (bn.running_mean._version, bn.running_var._version, bn.running_var.data_ptr(), cache_epoch())
+    cached = getattr(bn, '_occ_fold', None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            rstd = torch.rsqrt(bn.running_var + bn.eps)
+            cached = (key, rstd, bn.running_mean * rstd)
+        object.__setattr__(bn, '_occ_fold', cached)
+    _, rstd, mean_rstd = cached
+    s = bn.weight * rstd
     w = conv.weight * s.view(-1, 1, 1, 1)
-    b = bn.bias - bn.running_mean * s
+    b = torch.addcmul(bn.bias, bn.weight, mean_rstd, value=-1.0)
     if conv.bias is not None:
         b = b + conv.bias * s
     return F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)

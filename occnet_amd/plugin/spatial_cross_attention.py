@@ -16,6 +16,7 @@ There is no CPU branch: host tensors raise (the reference's CPU selector at :386
 only in oracle/).
 """
 import math
+import os
 import warnings
 
 import torch
@@ -102,31 +103,48 @@ class MSDeformableAttention3D(BaseModule):
         n_off = self.sampling_offsets.out_features
         return out[..., :n_off], out[..., n_off:]
 
+    def query_linears_autograd(self, query):
+        """Training form of query_linears: sampling_offsets and attention_weights as ONE differentiable GEMM
+        (the concatenation is part of the graph, so both layers receive their gradients) -> (…, n_off + n_att)."""
+        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
+        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+        return ext.linear_autograd(query, w, b)
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, **kwargs):
+                level_start_index=None, query_proj=None, **kwargs):
         """Unfused form, reference semantics: query (bs, num_query, C), value (bs, num_value, C),
-        reference_points (bs, num_query, Z, 2) -> (bs, num_query, C)."""
+        reference_points (bs, num_query, Z, 2) -> (bs, num_query, C).  `query_proj` (bs, num_query, n_off + n_att):
+        the two query-side Linears already applied (SpatialCrossAttention computes them once per BEV query and
+        rebatches the RESULT per camera instead of the input — a Linear is row-wise, so that is the same function
+        with 40 000 instead of 6 x 9 900 GEMM rows); `query` is then ignored."""
         if value is None:
             value = query
         if identity is None:
             identity = query
-        if query_pos is not None:
+        if query_pos is not None and query_proj is None:
             query = query + query_pos
         if not self.batch_first:
-            query = query.permute(1, 0, 2)
+            query = None if query_proj is not None else query.permute(1, 0, 2)
             value = value.permute(1, 0, 2)
         _require_device(value, 'MSDeformableAttention3D')
-        bs, num_query, _ = query.shape
+        bs, num_query, _ = (query_proj if query_proj is not None else query).shape
         bs, num_value, _ = value.shape
         value = self.value_proj(value)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         value = value.view(bs, num_value, self.num_heads, -1)
-        sampling_offsets = self.sampling_offsets(query).view(
-            bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
-        attention_weights = self.attention_weights(query).view(
-            bs, num_query, self.num_heads, self.num_levels * self.num_points)
+        if query_proj is not None:
+            n_off = self.sampling_offsets.out_features
+            sampling_offsets = query_proj[..., :n_off].reshape(
+                bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+            attention_weights = query_proj[..., n_off:].reshape(
+                bs, num_query, self.num_heads, self.num_levels * self.num_points)
+        else:
+            sampling_offsets = self.sampling_offsets(query).view(
+                bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+            attention_weights = self.attention_weights(query).view(
+                bs, num_query, self.num_heads, self.num_levels * self.num_points)
         attention_weights = attention_weights.softmax(-1).view(
             bs, num_query, self.num_heads, self.num_levels, self.num_points)
         if reference_points.shape[-1] != 2:
@@ -237,39 +255,76 @@ class SpatialCrossAttention(BaseModule):
             return None
 
     # ------------------------------------------------------------------ unfused path
+    # False (OCC_SCA_TRAIN_REBATCH=reference): the reference's literal order (rebatch the queries, then the Linears)
+    rebatch_projected = os.environ.get("OCC_SCA_TRAIN_REBATCH", "projected") != "reference"
+
+    def _rebatch_plan(self, bev_mask, reference_points_cam):
+        """Visible-query lists of every camera from batch element 0's mask (reference :138-140) as ONE padded index
+        tensor, built once per mask TENSOR (the encoder hands the same bev_mask to all layers; nonzero() is a host
+        sync): idx (num_cams * max_len,) BEV query per padded row (clamped), valid (num_cams * max_len, 1) 0/1,
+        ref (bs, num_cams, max_len, Z, 2) the rebatched reference points (zeros on padded rows, as the reference)."""
+        plan = getattr(bev_mask, '_occ_rebatch', None)
+        if plan is not None:
+            return plan
+        indexes = getattr(bev_mask, '_occ_indexes', None)
+        if indexes is None:
+            indexes = [m[0].sum(-1).nonzero().squeeze(-1) for m in bev_mask]
+        max_len = max(len(each) for each in indexes)
+        nc = len(indexes)
+        dev = bev_mask.device
+        idx = torch.zeros(nc, max_len, dtype=torch.long, device=dev)
+        valid = torch.zeros(nc, max_len, dtype=torch.float32, device=dev)
+        for i, each in enumerate(indexes):
+            idx[i, :len(each)] = each
+            valid[i, :len(each)] = 1.0
+        cam = torch.arange(nc, device=dev).view(nc, 1).expand(nc, max_len)
+        # reference_points_cam (num_cams, bs, Q, Z, 2) -> (bs, num_cams, max_len, Z, 2)
+        ref = reference_points_cam[cam, :, idx].permute(2, 0, 1, 3, 4) * valid.view(1, nc, max_len, 1, 1)
+        plan = dict(indexes=indexes, max_len=max_len, idx=idx.view(-1), valid=valid.view(-1, 1),
+                    ref=ref.contiguous())
+        try:
+            bev_mask._occ_indexes = indexes
+            bev_mask._occ_rebatch = plan
+        except AttributeError:
+            pass
+        return plan
+
     def _unfused_slots(self, query, key, value, reference_points_cam, bev_mask, spatial_shapes,
                        level_start_index):
         bs, num_query, _ = query.size()
         D = reference_points_cam.size(3)
-        slots = torch.zeros_like(query)
-        # visible-query lists come from batch element 0's mask (reference :138-140).  nonzero() is a host sync: the
-        # lists are built once per mask TENSOR (the encoder hands the same bev_mask to every layer) instead of once
-        # per layer and camera
-        cached = getattr(bev_mask, '_occ_indexes', None)
-        if cached is None:
-            cached = [m[0].sum(-1).nonzero().squeeze(-1) for m in bev_mask]
-            try:
-                bev_mask._occ_indexes = cached
-            except AttributeError:
-                pass
-        indexes = cached
-        max_len = max(len(each) for each in indexes)
-        queries_rebatch = query.new_zeros([bs, self.num_cams, max_len, self.embed_dims])
-        reference_points_rebatch = reference_points_cam.new_zeros([bs, self.num_cams, max_len, D, 2])
-        for i, idx in enumerate(indexes):
-            queries_rebatch[:, i, :len(idx)] = query[:, idx]
-            reference_points_rebatch[:, i, :len(idx)] = reference_points_cam[i][:, idx]
+        plan = self._rebatch_plan(bev_mask, reference_points_cam)
+        indexes, max_len = plan['indexes'], plan['max_len']
         num_cams, l, bs, embed_dims = key.shape
         key = key.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
         value = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
-        queries = self.deformable_attention(
-            query=queries_rebatch.view(bs * self.num_cams, max_len, self.embed_dims), key=key,
-            value=value,
-            reference_points=reference_points_rebatch.view(bs * self.num_cams, max_len, D, 2),
-            spatial_shapes=spatial_shapes, level_start_index=level_start_index).view(
-                bs, self.num_cams, max_len, self.embed_dims)
-        for i, idx in enumerate(indexes):
-            slots[:, idx] += queries[:, i, :len(idx)]
+        da = self.deformable_attention
+        if self.rebatch_projected and hasattr(da, 'query_linears_autograd') and query.is_cuda:
+            # the two query-side Linears once per BEV query; their OUTPUT rows are then dealt to the cameras
+            # (index_select + padding mask: two launches instead of 12 indexed copies, and a third fewer GEMM rows)
+            proj = da.query_linears_autograd(query)                                     # (bs, Q, n_off + n_att)
+            proj_rb = proj.index_select(1, plan['idx']) * plan['valid']                 # (bs, cams * max_len, .)
+            queries = da(query=None, key=key, value=value,
+                         query_proj=proj_rb.view(bs * self.num_cams, max_len, proj.shape[-1]),
+                         reference_points=plan['ref'].view(bs * self.num_cams, max_len, D, 2),
+                         spatial_shapes=spatial_shapes, level_start_index=level_start_index)
+            slots = query.new_zeros(bs, num_query, self.embed_dims).index_add_(
+                1, plan['idx'], queries.view(bs, self.num_cams * max_len, self.embed_dims) * plan['valid'])
+        else:
+            slots = torch.zeros_like(query)
+            queries_rebatch = query.new_zeros([bs, self.num_cams, max_len, self.embed_dims])
+            reference_points_rebatch = reference_points_cam.new_zeros([bs, self.num_cams, max_len, D, 2])
+            for i, idx in enumerate(indexes):
+                queries_rebatch[:, i, :len(idx)] = query[:, idx]
+                reference_points_rebatch[:, i, :len(idx)] = reference_points_cam[i][:, idx]
+            queries = da(
+                query=queries_rebatch.view(bs * self.num_cams, max_len, self.embed_dims), key=key,
+                value=value,
+                reference_points=reference_points_rebatch.view(bs * self.num_cams, max_len, D, 2),
+                spatial_shapes=spatial_shapes, level_start_index=level_start_index).view(
+                    bs, self.num_cams, max_len, self.embed_dims)
+            for i, idx in enumerate(indexes):
+                slots[:, idx] += queries[:, i, :len(idx)]
         count = (bev_mask.sum(-1) > 0).permute(1, 2, 0).sum(-1)
         count = torch.clamp(count, min=1.0)
         return slots / count[..., None]

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import cache_epoch, ext
 from .._lib import OccAmdUnsupported
-from .bricks import BaseModule, ConvModule
+from .bricks import BaseModule, ConvModule, X3Linear
 from .registry import TRANSFORMER, build_transformer_layer_sequence
 from .spatial_cross_attention import MSDeformableAttention3D, _require_device
 from .temporal_self_attention import TemporalSelfAttention
@@ -170,10 +170,12 @@ class TransformerOcc(BaseModule):
                            act_cfg=act_cfg),
                 ConvModule(out_dim, out_dim, kernel_size=3, stride=1, padding=1, bias=use_bias_3d,
                            conv_cfg=dict(type='Conv3d'), norm_cfg=norm_cfg_3d, act_cfg=act_cfg))
-        self.predicter = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.Softplus(),
-                                       nn.Linear(out_dim * 2, num_classes))
-        self.flow_predicter = nn.Sequential(nn.Linear(out_dim, out_dim * 2), nn.ReLU(),
-                                            nn.Linear(out_dim * 2, 2))
+        # X3Linear: nn.Linear whose training forward/backward run on the own kernels (640 000 voxel rows: the weight
+        # and bias gradients are the expensive part in ATen)
+        self.predicter = nn.Sequential(X3Linear(out_dim, out_dim * 2), nn.Softplus(),
+                                       X3Linear(out_dim * 2, num_classes))
+        self.flow_predicter = nn.Sequential(X3Linear(out_dim, out_dim * 2), nn.ReLU(),
+                                            X3Linear(out_dim * 2, 2))
         self.two_stage_num_proposals = two_stage_num_proposals
         self.init_layers()
         self.rotate_center = rotate_center

@@ -161,3 +161,36 @@ def test_head_forward_with_rotated_history_bev():
         d = maxdiff(out_p[k], out_o[k])
         print(f"rotated prev_bev {k}: max|hip - oracle| = {d:.3e}")
         assert d < TOL
+
+
+def test_sca_training_path_projected_rebatch_equals_reference_order():
+    """SpatialCrossAttention's autograd path: the query-side Linears applied once per BEV query with their OUTPUT
+    rows dealt to the cameras (default) vs the reference's literal order (rebatch the queries, then the Linears)
+    — same losses, same parameter gradients (a Linear is row-wise; only the summation order of the weight gradient
+    differs)."""
+    from occnet_amd.plugin.spatial_cross_attention import SpatialCrossAttention
+    g = small_cfg(bev=(20, 20), num_layers=2)
+    feats = synthetic.make_features(g, seed=5)
+    metas = synthetic.make_img_metas(g)
+    sem, flow, mask = _targets(g)
+    res = {}
+    for flag in (True, False):
+        SpatialCrossAttention.rebatch_projected = flag
+        try:
+            prod, _ = build_pair(g, seed=5)
+            out = prod([f.cuda() for f in feats], metas)
+            lp = prod.loss(sem.cuda(), flow.cuda(), mask.cuda(), out)
+            (lp['loss_occ'] + lp['loss_flow']).backward()
+            res[flag] = ({k: float(v) for k, v in lp.items()},
+                         {n: p.grad.detach().clone() for n, p in prod.named_parameters() if p.grad is not None})
+        finally:
+            SpatialCrossAttention.rebatch_projected = True
+    for k in res[True][0]:
+        assert abs(res[True][0][k] - res[False][0][k]) < 1e-5
+    assert res[True][1].keys() == res[False][1].keys()
+    worst = 0.0
+    for n, gr in res[False][1].items():
+        d = float((res[True][1][n] - gr).abs().max())
+        assert d < 1e-3 * float(gr.abs().max()) + 1e-5, (n, d)
+        worst = max(worst, d / (float(gr.abs().max()) + 1e-12))
+    print(f"projected-rebatch vs reference order: worst relative gradient difference {worst:.2e}")

@@ -310,46 +310,72 @@ __global__ __launch_bounds__(kBinBlockThreads) void msda_bwd_bin_block_kernel(
 }
 
 // exclusive prefix sum of counts[0..n) into counts (in place) and cursor; counts[n] = total.  One block.
+// The same pass writes the REPLAY WORK LIST: every non-empty bin becomes ceil(count / kReplayCap) entries
+// {bin, first item, last item + 1, split?} (second prefix sum over the entry counts), work_count[0] = entries.
+// A bin of the coarsest FPN level collects ~50 000 row items; replayed by ONE block (latency-bound: ~0.2 us per
+// item and half-wave) those few blocks were the whole kernel (PMC: 0.6 waves per SIMD resident, 2.3 ms per SCA
+// launch); split into 2048-item pieces they spread over the chip, and empty bins cost no block at all.
+constexpr int kReplayCap = 2048;
+
 __global__ __launch_bounds__(1024) void msda_bwd_scan_kernel(int* __restrict__ counts, int* __restrict__ cursor,
-                                                             int n) {
+                                                             int n, int4* __restrict__ work,
+                                                             int* __restrict__ work_count) {
   __shared__ int part[1024];
+  __shared__ int wpart[1024];
   const int tid = threadIdx.x;
   const int per = (n + 1023) / 1024;
   const int lo = tid * per, hi = min(lo + per, n);
-  int sum = 0;
-  for (int i = lo; i < hi; ++i) sum += counts[i];
+  int sum = 0, wsum = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int c = counts[i];
+    sum += c;
+    wsum += (c + kReplayCap - 1) / kReplayCap;
+  }
   part[tid] = sum;
+  wpart[tid] = wsum;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {                // Hillis-Steele inclusive scan of the partials
     const int v = tid >= d ? part[tid - d] : 0;
+    const int wv = tid >= d ? wpart[tid - d] : 0;
     __syncthreads();
     part[tid] += v;
+    wpart[tid] += wv;
     __syncthreads();
   }
   int run = tid ? part[tid - 1] : 0;
+  int wrun = tid ? wpart[tid - 1] : 0;
   for (int i = lo; i < hi; ++i) {
     const int c = counts[i];
     counts[i] = run;
     cursor[i] = run;
+    const int nw = (c + kReplayCap - 1) / kReplayCap;
+    for (int k = 0; k < nw; ++k)
+      work[wrun + k] = make_int4(i, run + k * kReplayCap, min(run + c, run + (k + 1) * kReplayCap), nw > 1);
+    wrun += nw;
     run += c;
   }
-  if (tid == 1023) counts[n] = part[1023];
+  if (tid == 1023) {
+    counts[n] = part[1023];
+    work_count[0] = wpart[1023];
+  }
 }
 
-// one block = one bin: its items offsets[bin] .. offsets[bin + 1] are dealt to the block's 8 half-waves, each with
+// one block = one work-list entry (a bin, or a 2048-item piece of a hot bin): its items are dealt to the block's 8 half-waves, each with
 // a private 32 pixels x 32 channels accumulator in LDS (lane = channel; plain read-add-write, no conflicts); the 8
 // copies are summed and added to grad_value by the block, the bin's only writer.  (One WAVE per bin left the hot
 // bins of the coarse FPN levels — thousands of items — on a single wave: 24 ms of a training step.)
 __global__ __launch_bounds__(256) void msda_bwd_replay_kernel(
-    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lstart, const int* __restrict__ offsets,
-    const BwdItem* __restrict__ items, const float* __restrict__ grad_out, float* __restrict__ grad_value, int S,
-    int M, int L, int Lq, int bins_per_bm, long n_bins) {
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lstart, const int4* __restrict__ work,
+    const int* __restrict__ work_count, const BwdItem* __restrict__ items, const float* __restrict__ grad_out,
+    float* __restrict__ grad_value, int S, int M, int L, int Lq, int bins_per_bm) {
   constexpr int D = 32;
   __shared__ float acc_s[8][(kBinPix + 1) * D];        // per half-wave; +1 pixel: the w1 lane of pixel 31
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ch = lane & 31;
-  const long bin_g = blockIdx.x;
-  const int beg = offsets[bin_g], end = offsets[bin_g + 1];
-  if (beg == end) return;                              // block-uniform: nothing to add
+  if ((int)blockIdx.x >= work_count[0]) return;        // the grid is an upper bound of the work list
+  const int4 wk = work[blockIdx.x];
+  const long bin_g = wk.x;
+  const int beg = wk.y, end = wk.z;
+  const bool shared_bin = wk.w != 0;                   // other blocks add into the same 32 pixels
   const int hw = wave * 2 + half;
   float* acc = acc_s[hw];
 #pragma unroll
@@ -400,10 +426,18 @@ __global__ __launch_bounds__(256) void msda_bwd_replay_kernel(
       const float4 u = *reinterpret_cast<const float4*>(acc_s[k] + px * D + c4 * 4);
       sum.x += u.x; sum.y += u.y; sum.z += u.z; sum.w += u.w;
     }
-    float4* dst = reinterpret_cast<float4*>(grad_value + ((b * S + st + p0 + px) * M + m) * D + c4 * 4);
-    float4 o = *dst;
-    o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += sum.w;
-    *dst = o;
+    float* dstf = grad_value + ((b * S + st + p0 + px) * M + m) * D + c4 * 4;
+    if (shared_bin) {                                  // a split bin: a few dozen blocks per bin at most
+      unsafeAtomicAdd(dstf + 0, sum.x);
+      unsafeAtomicAdd(dstf + 1, sum.y);
+      unsafeAtomicAdd(dstf + 2, sum.z);
+      unsafeAtomicAdd(dstf + 3, sum.w);
+    } else {
+      float4* dst = reinterpret_cast<float4*>(dstf);
+      float4 o = *dst;
+      o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += sum.w;
+      *dst = o;
+    }
   }
 }
 
@@ -482,7 +516,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
 }  // namespace occ
 
 namespace occ {
-struct BwdWsLayout { size_t off_cnt, off_cur, off_items, bytes; long n_bins, n_samples, max_items; int bins_per_bm; bool ok; };
+struct BwdWsLayout { size_t off_cnt, off_cur, off_work, off_items, bytes; long n_bins, n_samples, max_items, work_cap; int bins_per_bm; bool ok; };
 static BwdWsLayout bwd_ws_layout(int B, int S, int M, int L, int Lq, int P) {
   BwdWsLayout w;
   const long n_items = (long)B * Lq * M;
@@ -492,9 +526,11 @@ static BwdWsLayout bwd_ws_layout(int B, int S, int M, int L, int Lq, int P) {
   w.max_items = 4 * w.n_samples;                                      // 2 rows x (1 or 2 items)
   w.off_cnt = ((size_t)n_items + 255) & ~(size_t)255;
   w.off_cur = w.off_cnt + (((size_t)(w.n_bins + 1) * 4 + 255) & ~(size_t)255);
-  w.off_items = w.off_cur + (((size_t)(w.n_bins + 1) * 4 + 255) & ~(size_t)255);
+  w.off_work = w.off_cur + (((size_t)(w.n_bins + 1) * 4 + 255) & ~(size_t)255);
+  w.work_cap = w.n_bins + w.max_items / kReplayCap + 1;               // >= sum_bins ceil(count / kReplayCap)
+  w.off_items = w.off_work + (((size_t)(w.work_cap + 1) * 16 + 255) & ~(size_t)255);   // [0] = entry count
   w.bytes = w.off_items + (size_t)w.max_items * sizeof(BwdItem);
-  w.ok = Lq < (1 << 26) && w.n_bins < (1L << 30) && w.max_items < (1L << 31);
+  w.ok = Lq < (1 << 26) && w.n_bins < (1L << 30) && w.max_items < (1L << 31) && w.work_cap < (1L << 31);
   return w;
 }
 }  // namespace occ
@@ -559,6 +595,8 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
       int* counts = reinterpret_cast<int*>(ws + w.off_cnt);
       int* cursor = reinterpret_cast<int*>(ws + w.off_cur);
       BwdItem* items = reinterpret_cast<BwdItem*>(ws + w.off_items);
+      int* work_count = reinterpret_cast<int*>(ws + w.off_work);
+      int4* work = reinterpret_cast<int4*>(ws + w.off_work + 16);
       const dim3 grid_s((unsigned)((w.n_samples + 255) / 256));
       hipLaunchKernelGGL(msda_bwd_d32_kernel<false>, grid1, dim3(256), 0, st, value, spatial_shapes,
                          level_start_index, sampling_loc, attn_weight, grad_output, grad_value,
@@ -580,7 +618,8 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
         hipLaunchKernelGGL(msda_bwd_bin_kernel<false>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
                            attn_weight, flags, counts, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
       }
-      hipLaunchKernelGGL(msda_bwd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, cursor, (int)w.n_bins);
+      hipLaunchKernelGGL(msda_bwd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, cursor, (int)w.n_bins, work,
+                         work_count);
       if (block_bins) {
         hipLaunchKernelGGL(msda_bwd_bin_block_kernel<true>, dim3((unsigned)grid_b), dim3(kBinBlockThreads), lds_b,
                            st, spatial_shapes, sampling_loc, attn_weight, flags, cursor, items, M, L, Lq, P,
@@ -589,9 +628,9 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
         hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
                            attn_weight, flags, cursor, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
       }
-      hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)w.n_bins), dim3(256), 0, st,
-                         spatial_shapes, level_start_index, counts, items, grad_output, grad_value, S, M, L, Lq,
-                         w.bins_per_bm, w.n_bins);
+      hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)w.work_cap), dim3(256), 0, st,
+                         spatial_shapes, level_start_index, work, work_count, items, grad_output, grad_value, S, M,
+                         L, Lq, w.bins_per_bm);
       if (own) (void)hipFreeAsync(ws, st);
     } else {
       if (own && ws) (void)hipFreeAsync(ws, st);

@@ -47,6 +47,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12   # B/s, MI355X spec (guides/MI355X_MICROARCH.md)
 L1_PEAK = 256 * 64 * 2.4e9   # B/s through the texture-addresser / vector-L1 path: 256 CU x 64 B/clk x 2.4 GHz
+L1_MEASURED_PEAK = 256 * 0.39 * 128 * 2.4e9   # measured ceiling of that path for 128-byte row gathers (cache-resident rows)
 
 
 def self_launch(args):
@@ -585,6 +586,10 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "frac_hbm": (traffic / sec / HBM_PEAK) if traffic else None,
                 "frac_l1": l1_bytes / sec / L1_PEAK, "l1_bytes_per_launch": l1_bytes, "l1_peak_gbps": L1_PEAK / 1e9,
+                # what the TA/L1 path DELIVERS for this access shape (8 lanes x 16 B per 128-byte row, 16 loads in
+                # flight, 3 waves/SIMD) on cache-resident rows: 0.39 rows/clk/CU = 50 B/clk/CU, measured with
+                # tools_dev/ta_probe.hip (profiles/r02_ta_row_gather_probe_3waves.txt); rows from HBM: 0.091
+                "l1_measured_peak_gbps": L1_MEASURED_PEAK / 1e9, "frac_l1_measured": l1_bytes / sec / L1_MEASURED_PEAK,
                 "compulsory_bytes": compulsory,
                 "compulsory_frac_hbm": compulsory / sec / HBM_PEAK,
                 "traffic_over_compulsory": (traffic / compulsory) if traffic else None,

@@ -262,6 +262,14 @@ int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2
                           const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N,
                           void* stream);
 
+/* Row gather-sum (csrc/rows_index.hip): out[b][r][:] = sum over k < K with index[r*K + k] >= 0 of x[b][index[r*K + k]][:].
+ * x (B, rows_in, F) with batch stride x_batch_stride (floats), index (rows_out, K) int64 (-1 = no row), out
+ * (B, rows_out, F) contiguous; F % 4 == 0, 16-byte aligned.  K = 1: SpatialCrossAttention's per-camera rebatch of the
+ * visible BEV queries (spatial_cross_attention.py:145-153); index = the inverse map: the scatter back into the BEV
+ * slots (:165-167); each is the other's gradient, so the training path needs no float-atomic index_add. */
+int occ_rows_gather_sum_f32(const float* x, int64_t x_batch_stride, const int64_t* index, int K, float* out, int B,
+                            int64_t rows_out, int64_t rows_in, int F, void* stream);
+
 /* Training partner of occ_linear_bf16x3_f32 (csrc/linear_wgrad.hip): weight and bias gradient of a Linear,
  *     dw[n][k] = sum_m dy[m][n] * x[m][k]      db[n] = sum_m dy[m][n]      (db may be NULL)
  * on the bf16 matrix cores with the same hi/lo operand split (product error <= 2^-16), f32 accumulation.

@@ -67,6 +67,75 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
   if (((any >> (threadIdx.x & 56)) & 0xffull) == 0ull) return;
   if (!VALUE_ATOMICS && c4 == 0) nzflag[item] = 1;     // the binning kernels skip the other items
   const int LP = L * P;
+  if (!VALUE_ATOMICS) {
+    // four samples per step, their 16 corner rows requested together: every load is unconditional (a corner outside
+    // the map reads row 0 of the batch entry and is replaced by 0 afterwards), so nothing separates the loads of
+    // different samples.  One sample per step left 4 rows in flight per lane: 0.9 ms per SCA launch, latency-bound.
+    constexpr int U = 4;
+    for (int s0 = 0; s0 < LP; s0 += U) {
+      float4 v[U][4];
+      float lh_[U], lw_[U], a_[U], Hf[U], Wf[U];
+      bool ok[U][4], live[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = s0 + u < LP ? s0 + u : LP - 1;
+        live[u] = s0 + u < LP;
+        const int l = s / P;
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const long st = lstart[l];
+        const long si = item * LP + s;
+        const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
+        a_[u] = attn[si];
+        Hf[u] = (float)H; Wf[u] = (float)W;
+        const float h_im = xy.y * (float)H - 0.5f;
+        const float w_im = xy.x * (float)W - 0.5f;
+        const bool in = live[u] && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = (int)hf, w_low = (int)wf;
+        lh_[u] = in ? h_im - hf : 0.f;        // a non-finite location must give 0, not 0 * NaN
+        lw_[u] = in ? w_im - wf : 0.f;
+        const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
+        ok[u][0] = in && t_ok && l_ok; ok[u][1] = in && t_ok && r_ok;
+        ok[u][2] = in && b_ok && l_ok; ok[u][3] = in && b_ok && r_ok;
+        const long base = (st + (long)h_low * W + w_low) * row_stride;
+        v[u][0] = *reinterpret_cast<const float4*>(vb + (ok[u][0] ? base : 0));
+        v[u][1] = *reinterpret_cast<const float4*>(vb + (ok[u][1] ? base + row_stride : 0));
+        v[u][2] = *reinterpret_cast<const float4*>(vb + (ok[u][2] ? base + (long)W * row_stride : 0));
+        v[u][3] = *reinterpret_cast<const float4*>(vb + (ok[u][3] ? base + (long)(W + 1) * row_stride : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v1 = ok[u][0] ? v[u][0] : z4, v2 = ok[u][1] ? v[u][1] : z4;
+        const float4 v3 = ok[u][2] ? v[u][2] : z4, v4 = ok[u][3] ? v[u][3] : z4;
+        const float lh = lh_[u], lw = lw_[u], hh = 1.f - lh, hw = 1.f - lw, a = a_[u];
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const float tx[4] = {top.x, top.y, top.z, top.w};
+        const float a1[4] = {v1.x, v1.y, v1.z, v1.w}, a2[4] = {v2.x, v2.y, v2.z, v2.w};
+        const float a3[4] = {v3.x, v3.y, v3.z, v3.w}, a4[4] = {v4.x, v4.y, v4.z, v4.w};
+        float g_attn = 0.f, g_x = 0.f, g_y = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float ta = tx[k] * a;
+          g_attn += tx[k] * (w1 * a1[k] + w2 * a2[k] + w3 * a3[k] + w4 * a4[k]);
+          g_x += ta * (hh * (a2[k] - a1[k]) + lh * (a4[k] - a3[k]));
+          g_y += ta * (hw * (a3[k] - a1[k]) + lw * (a4[k] - a2[k]));
+        }
+        g_x *= Wf[u];
+        g_y *= Hf[u];
+        g_attn = group8_sum(g_attn);
+        g_x = group8_sum(g_x);
+        g_y = group8_sum(g_y);
+        if (c4 == 0 && live[u]) {
+          const long si = item * LP + s0 + u;
+          grad_attn[si] = g_attn;
+          grad_loc[si * 2] = g_x;
+          grad_loc[si * 2 + 1] = g_y;
+        }
+      }
+    }
+    return;
+  }
   for (int s = 0; s < LP; ++s) {
     const int l = s / P;
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
@@ -393,25 +462,42 @@ __global__ __launch_bounds__(256) void msda_bwd_replay_kernel(
   }
   if (l >= L) return;                                  // slack bins of the upper bound (never filled)
   const float* go = grad_out + (b * Lq * (long)M + m) * D + ch;        // + q * M * D
-  for (int base = beg; base < end; base += 64) {       // 8 items per half-wave per step, loads first
-    int qpl[8];
-    float w0[8], w1[8], g[8];
+  // 8 items per half-wave per step, software-pipelined over three steps: the item records of step i+2 and the
+  // output-gradient rows of step i+1 are in flight while step i is added into LDS (two dependent global loads per
+  // item made every step cost both latencies: ~1.5 us per 64 items and block)
+  int qA[8], qB[8], qC[8];
+  float w0A[8], w1A[8], w0B[8], w1B[8], w0C[8], w1C[8], gA[8], gB[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + hw + 8 * u;
+  for (int u = 0; u < 8; ++u) {
+    const int i0 = beg + hw + 8 * u, i1 = i0 + 64;
+    const BwdItem a = items[i0 < end ? i0 : beg];
+    const BwdItem c = items[i1 < end ? i1 : beg];
+    qA[u] = i0 < end ? a.qpl : -1; w0A[u] = a.w0; w1A[u] = a.w1;
+    qB[u] = i1 < end ? c.qpl : -1; w0B[u] = c.w0; w1B[u] = c.w1;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) gA[u] = go[(long)(qA[u] < 0 ? 0 : qA[u] >> 5) * M * D];
+  for (int base = beg; base < end; base += 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {                      // item records two steps ahead
+      const int idx = base + 128 + hw + 8 * u;
       const BwdItem it = items[idx < end ? idx : beg];
-      qpl[u] = idx < end ? it.qpl : -1;
-      w0[u] = it.w0; w1[u] = it.w1;
+      qC[u] = idx < end ? it.qpl : -1; w0C[u] = it.w0; w1C[u] = it.w1;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) g[u] = go[(long)(qpl[u] < 0 ? 0 : qpl[u] >> 5) * M * D];
+    for (int u = 0; u < 8; ++u) gB[u] = go[(long)(qB[u] < 0 ? 0 : qB[u] >> 5) * M * D];   // rows one step ahead
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (qpl[u] >= 0) {
-        const int pl = qpl[u] & 31;
-        acc[pl * D + ch] += g[u] * w0[u];
-        acc[(pl + 1) * D + ch] += g[u] * w1[u];        // w1 == 0 for single items (pixel 32 is a dummy row)
+      if (qA[u] >= 0) {
+        const int pl = qA[u] & 31;
+        acc[pl * D + ch] += gA[u] * w0A[u];
+        acc[(pl + 1) * D + ch] += gA[u] * w1A[u];      // w1 == 0 for single items (pixel 32 is a dummy row)
       }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      qA[u] = qB[u]; w0A[u] = w0B[u]; w1A[u] = w1B[u]; gA[u] = gB[u];
+      qB[u] = qC[u]; w0B[u] = w0C[u]; w1B[u] = w1C[u];
     }
   }
   __syncthreads();

@@ -613,6 +613,40 @@ class LinearX3Function(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+def rows_gather_sum(x, index):
+    """out[b, r] = sum_k x[b, index[r, k]] over the entries with index >= 0 (csrc/rows_index.hip).  x (B, rows_in, F)
+    float32 contiguous, index (rows_out, K) int64 on the device -> (B, rows_out, F)."""
+    _need_cuda_f32("x", x)
+    if x.dim() != 3 or index.dim() != 2 or index.dtype != torch.int64 or not index.is_cuda \
+            or not index.is_contiguous():
+        raise OccAmdError("rows_gather_sum: x must be (B, rows, F), index a contiguous (rows_out, K) int64 device "
+                          "tensor")
+    B, rows_in, F = x.shape
+    rows_out, K = index.shape
+    out = torch.empty((B, rows_out, F), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed('rows_gather_sum'):
+        rc = _lib.lib().occ_rows_gather_sum_f32(ptr(x), i64(rows_in * F), ptr(index), i32(K), ptr(out), i32(B),
+                                                i64(rows_out), i64(rows_in), i32(F), stream_ptr(x.device))
+    _lib.check(rc, "rows_gather_sum")
+    return out
+
+
+class RowsGatherSumFunction(torch.autograd.Function):
+    """rows_gather_sum with its gradient expressed as the gather-sum over the INVERSE index (the caller supplies
+    both maps; they must be each other's transpose as relations)."""
+
+    @staticmethod
+    def forward(ctx, x, index, inverse_index):
+        ctx.save_for_backward(inverse_index)
+        return rows_gather_sum(x.contiguous(), index)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        (inverse_index,) = ctx.saved_tensors
+        return rows_gather_sum(gout.contiguous(), inverse_index), None, None
+
+
 class LinearWgradFunction(torch.autograd.Function):
     """y = x @ W^T + b for the shapes linear_bf16x3 does not cover (the occupancy heads' 64 -> 17 and 64 -> 2 layers:
     N not a multiple of 16) but whose WEIGHT gradient is the expensive part: 640 000 voxels reduced into a 17 x 64

@@ -257,6 +257,8 @@ class SpatialCrossAttention(BaseModule):
     # ------------------------------------------------------------------ unfused path
     # False (OCC_SCA_TRAIN_REBATCH=reference): the reference's literal order (rebatch the queries, then the Linears)
     rebatch_projected = os.environ.get("OCC_SCA_TRAIN_REBATCH", "projected") != "reference"
+    # the two row shuffles of that path on ext.rows_gather_sum (OCC_SCA_TRAIN_ROWS=torch: index_select / index_add_)
+    rebatch_kernel = os.environ.get("OCC_SCA_TRAIN_ROWS", "kernel") != "torch"
 
     def _rebatch_plan(self, bev_mask, reference_points_cam):
         """Visible-query lists of every camera from batch element 0's mask (reference :138-140) as ONE padded index
@@ -280,8 +282,23 @@ class SpatialCrossAttention(BaseModule):
         cam = torch.arange(nc, device=dev).view(nc, 1).expand(nc, max_len)
         # reference_points_cam (num_cams, bs, Q, Z, 2) -> (bs, num_cams, max_len, Z, 2)
         ref = reference_points_cam[cam, :, idx].permute(2, 0, 1, 3, 4) * valid.view(1, nc, max_len, 1, 1)
+        # gather maps for ext.RowsGatherSumFunction: row_to_query (rows, 1) with -1 on padded rows, and its inverse
+        # query_to_rows (Q, Kmax): the <= Kmax padded rows that hold a BEV query (-1 = none), in camera order
+        num_query = bev_mask.shape[2]
+        rows = torch.nonzero(valid.view(-1) > 0).squeeze(-1)                 # valid padded rows, ascending
+        q_of = idx.view(-1)[rows]
+        cnt = torch.bincount(q_of, minlength=num_query)
+        kmax = max(int(cnt.max()), 1)
+        order = torch.argsort(q_of, stable=True)                             # camera order inside a query
+        sq = q_of[order]
+        start = torch.cumsum(cnt, 0) - cnt
+        pos = torch.arange(sq.numel(), device=dev) - start[sq]
+        query_to_rows = torch.full((num_query, kmax), -1, dtype=torch.long, device=dev)
+        query_to_rows[sq, pos] = rows[order]
+        row_to_query = torch.where(valid.view(-1) > 0, idx.view(-1), torch.full_like(idx.view(-1), -1)).view(-1, 1)
         plan = dict(indexes=indexes, max_len=max_len, idx=idx.view(-1), valid=valid.view(-1, 1),
-                    ref=ref.contiguous())
+                    ref=ref.contiguous(), row_to_query=row_to_query.contiguous(),
+                    query_to_rows=query_to_rows.contiguous())
         try:
             bev_mask._occ_indexes = indexes
             bev_mask._occ_rebatch = plan
@@ -303,13 +320,22 @@ class SpatialCrossAttention(BaseModule):
             # the two query-side Linears once per BEV query; their OUTPUT rows are then dealt to the cameras
             # (index_select + padding mask: two launches instead of 12 indexed copies, and a third fewer GEMM rows)
             proj = da.query_linears_autograd(query)                                     # (bs, Q, n_off + n_att)
-            proj_rb = proj.index_select(1, plan['idx']) * plan['valid']                 # (bs, cams * max_len, .)
+            gather = self.rebatch_kernel and proj.dtype == torch.float32
+            if gather:      # one copy kernel; its gradient is the gather-sum over the inverse map (no float atomics)
+                proj_rb = ext.RowsGatherSumFunction.apply(proj, plan['row_to_query'], plan['query_to_rows'])
+            else:
+                proj_rb = proj.index_select(1, plan['idx']) * plan['valid']             # (bs, cams * max_len, .)
             queries = da(query=None, key=key, value=value,
                          query_proj=proj_rb.view(bs * self.num_cams, max_len, proj.shape[-1]),
                          reference_points=plan['ref'].view(bs * self.num_cams, max_len, D, 2),
                          spatial_shapes=spatial_shapes, level_start_index=level_start_index)
-            slots = query.new_zeros(bs, num_query, self.embed_dims).index_add_(
-                1, plan['idx'], queries.view(bs, self.num_cams * max_len, self.embed_dims) * plan['valid'])
+            if gather and queries.dtype == torch.float32:
+                slots = ext.RowsGatherSumFunction.apply(
+                    queries.view(bs, self.num_cams * max_len, self.embed_dims), plan['query_to_rows'],
+                    plan['row_to_query'])
+            else:
+                slots = query.new_zeros(bs, num_query, self.embed_dims).index_add_(
+                    1, plan['idx'], queries.view(bs, self.num_cams * max_len, self.embed_dims) * plan['valid'])
         else:
             slots = torch.zeros_like(query)
             queries_rebatch = query.new_zeros([bs, self.num_cams, max_len, self.embed_dims])

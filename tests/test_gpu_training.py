@@ -194,3 +194,41 @@ def test_sca_training_path_projected_rebatch_equals_reference_order():
         assert d < 1e-3 * float(gr.abs().max()) + 1e-5, (n, d)
         worst = max(worst, d / (float(gr.abs().max()) + 1e-12))
     print(f"projected-rebatch vs reference order: worst relative gradient difference {worst:.2e}")
+
+
+def test_rows_gather_sum_matches_torch_index_ops_and_gradient():
+    """ext.rows_gather_sum (the SCA training path's rebatch / scatter-back) vs index_select / index_add_, forward
+    and gradient, incl. padding (-1), queries seen by 0..3 cameras and a batch of 2."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(11)
+    Q, nc, F = 300, 4, 64
+    lists = [torch.nonzero(torch.rand(Q, generator=g) > 0.55).squeeze(-1) for _ in range(nc)]
+    max_len = max(len(l) for l in lists)
+    r2q = torch.full((nc * max_len, 1), -1, dtype=torch.long)
+    for i, l in enumerate(lists):
+        r2q[i * max_len:i * max_len + len(l), 0] = l
+    kmax = max(int(torch.bincount(torch.cat(lists), minlength=Q).max()), 1)
+    q2r = torch.full((Q, kmax), -1, dtype=torch.long)
+    fill = [0] * Q
+    for i, l in enumerate(lists):
+        for j, q in enumerate(l.tolist()):
+            q2r[q, fill[q]] = i * max_len + j
+            fill[q] += 1
+    x = torch.randn(2, Q, F, generator=g)
+    # reference on the host in float64
+    xr = x.double().requires_grad_()
+    valid = (r2q[:, 0] >= 0).double().view(1, -1, 1)
+    yr = xr.index_select(1, r2q[:, 0].clamp(min=0)) * valid
+    go = torch.randn(2, nc * max_len, F, generator=g)
+    yr.backward(go.double())
+    xd = x.cuda().requires_grad_()
+    y = ext.RowsGatherSumFunction.apply(xd, r2q.cuda(), q2r.cuda())
+    y.backward(go.cuda())
+    torch.cuda.synchronize()
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) == 0.0          # a copy
+    assert float((xd.grad.cpu().double() - xr.grad).abs().max()) < 1e-5
+    # the other direction: scatter-back = gather-sum over the inverse map
+    o = torch.randn(2, nc * max_len, F, generator=g)
+    s_ref = torch.zeros(2, Q, F, dtype=torch.double).index_add_(1, r2q[:, 0].clamp(min=0), o.double() * valid)
+    s = ext.rows_gather_sum(o.cuda(), q2r.cuda())
+    assert float((s.cpu().double() - s_ref).abs().max()) < 1e-5

@@ -198,10 +198,22 @@ class TemporalSelfAttention(BaseModule):
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         value = value.reshape(bs * self.num_bev_queue, num_value, self.num_heads, -1)
-        sampling_offsets = self.sampling_offsets(query).view(
-            bs, num_query, self.num_heads, self.num_bev_queue, self.num_levels, self.num_points, 2)
-        attention_weights = self.attention_weights(query).view(
-            bs, num_query, self.num_heads, self.num_bev_queue, self.num_levels * self.num_points)
+        if query.is_cuda and torch.is_grad_enabled():
+            # training: both query-side Linears as ONE differentiable GEMM (forward, dx and dW each once instead of
+            # twice); the concatenation is part of the graph, so both layers receive their gradients
+            n_off = self.sampling_offsets.out_features
+            proj = ext.linear_autograd(
+                query, torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
+                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
+            sampling_offsets = proj[..., :n_off].reshape(
+                bs, num_query, self.num_heads, self.num_bev_queue, self.num_levels, self.num_points, 2)
+            attention_weights = proj[..., n_off:].reshape(
+                bs, num_query, self.num_heads, self.num_bev_queue, self.num_levels * self.num_points)
+        else:
+            sampling_offsets = self.sampling_offsets(query).view(
+                bs, num_query, self.num_heads, self.num_bev_queue, self.num_levels, self.num_points, 2)
+            attention_weights = self.attention_weights(query).view(
+                bs, num_query, self.num_heads, self.num_bev_queue, self.num_levels * self.num_points)
         attention_weights = attention_weights.softmax(-1).view(
             bs, num_query, self.num_heads, self.num_bev_queue, self.num_levels, self.num_points)
         attention_weights = attention_weights.permute(0, 3, 1, 2, 4, 5).reshape(

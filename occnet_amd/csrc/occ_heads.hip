@@ -205,34 +205,21 @@ __global__ __launch_bounds__(256, 2) void occ_heads_x3_kernel(
   const hx_bf16x8* W2 = reinterpret_cast<const hx_bf16x8*>(w2s) + lane;
 
   const long n_tiles = (n_rows + 31) / 32;
-  const long tile_step = (long)gridDim.x * kHeadWaves;
-  // the next tile's 64 bytes per lane are requested before the current tile is computed: with two waves per SIMD the
-  // load latency of every tile was exposed (0.081 ms for 136 MB of traffic)
-  float4 nx[4];
-  {
-    long row = ((long)blockIdx.x * kHeadWaves + wave) * 32 + vi;
-    if (row >= n_rows) row = n_rows - 1;
-    const float* src = feat + row * C + 8 * g;
-    nx[0] = *reinterpret_cast<const float4*>(src);      nx[1] = *reinterpret_cast<const float4*>(src + 4);
-    nx[2] = *reinterpret_cast<const float4*>(src + 16); nx[3] = *reinterpret_cast<const float4*>(src + 20);
-  }
-  for (long tile = (long)blockIdx.x * kHeadWaves + wave; tile < n_tiles; tile += tile_step) {
+  for (long tile = (long)blockIdx.x * kHeadWaves + wave; tile < n_tiles; tile += (long)gridDim.x * kHeadWaves) {
     const long row0 = tile * 32;
     // X^T fragments: lane (voxel vi, half g) holds channels 16 s + 8 g .. + 7 of its voxel, hi + lo
     uint4 xh[2], xl[2];
     {
-      const float4 p0 = nx[0], q0 = nx[1], p1 = nx[2], q1 = nx[3];
-      if (tile + tile_step < n_tiles) {                        // wave-uniform
-        long row = (tile + tile_step) * 32 + vi;
-        if (row >= n_rows) row = n_rows - 1;
-        const float* src = feat + row * C + 8 * g;
-        nx[0] = *reinterpret_cast<const float4*>(src);      nx[1] = *reinterpret_cast<const float4*>(src + 4);
-        nx[2] = *reinterpret_cast<const float4*>(src + 16); nx[3] = *reinterpret_cast<const float4*>(src + 20);
+      long row = row0 + vi;
+      if (row >= n_rows) row = n_rows - 1;
+      const float* src = feat + row * C + 8 * g;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float4 p = *reinterpret_cast<const float4*>(src + 16 * s);
+        const float4 q = *reinterpret_cast<const float4*>(src + 16 * s + 4);
+        hx_split2(p.x, p.y, xh[s].x, xl[s].x); hx_split2(p.z, p.w, xh[s].y, xl[s].y);
+        hx_split2(q.x, q.y, xh[s].z, xl[s].z); hx_split2(q.z, q.w, xh[s].w, xl[s].w);
       }
-      hx_split2(p0.x, p0.y, xh[0].x, xl[0].x); hx_split2(p0.z, p0.w, xh[0].y, xl[0].y);
-      hx_split2(q0.x, q0.y, xh[0].z, xl[0].z); hx_split2(q0.z, q0.w, xh[0].w, xl[0].w);
-      hx_split2(p1.x, p1.y, xh[1].x, xl[1].x); hx_split2(p1.z, p1.w, xh[1].y, xl[1].y);
-      hx_split2(q1.x, q1.y, xh[1].z, xl[1].z); hx_split2(q1.z, q1.w, xh[1].w, xl[1].w);
     }
     // ---- H^T = W1cat . X^T : 4 hidden tiles, the MFMAs of different tiles interleaved (no back-to-back MFMAs on one
     // accumulator)

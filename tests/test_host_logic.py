@@ -336,3 +336,48 @@ def test_conv_bn_folded_matches_eval_batchnorm_with_gradients():
     assert float((y - y_ref).abs().max()) < 1e-12
     for a, b in zip(g, g_ref):
         assert float((a - b).abs().max()) < 1e-10 * max(1.0, float(b.abs().max()))
+
+
+def test_sca_rebatch_plan_index_maps_are_inverse_relations():
+    """SpatialCrossAttention._rebatch_plan (training path): the padded per-camera row list, its inverse map and the
+    rebatched reference points, against a brute-force construction (host tensors: pure index arithmetic)."""
+    from occnet_amd.plugin.spatial_cross_attention import SpatialCrossAttention
+    torch.manual_seed(4)
+    nc, bs, Q, Z = 5, 2, 60, 4
+    sca = SpatialCrossAttention(embed_dims=32, num_cams=nc,
+                                deformable_attention=dict(type='MSDeformableAttention3D', embed_dims=32, num_heads=4,
+                                                          num_levels=1, num_points=4))
+    bev_mask = torch.rand(nc, bs, Q, Z) > 0.8
+    ref = torch.randn(nc, bs, Q, Z, 2)
+    plan = sca._rebatch_plan(bev_mask, ref)
+    lists = [m[0].sum(-1).nonzero().squeeze(-1) for m in bev_mask]
+    max_len = max(len(l) for l in lists)
+    assert plan['max_len'] == max_len
+    r2q = plan['row_to_query'].view(nc, max_len)
+    for c, l in enumerate(lists):
+        assert r2q[c, :len(l)].tolist() == l.tolist() and (r2q[c, len(l):] == -1).all()
+        assert torch.equal(plan['ref'][:, c, :len(l)], ref[c][:, l])
+        assert float(plan['ref'][:, c, len(l):].abs().max() if len(l) < max_len else 0.0) == 0.0
+    q2r = plan['query_to_rows']
+    for q in range(Q):
+        exp = [c * max_len + int((lists[c] == q).nonzero()[0]) for c in range(nc) if (lists[c] == q).any()]
+        assert [int(v) for v in q2r[q] if v >= 0] == exp
+    # cached on the mask tensor: the encoder's layers share one plan
+    assert sca._rebatch_plan(bev_mask, ref) is plan
+
+
+def test_x3linear_on_host_is_a_plain_linear():
+    """X3Linear without a device tensor / without autograd is F.linear (the training kernels are device-only; the
+    module must still construct, load state and run its reference arithmetic anywhere)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from occnet_amd.plugin.bricks import X3Linear
+    m = X3Linear(16, 8)
+    ref = nn.Linear(16, 8)
+    ref.load_state_dict(m.state_dict())
+    x = torch.randn(3, 5, 16, requires_grad=True)
+    y = m(x)
+    assert torch.equal(y, F.linear(x, m.weight, m.bias))
+    assert torch.equal(m(x, act='relu'), torch.relu(y))
+    y.sum().backward()
+    assert m.weight.grad is not None and x.grad is not None

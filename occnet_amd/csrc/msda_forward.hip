@@ -18,18 +18,24 @@ namespace occ {
 
 constexpr int kWavesPerBlock = 4;
 
+// BUF: corner rows through buffer loads over the WHOLE value tensor (it must be smaller than kOobOffset bytes): a corner
+// outside its map carries an out-of-range offset and returns 0 without a memory request — no dummy load of row 0, so
+// a NaN / Inf there cannot leak into border samples (0 * Inf).  Larger tensors keep the pointer form.
+template <bool BUF>
 __global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lstart, const float* __restrict__ loc,
     const float* __restrict__ attn, float* __restrict__ out, int S, int M, int L, int Lq, int P,
-    long n_items) {
+    long n_items, unsigned value_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 32;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int LP = L * P;
   const int LPp = LP + 1;  // +32 B per item: neighbouring groups land on different LDS banks
+  static_assert(sizeof(SampleParam) == sizeof(SampleParamB), "one LDS layout for both forms");
   SampleParam* sp = reinterpret_cast<SampleParam*>(smem) + (size_t)wave * 8 * LPp;
+  SampleParamB* spb = reinterpret_cast<SampleParamB*>(smem) + (size_t)wave * 8 * LPp;
   const long item0 = ((long)blockIdx.x * kWavesPerBlock + wave) * 8;
   if (item0 >= n_items) return;
   const int row_stride = M * D;
@@ -37,18 +43,24 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
   for (int i = lane; i < 8 * LP; i += 64) {
     const int g = i / LP, s = i - g * LP;
     const long item = item0 + g;
-    SampleParam p;
-    p.w[0] = p.w[1] = p.w[2] = p.w[3] = 0.f;
-    p.o[0] = p.o[1] = p.o[2] = p.o[3] = 0;
-    if (item < n_items) {
-      const int l = s / P;
-      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-      const int st = (int)lstart[l];
-      const long si = item * LP + s;
-      const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
-      bilinear_setup(xy.x, xy.y, attn[si], H, W, st, row_stride, p);
+    const bool live = item < n_items;
+    const int l = s / P;
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const int st = (int)lstart[l];
+    const long si = (live ? item : n_items - 1) * LP + s;
+    const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
+    const float a = attn[si];
+    if (BUF) {
+      SampleParamB p;
+      bilinear_setup_b(xy.x, xy.y, a, H, W, st, (unsigned)row_stride * 4u, kOobOffset, live, p);
+      spb[g * LPp + s] = p;
+    } else {
+      SampleParam p;
+      p.w[0] = p.w[1] = p.w[2] = p.w[3] = 0.f;
+      p.o[0] = p.o[1] = p.o[2] = p.o[3] = 0;
+      if (live) bilinear_setup(xy.x, xy.y, a, H, W, st, row_stride, p);
+      sp[g * LPp + s] = p;
     }
-    sp[g * LPp + s] = p;
   }
   wave_lds_sync();
 
@@ -57,9 +69,15 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
   if (item < n_items) {
     const long m = item % M;
     const long b = item / ((long)M * Lq);
-    const float* vb = value + b * (long)S * row_stride + m * D + c4 * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    acc = gather_samples<4>(vb, sp + g * LPp, LP, acc);
+    if (BUF) {
+      const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(value, value_bytes);
+      const unsigned lane_off = (unsigned)((b * (long)S * row_stride + m * D + c4 * 4) * 4);
+      acc = gather_samples_buf<4>(rsrc, lane_off, spb + g * LPp, LP, acc);
+    } else {
+      const float* vb = value + b * (long)S * row_stride + m * D + c4 * 4;
+      acc = gather_samples<4>(vb, sp + g * LPp, LP, acc);
+    }
     *reinterpret_cast<float4*>(out + item * D + c4 * 4) = acc;
   }
 }
@@ -132,9 +150,15 @@ extern "C" int occ_ms_deform_attn_forward_f32(const float* value, const int64_t*
   if (D == 32 && lds <= 64 * 1024) {
     const long waves = (n_items + 7) / 8;
     const long blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(msda_fwd_d32_kernel, dim3((unsigned)blocks), dim3(256), lds, st, value,
-                       spatial_shapes, level_start_index, sampling_loc, attn_weight, out, S, M, L,
-                       Lq, P, n_items);
+    const long value_bytes = (long)B * S * M * D * 4;
+    if (value_bytes < (long)kOobOffset)
+      hipLaunchKernelGGL(msda_fwd_d32_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, value,
+                         spatial_shapes, level_start_index, sampling_loc, attn_weight, out, S, M, L,
+                         Lq, P, n_items, (unsigned)value_bytes);
+    else
+      hipLaunchKernelGGL(msda_fwd_d32_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, value,
+                         spatial_shapes, level_start_index, sampling_loc, attn_weight, out, S, M, L,
+                         Lq, P, n_items, 0u);
   } else {
     const long n_out = n_items * D;
     const long blocks = (n_out + 255) / 256;

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
     int B, int Nq, int bev_h, int bev_w) {
   constexpr int M = 8, D = 32, P = 4, NS = 2 * P;  // samples per head
   constexpr int NSp = NS + 1;
-  __shared__ __attribute__((aligned(16))) SampleParam smem[kTsaWaves * M * NSp];
+  __shared__ __attribute__((aligned(16))) SampleParamB smem[kTsaWaves * M * NSp];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const long wg = (long)blockIdx.x * kTsaWaves + wave;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
   const int b = (int)(wg / Nq);
   const int r = (int)(wg - (long)b * Nq);
   const int q = order ? order[r] : r;
-  SampleParam* sp = smem + wave * M * NSp;
+  SampleParamB* sp = smem + wave * M * NSp;
   constexpr int row_stride = M * D;
 
   // lane = m*8 + t*4 + p : exactly the memory order of both Linear outputs
@@ -45,18 +45,22 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
   const float aw = e / sum;
   const float2 o = *reinterpret_cast<const float2*>(offs + ((long)b * Nq + q) * offs_stride + 2 * lane);
   const float2 rf = *reinterpret_cast<const float2*>(ref_2d + (((long)b * 2 + t) * Nq + q) * 2);
-  SampleParam p;
-  bilinear_setup(rf.x + o.x / (float)bev_w, rf.y + o.y / (float)bev_h, aw, bev_h, bev_w, 0,
-                 row_stride, p);
+  // corners outside the BEV map carry an out-of-range byte offset: the buffer load returns 0 without a request (no
+  // dummy load of row 0, no 0 * Inf)
+  SampleParamB p;
+  bilinear_setup_b(rf.x + o.x / (float)bev_w, rf.y + o.y / (float)bev_h, aw, bev_h, bev_w, 0,
+                   (unsigned)row_stride * 4u, kOobOffset, true, p);
   sp[m * NSp + (lane & 7)] = p;
   wave_lds_sync();
 
   const int g = lane >> 3, c4 = lane & 7;
-  const float* v0 = value + ((long)b * 2 + 0) * value_bt_stride + g * D + c4 * 4;
-  const float* v1 = value + ((long)b * 2 + 1) * value_bt_stride + g * D + c4 * 4;
+  const unsigned map_bytes = (unsigned)bev_h * (unsigned)bev_w * (unsigned)row_stride * 4u;
+  const __amdgpu_buffer_rsrc_t r0 = uniform_rsrc(value + ((long)b * 2 + 0) * value_bt_stride, map_bytes);
+  const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(value + ((long)b * 2 + 1) * value_bt_stride, map_bytes);
+  const unsigned lane_off = (unsigned)(g * D + c4 * 4) * 4u;
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-  a0 = gather_samples<4>(v0, sp + g * NSp, P, a0);
-  a1 = gather_samples<4>(v1, sp + g * NSp + P, P, a1);
+  a0 = gather_samples_buf<4>(r0, lane_off, sp + g * NSp, P, a0);
+  a1 = gather_samples_buf<4>(r1, lane_off, sp + g * NSp + P, P, a1);
   float4 o4 = make_float4((a0.x + a1.x) * 0.5f, (a0.y + a1.y) * 0.5f, (a0.z + a1.z) * 0.5f,
                           (a0.w + a1.w) * 0.5f);
   *reinterpret_cast<float4*>(out + ((long)b * Nq + q) * row_stride + g * D + c4 * 4) = o4;
@@ -73,6 +77,7 @@ extern "C" int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_st
   using namespace occ;
   OCC_CHECK_ARG(value && offs && logits && ref_2d && out, "tsa_fused_forward: null pointer argument");
   OCC_CHECK_ARG(B > 0 && Nq > 0 && bev_h > 0 && bev_w > 0, "tsa_fused_forward: bad dimension");
+  OCC_CHECK_ARG((long)bev_h * bev_w * M * D * 4 < (long)occ::kOobOffset, "tsa_fused_forward: BEV map too large");
   OCC_CHECK_ARG(value_bt_stride >= 0, "tsa_fused_forward: negative value stride");
   OCC_CHECK_ARG(offs_stride >= (int64_t)M * 2 * P * 2 && logits_stride >= (int64_t)M * 2 * P,
                 "tsa_fused_forward: row strides smaller than a row");

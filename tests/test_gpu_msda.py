@@ -108,3 +108,59 @@ def test_errors_are_raised():
     with pytest.raises(OccAmdError):     # inconsistent shapes
         ext.ms_deform_attn_forward(value.cuda(), shapes_t.cuda(), start.cuda(), loc.cuda()[:, :5],
                                    attn.cuda(), im2col_step=64)
+
+
+def test_generic_forward_never_reads_corners_outside_the_map():
+    """ADVICE r1 (low) for the generic operator: a corner outside its map must not be loaded at all (round 1 loaded
+    row 0 of the batch entry with weight 0: 0 * Inf = NaN).  Non-finite values at pixel 0 of level 0 may only show
+    up in rows that really sample that pixel; every other row is bit-identical to the clean run."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(21)
+    B, M, D, Lq, P = 2, 8, 32, 333, 4
+    shapes = torch.tensor([[12, 20], [6, 10], [3, 5]])
+    L = shapes.shape[0]
+    S = int(shapes.prod(1).sum())
+    start = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    value = torch.randn(B, S, M, D, generator=g)
+    loc = torch.rand(B, Lq, M, L, P, 2, generator=g) * 1.3 - 0.15            # a good share of corners off the maps
+    attn = torch.softmax(torch.randn(B, Lq, M, L * P, generator=g), -1).view(B, Lq, M, L, P)
+    args = (shapes.cuda(), start.cuda(), loc.cuda(), attn.cuda())
+    clean = ext.ms_deform_attn_forward(value.cuda(), *args, im2col_step=64)
+    value[:, 0] = float('inf')
+    value[:, 0, :, ::2] = float('nan')
+    dirty = ext.ms_deform_attn_forward(value.cuda(), *args, im2col_step=64)
+    touched = ~torch.isfinite(dirty.view(B, Lq, M, D)).all(-1)
+    # rows whose level-0 samples have pixel (0, 0) among their in-map corners: h_im, w_im in (-1, 1)
+    H0, W0 = int(shapes[0, 0]), int(shapes[0, 1])
+    hx = loc[..., 0, :, 0] * W0 - 0.5
+    hy = loc[..., 0, :, 1] * H0 - 0.5
+    may = ((hx > -1) & (hx < 1) & (hy > -1) & (hy < 1)).any(-1)            # (B, Lq, M)
+    assert not bool((touched.cpu() & ~may).any()), "a row that cannot reach pixel (0,0) became non-finite"
+    assert 0.0 < float(touched.float().mean()) < 0.5
+    assert torch.equal(dirty.view(B, Lq, M, D)[~touched], clean.view(B, Lq, M, D)[~touched])
+
+
+def test_tsa_fused_never_reads_corners_outside_the_map():
+    """Same property for the fused temporal self-attention gather (its BEV value maps)."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(22)
+    B, M, D, P, bh, bw = 1, 8, 32, 4, 12, 14
+    Nq = bh * bw
+    value = torch.randn(B * 2, Nq, M, D, generator=g)
+    offs = torch.randn(B, Nq, M * 2 * P * 2, generator=g) * 4.0
+    logits = torch.randn(B, Nq, M * 2 * P, generator=g)
+    ref = torch.rand(B * 2, Nq, 1, 2, generator=g)
+    args = (offs.cuda(), logits.cuda(), ref.cuda(), bh, bw, M, P)
+    clean = ext.tsa_fused_forward(value.cuda(), *args).view(B, Nq, M, D)
+    value[:, 0] = float('inf')
+    value[:, 0, :, ::2] = float('nan')
+    dirty = ext.tsa_fused_forward(value.cuda(), *args).view(B, Nq, M, D)
+    touched = ~torch.isfinite(dirty).all(-1)
+    assert 0.0 < float(touched.float().mean()) < 0.6
+    assert torch.equal(dirty[~touched], clean[~touched])
+    # rows that cannot reach pixel (0, 0): all of a head's 8 samples at h_im >= 1 or w_im >= 1
+    o = offs.view(B, Nq, M, 2, P, 2)
+    lx = (ref.view(B, 2, Nq, 1, 1, 2)[..., 0].permute(0, 2, 3, 1, 4) + o[..., 0] / bw) * bw - 0.5   # (B,Nq,M,2,P)
+    ly = (ref.view(B, 2, Nq, 1, 1, 2)[..., 1].permute(0, 2, 3, 1, 4) + o[..., 1] / bh) * bh - 0.5
+    may = ((lx > -1) & (lx < 1) & (ly > -1) & (ly < 1)).flatten(3).any(-1)
+    assert not bool((touched.cpu() & ~may).any())

@@ -26,6 +26,9 @@ from .registry import (TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_atte
 from .spatial_cross_attention import _require_device
 
 
+_VPROJ_OVERLAP = os.environ.get("OCC_VPROJ_OVERLAP", "0") == "1"
+
+
 @TRANSFORMER_LAYER.register_module()
 class MyCustomBaseTransformerLayer(BaseModule):
     """Generic transformer layer container: attentions / FFNs / norms built from cfg and applied in
@@ -398,6 +401,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
                      bev_order_flat=self._bev_order(bev_h, bev_w, bev_query.device, flat=True),
                      tsa_spatial_shapes=tsa_shapes, tsa_level_start_index=tsa_start)
         output = bev_query
+        if _VPROJ_OVERLAP and hasattr(value, 'prefetch') and not torch.is_grad_enabled():
+            vps = [getattr(getattr(a, 'deformable_attention', None), 'value_proj', None)
+                   for layer in self.layers for a in layer.attentions]
+            value.prefetch([vp for vp in vps if vp is not None])
         for lid, layer in enumerate(self.layers):
             output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
                            ref_3d=ref_3d, bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,

@@ -101,9 +101,35 @@ class LazyFeatures:
             self._flat = flat.view(self.bs, self.num_cam, flat.shape[1], flat.shape[2]).permute(1, 2, 0, 3)
         return self._flat
 
+    _side_streams = {}
+
+    def prefetch(self, value_projs):
+        """Start project() for several layers' value_proj modules on a side stream (the projections depend on the
+        camera features only, not on the BEV queries, so they can run under the first layers' TSA / Linear kernels
+        instead of serially before each gather).  project() later hands the tensor out after making the consuming
+        stream wait for the side stream's event.  OCC_VPROJ_OVERLAP=1 (experiment; off by default)."""
+        dev = self.mlvl_feats[0].device
+        side = self._side_streams.get(str(dev))
+        if side is None:
+            side = self._side_streams[str(dev)] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)                               # the feature maps (and cached biases) are ready
+        self._pending = {}
+        with torch.cuda.stream(side):
+            for vp in value_projs:
+                out = self.project(vp)
+                out.record_stream(main)                      # consumed (and released) on the main stream
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self._pending[id(vp)] = (out, ev)
+
     def project(self, value_proj):
         """value_proj(feat + embeds) for every camera pixel -> (bs*num_cam, sum hw, N) fp32 (fp16 in the opt-in
         OCC_SCA_VALUES=f16 mode)."""
+        hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
+        if hit is not None:
+            torch.cuda.current_stream(hit[0].device).wait_event(hit[1])
+            return hit[0]
         w, b = value_proj.weight, value_proj.bias
         n = w.shape[0]
         # per-(level, camera) bias = (cams_embeds + level_embeds) . W^T + b: constant while the parameters are,

@@ -119,3 +119,23 @@ def test_bench_multi_rank_plumbing(tmp_path):
     assert out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
     assert abs(out["value"] - 2 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-6
     assert "roofline" in out and "cpu_baseline" not in out
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun (how a user, and possibly the driver, invokes it; the reference's
+    tools/dist_train.sh:9-11 role): bench.py re-executes itself under torch.distributed.run on 127.0.0.1 and rank 0
+    prints one JSON line with n_gpus = 2.  Both ranks share the test box's single GPU (gloo group)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env.update(OCC_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--scope", "hotpath", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["parallelism"] == "dp2"

@@ -107,7 +107,7 @@ class LazyFeatures:
         """Start project() for several layers' value_proj modules on a side stream (the projections depend on the
         camera features only, not on the BEV queries, so they can run under the first layers' TSA / Linear kernels
         instead of serially before each gather).  project() later hands the tensor out after making the consuming
-        stream wait for the side stream's event.  OCC_VPROJ_OVERLAP=1 (experiment; off by default)."""
+        stream wait for the side stream's event.  OCC_VPROJ_OVERLAP=0 turns it off."""
         dev = self.mlvl_feats[0].device
         side = self._side_streams.get(str(dev))
         if side is None:

@@ -146,10 +146,12 @@ int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_stride, const
  *   grad_output (B, Lq, M*D) f32 in;  grad_value (B, S, M, D), grad_sampling_loc (B, Lq, M, L, P, 2),
  *   grad_attn_weight (B, Lq, M, L, P) f32 out — PRE-ZEROED BY THE CALLER (the reference's autograd
  *   Function allocates them with zeros_like, multi_scale_deformable_attn_function.py:146-148);
- *   grad_value: for D == 32 WITHOUT floating-point atomics (counting sort of the bilinear row items into
- *   32-pixel bins + one owner block per bin, csrc/msda_backward.hip); the item order inside a bin follows
- *   integer-atomic slot order, so the f32 summation order — and the last bits of grad_value — may differ from
- *   run to run, as they do with mmcv's atomicAdd.  Other D (and OCC_MSDA_BWD_ATOMICS=1): f32 atomics.
+ *   grad_value: for D == 32 (almost) WITHOUT floating-point atomics (counting sort of the bilinear row items into
+ *   32-pixel bins, replayed by owner blocks from a device-built work list, csrc/msda_backward.hip): a bin with
+ *   more than 2048 items is split over several blocks that combine with f32 atomics (a few dozen per bin); the
+ *   item order inside a bin follows integer-atomic slot order.  The f32 summation order — and the last bits of
+ *   grad_value — may therefore differ from run to run, as they do with mmcv's atomicAdd.  Other D (and
+ *   OCC_MSDA_BWD_ATOMICS=1): f32 atomics throughout.
  */
 int occ_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes,
                                     const int64_t* level_start_index, const float* sampling_loc,

@@ -17,12 +17,19 @@
 //      gradient is non-zero;
 //   2. every value map is cut into BINS of 32 consecutive pixels; a sample contributes one "row item" per bilinear
 //      row (left + right corner weights, already multiplied by the attention weight) to the bin of its left
-//      pixel (two items when the pair straddles a bin edge).  COUNT (integer atomics, aggregated inside the wave:
-//      threads are ordered (batch, head, level, query, point), so a wave's 64 samples mostly share a few bins)
-//      -> exclusive SCAN -> FILL writes the items (12 bytes: query, pixel in bin, two weights) bin by bin;
-//   3. REPLAY: one block owns one bin: 32 pixels x 32 channels accumulators in LDS, private per half-wave (lane =
-//      channel, the items dealt round-robin to the 8 half-waves), plain read-add-write — no atomics, no
-//      conflicts; the 8 copies are summed and added to grad_value by the bin's only owner.
+//      pixel (two items when the pair straddles a bin edge).  COUNT -> exclusive SCAN -> FILL writes the items
+//      (12 bytes: query, pixel in bin, two weights) bin by bin.  Both passes run as 1024-thread blocks that own 1024
+//      consecutive (query, point) samples of one (batch, head, level) and keep that level's bins as a dense
+//      histogram in LDS: ONE global integer atomic per block and touched bin (msda_bwd_bin_block_kernel).  The
+//      round-1 form (one atomic per wave and bin, msda_bwd_bin_kernel, OCC_MSDA_BWD_BIN=wave) sent thousands of
+//      device-scope atomics to the same counter of a coarse-level bin; those retire one round trip at a time and
+//      were 20 of the backward's 34 ms per training step;
+//   3. the SCAN also writes the replay WORK LIST: a non-empty bin = ceil(count / 2048) entries;
+//   4. REPLAY: one block per work entry: 32 pixels x 32 channels accumulators in LDS, private per half-wave (lane =
+//      channel, the items dealt round-robin to the 8 half-waves), plain read-add-write — no atomics, no conflicts;
+//      item records and output-gradient rows are prefetched two / one step ahead; the 8 copies are summed and added
+//      to grad_value (plain read-add-write when the block is the bin's only owner, float atomics for the pieces
+//      of a split bin: a few dozen blocks at most).
 //
 // Decomposition (D == 32): 8 lanes x 4 channels per (b,q,m) item, 8 items per wave — the forward's
 // layout, so a corner is one 128-byte row per group; the channel sums are 3-step DPP/shuffle

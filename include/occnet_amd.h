@@ -264,6 +264,20 @@ int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2
                           const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N,
                           void* stream);
 
+/* Training path of SpatialCrossAttention, query side (csrc/sca_prep.hip; reference spatial_cross_attention.py:338-373
+ * applied to the per-camera rebatched rows): from proj (B, Q, >= 3*M*L*P) = [sampling_offsets | attention_weights]
+ * Linear outputs per BEV query, row_to_query (R) (-1 = padded row) and the rebatched reference points ref_rb
+ * (B, R, Z, 2):  attn (B, R, M, L, P) = softmax over L*P,  loc (B, R, M, L, P, 2) = ref_rb[.., p % Z, :] +
+ * offsets / (W_l, H_l) — the layouts ms_deform_attn_forward takes.  The backward accumulates, per BEV query over the
+ * <= Kq rows of query_to_rows (Q, Kq) (-1 = none), d proj (B, Q, proj_ld) from grad_loc / grad_attn (every row of
+ * dproj is written).  M = 8, L = 4, P = 8 only (OCC_E_UNSUPPORTED otherwise: the caller keeps the ATen ops). */
+int occ_sca_prep_forward_f32(const float* proj, int64_t proj_batch_stride, int proj_ld, const int64_t* row_to_query,
+                             const float* ref_rb, const int64_t* spatial_shapes, float* loc, float* attn, int B,
+                             int64_t R, int M, int L, int P, int Z, void* stream);
+int occ_sca_prep_backward_f32(const float* grad_loc, const float* grad_attn, const float* attn,
+                              const int64_t* query_to_rows, int Kq, const int64_t* spatial_shapes, float* dproj,
+                              int proj_ld, int B, int64_t R, int64_t Q, int M, int L, int P, void* stream);
+
 /* Row gather-sum (csrc/rows_index.hip): out[b][r][:] = sum over k < K with index[r*K + k] >= 0 of x[b][index[r*K + k]][:].
  * x (B, rows_in, F) with batch stride x_batch_stride (floats), index (rows_out, K) int64 (-1 = no row), out
  * (B, rows_out, F) contiguous; F % 4 == 0, 16-byte aligned.  K = 1: SpatialCrossAttention's per-camera rebatch of the

@@ -647,6 +647,50 @@ class RowsGatherSumFunction(torch.autograd.Function):
         return rows_gather_sum(gout.contiguous(), inverse_index), None, None
 
 
+class SCAPrepFunction(torch.autograd.Function):
+    """(loc, attn) of SpatialCrossAttention's training path from the per-query Linear outputs: rebatch + softmax +
+    offset normalisation + anchor add as one kernel, and its gradient as one kernel (csrc/sca_prep.hip).
+    proj (B, Q, 3*M*L*P) float32, row_to_query (R, 1) / query_to_rows (Q, K) int64 (the maps of
+    RowsGatherSumFunction), ref_rb (B, R, Z, 2), spatial_shapes (L, 2) int64 ->
+    loc (B, R, M, L, P, 2), attn (B, R, M, L, P)."""
+
+    @staticmethod
+    def forward(ctx, proj, row_to_query, query_to_rows, ref_rb, spatial_shapes, M, L, P):
+        _need_cuda_f32("proj", proj)
+        _need_cuda_f32("ref_rb", ref_rb)
+        B, Q, ld = proj.shape
+        R = row_to_query.shape[0]
+        Z = ref_rb.shape[2]
+        loc = torch.empty((B, R, M, L, P, 2), dtype=torch.float32, device=proj.device)
+        attn = torch.empty((B, R, M, L, P), dtype=torch.float32, device=proj.device)
+        with torch.cuda.device(proj.device), _timed('sca_prep'):
+            rc = _lib.lib().occ_sca_prep_forward_f32(ptr(proj), i64(Q * ld), i32(ld), ptr(row_to_query), ptr(ref_rb),
+                                                     ptr(spatial_shapes), ptr(loc), ptr(attn), i32(B), i64(R),
+                                                     i32(M), i32(L), i32(P), i32(Z), stream_ptr(proj.device))
+        _lib.check(rc, "sca_prep_forward")
+        ctx.save_for_backward(attn, query_to_rows, spatial_shapes)
+        ctx.dims = (B, Q, ld, R, M, L, P)
+        return loc, attn
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loc, g_attn):
+        attn, query_to_rows, spatial_shapes = ctx.saved_tensors
+        B, Q, ld, R, M, L, P = ctx.dims
+        g_loc = (torch.zeros_like(attn).unsqueeze(-1).expand(*attn.shape, 2) if g_loc is None else g_loc).contiguous()
+        g_attn = (torch.zeros_like(attn) if g_attn is None else g_attn).contiguous()
+        dproj = torch.empty((B, Q, ld), dtype=torch.float32, device=attn.device)
+        if ld > 3 * M * L * P:
+            dproj.zero_()
+        with torch.cuda.device(attn.device), _timed('sca_prep_bwd'):
+            rc = _lib.lib().occ_sca_prep_backward_f32(ptr(g_loc), ptr(g_attn), ptr(attn), ptr(query_to_rows),
+                                                      i32(query_to_rows.shape[1]), ptr(spatial_shapes), ptr(dproj),
+                                                      i32(ld), i32(B), i64(R), i64(Q), i32(M), i32(L), i32(P),
+                                                      stream_ptr(attn.device))
+        _lib.check(rc, "sca_prep_backward")
+        return dproj, None, None, None, None, None, None, None
+
+
 class LinearWgradFunction(torch.autograd.Function):
     """y = x @ W^T + b for the shapes linear_bf16x3 does not cover (the occupancy heads' 64 -> 17 and 64 -> 2 layers:
     N not a multiple of 16) but whose WEIGHT gradient is the expensive part: 640 000 voxels reduced into a 17 x 64

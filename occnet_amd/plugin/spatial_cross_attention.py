@@ -112,12 +112,25 @@ class MSDeformableAttention3D(BaseModule):
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, query_proj=None, **kwargs):
+                level_start_index=None, query_proj=None, sampling=None, **kwargs):
         """Unfused form, reference semantics: query (bs, num_query, C), value (bs, num_value, C),
         reference_points (bs, num_query, Z, 2) -> (bs, num_query, C).  `query_proj` (bs, num_query, n_off + n_att):
         the two query-side Linears already applied (SpatialCrossAttention computes them once per BEV query and
         rebatches the RESULT per camera instead of the input — a Linear is row-wise, so that is the same function
-        with 40 000 instead of 6 x 9 900 GEMM rows); `query` is then ignored."""
+        with 40 000 instead of 6 x 9 900 GEMM rows); `query` is then ignored.  `sampling` = (sampling_locations,
+        attention_weights) already prepared (ext.SCAPrepFunction): only the value projection and the operator run."""
+        if sampling is not None:
+            if not self.batch_first:
+                value = value.permute(1, 0, 2)
+            _require_device(value, 'MSDeformableAttention3D')
+            bs, num_value, _ = value.shape
+            value = self.value_proj(value)
+            if key_padding_mask is not None:
+                value = value.masked_fill(key_padding_mask[..., None], 0.0)
+            value = value.view(bs, num_value, self.num_heads, -1)
+            output = MultiScaleDeformableAttnFunction_fp32.apply(
+                value, spatial_shapes, level_start_index, sampling[0], sampling[1], self.im2col_step)
+            return output if self.batch_first else output.permute(1, 0, 2)
         if value is None:
             value = query
         if identity is None:
@@ -259,6 +272,8 @@ class SpatialCrossAttention(BaseModule):
     rebatch_projected = os.environ.get("OCC_SCA_TRAIN_REBATCH", "projected") != "reference"
     # the two row shuffles of that path on ext.rows_gather_sum (OCC_SCA_TRAIN_ROWS=torch: index_select / index_add_)
     rebatch_kernel = os.environ.get("OCC_SCA_TRAIN_ROWS", "kernel") != "torch"
+    # rebatch + softmax + offset normalisation + anchor add as one kernel (OCC_SCA_TRAIN_PREP=torch: ATen ops)
+    prep_kernel = os.environ.get("OCC_SCA_TRAIN_PREP", "kernel") != "torch"
 
     def _rebatch_plan(self, bev_mask, reference_points_cam):
         """Visible-query lists of every camera from batch element 0's mask (reference :138-140) as ONE padded index
@@ -321,14 +336,25 @@ class SpatialCrossAttention(BaseModule):
             # (index_select + padding mask: two launches instead of 12 indexed copies, and a third fewer GEMM rows)
             proj = da.query_linears_autograd(query)                                     # (bs, Q, n_off + n_att)
             gather = self.rebatch_kernel and proj.dtype == torch.float32
-            if gather:      # one copy kernel; its gradient is the gather-sum over the inverse map (no float atomics)
-                proj_rb = ext.RowsGatherSumFunction.apply(proj, plan['row_to_query'], plan['query_to_rows'])
+            prep = (gather and self.prep_kernel and (da.num_heads, da.num_levels, da.num_points) == (8, 4, 8)
+                    and da.num_points % D == 0 and True)
+            if prep:
+                # rebatch + softmax + offset normalisation + anchor add as ONE kernel (and one in backward)
+                loc, att = ext.SCAPrepFunction.apply(proj.contiguous(), plan['row_to_query'], plan['query_to_rows'],
+                                                     plan['ref'].view(bs, self.num_cams * max_len, D, 2),
+                                                     spatial_shapes, da.num_heads, da.num_levels, da.num_points)
+                shp = (bs * self.num_cams, max_len, da.num_heads, da.num_levels, da.num_points)
+                queries = da(query=None, key=key, value=value, sampling=(loc.view(*shp, 2), att.view(*shp)),
+                             spatial_shapes=spatial_shapes, level_start_index=level_start_index)
             else:
-                proj_rb = proj.index_select(1, plan['idx']) * plan['valid']             # (bs, cams * max_len, .)
-            queries = da(query=None, key=key, value=value,
-                         query_proj=proj_rb.view(bs * self.num_cams, max_len, proj.shape[-1]),
-                         reference_points=plan['ref'].view(bs * self.num_cams, max_len, D, 2),
-                         spatial_shapes=spatial_shapes, level_start_index=level_start_index)
+                if gather:  # one copy kernel; its gradient is the gather-sum over the inverse map (no float atomics)
+                    proj_rb = ext.RowsGatherSumFunction.apply(proj, plan['row_to_query'], plan['query_to_rows'])
+                else:
+                    proj_rb = proj.index_select(1, plan['idx']) * plan['valid']         # (bs, cams * max_len, .)
+                queries = da(query=None, key=key, value=value,
+                             query_proj=proj_rb.view(bs * self.num_cams, max_len, proj.shape[-1]),
+                             reference_points=plan['ref'].view(bs * self.num_cams, max_len, D, 2),
+                             spatial_shapes=spatial_shapes, level_start_index=level_start_index)
             if gather and queries.dtype == torch.float32:
                 slots = ext.RowsGatherSumFunction.apply(
                     queries.view(bs, self.num_cams * max_len, self.embed_dims), plan['query_to_rows'],

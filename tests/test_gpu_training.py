@@ -232,3 +232,50 @@ def test_rows_gather_sum_matches_torch_index_ops_and_gradient():
     s_ref = torch.zeros(2, Q, F, dtype=torch.double).index_add_(1, r2q[:, 0].clamp(min=0), o.double() * valid)
     s = ext.rows_gather_sum(o.cuda(), q2r.cuda())
     assert float((s.cpu().double() - s_ref).abs().max()) < 1e-5
+
+
+def test_sca_prep_function_matches_torch_ops_and_gradient():
+    """ext.SCAPrepFunction (rebatch + softmax + offset normalisation + anchor add, and its backward) vs the same
+    arithmetic in float64 torch ops with autograd."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(12)
+    bs, Q, nc, M, L, P, Z = 2, 150, 3, 8, 4, 8, 4
+    lists = [torch.nonzero(torch.rand(Q, generator=g) > 0.5).squeeze(-1) for _ in range(nc)]
+    max_len = max(len(l) for l in lists)
+    R = nc * max_len
+    r2q = torch.full((R, 1), -1, dtype=torch.long)
+    for i, l in enumerate(lists):
+        r2q[i * max_len:i * max_len + len(l), 0] = l
+    kmax = max(int(torch.bincount(torch.cat(lists), minlength=Q).max()), 1)
+    q2r = torch.full((Q, kmax), -1, dtype=torch.long)
+    fill = [0] * Q
+    for i, l in enumerate(lists):
+        for j, q in enumerate(l.tolist()):
+            q2r[q, fill[q]] = i * max_len + j
+            fill[q] += 1
+    shapes = torch.tensor([[20, 30], [10, 15], [5, 8], [3, 4]])
+    proj = torch.randn(bs, Q, 3 * M * L * P, generator=g)
+    ref = torch.rand(bs, R, Z, 2, generator=g)
+    g_loc = torch.randn(bs, R, M, L, P, 2, generator=g)
+    g_att = torch.randn(bs, R, M, L, P, generator=g)
+    # float64 reference with autograd
+    pr = proj.double().requires_grad_()
+    valid = (r2q[:, 0] >= 0).double().view(1, R, 1)
+    rb = pr.index_select(1, r2q[:, 0].clamp(min=0)) * valid
+    n_off = M * L * P * 2
+    off = rb[..., :n_off].reshape(bs, R, M, L, P, 2)
+    att = rb[..., n_off:].reshape(bs, R, M, L * P).softmax(-1).view(bs, R, M, L, P)
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).double()
+    off = off / norm[None, None, None, :, None, :]
+    loc = ref.double()[:, :, None, None, None, :, :] + off.view(bs, R, M, L, P // Z, Z, 2)
+    loc = loc.view(bs, R, M, L, P, 2)
+    (loc * g_loc.double()).sum().add((att * g_att.double()).sum()).backward()
+    pd = proj.cuda().requires_grad_()
+    loc_d, att_d = ext.SCAPrepFunction.apply(pd, r2q.cuda(), q2r.cuda(), ref.cuda(), shapes.cuda(), M, L, P)
+    ((loc_d * g_loc.cuda()).sum() + (att_d * g_att.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    e_loc = float((loc_d.detach().cpu().double() - loc.detach()).abs().max())
+    e_att = float((att_d.detach().cpu().double() - att.detach()).abs().max())
+    e_g = float((pd.grad.cpu().double() - pr.grad).abs().max() / pr.grad.abs().max())
+    print(f"sca_prep: loc {e_loc:.2e} attn {e_att:.2e} grad rel {e_g:.2e}")
+    assert e_loc < 1e-5 and e_att < 1e-6 and e_g < 1e-5

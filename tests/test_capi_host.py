@@ -101,3 +101,41 @@ def test_ext_loader_surface():
                                    MultiScaleDeformableAttnFunction_fp32)
     assert hasattr(MultiScaleDeformableAttnFunction_fp32, 'apply')
     assert hasattr(MultiScaleDeformableAttnFunction_fp16, 'apply')
+
+
+def test_training_entry_points_validate_without_gpu():
+    """Round-2 training entry points (Linear weight gradient, row gather-sum, SCA query-side preparation, backward
+    with caller-provided scratch): argument checks and workspace sizing run before any launch."""
+    lib = _lib.lib()
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    i64 = ctypes.c_int64
+    lib.occ_linear_wgrad_workspace_bytes.restype = ctypes.c_int64
+    lib.occ_ms_deform_attn_backward_workspace_bytes.restype = ctypes.c_int64
+    # one partial (N*K + N floats) per row chunk; 512 blocks when the rows allow it
+    ws = lib.occ_linear_wgrad_workspace_bytes(40000, 512, 256)
+    assert ws > 0 and ws % ((512 * 256 + 512) * 4) == 0 and ws // ((512 * 256 + 512) * 4) == 63    # 640-row chunks
+    assert lib.occ_linear_wgrad_workspace_bytes(10, 512, 256) == (512 * 256 + 512) * 4           # one chunk
+    assert lib.occ_linear_wgrad_workspace_bytes(0, 512, 256) == 0
+    assert lib.occ_linear_wgrad_bf16x3_f32(null, i64(8), p, i64(8), p, p, p, i64(1 << 20), 4, 8, 8, null) == -1
+    assert lib.occ_linear_wgrad_bf16x3_f32(p, i64(4), p, i64(8), p, p, p, i64(1 << 20), 4, 8, 8, null) == -1
+    assert b'row strides' in lib.occ_last_error()
+    assert lib.occ_linear_wgrad_bf16x3_f32(p, i64(8), p, i64(8), p, p, p, i64(16), 4, 8, 8, null) == -1
+    assert b'workspace too small' in lib.occ_last_error()
+    idx = (ctypes.c_int64 * 4)(0, 1, -1, 2)
+    ip = ctypes.cast(idx, ctypes.c_void_p)
+    assert lib.occ_rows_gather_sum_f32(null, i64(16), ip, 1, p, 1, i64(4), i64(4), 4, null) == -1
+    assert lib.occ_rows_gather_sum_f32(p, i64(16), ip, 1, p, 1, i64(4), i64(4), 6, null) == -1   # F % 4
+    assert b'16-byte aligned' in lib.occ_last_error()
+    assert lib.occ_sca_prep_forward_f32(p, i64(768), 768, ip, p, ip, p, p, 1, i64(4), 4, 4, 8, 4, null) == -3   # M=4
+    assert lib.occ_sca_prep_forward_f32(p, i64(768), 768, ip, p, ip, p, p, 1, i64(4), 8, 4, 8, 3, null) == -1   # P % Z
+    assert lib.occ_sca_prep_forward_f32(p, i64(512), 512, ip, p, ip, p, p, 1, i64(4), 8, 4, 8, 4, null) == -1   # short rows
+    assert lib.occ_sca_prep_backward_f32(p, p, p, ip, 2, ip, p, 768, 1, i64(4), i64(2), 8, 2, 8, null) == -3
+    # backward scratch: flags + counters + work list + 4 * samples row items of 12 bytes; 0 for other head sizes
+    B, S, M, D, L, Lq, P = 6, 30825, 8, 32, 4, 9900, 8
+    need = lib.occ_ms_deform_attn_backward_workspace_bytes(B, S, M, D, L, Lq, P)
+    assert need > 4 * (B * Lq * M * L * P) * 12 and need < 1.1 * 4 * (B * Lq * M * L * P) * 12 + (64 << 20)
+    assert lib.occ_ms_deform_attn_backward_workspace_bytes(B, S, M, 64, L, Lq, P) == 0
+    rc = lib.occ_ms_deform_attn_backward_ws_f32(p, p, p, p, p, p, p, p, p, 1, 4, 8, 32, 1, 4, 4, 64, p, i64(16), null)
+    assert rc == -1 and b'workspace too small' in lib.occ_last_error()

@@ -92,6 +92,10 @@ def parse():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer (default, the BASELINE metric): forward pass; train: forward + loss + "
                          "backward + DDP/RCCL gradient all-reduce + clip + AdamW step per sample")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="infer only, experiment: samples dealt round-robin to this many HIP streams, so the backbone "
+                         "of sample i+1 can run under the hot path of sample i (throughput, not latency; default 1 = "
+                         "the metric as defined: one sample at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -497,12 +501,21 @@ def main():
     # every instrumented kernel is timed in the first `detail` steps; after that only the roofline kernel (the
     # SCA gather) keeps its two event records per launch — 78 records per step cost ~0.3 ms of queue time
     detail = min(args.steps, 3)
+    lanes = None
+    if args.streams > 1 and args.mode == "infer" and args.input == "resident-f32":
+        lanes = [torch.cuda.Stream(device=device) for _ in range(args.streams)]
+        for s_ in lanes:
+            s_.wait_stream(torch.cuda.current_stream())
     for step_i in range(args.steps):
         if record is not None and step_i == detail:
             ext.kernel_timing_only({"sca_fused_forward"})
         if args.per_step:       # GPU-side time of every step (events on the current stream; no host sync)
             e0 = torch.cuda.Event(enable_timing=True); e0.record()
-        stepper()
+        if lanes is not None:
+            with torch.cuda.stream(lanes[step_i % len(lanes)]):
+                stepper()
+        else:
+            stepper()
         if args.per_step:
             e1 = torch.cuda.Event(enable_timing=True); e1.record()
             step_events.append((e0, e1))
@@ -544,7 +557,7 @@ def main():
                              "bevformer_base_occ hot path only: 4 FPN maps (6 cams) -> voxels"),
                 "mode": args.mode, "scope": stepper.scope, "input": args.input if stepper.scope == "e2e" else None,
                 "samples_per_gpu": 1, "global_batch": world,
-                "parallelism": f"dp{world}", "hot_path_dtype": "f32",
+                "parallelism": f"dp{world}", "streams": args.streams, "hot_path_dtype": "f32",
                 "linear_precision": ext.LINEAR_PRECISION,
                 "backbone_dtype": args.backbone_dtype if stepper.scope == "e2e" else None,
                 "hot_feat_format": None if stepper.scope == "e2e" else (

@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
-from tests.golden_cases import CASES, METRIC_SEEDS, case_inputs, checksum, metric_scene  # noqa: E402
+from tests.golden_cases import (CASES, FULL_CASES, FULL_KEYS, METRIC_SEEDS, case_inputs, checksum, digest,  # noqa: E402
+                                full_case_inputs, metric_scene)
 
 
 def metric_golden():
@@ -117,7 +118,52 @@ def main():
               f'occ {arrays["occ"].shape} mean|occ| {np.abs(arrays["occ"]).mean():.4f}')
 
 
+def fullsize_golden():
+    """The reference's own module files at the BENCHMARKED geometry (BASELINE.json configs[1] / configs[2]): 40 000
+    BEV queries, 6 cameras x 30 825 keys, max_len ~ 9 900 padded rows per camera (spatial_cross_attention.py:136-173),
+    one encoder layer, without and with a rotated history BEV (transformer_occ.py:189-205,
+    temporal_self_attention.py:177-204).  Stored: tests.golden_cases.digest of every output (strided subsample +
+    float64 sums), a few MB of RAM and ~1 minute of CPU per case."""
+    import time
+    from oracle import refshim
+    ref = refshim.install()
+    from tests.util import head_cfg, randomize
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name, case in FULL_CASES.items():
+        t0 = time.time()
+        cfg = head_cfg(case['geometry'])
+        head = ref.build_head(copy.deepcopy(cfg))
+        assert type(head).__module__.startswith('projects.mmdet3d_plugin'), type(head).__module__
+        randomize(head, case['seed'])
+        head.eval()
+        feats, metas, prev_bev = full_case_inputs(case)
+        taps = {}
+        layer0 = head.transformer.encoder.layers[0]
+        hs = [layer0.attentions[0].register_forward_hook(
+                  lambda m, a, o: taps.__setitem__('layer0_tsa_out', o.detach().clone())),
+              layer0.attentions[1].register_forward_hook(
+                  lambda m, a, o: taps.__setitem__('layer0_sca_out', o.detach().clone()))]
+        with torch.no_grad():
+            out = head(feats, metas, prev_bev=None if prev_bev is None else prev_bev.clone())
+        for h in hs:
+            h.remove()
+        out = dict(out, **taps)
+        arrays = dict(weights_checksum=np.float64(checksum(head.state_dict().values())),
+                      inputs_checksum=np.float64(checksum(feats)))
+        for k in FULL_KEYS:
+            arrays.update({f'{k}_{kk}': v for kk, v in digest(out[k]).items()})
+            arrays[f'{k}_shape'] = np.asarray(out[k].shape, np.int64)
+        path = os.path.join(OUT, f'{name}.npz')
+        np.savez_compressed(path, **arrays)
+        print(f'{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB) in {time.time() - t0:.0f} s; '
+              f'occ {tuple(out["occ"].shape)} mean|occ| {float(out["occ"].abs().mean()):.4f}')
+
+
 if __name__ == '__main__':
+    if '--full-only' in sys.argv:
+        fullsize_golden()
+        sys.exit(0)
     if '--metrics-only' not in sys.argv:
         main()
+        fullsize_golden()
     metric_golden()

@@ -182,3 +182,70 @@ def test_images_to_voxels_fp32_backbone():
         d = maxdiff(out_p[k], out_o[k])
         print(f"images->voxels fp32 backbone {k}: max|hip - oracle| = {d:.3e} (scale {scale:.2f}, rel {d / scale:.2e})")
         assert d / scale < TOL, (k, d, scale)
+
+
+# ---- pinned to the reference at the benchmarked geometry (VERDICT r2 missing #2, #3) -------------------------------
+@pytest.mark.parametrize('name', ['base_full_nohist', 'base_full_hist'])
+def test_product_matches_reference_golden_at_base_geometry(name):
+    """HIP head vs tests/golden/base_full_*.npz: digests of what the reference's OWN module files produced at
+    40 000 queries / 6 x 30 825 keys / max_len ~ 9 900 / 106 camera-less queries, one layer, without and with a
+    history BEV rotated by 7.5 degrees (oracle/gen_golden.py::fullsize_golden; reference
+    spatial_cross_attention.py:136-173, transformer_occ.py:189-205, temporal_self_attention.py:177-204).
+    No oracle in the loop."""
+    import numpy as np
+    from occnet_amd.plugin import build_head
+    from tests.golden_cases import FULL_CASES, FULL_KEYS, checksum, compare_digest, full_case_inputs
+    from tests.util import head_cfg, randomize
+    case = FULL_CASES[name]
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', f'{name}.npz'))
+    head = build_head(head_cfg(case['geometry']))
+    randomize(head, case['seed'])
+    assert abs(checksum(head.state_dict().values()) / float(gold['weights_checksum']) - 1) < 1e-9
+    head = head.cuda().eval()
+    feats, metas, prev_bev = full_case_inputs(case)
+    assert abs(checksum(feats) / float(gold['inputs_checksum']) - 1) < 1e-9
+    with torch.no_grad():
+        out = head([f.cuda() for f in feats], metas, prev_bev=None if prev_bev is None else prev_bev.cuda())
+    for k in ('bev_embed', 'occ', 'flow'):
+        assert tuple(out[k].shape) == tuple(int(v) for v in gold[f'{k}_shape'])
+        sub, slab = compare_digest(k, out[k], gold, TOL)
+        print(f"reference golden {name}/{k}: subsample max|hip - reference| = {sub:.3e}, slab mean diff {slab:.2e}")
+
+
+def test_base_geometry_with_history():
+    """BASELINE.json configs[2] at FULL size: BEVFormerOcc.obtain_history_bev over a 3-frame queue (reference
+    bevformer_occ.py:159-178) followed by the current frame's full head pass with that history — TSA with a real,
+    rotated prev_bev (value_bt_stride != 0, two K segments) at 200 x 200 — against the oracle driven through the same
+    chain, 2 encoder layers."""
+    from occnet_amd.plugin import BEVFormerOcc
+    g = _base(2)
+    prod, ora = build_pair(g, seed=17)
+    det = BEVFormerOcc.__new__(BEVFormerOcc)
+    torch.nn.Module.__init__(det)
+    det.pts_bbox_head = prod
+    det.video_test_mode = True
+    L = 3
+    frames = [synthetic.make_features(g, seed=170 + i) for i in range(L + 1)]
+    metas_list = [[]]
+    for i in range(L + 1):
+        m = synthetic.make_img_metas(g, seed=i)[0]
+        m['prev_bev_exists'] = i != 1          # frame 1 starts a new scene: frame 0's BEV is dropped
+        m['can_bus'][-1] = 2.5 * i - 3.0       # ego yaw change since the previous frame (degrees)
+        metas_list[0].append(m)
+    stacked = [torch.stack([frames[i][l][0] for i in range(L)], 0)[None].cuda() for l in range(len(frames[0]))]
+    det.extract_feat = lambda img, img_metas=None, len_queue=None: stacked
+    imgs = torch.zeros(1, L, g['num_cams'], 3, 8, 8, device='cuda')
+    prev_p = det.obtain_history_bev(imgs, [metas_list[0][:L]])
+    cur = metas_list[0][L]
+    with torch.no_grad():
+        out_p = prod([f.cuda() for f in frames[L]], [cur], prev_bev=prev_p)
+        prev = None
+        for i in range(L):
+            if not metas_list[0][i]['prev_bev_exists']:
+                prev = None
+            prev = ora(frames[i], [metas_list[0][i]], prev, only_bev=True)
+        d = maxdiff(prev_p, prev)
+        print(f"3-frame history BEV at 200x200: max|hip - oracle| = {d:.3e}")
+        assert d < TOL
+        out_o = ora(frames[L], [cur], prev_bev=prev)
+    _check(out_p, out_o, "base 2 layers + 3-frame history")

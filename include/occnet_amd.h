@@ -99,6 +99,16 @@ int occ_sca_fused_forward_f32(const float* value, const int64_t* spatial_shapes,
                               float* slots, uint64_t* stats, int B, int NC, int S, int M, int D,
                               int L, int P, int Z, int Nq, void* stream);
 
+/* The same gather over fp16 VALUE maps (SURVEY.md §8d's e_v = 2 variant): value (B*NC, S, M, D) fp16 as written by
+ * occ_value_proj_bf16_f16.  One head row of a pixel is 64 bytes = 4 lanes x 16 bytes, so a wave load fetches 16 rows
+ * instead of 8 (the texture path retires wave loads, not bytes: csrc/sca_fused.hip).  Sampling arithmetic, attention
+ * weights and accumulation stay fp32 (v_fma_mix_f32); the value elements carry 11 significant bits. */
+int occ_sca_fused_forward_f16v(const void* value_f16, const int64_t* spatial_shapes,
+                               const int64_t* level_start_index, const float* offs, int64_t offs_stride,
+                               const float* logits, int64_t logits_stride, const float* ref_cam,
+                               const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats,
+                               int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused spatial cross-attention gather, HEAD-MAJOR decomposition (csrc/sca_head.hip): same arguments, semantics
  * and reference lines as occ_sca_fused_forward_f32 — a block works on ONE attention head (= one XCD's L2 holds one

@@ -13,6 +13,20 @@
 // the camera and are computed once per query.  Per (query, camera): 256 samples are resolved by the
 // wave (4 per lane) into LDS, then every 8-lane group gathers its head's 32 samples:
 // 128 x 16-byte loads per lane, 16 in flight.
+//
+// HALFV (default for inference since round 3): the projected value maps are stored as fp16 (value_proj_bf16's fp16
+// epilogue), so one head's 32 channels of one pixel are 64 bytes = FOUR lanes x 16 bytes.  The texture path retires
+// ~one 1 KB wave load per ~21 clocks whatever the lanes ask for (tools_dev/ta_probe.hip: 47-50 B/clk/CU for random
+// 128-byte rows, random 64-byte rows fetched 8 B per lane, and fully coalesced 1 KB alike), so the cost of a row is the
+// number of LANES it occupies: with 16 B per lane a wave instruction fetches 16 fp16 rows instead of 8 fp32 rows.
+// The wave's 16 lane-groups = 8 heads x 2 halves of the head's L*P samples; every lane keeps 8 fp32 accumulators
+// (v_fma_mix_f32 widens the fp16 operand inside the FMA) and the two halves meet in one cross-lane add at the end.
+// Round 2's fp16 experiment (sca_head_h_kernel) kept 8 lanes x 8 B per row — the same number of wave loads per row —
+// and measured no gain for exactly this reason.  Sampling arithmetic, weights and accumulation stay fp32; the value
+// elements carry 11 significant bits (end-to-end effect at full size: tests/test_gpu_fullsize.py, bench parity leg).
+// Both variants issue their loads as a ROLLING window (the loads of sample j + 4 are requested as soon as sample j is
+// consumed) instead of batches of 16 that drain to zero before the next batch is requested.
+#include <stdlib.h>
 #include "common.h"
 
 namespace occ {
@@ -139,16 +153,155 @@ static int launch_sca(const float* value, const int64_t* shapes, const int64_t* 
   return OCC_OK;
 }
 
+// fp16 value rows (see the file header): 4 lanes x 16 B per head row, two sample halves per head, rolling load window
+template <int L, int P, int WPS, int DEPTH>
+__global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
+    const void* __restrict__ value_, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lstart, const float* __restrict__ offs, long offs_stride,
+    const float* __restrict__ logits, long logits_stride, const float* __restrict__ ref_cam,
+    const uint32_t* __restrict__ vis_bits, const int32_t* __restrict__ order,
+    float* __restrict__ slots, unsigned long long* __restrict__ stats, int B, int NC, int S, int Z,
+    int Nq) {
+  constexpr int M = 8, D = 32, LP = L * P;
+  constexpr int K = M * LP / 64;  // samples resolved per lane
+  static_assert(LP >= 8 && LP <= 32 && (LP & (LP - 1)) == 0, "L*P must be a power of two in [8,32]");
+  constexpr int LPp = LP + 1;
+  __shared__ __attribute__((aligned(16))) SampleParamB smem[kScaWaves * M * LPp];
+  // the camera-independent per-sample terms (softmax weight, normalised offset) wait in LDS, not in registers:
+  // live across the gather they push the kernel over the 168 VGPRs of three waves per SIMD (10 scratch spills =
+  // 100 MB of extra writes per launch)
+  __shared__ __attribute__((aligned(16))) float pre[kScaWaves][3][K][64];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const long wg = (long)blockIdx.x * kScaWaves + wave;
+  if (wg >= (long)B * Nq) return;
+  const int b = (int)(wg / Nq);
+  const int r = (int)(wg - (long)b * Nq);
+  const int q = order ? order[r] : r;
+  SampleParamB* sp = smem + wave * M * LPp;
+
+  constexpr int row_stride = M * D;
+  constexpr bool HALFV = true;
+  constexpr unsigned EV = 2u;                              // bytes per value element
+  const char* value = reinterpret_cast<const char*>(value_);
+  const uint32_t vis = vis_bits[q];                       // batch 0's mask picks the cameras
+  const uint32_t own = vis_bits[(long)b * Nq + q];        // this batch's mask gives the divisor
+  const int count = __builtin_popcount(own);
+
+  // ---- camera-independent part: softmax(logits) and offsets / (W_l, H_l) ------------------
+  float aw[K], ox[K], oy[K];
+  // sample index s = (lane + 64 k) % LP does not depend on k (64 % LP == 0): one level per lane
+  static_assert(64 % LP == 0, "the lane's level must not depend on k");
+  const int lane_l = (lane % LP) / P;
+  const int lvH = (int)shapes[2 * lane_l], lvW = (int)shapes[2 * lane_l + 1], lvS = (int)lstart[lane_l];
+  const float* lrow = logits + ((long)b * Nq + q) * logits_stride;
+  const float* orow = offs + ((long)b * Nq + q) * offs_stride;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int idx = lane + 64 * k;  // = m*LP + s
+    float x = lrow[idx];
+    float mx = x;
+#pragma unroll
+    for (int d = LP / 2; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    const float e = expf(x - mx);
+    float sum = e;
+#pragma unroll
+    for (int d = LP / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    aw[k] = e / sum;
+    const float2 o = *reinterpret_cast<const float2*>(orow + 2 * idx);
+    ox[k] = o.x / (float)lvW;
+    oy[k] = o.y / (float)lvH;
+    pre[wave][0][k][lane] = aw[k];
+    pre[wave][1][k][lane] = ox[k];
+    pre[wave][2][k][lane] = oy[k];
+  }
+
+  // f32 rows: 8 lanes x 4 channels per head; fp16 rows: 4 lanes x 8 channels per head and two sample halves
+  const int g = HALFV ? (lane >> 2) & 7 : lane >> 3, c4 = HALFV ? lane & 3 : lane & 7;
+  const int half = HALFV ? lane >> 5 : 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
+  unsigned n_in = 0, n_rows = 0;
+
+  for (int c = 0; c < NC; ++c) {
+    if (!((vis >> c) & 1u)) continue;  // wave-uniform
+    const float* rp = ref_cam + (((long)c * B + b) * Nq + q) * Z * 2;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int idx = lane + 64 * k;
+      const int m = idx / LP, s = idx % LP;
+      const int z = (s % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
+      const float2 rxy = *reinterpret_cast<const float2*>(rp + 2 * z);
+      SampleParamB p;
+      const float aw_k = pre[wave][0][k][lane], ox_k = pre[wave][1][k][lane], oy_k = pre[wave][2][k][lane];
+      n_in += bilinear_setup_b(rxy.x + ox_k, rxy.y + oy_k, aw_k, lvH, lvW, lvS,
+                               (unsigned)row_stride * EV, kOobOffset, true, p);
+      sp[m * LPp + s] = p;
+    }
+    wave_lds_sync();
+    // corners outside their map carry an out-of-range byte offset: the buffer load returns 0 without a request
+    // (round 1 issued a dummy load of row 0 for them: 9 % of the rows through the texture path, and 0 * Inf)
+    const __amdgpu_buffer_rsrc_t rsrc =
+        uniform_rsrc(value + ((long)b * NC + c) * S * row_stride * EV, (unsigned)S * row_stride * EV);
+    if (HALFV)
+      gather_samples_buf_h<LP / 2, DEPTH>(rsrc, (unsigned)(g * D + c4 * 8) * 2u, sp + g * LPp + half * (LP / 2), acc,
+                                          acc2);
+    else
+      acc = gather_samples_buf<4>(rsrc, (unsigned)(g * D + c4 * 4) * 4u, sp + g * LPp, LP, acc);
+    wave_lds_sync();  // WAR: next camera rewrites the LDS slab
+    ++n_rows;
+  }
+
+  const float inv = (float)(count > 0 ? count : 1);
+  if (HALFV) {
+    // the two sample halves of a head sit 32 lanes apart
+    acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32);
+    acc.w += __shfl_xor(acc.w, 32);
+    acc2.x += __shfl_xor(acc2.x, 32); acc2.y += __shfl_xor(acc2.y, 32); acc2.z += __shfl_xor(acc2.z, 32);
+    acc2.w += __shfl_xor(acc2.w, 32);
+    if (half == 0) {
+      float* dst = slots + ((long)b * Nq + q) * row_stride + g * D + c4 * 8;
+      *reinterpret_cast<float4*>(dst) = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(acc2.x / inv, acc2.y / inv, acc2.z / inv, acc2.w / inv);
+    }
+  } else {
+    float4 o4 = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
+    *reinterpret_cast<float4*>(slots + ((long)b * Nq + q) * row_stride + g * D + c4 * 4) = o4;
+  }
+
+  if (stats) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_in += __shfl_xor(n_in, d);
+    if (lane == 0) {
+      atomicAdd(&stats[0], (unsigned long long)n_rows);
+      atomicAdd(&stats[1], (unsigned long long)n_in);
+    }
+  }
+}
+
+template <int L, int P, int WPS = 3, int DEPTH = 4>
+static int launch_sca_h(const void* value, const int64_t* shapes, const int64_t* lstart,
+                        const float* offs, long offs_stride, const float* logits, long logits_stride,
+                        const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
+                        float* slots, uint64_t* stats, int B, int NC, int S, int Z, int Nq,
+                        hipStream_t st) {
+  const long waves = (long)B * Nq;
+  const long blocks = (waves + kScaWaves - 1) / kScaWaves;
+  hipLaunchKernelGGL((sca_fused_h_kernel<L, P, WPS, DEPTH>), dim3((unsigned)blocks), dim3(256), 0, st, value,
+                     shapes, lstart, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits,
+                     order, slots, reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq);
+  OCC_CHECK_LAUNCH("sca_fused_forward_f16v");
+  return OCC_OK;
+}
+
 }  // namespace occ
 
-extern "C" int occ_sca_fused_forward_f32(const float* value, const int64_t* spatial_shapes,
-                                         const int64_t* level_start_index, const float* offs,
-                                         int64_t offs_stride, const float* logits,
-                                         int64_t logits_stride, const float* ref_cam,
-                                         const uint32_t* vis_bits, const int32_t* order,
-                                         float* slots, uint64_t* stats, int B, int NC, int S, int M,
-                                         int D, int L, int P, int Z, int Nq, void* stream) {
-  using namespace occ;
+namespace occ {
+static int sca_dispatch(const void* value, bool halfv, const int64_t* spatial_shapes,
+                        const int64_t* level_start_index, const float* offs, int64_t offs_stride,
+                        const float* logits, int64_t logits_stride, const float* ref_cam,
+                        const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats, int B,
+                        int NC, int S, int M, int D, int L, int P, int Z, int Nq, void* stream) {
   OCC_CHECK_ARG(value && spatial_shapes && level_start_index && offs && logits && ref_cam &&
                     vis_bits && slots,
                 "sca_fused_forward: null pointer argument");
@@ -164,11 +317,24 @@ extern "C" int occ_sca_fused_forward_f32(const float* value, const int64_t* spat
     set_error("sca_fused_forward: no fused kernel for M=%d D=%d", M, D);
     return OCC_E_UNSUPPORTED;
   }
-#define OCC_SCA_CASE(LL, PP)                                                                      \
-  if (L == LL && P == PP)                                                                         \
-    return launch_sca<LL, PP>(value, spatial_shapes, level_start_index, offs, (long)offs_stride,  \
-                              logits, (long)logits_stride, ref_cam, vis_bits, order, slots, stats, \
-                              B, NC, S, Z, Nq, st);
+  // development switch (tools_dev/sca_probe.py): 1 = four waves per SIMD with a 2-sample window, 2 = three waves, 3-sample
+  const char* hv_ = getenv("OCC_SCA_H_VARIANT");
+  const int hvar = hv_ ? atoi(hv_) : 0;
+  if (halfv && L == 4 && P == 8 && hvar == 1)
+    return launch_sca_h<4, 8, 4, 2>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits,
+                                        (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st);
+  if (halfv && L == 4 && P == 8 && hvar == 2)
+    return launch_sca_h<4, 8, 3, 2>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits,
+                                        (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st);
+#define OCC_SCA_CASE(LL, PP)                                                                       \
+  if (L == LL && P == PP) {                                                                        \
+    if (halfv)                                                                                     \
+      return launch_sca_h<LL, PP>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits,     \
+                                  (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st); \
+    return launch_sca<LL, PP>(reinterpret_cast<const float*>(value), spatial_shapes, level_start_index, offs,    \
+                              (long)offs_stride, logits, (long)logits_stride, ref_cam, vis_bits, order, slots,   \
+                              stats, B, NC, S, Z, Nq, st);                                                       \
+  }
   OCC_SCA_CASE(4, 8)
   OCC_SCA_CASE(4, 4)
   OCC_SCA_CASE(2, 8)
@@ -176,4 +342,27 @@ extern "C" int occ_sca_fused_forward_f32(const float* value, const int64_t* spat
 #undef OCC_SCA_CASE
   set_error("sca_fused_forward: no fused kernel for L=%d P=%d", L, P);
   return OCC_E_UNSUPPORTED;
+}
+}  // namespace occ
+
+extern "C" int occ_sca_fused_forward_f32(const float* value, const int64_t* spatial_shapes,
+                                         const int64_t* level_start_index, const float* offs,
+                                         int64_t offs_stride, const float* logits,
+                                         int64_t logits_stride, const float* ref_cam,
+                                         const uint32_t* vis_bits, const int32_t* order,
+                                         float* slots, uint64_t* stats, int B, int NC, int S, int M,
+                                         int D, int L, int P, int Z, int Nq, void* stream) {
+  return occ::sca_dispatch(value, false, spatial_shapes, level_start_index, offs, offs_stride, logits, logits_stride,
+                           ref_cam, vis_bits, order, slots, stats, B, NC, S, M, D, L, P, Z, Nq, stream);
+}
+
+extern "C" int occ_sca_fused_forward_f16v(const void* value_f16, const int64_t* spatial_shapes,
+                                          const int64_t* level_start_index, const float* offs,
+                                          int64_t offs_stride, const float* logits,
+                                          int64_t logits_stride, const float* ref_cam,
+                                          const uint32_t* vis_bits, const int32_t* order,
+                                          float* slots, uint64_t* stats, int B, int NC, int S, int M,
+                                          int D, int L, int P, int Z, int Nq, void* stream) {
+  return occ::sca_dispatch(value_f16, true, spatial_shapes, level_start_index, offs, offs_stride, logits,
+                           logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, M, D, L, P, Z, Nq, stream);
 }

@@ -32,10 +32,11 @@ constexpr int kStMS = 144;                     // conv pixel slot: 64 bf16 + 16 
 constexpr int kStConv = 320 * kStMS;           // 10 row tiles of 32 slots
 
 // U8 (the input side of the path): x is the RAW camera image, uint8 HWC (N, Hs, Ws, 3), and the
-// pipeline's NormalizeMultiviewImage ((x[to_rgb ? 2 - c : c] - mean[c]) / std[c], float32) and PadMultiViewImage
+// pipeline's NormalizeMultiviewImage ((x[to_rgb ? 2 - c : c] - mean[c]) * (1 / std[c]) in float32 — mmcv.imnormalize_
+// subtracts the mean and MULTIPLIES by the reciprocal of std, it does not divide) and PadMultiViewImage
 // (zeros to H x W = the next multiple of 32; reference P/datasets/pipelines/transform_3d.py:31-45,82-94) happen
 // while the tile is staged: the 107 MB fp32 tensor of the six images is never built, 26 MB of uint8 cross PCIe
-struct StemNorm { float mean[3], std[3]; int Hs, Ws, to_rgb; };
+struct StemNorm { float mean[3], stdinv[3]; int Hs, Ws, to_rgb; };
 
 template <bool U8>
 __global__ __launch_bounds__(256, 2) void stem_conv7x7_pool_kernel(
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv7x7_pool_kernel(
         const int sy = min(cy, nrm.Hs - 1), sx = min(cx, nrm.Ws - 1), sc = nrm.to_rgb ? 2 - cc : cc;
         const float raw = (float)xu[((long)sy * nrm.Ws + sx) * 3 + sc];
         const float mu = cc == 0 ? nrm.mean[0] : (cc == 1 ? nrm.mean[1] : nrm.mean[2]);
-        const float sd = cc == 0 ? nrm.std[0] : (cc == 1 ? nrm.std[1] : nrm.std[2]);
-        v[j] = (cy < nrm.Hs && cx < nrm.Ws) ? (raw - mu) / sd : 0.f;       // bottom / right pad: normalised zeros
+        const float si = cc == 0 ? nrm.stdinv[0] : (cc == 1 ? nrm.stdinv[1] : nrm.stdinv[2]);
+        v[j] = (cy < nrm.Hs && cx < nrm.Ws) ? (raw - mu) * si : 0.f;       // bottom / right pad: normalised zeros
       } else {
         v[j] = xi[cc * plane + (long)cy * W + cx];
       }
@@ -196,7 +197,7 @@ extern "C" int occ_stem_conv7x7_pool_f32_bf16(const float* x, const void* weight
   return OCC_OK;
 }
 
-// Raw camera images in: x (batch, Hs, Ws, 3) uint8 HWC; the stem sees (x[to_rgb ? 2-c : c] - mean[c]) / std[c]
+// Raw camera images in: x (batch, Hs, Ws, 3) uint8 HWC; the stem sees (x[to_rgb ? 2-c : c] - mean[c]) * (1 / std[c])
 // zero-padded bottom/right to H x W (H >= Hs, W >= Ws) — NormalizeMultiviewImage + PadMultiViewImage fused into
 // the tile staging.  mean / std: 3 host floats each, in the network's channel order.
 extern "C" int occ_stem_conv7x7_pool_u8_bf16(const uint8_t* x, const void* weight_frag, const float* bias,
@@ -210,7 +211,7 @@ extern "C" int occ_stem_conv7x7_pool_u8_bf16(const uint8_t* x, const void* weigh
   const int Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
   const int tiles_x = (Wp + kStP - 1) / kStP, tiles_y = (Hp + kStP - 1) / kStP;
   StemNorm nrm;
-  for (int c = 0; c < 3; ++c) { nrm.mean[c] = mean[c]; nrm.std[c] = std[c]; }
+  for (int c = 0; c < 3; ++c) { nrm.mean[c] = mean[c]; nrm.stdinv[c] = (float)(1.0 / (double)std[c]); }   // stdinv in f64 (mmcv), used in f32
   nrm.Hs = Hs; nrm.Ws = Ws; nrm.to_rgb = to_rgb ? 1 : 0;
   hipLaunchKernelGGL(stem_conv7x7_pool_kernel<true>, dim3((unsigned)((long)batch * tiles_x * tiles_y)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<const uint4*>(weight_frag), bias,

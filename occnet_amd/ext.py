@@ -174,7 +174,7 @@ _SCA_NAMES = {0: "sca_fused_kernel<4,8> (query-major)", 1: "sca_head_kernel<4,8,
 
 def sca_variant_name(kernel=None):
     if kernel is None and SCA_VALUES == "f16":
-        return "sca_head_h_kernel<4,8> (head-major, fp16 values)"
+        return "sca_fused_h_kernel<4,8> (query-major, fp16 values)"
     return _SCA_NAMES[SCA_KERNEL if kernel is None else kernel]
 
 
@@ -216,7 +216,7 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
     slots = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
     with torch.cuda.device(value.device), _timed('sca_fused_forward'):
         if half:
-            rc = _lib.lib().occ_sca_head_forward_f16v(
+            rc = _lib.lib().occ_sca_fused_forward_f16v(
                 ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
                 i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
                 ptr(order), ptr(slots), ptr(stats), i32(B), i32(NC), i32(S), i32(M), i32(D), i32(L),

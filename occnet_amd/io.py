@@ -9,6 +9,7 @@ or the nuScenes devkit.  Host-side formatting only (no model compute lives here)
   camera_matrices                                  P/datasets/nuscenes_occ.py:87-120 (lidar2img = K_pad @ lidar2cam)
   load_occ_gt / save_occ_gt                        P/datasets/pipelines/loading.py:21-33 (.npz: semantics, flow)
   make_img_meta                                    the img_metas keys the path consumes (encoder.py:94-101,133-134)
+  lidar_origins                                    tools/ray_iou/ego_pose_extractor.py:84-121 (origins the rays start from)
   format_submission / read_submission              P/datasets/nuscenes_occ.py:189-257 (submission.gz)
 """
 import gzip
@@ -42,15 +43,17 @@ def pad_multiview(imgs, size_divisor=32, size=None, pad_val=0):
 
 
 def normalize_multiview(imgs, mean, std, to_rgb=True):
-    """(img[..., ::-1] if to_rgb) - mean) / std in float32 (mmcv.imnormalize)."""
+    """((img[..., ::-1] if to_rgb) - mean) * (1 / std) in float32: mmcv.imnormalize subtracts the mean and multiplies
+    by the reciprocal of std (formed in float64), it does not divide (NormalizeMultiviewImage, transform_3d.py:82-94)."""
     mean = np.asarray(mean, dtype=np.float32).reshape(1, 1, -1)
     std = np.asarray(std, dtype=np.float32).reshape(1, 1, -1)
+    stdinv = (1 / np.float64(std)).astype(np.float32)
     out = []
     for img in imgs:
         x = img.astype(np.float32)
         if to_rgb:
             x = x[..., ::-1]
-        out.append((x - mean) / std)
+        out.append((x - mean) * stdinv)
     return out, dict(mean=mean.reshape(-1), std=std.reshape(-1), to_rgb=to_rgb)
 
 
@@ -119,6 +122,49 @@ def make_img_meta(cams, lidar2ego_translation, lidar2ego_rotation, img_shapes, c
                 prev_bev_exists=prev_bev_exists)
     meta.update(extra)
     return meta
+
+
+PSEUDO_LIDAR2EGO = np.array([[0., 1., 0., 0.94], [-1., 0., 0., 0.], [0., 0., 1., 1.84], [0., 0., 0., 1.]])
+
+
+def lidar_origins(data_infos, index, dataset_type='openocc_v2', max_origins=8, xy_range=39.0):
+    """Lidar origins the ray metric / the submission cast from for sample `index`: the lidar position of EVERY frame
+    of the sample's scene expressed in the sample's ego frame, kept when |x|, |y| < 39 m, thinned to 8 evenly spaced
+    ones (reference tools/ray_iou/ego_pose_extractor.py:84-121, driven by nuscenes_occ.py:142-166,196-224).
+    data_infos: the nuScenes info dicts (`token`, `lidar2ego_translation/rotation`, `ego2global_translation/rotation`,
+    `scene_token` or `occ_path`).  -> (token, float tensor (1, T, 3)) — the batch a DataLoader(batch_size=1) yields."""
+    def scene_of(info):
+        if dataset_type == 'openocc_v2' and 'scene_token' not in info:
+            return info['occ_path'].split('openocc_v2/')[-1].split('/')[0]
+        return info['scene_token']
+
+    def ego_from_lidar(info):
+        if dataset_type == 'lightwheelocc':
+            return PSEUDO_LIDAR2EGO
+        return transform_matrix(info['lidar2ego_translation'], info['lidar2ego_rotation'])
+
+    def global_from_lidar(info):
+        return transform_matrix(info['ego2global_translation'], info['ego2global_rotation']).dot(ego_from_lidar(info))
+    info = data_infos[index]
+    frames = [f for f in data_infos if scene_of(f) == scene_of(info)]
+    ref_index = next(i for i, f in enumerate(frames) if f is info)
+    ref_lidar_from_global = np.linalg.inv(global_from_lidar(info))
+    ref_ego_from_lidar = ego_from_lidar(info)
+    origins = []
+    for i, frame in enumerate(frames):
+        if i == ref_index:
+            o = np.array([0.0, 0.0, 0.0], dtype=np.float32)
+        else:
+            o = np.array(ref_lidar_from_global.dot(global_from_lidar(frame))[:3, 3], dtype=np.float32)
+        pad = np.ones([4])
+        pad[:3] = o
+        o = np.dot(ref_ego_from_lidar[:3], pad.T).T
+        if np.abs(o[0]) < xy_range and np.abs(o[1]) < xy_range:
+            origins.append(o)
+    if len(origins) > max_origins:
+        sel = np.round(np.linspace(0, len(origins) - 1, max_origins)).astype(np.int64)
+        origins = [origins[i] for i in sel]
+    return info['token'], torch.from_numpy(np.stack(origins))[None]
 
 
 # ----------------------------------------------------------------------------- occupancy ground truth

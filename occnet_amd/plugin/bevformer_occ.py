@@ -136,7 +136,8 @@ class BEVFormerOcc(BaseModule):
             x = img_u8.reshape(B * N, Hs, Ws, 3).float()
             if to_rgb:
                 x = x.flip(-1)
-            x = (x - x.new_tensor(mean)) / x.new_tensor(std)
+            stdinv = [float(1.0 / float(torch.tensor(v, dtype=torch.float32))) for v in std]   # mmcv: * (1 / std)
+            x = (x - x.new_tensor(mean)) * x.new_tensor(stdinv)
             d = int(size_divisor)
             H, W = (Hs + d - 1) // d * d, (Ws + d - 1) // d * d
             x = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (0, W - Ws, 0, H - Hs))

@@ -159,11 +159,84 @@ def fullsize_golden():
               f'occ {tuple(out["occ"].shape)} mean|occ| {float(out["occ"].abs().mean()):.4f}')
 
 
+def datasets_golden():
+    """Input / output FORMAT fixtures from the reference's own dataset / pipeline files run in place
+    (refshim.install_datasets): NormalizeMultiviewImage + PadMultiViewImage on seeded uint8 frames
+    (transform_3d.py:31-45,82-94), LoadOccGTFromFile (loading.py:21-33), NuSceneOcc.get_data_info
+    (nuscenes_occ.py:49-126: lidar2img / lidar2cam / cam_intrinsic / ego2lidar), EgoPoseDataset origins and
+    NuSceneOcc.format_results (nuscenes_occ.py:189-257: the submission.gz content)."""
+    import pickle
+    import tempfile
+    from oracle import refshim
+    from occnet_amd import io as oio
+    from tests.golden_cases import PIPELINE_CASES, dataset_infos, metric_scene, pipeline_images
+    ns = refshim.install_datasets()
+    print('reference dataset / pipeline files executed:')
+    for f in ns.files:
+        print('  ', f)
+    arrays = {}
+    for name, case in PIPELINE_CASES.items():
+        results = dict(img=[im.astype(np.float32) for im in pipeline_images(case)])   # LoadMultiViewImageFromFiles(to_float32)
+        results = ns.NormalizeMultiviewImage(mean=case['mean'], std=case['std'], to_rgb=case['to_rgb'])(results)
+        results = ns.PadMultiViewImage(size_divisor=32)(results)
+        arrays[f'{name}_img'] = np.stack(results['img'])
+        arrays[f'{name}_img_shape'] = np.asarray(results['img_shape'])
+        arrays[f'{name}_ori_shape'] = np.asarray(results['ori_shape'])
+        arrays[f'{name}_pad_shape'] = np.asarray(results['pad_shape'])
+    with tempfile.TemporaryDirectory() as tmp:
+        # occupancy ground-truth file, read by the reference's loader (present and missing)
+        sp, sg, fp, fg, _ = metric_scene(43)
+        gt_path = os.path.join(tmp, 'labels.npz')
+        oio.save_occ_gt(gt_path, sg, fg)
+        res = ns.LoadOccGTFromFile()(dict(occ_path=gt_path))
+        arrays['gt_semantics_sum'] = np.int64(res['voxel_semantics'].astype(np.int64).sum())
+        arrays['gt_flow_abs_sum'] = np.float64(np.abs(res['voxel_flow'].astype(np.float64)).sum())
+        assert np.array_equal(res['voxel_semantics'], sg) and np.array_equal(res['voxel_flow'], fg)
+        miss = ns.LoadOccGTFromFile()(dict(occ_path=os.path.join(tmp, 'missing.npz')))
+        arrays['gt_missing_semantics_shape'] = np.asarray(miss['voxel_semantics'].shape)
+        arrays['gt_missing_flow_shape'] = np.asarray(miss['voxel_flow'].shape)
+        arrays['gt_missing_dtypes'] = np.asarray([str(miss['voxel_semantics'].dtype), str(miss['voxel_flow'].dtype)])
+        # dataset: annotation file -> get_data_info -> camera matrices; format_results -> submission.gz
+        ann = os.path.join(tmp, 'infos.pkl')
+        with open(ann, 'wb') as f:
+            pickle.dump(dataset_infos(), f)
+        ds = ns.NuSceneOcc(ann_file=ann, data_root=tmp, modality=dict(use_camera=True), test_mode=True)
+        for i in range(len(ds.data_infos)):
+            d = ds.get_data_info(i)
+            arrays[f'info{i}_lidar2img'] = np.stack(d['lidar2img'])
+            arrays[f'info{i}_lidar2cam'] = np.stack(d['lidar2cam'])
+            arrays[f'info{i}_cam_intrinsic'] = np.stack(d['cam_intrinsic'])
+            arrays[f'info{i}_ego2lidar'] = np.asarray(d['ego2lidar'])
+            tok, org = ns.EgoPoseDataset(ds.data_infos, dataset_type='openocc_v2')[i]
+            arrays[f'info{i}_origins'] = org.numpy()
+        occ_results = []
+        for i in range(len(ds.data_infos)):
+            sp, _, fp, _, _ = metric_scene(44 + i)
+            occ_results.append(dict(occ_results=torch.from_numpy(sp.astype(np.int64)).reshape(1, 200, 200, 16),
+                                    flow_results=torch.from_numpy(fp).reshape(1, 200, 200, 16, 2)))
+        # num_workers=8 in the reference's DataLoader: forked workers inherit the stub modules
+        with ns.on_host():
+            ds.format_results(occ_results, os.path.join(tmp, 'sub'))
+        sub = oio.read_submission(os.path.join(tmp, 'sub', 'submission.gz'))
+        arrays['sub_header_keys'] = np.asarray(sorted(k for k in sub if k != 'results'))
+        arrays['sub_tokens'] = np.asarray(list(sub['results']))
+        for tok, r in sub['results'].items():
+            for k, v in r.items():
+                arrays[f'sub_{tok}_{k}'] = v
+    path = os.path.join(OUT, 'datasets.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'datasets: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)')
+
+
 if __name__ == '__main__':
+    if '--datasets-only' in sys.argv:
+        datasets_golden()
+        sys.exit(0)
     if '--full-only' in sys.argv:
         fullsize_golden()
         sys.exit(0)
     if '--metrics-only' not in sys.argv:
         main()
         fullsize_golden()
+        datasets_golden()
     metric_golden()

@@ -284,3 +284,122 @@ def install_metrics():
             sys.modules['prettytable'] = saved_pt
     return types.SimpleNamespace(ray_metrics=mods['ref_ray_metrics'], metric=mods['ref_ray_iou_metric'],
                                  on_host=_cpu_cuda, files=[m.__file__ for m in mods.values()])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The reference's INPUT / OUTPUT FORMAT code, executed from where it lies:
+#   projects/mmdet3d_plugin/datasets/pipelines/transform_3d.py  (PadMultiViewImage :12-62, NormalizeMultiviewImage :65-101)
+#   projects/mmdet3d_plugin/datasets/pipelines/loading.py       (LoadOccGTFromFile :7-38)
+#   projects/mmdet3d_plugin/datasets/nuscenes_occ.py            (NuSceneOcc.get_data_info :49-126, format_results :189-257)
+#   tools/ray_iou/ego_pose_extractor.py                         (EgoPoseDataset: the lidar origins format_results casts from)
+# Third-party leaves restated (none of them is under /root/reference): mmcv.impad / impad_to_multiple / imnormalize
+# (mmcv/image/geometric.py, photometric.py: bottom/right constant padding; `(img - mean) * (1 / std)` in float32 with
+# optional BGR->RGB), mmcv.load (pickle), pyquaternion.Quaternion.rotation_matrix and
+# nuscenes.utils.geometry_utils.transform_matrix (taken from occnet_amd.io — the goldens compare those two leaves with
+# themselves, as with FFN / ConvModule above), NuScenesDataset (attribute holder), tqdm (real), cv2 (unused here).
+# nuscenes_occ.py does `from ....tools.ray_iou.ego_pose_extractor import EgoPoseDataset` — a relative import that climbs
+# above `projects`; the files are therefore mounted under a synthetic top-level package `occref` = /root/reference.
+def install_datasets():
+    """-> namespace(PadMultiViewImage, NormalizeMultiviewImage, LoadOccGTFromFile, NuSceneOcc, EgoPoseDataset, files)."""
+    import importlib.util
+    import pickle
+    import numpy as np
+    import torch.utils.cpp_extension as cpp_ext
+    from occnet_amd import io as oio
+    from occnet_amd.plugin.registry import Registry
+
+    PIPELINES, DATASETS = Registry('pipeline'), Registry('dataset')
+
+    def impad(img, *, shape=None, padding=None, pad_val=0, padding_mode='constant'):
+        assert padding_mode == 'constant' and shape is not None
+        out = np.full((shape[0], shape[1]) + img.shape[2:], pad_val, dtype=img.dtype)
+        out[:img.shape[0], :img.shape[1]] = img
+        return out
+
+    def impad_to_multiple(img, divisor, pad_val=0):
+        pad_h = int(np.ceil(img.shape[0] / divisor)) * divisor
+        pad_w = int(np.ceil(img.shape[1] / divisor)) * divisor
+        return impad(img, shape=(pad_h, pad_w), pad_val=pad_val)
+
+    def imnormalize(img, mean, std, to_rgb=True):
+        img = img.copy().astype(np.float32)
+        mean64 = np.float64(mean.reshape(1, -1))
+        stdinv = 1 / np.float64(std.reshape(1, -1))
+        if to_rgb:
+            img = img[..., ::-1]
+        # cv2.subtract / cv2.multiply on a float32 image with a double scalar: float32 result
+        return ((img - mean64.astype(np.float32)) * stdinv.astype(np.float32)).astype(np.float32)
+
+    class Quaternion:
+        def __init__(self, *a, **k):
+            q = a[0] if len(a) == 1 else a
+            self.q = np.asarray(q.q if isinstance(q, Quaternion) else q, dtype=np.float64)
+
+        @property
+        def rotation_matrix(self):
+            return oio.quaternion_rotation_matrix(self.q)
+
+    class NuScenesDataset:
+        def __init__(self, ann_file=None, data_root=None, modality=None, test_mode=False, load_interval=1, **kw):
+            self.ann_file, self.data_root, self.test_mode, self.load_interval = ann_file, data_root, test_mode, load_interval
+            self.modality = modality or dict(use_camera=True)
+
+    def mmcv_load(path):
+        with open(path, 'rb') as f:
+            return pickle.load(f)
+
+    saved = {k: sys.modules.get(k) for k in ('mmcv', 'mmdet', 'mmdet3d', 'cv2', 'nuscenes', 'pyquaternion', 'prettytable')}
+    _mod('mmcv', impad=impad, impad_to_multiple=impad_to_multiple, imnormalize=imnormalize, load=mmcv_load,
+         mkdir_or_exist=lambda d: os.makedirs(d, exist_ok=True))
+    _mod('mmcv.parallel', DataContainer=object)
+    _mod('mmdet')
+    _mod('mmdet.datasets', DATASETS=DATASETS)
+    _mod('mmdet.datasets.builder', PIPELINES=PIPELINES)
+    _mod('mmdet3d')
+    _mod('mmdet3d.datasets', NuScenesDataset=NuScenesDataset)
+    _mod('cv2')
+    _mod('nuscenes')
+    _mod('nuscenes.eval')
+    _mod('nuscenes.eval.common')
+    _mod('nuscenes.eval.common.utils', quaternion_yaw=None, Quaternion=Quaternion)
+    _mod('nuscenes.utils')
+    _mod('nuscenes.utils.geometry_utils',
+         transform_matrix=lambda translation=np.array([0, 0, 0]), rotation=Quaternion([1, 0, 0, 0]), inverse=False:
+         oio.transform_matrix(translation, rotation.q, inverse=inverse))
+    _mod('nuscenes.nuscenes', NuScenes=None)
+    _mod('pyquaternion', Quaternion=Quaternion)
+
+    class PrettyTable:
+        def __init__(self, field_names=None):
+            self.field_names, self.rows, self.float_format = field_names, [], ''
+
+        def add_row(self, row, divider=False):
+            self.rows.append(list(row))
+    _mod('prettytable', PrettyTable=PrettyTable)
+    saved_load = cpp_ext.load
+    cpp_ext.load = lambda name, sources=None, **kw: _reference_dvr()
+    try:
+        _pkg('occref', REF_ROOT)
+        _pkg('occref.tools', os.path.join(REF_ROOT, 'tools'))
+        _pkg('occref.tools.ray_iou', os.path.join(REF_ROOT, 'tools', 'ray_iou'))
+        P = os.path.join(REF_ROOT, 'projects')
+        _pkg('occref.projects', P)
+        _pkg('occref.projects.mmdet3d_plugin', os.path.join(P, 'mmdet3d_plugin'))
+        _pkg('occref.projects.mmdet3d_plugin.datasets', os.path.join(P, 'mmdet3d_plugin', 'datasets'))
+        _pkg('occref.projects.mmdet3d_plugin.datasets.pipelines', os.path.join(P, 'mmdet3d_plugin', 'datasets', 'pipelines'))
+        base = 'occref.projects.mmdet3d_plugin.datasets.'
+        t3d = importlib.import_module(base + 'pipelines.transform_3d')
+        loading = importlib.import_module(base + 'pipelines.loading')
+        nus = importlib.import_module(base + 'nuscenes_occ')
+        ego = importlib.import_module('occref.tools.ray_iou.ego_pose_extractor')
+    finally:
+        cpp_ext.load = saved_load
+        for k, v in saved.items():          # leave the stubs of install() / install_metrics() as they were
+            if v is not None:
+                sys.modules[k] = v
+    for m in (t3d, loading, nus, ego):
+        assert m.__file__.startswith(REF_ROOT), m.__file__
+    return types.SimpleNamespace(
+        PadMultiViewImage=t3d.PadMultiViewImage, NormalizeMultiviewImage=t3d.NormalizeMultiviewImage,
+        LoadOccGTFromFile=loading.LoadOccGTFromFile, NuSceneOcc=nus.NuSceneOcc, EgoPoseDataset=ego.EgoPoseDataset,
+        nuscenes_occ_module=nus, on_host=_cpu_cuda, files=[m.__file__ for m in (t3d, loading, nus, ego)])

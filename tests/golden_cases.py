@@ -122,3 +122,45 @@ def metric_scene(seed):
         fpred[x0 + dx:x0 + dx + sx, y0 + dy:y0 + dy + sy, 2:2 + sz] = vel + rng.normal(scale=0.4, size=2)
     origins = torch.tensor([[[0.9858, 0.0, 1.8402], [2.4, -0.7, 1.84]]], dtype=torch.float32)
     return pred, gt, fpred, fgt, origins
+
+
+# ---- input / output formats ---------------------------------------------------------------------
+PIPELINE_CASES = {
+    # the shipped configs' normalisation (bevformer_base_occ.py:14-15) on 6 small "camera" frames: 70 x 100 -> 96 x 128
+    'base_norm': dict(seed=31, n=6, hw=(70, 100), mean=[103.530, 116.280, 123.675], std=[1.0, 1.0, 1.0], to_rgb=False),
+    # a general normalisation (ImageNet statistics, BGR -> RGB): exercises the reciprocal-std and channel-flip paths
+    'rgb_norm': dict(seed=32, n=2, hw=(64, 96), mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True),
+}
+
+
+def pipeline_images(case):
+    import numpy as np
+    rng = np.random.default_rng(case['seed'])
+    return [rng.integers(0, 256, case['hw'] + (3,), dtype=np.uint8) for _ in range(case['n'])]
+
+
+def dataset_infos(occ_dir='/nonexistent/openocc_v2'):
+    """Three keyframes of one synthetic scene in the nuScenes `infos` layout NuSceneOcc reads (nuscenes_occ.py:60-120,
+    ego_pose_extractor.py:36-80): 6 cameras of the synthetic rig (sensor2lidar extrinsics as 3x3 matrices), a lidar
+    mounted 0.94 m ahead / 1.84 m up with a small yaw, an ego driving forward ~4 m per frame while turning."""
+    import math
+    import numpy as np
+    from occnet_amd import synthetic
+    rng = np.random.default_rng(33)
+    infos = []
+    for i in range(3):
+        yaw = 0.03 * i
+        cams = {}
+        for c, (cam_yaw, t, f) in enumerate(synthetic._RIG):
+            psi = math.radians(cam_yaw + rng.normal(0, 0.2))
+            R_l2c = np.array([[math.sin(psi), -math.cos(psi), 0.0], [0.0, 0.0, -1.0], [math.cos(psi), math.sin(psi), 0.0]])
+            cams[f'CAM_{c}'] = dict(data_path=f'samples/CAM_{c}/{i:04d}.jpg', sensor2lidar_rotation=R_l2c.T,
+                                    sensor2lidar_translation=np.asarray(t) + rng.normal(0, 0.01, 3),
+                                    cam_intrinsic=np.array([[f, 0.0, 816.0 + c], [0.0, f, 491.0 - c], [0.0, 0.0, 1.0]]))
+        infos.append(dict(
+            token=f'tok{i}', timestamp=1.5e15 + 5e5 * i, cams=cams,
+            occ_path=f'{occ_dir}/scene-0001/tok{i}/labels.npz',
+            lidar2ego_translation=[0.94, 0.0, 1.84], lidar2ego_rotation=[math.cos(0.004), 0.0, 0.0, math.sin(0.004)],
+            ego2global_translation=[600.0 + 4.1 * i, 1600.0 + 0.3 * i * i, 0.0],
+            ego2global_rotation=[math.cos(yaw / 2), 0.0, 0.0, math.sin(yaw / 2)]))
+    return dict(infos=infos, metadata=dict(version='v1.0-trainval'))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Time the SCA gather kernel variants on the REAL inputs of the base config (captured from one forward of the
-bench model's first layer) and check them against each other.  usage: python tools_dev/sca_probe.py [iters]"""
+"""Time the SCA gather kernels on the REAL inputs of the base config (captured from one forward of the bench model's
+last layer) and check them against each other: the fp32-value kernel (sca_fused_kernel) against the fp16-value kernel
+(sca_fused_h_kernel; OCC_SCA_H_VARIANT 0 = 3 waves/SIMD + 4-sample window, 1 = 4 waves + 2-sample window, 2 = 3 waves
++ 2-sample window), plus the value projection with fp32 / fp16 output.   usage: python tools_dev/sca_probe.py [iters]"""
 import json
 import os
 import sys
@@ -9,40 +11,60 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench                      # noqa: E402
 from occnet_amd import ext        # noqa: E402
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-variants = [int(v) for v in os.environ.get("SCA_PROBE_VARIANTS", "0,1,2,3").split(",")]
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda", 0)
 cfg, model, geo = bench.build(os.path.join(bench.ROOT, "configs", "occ_base_200x200x16.py"), dev)
 st = bench.Stepper(model, geo, "hotpath", "bf16", dev, seed=0, plan="folded", hot_feat_format="backbone")
 captured = []
 orig = ext.sca_fused_forward
 ext.sca_fused_forward = lambda *a, **k: (captured.append((a, k)), orig(*a, **k))[1]
+ext.SCA_VALUES = "f32"
 st()
 torch.cuda.synchronize()
 ext.sca_fused_forward = orig
 a, k = captured[-1]              # last layer: realistic, query-dependent offsets
-k = {kk: v for kk, v in k.items() if kk not in ("kernel", "stats", "order")}
-enc = model.pts_bbox_head.transformer.encoder
-head = model.pts_bbox_head
-orders = {False: enc._bev_order(head.bev_h, head.bev_w, dev), True: enc._bev_order(head.bev_h, head.bev_w, dev, flat=True)}
-ref = None
-res = {}
-for var in variants:
-    stats = torch.zeros(2, dtype=torch.int64, device=dev)
-    k['order'] = orders[var != 0]
-    out = orig(*a, **k, kernel=var, stats=stats)
-    torch.cuda.synchronize()
-    if ref is None:
-        ref = out
+k = {kk: v for kk, v in k.items() if kk not in ("kernel", "stats")}
+v32 = a[0]
+v16 = v32.half()
+print(f"value {tuple(v32.shape)}; fp16 rounding of the values: max abs {float((v16.float() - v32).abs().max()):.3e}", flush=True)
+
+
+def timed(fn):
     for _ in range(5):
-        orig(*a, **k, kernel=var)
+        fn()
     evs = []
     for _ in range(iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); orig(*a, **k, kernel=var); e1.record()
+        e0.record(); fn(); e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
     ms = sorted(x.elapsed_time(y) for x, y in evs)
-    res[var] = dict(name=ext.sca_variant_name(var), median_ms=ms[len(ms) // 2], min_ms=ms[0], max_ms=ms[-1],
-                    maxdiff_vs_first=float((out - ref).abs().max()), rows=int(stats[0]), n_in=int(stats[1]))
-    print(var, json.dumps(res[var]), flush=True)
+    return ms[len(ms) // 2], ms[0]
+
+
+ref = orig(v32, *a[1:], **k)
+ref16 = None
+for name, val, hv in (("f32 values (sca_fused_kernel)", v32, "0"), ("f16 values, 3 waves, window 4", v16, "0"),
+                      ("f16 values, 4 waves, window 2", v16, "1"), ("f16 values, 3 waves, window 2", v16, "2")):
+    os.environ["OCC_SCA_H_VARIANT"] = hv
+    stats = torch.zeros(2, dtype=torch.int64, device=dev)
+    out = orig(val, *a[1:], **k, stats=stats)
+    torch.cuda.synchronize()
+    med, mn = timed(lambda: orig(val, *a[1:], **k))
+    if val is v16 and ref16 is None:
+        ref16 = out
+    print(json.dumps(dict(kernel=name, median_ms=med, min_ms=mn, maxdiff_vs_f32_kernel=float((out - ref).abs().max()),
+                          maxdiff_vs_first_f16=None if ref16 is None else float((out - ref16).abs().max()),
+                          rows=int(stats[0]), n_in=int(stats[1]))), flush=True)
+os.environ["OCC_SCA_H_VARIANT"] = "0"
+
+# the value projection that feeds it: fp32 vs fp16 output (LazyFeatures.project of the last layer's value_proj)
+tr = model.pts_bbox_head.transformer
+from occnet_amd.plugin.transformer_occ import LazyFeatures   # noqa: E402
+lf = LazyFeatures(tr, st.feats)
+vp = tr.encoder.layers[-1].attentions[1].deformable_attention.value_proj
+for mode in ("f32", "f16"):
+    ext.SCA_VALUES = mode
+    med, mn = timed(lambda: lf.project(vp))
+    print(json.dumps(dict(kernel=f"value_proj_bf16 -> {mode}", median_ms=med, min_ms=mn)), flush=True)
+ext.SCA_VALUES = "f32"

@@ -110,31 +110,6 @@ int occ_sca_fused_forward_f16v(const void* value_f16, const int64_t* spatial_sha
                                int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Fused spatial cross-attention gather, HEAD-MAJOR decomposition (csrc/sca_head.hip): same arguments, semantics
- * and reference lines as occ_sca_fused_forward_f32 — a block works on ONE attention head (= one XCD's L2 holds one
- * head's slice of the value maps), a wave on 8 neighbouring queries, out-of-map corners are not requested (buffer
- * loads with an out-of-range offset), and for variant >= 2 the coarsest level's map of (camera, head) is staged
- * in LDS (stage_pix = H*W of the last level; needs stage_pix*128 B <= 64 KB, else variant 1 is taken).
- *   variant 1: 4 waves x 8 queries, every level through buffer loads
- *   variant 2: 8 waves x 16 queries, last level from LDS      variant 3: 6 waves x 16 queries, last level from LDS
- */
-int occ_sca_head_forward_f32(const float* value, const int64_t* spatial_shapes,
-                             const int64_t* level_start_index, const float* offs, int64_t offs_stride,
-                             const float* logits, int64_t logits_stride, const float* ref_cam,
-                             const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats,
-                             int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq, int stage_pix,
-                             int variant, void* stream);
-
-/* Opt-in fp16 VALUE maps for the gather above (SURVEY.md §8d's e_v = 2 variant): value (B*NC, S, M, D) fp16 as
- * written by occ_value_proj_bf16_f16; sampling arithmetic and accumulation stay fp32.  Not the default: the value
- * elements are rounded to 11 significant bits (measured effect in DESIGN.md §3). */
-int occ_sca_head_forward_f16v(const void* value_f16, const int64_t* spatial_shapes,
-                              const int64_t* level_start_index, const float* offs, int64_t offs_stride,
-                              const float* logits, int64_t logits_stride, const float* ref_cam,
-                              const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats,
-                              int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq, void* stream);
-
-/* ------------------------------------------------------------------------------------------
  * Fused temporal self-attention gather over the 2-deep BEV queue (single level):
  *   out[b,q,:] = 0.5 * sum_{t in {0,1}} MSDA( value[b*2+t], softmax_p(logits[b,q,m,t,:]),
  *                                            ref_2d[b*2+t,q] + offs[b,q,m,t,p]/(W,H) )
@@ -308,28 +283,27 @@ int64_t occ_linear_wgrad_workspace_bytes(int M, int N, int K);
 int occ_linear_wgrad_bf16x3_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
                                 void* workspace, int64_t workspace_bytes, int M, int N, int K, void* stream);
 
-/* Round-2 variant of occ_linear_bf16x3_f32 (same arguments, same packed weights, same arithmetic): 160-row blocks,
- * 32-k chunks, weights staged once per block in LDS (csrc/linear_x3s.hip).  Needs K1 % 32 == 0 and K2 % 32 == 0;
- * OCC_E_UNSUPPORTED otherwise (the caller then takes occ_linear_bf16x3_f32). */
-int occ_linear_bf16x3s_f32(const float* a1, int64_t lda1, int K1, const float* a2, const float* a2_add,
-                           int64_t lda2, int K2, const void* weight_packed, const float* bias, int act,
-                           const float* residual, int64_t ldres, const float* ln_gamma, const float* ln_beta,
-                           float ln_eps, float* out, int64_t ldo, int M, int N, void* stream);
-
 /* ------------------------------------------------------------------------------------------
- * The encoder's feed-forward block + its LayerNorm as ONE kernel (csrc/ffn_fused.hip):
+ * Weight-stationary persistent form of occ_linear_bf16x3_f32 for the encoder's tall GEMMs with K == 256
+ * (csrc/linear_ws.hip; same arithmetic, same packed weights, same reference call sites): one 8-wave block per CU keeps
+ * its 32 columns' hi/lo fragments in registers for a contiguous range of rows, the rows stream through LDS by LDS-DMA
+ * in 64-row tiles, every input byte is read once.  residual (M, residual_cols) is added to the first residual_cols
+ * (multiple of 4, <= N) outputs only.  Needs K == 256, N % 4 == 0, 16-byte aligned rows, N <= 256 with LayerNorm;
+ * OCC_E_UNSUPPORTED otherwise (the caller takes occ_linear_bf16x3_f32). */
+int occ_linear_ws_bf16x3_f32(const float* a, int64_t lda, int K, const void* weight_packed, const float* bias, int act,
+                             const float* residual, int64_t ldres, int residual_cols, const float* ln_gamma,
+                             const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N, void* stream);
+
+/* The encoder's feed-forward block + its LayerNorm as ONE launch on the same structure (csrc/linear_ws.hip):
  *     out = LayerNorm( x + W2 . relu(W1 . x + b1) + b2 )
  * = mmcv FFN (Linear, ReLU, Linear, + identity) and the `norm` that follows it in the layer's operation_order
- * (P/bevformer/modules/encoder.py:377-404; custom_base_transformer_layer.py:74-99).  bf16x3 arithmetic as
- * occ_linear_bf16x3_f32; the 512-wide hidden activations never leave the registers.
- *   w1 (hidden, C), w2 (C, hidden) f32 torch Linear layouts -> packed: 8*C*hidden bytes (both matrices, bf16 hi + lo, MFMA fragment
- *   order, W2 with the k order the hidden registers come in).  Kernel exists for C = 256, hidden = 512.
- *   x (M, C) f32 rows of stride ldx; ln_gamma / ln_beta both NULL = no LayerNorm; out (M, C) rows of stride ldo.
- */
-int occ_ffn_pack_weights_bf16x3(const float* w1, const float* w2, void* packed, int C, int hidden, void* stream);
-int occ_ffn_fused_bf16x3_f32(const float* x, int64_t ldx, const void* packed, const float* b1, const float* b2,
-                             const float* ln_gamma, const float* ln_beta, float ln_eps, float* out, int64_t ldo,
-                             int M, int C, int hidden, void* stream);
+ * (P/bevformer/modules/encoder.py:377-404; custom_base_transformer_layer.py:74-99).  The 512-wide hidden activations
+ * go through LDS in two halves and never reach HBM.  w1_packed = occ_linear_pack_weight_bf16x3(W1 (hidden, C)),
+ * w2_packed = occ_linear_pack_weight_bf16x3(W2 (C, hidden)); ln_gamma / ln_beta both NULL = no LayerNorm.
+ * Kernel exists for C = 256, hidden = 512; OCC_E_UNSUPPORTED otherwise (the caller runs two Linear launches). */
+int occ_ffn_ws_bf16x3_f32(const float* x, int64_t ldx, const void* w1_packed, const float* b1, const void* w2_packed,
+                          const float* b2, const float* ln_gamma, const float* ln_beta, float ln_eps, float* out,
+                          int64_t ldo, int M, int C, int hidden, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ray casting through an occupancy grid (RayIoU metric) — replaces the reference's `dvr.render_forward`
@@ -370,7 +344,7 @@ int occ_value_proj_bf16_f32(int n_segments, const void* const* a, const int64_t*
                             const int64_t* rows_per_group, const int64_t* out_row0,
                             const float* const* group_bias, int bias_groups, const void* weight_packed,
                             float* out, int64_t ldo, int K, int N, int64_t out_group_rows, void* stream);
-/* same with the output written as fp16 (ldo in fp16 elements): feeds occ_sca_head_forward_f16v */
+/* same with the output written as fp16 (ldo in fp16 elements): feeds occ_sca_fused_forward_f16v */
 int occ_value_proj_bf16_f16(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
                             const int64_t* rows_per_group, const int64_t* out_row0,
                             const float* const* group_bias, int bias_groups, const void* weight_packed,

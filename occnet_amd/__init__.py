@@ -14,8 +14,10 @@ __version__ = "0.1.0"
 # per-(level, camera) value-projection biases, the decoder's folded BatchNorm, the folded inference backbone)
 # are keyed on (data_ptr, tensor._version, cache_epoch()).  In-place updates through autograd-visible ops
 # (optimizer steps, p.copy_ under no_grad) bump _version; writes through `param.data` do not — so everything
-# that may write that way bumps the epoch instead: load_state_dict on any plugin module (post hook), a
-# train()/eval() mode change, and an explicit occnet_amd.invalidate_caches() after EMA / manual .data surgery.
+# that may write that way bumps the epoch instead: load_state_dict on any plugin module (post hook) and an explicit
+# occnet_amd.invalidate_caches() after EMA / manual .data surgery.  (A train()/eval() mode change does not: the folded
+# inference backbone, the one cache that holds COPIES without per-tensor keys, re-checks a (data_ptr, _version)
+# signature of its source parameters the first time it is used after the model has been in training mode.)
 _CACHE_EPOCH = 0
 
 
@@ -30,6 +32,5 @@ def invalidate_caches(model=None):
     _CACHE_EPOCH += 1
     from . import ext
     ext._PACKED_W.clear()
-    ext._PACKED_FFN.clear()
     if model is not None and getattr(model, '_inference_backbone', None) is not None:
         model.enable_fused_backbone(**model._inference_backbone_args)

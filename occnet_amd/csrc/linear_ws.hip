@@ -1,0 +1,436 @@
+// Weight-stationary persistent Linear for the encoder's tall-skinny GEMMs (M = 40 000 BEV queries, K = 256,
+// N = 192 / 256 / 512 / 768) on the gfx950 bf16 matrix cores, bf16x3 arithmetic (see linear_bf16x3.hip: hi/lo-split
+// operands, f32 accumulation, product error <= 2^-16) — same contract and call sites as occ_linear_bf16x3_f32
+// (reference: the nn.Linear / LayerNorm call sites of a BEVFormerLayer, encoder.py:377-404,
+// spatial_cross_attention.py:173,334-341, temporal_self_attention.py:198-209,266).
+//
+// Why another kernel (round 3): linear_bf16x3 gives every 64-row block its own pass over the weights and its own
+// 16-chunk barrier chain; with 625 blocks on 256 CUs every block runs exactly once, nothing reaches a steady state and
+// the launches sit at ~2x their HBM floor (profiles/r02_linear_probe.txt: 27-69 us against 13-26 us).  Here
+//   * ONE block of 8 waves per CU owns a contiguous range of ~157 rows and 256 output columns;
+//   * wave w keeps the hi + lo bf16 fragments of ITS 32 columns for all 256 k in registers (128 VGPRs: the weights are
+//     read from L2 once per block, not once per 64 rows, and the k loop has no barrier and no weight traffic);
+//   * the rows stream through LDS in 64-row tiles: the fp32 tile of step t+1 arrives by LDS-DMA
+//     (global_load_lds_dwordx4, no registers) while the matrix cores work on tile t, is split once per block into
+//     hi/lo bf16 planes (528-byte row pitch: conflict-free ds_read_b128 of the A fragments), and all 8 waves read
+//     the same planes;
+//   * the residual rows of tile t are requested before its k loop and are in registers when the epilogue needs them;
+//   * epilogue per tile through an LDS transpose (the planes' space): bias, ReLU, residual, two-pass LayerNorm by
+//     one wave per row, 16-byte stores.
+// A launch moves every input byte once and writes every output byte once; what is left is HBM time.
+#include "common.h"
+
+namespace occ {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int kWsK = 256;                 // k per pass (all of it: weight-stationary)
+constexpr int kWsTile = 64;               // rows per tile
+constexpr int kWsPitch = kWsK * 2 + 16;   // bytes per row of one bf16 plane (528: 132 dwords = 4 mod 64 banks)
+constexpr int kWsPlane = kWsTile * kWsPitch;            // 33 792
+constexpr int kWsRaw = kWsTile * kWsK * 4;              // 65 536: the fp32 tile as the DMA lands it
+constexpr int kWsOLd = 256 + 4;                         // floats per row of the epilogue tile
+static_assert(kWsTile * kWsOLd * 4 <= 2 * kWsPlane, "the epilogue tile overlays the two planes");
+
+__device__ __forceinline__ void ws_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2_rne(x0, x1);
+  lo = pack_bf16x2_rne(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ float ws_wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// DMA of one 64-row fp32 tile (rows row0 .. row0+63, clamped to [.., row_last]) into `raw`: wave w fetches rows
+// w, w+8, ..; one instruction = one 1 KB row, lane l's 16 bytes land at raw + r*1024 + 16*l
+__device__ __forceinline__ void ws_dma_tile(const float* __restrict__ a, long lda, long row0, long row_last,
+                                            char* raw, int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < kWsTile / 8; ++j) {
+    const int r = wave + 8 * j;
+    long m = row0 + r;
+    if (m > row_last) m = row_last;
+    __builtin_amdgcn_global_load_lds(a + m * lda + lane * 4, (lds_ptr_t)(raw + r * (kWsK * 4)), 16, 0, 0);
+  }
+}
+
+// raw fp32 tile -> hi / lo bf16 planes (each thread 8 x 16 bytes; a wave reads one full raw row per instruction)
+__device__ __forceinline__ void ws_split_tile(const char* raw, char* planes, int tid) {
+#pragma unroll
+  for (int j = 0; j < kWsTile * kWsK / 4 / 512; ++j) {
+    const int c = tid + 512 * j, r = c >> 6, q = c & 63;
+    const float4 f = *reinterpret_cast<const float4*>(raw + r * (kWsK * 4) + q * 16);
+    unsigned h01, h23, l01, l23;
+    ws_split2(f.x, f.y, h01, l01);
+    ws_split2(f.z, f.w, h23, l23);
+    *reinterpret_cast<uint2*>(planes + r * kWsPitch + q * 8) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(planes + kWsPlane + r * kWsPitch + q * 8) = make_uint2(l01, l23);
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void linear_ws_kernel(
+    const float* __restrict__ a, long lda, const uint4* __restrict__ wp, int NT32,
+    const float* __restrict__ bias, int act, const float* __restrict__ residual, long ldres, int nres,
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps, float* __restrict__ out,
+    long ldo, int M, int N, int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * kWsPlane + kWsRaw];
+  char* planes = lds;
+  char* raw = lds + 2 * kWsPlane;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vi = lane & 31, kb = lane >> 5;
+  const long r_begin = (long)blockIdx.x * rows_per_block;
+  long r_end = r_begin + rows_per_block;
+  if (r_end > M) r_end = M;
+  if (r_begin >= r_end) return;
+  const int n0 = blockIdx.y * 256;
+  const int ntiles = (int)((r_end - r_begin + kWsTile - 1) / kWsTile);
+
+  ws_dma_tile(a, lda, r_begin, r_end - 1, raw, wave, lane);
+
+  // this wave's 32 columns: hi / lo fragments of all 16 k-steps (waves past the last column tile idle in the k loop)
+  const int nt = n0 / 32 + wave;
+  const bool live = nt < NT32;
+  uint4 wh[16], wl[16];
+  {
+    const long base = (long)(live ? nt : NT32 - 1) * 128 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      wh[ks] = wp[(long)ks * NT32 * 128 + base];
+      wl[ks] = wp[(long)ks * NT32 * 128 + base + 64];
+    }
+  }
+  const int c = lane * 4;                                   // this lane's 4 columns of the block's 256 in the epilogue
+  const bool col_live = n0 + c < N;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = bv, bev = bv;
+  if (col_live) {
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + n0 + c);
+    if (ln_g) {
+      gv = *reinterpret_cast<const float4*>(ln_g + n0 + c);
+      bev = *reinterpret_cast<const float4*>(ln_b + n0 + c);
+    }
+  }
+  const bool res_live = residual != nullptr && col_live && n0 + c < nres;
+  const float inv_n = 1.f / (float)N;
+  float* sO = reinterpret_cast<float*>(planes);
+
+  __syncthreads();                     // the DMA of tile 0 has landed (the barrier's release waits vmcnt(0))
+  ws_split_tile(raw, planes, tid);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const long row0 = r_begin + (long)t * kWsTile;
+    if (t + 1 < ntiles) ws_dma_tile(a, lda, row0 + kWsTile, r_end - 1, raw, wave, lane);
+    // residual rows of this tile (8 per wave), requested now, consumed after the k loop
+    float4 rres[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      long m = row0 + wave * 8 + rr;
+      if (m > r_end - 1) m = r_end - 1;
+      rres[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res_live) rres[rr] = *reinterpret_cast<const float4*>(residual + m * ldres + n0 + c);
+    }
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    if (live) {
+      const char* pa = planes + vi * kWsPitch + kb * 16;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(pa + ks * 32);
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + ks * 32);
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch + ks * 32);
+        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + 32 * kWsPitch + ks * 32);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[ks]), bl = __builtin_bit_cast(bf16x8, wl[ks]);
+        // term-major (small terms first), alternating the two accumulators: no back-to-back dependent MFMAs
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc1, 0, 0, 0);
+      }
+    }
+    __syncthreads();                   // every wave is done with the planes; next tile's DMA + residual rows landed
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+      sO[row * kWsOLd + wave * 32 + vi] = acc0[r];
+      sO[(row + 32) * kWsOLd + wave * 32 + vi] = acc1[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;
+      const long m = row0 + row;
+      if (m >= r_end) break;                   // wave-uniform
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col_live) {
+        v = *reinterpret_cast<const float4*>(sO + row * kWsOLd + c);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (act == 1) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        v.x += rres[rr].x; v.y += rres[rr].y; v.z += rres[rr].z; v.w += rres[rr].w;
+      }
+      if (ln_g) {                              // LayerNorm over the N columns (N <= 256: one column group)
+        const float mean = ws_wave_sum(col_live ? (v.x + v.y) + (v.z + v.w) : 0.f) * inv_n;
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        const float var = ws_wave_sum(col_live ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : 0.f) * inv_n;
+        const float rstd = rsqrtf(var + ln_eps);
+        v.x = dx * rstd * gv.x + bev.x; v.y = dy * rstd * gv.y + bev.y;
+        v.z = dz * rstd * gv.z + bev.z; v.w = dw * rstd * gv.w + bev.w;
+      }
+      if (col_live) *reinterpret_cast<float4*>(out + m * ldo + n0 + c) = v;
+    }
+    if (t + 1 < ntiles) {
+      __syncthreads();                 // the epilogue tile is consumed before the planes are rewritten
+      ws_split_tile(raw, planes, tid);
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The encoder's feed-forward block + the LayerNorm that follows it as ONE launch on the same structure:
+//     out = LayerNorm( x + W2 . relu(W1 . x + b1) + b2 )          (C = 256, hidden = 512)
+// (mmcv FFN + norm, encoder.py:377-404, custom_base_transformer_layer.py:74-99).  Round 2's fused FFN kept the
+// hidden activations in registers at one wave per SIMD and lost to two launches; here the 64 x 512 hidden tile goes
+// through LDS in two halves and never reaches HBM (2 x 82 MB per layer).  Per 64-row tile, for hidden half p = 0, 1:
+//   GEMM1 (transposed: D = W1 . X^T, so a lane's four consecutive D registers are four consecutive hidden units of one
+//   row -> bias, ReLU, hi/lo split, 8-byte LDS stores straight into the A-operand planes of GEMM2), then
+//   GEMM2 accumulates out += H_p . W2[:, half p]^T.  Each of the four passes loads its 32 columns' weight fragments
+//   (128 VGPRs) from L2.  Two 67.5 KB LDS regions swap roles every tile: {X planes | H planes + epilogue tile}; the next
+//   tile's fp32 rows arrive by LDS-DMA in the X region as soon as the second GEMM1 pass has read it.
+__global__ __launch_bounds__(512, 2) void ffn_ws_kernel(
+    const float* __restrict__ x, long ldx, const uint4* __restrict__ w1p, const float* __restrict__ b1,
+    const uint4* __restrict__ w2p, const float* __restrict__ b2, const float* __restrict__ ln_g,
+    const float* __restrict__ ln_b, float ln_eps, float* __restrict__ out, long ldo, int M, int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * kWsPlane];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vi = lane & 31, kb = lane >> 5;
+  const long r_begin = (long)blockIdx.x * rows_per_block;
+  long r_end = r_begin + rows_per_block;
+  if (r_end > M) r_end = M;
+  if (r_begin >= r_end) return;
+  const int ntiles = (int)((r_end - r_begin + kWsTile - 1) / kWsTile);
+  const int c = lane * 4;
+  const float4 b2v = *reinterpret_cast<const float4*>(b2 + c);
+  float4 gv = make_float4(1.f, 1.f, 1.f, 1.f), bev = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ln_g) {
+    gv = *reinterpret_cast<const float4*>(ln_g + c);
+    bev = *reinterpret_cast<const float4*>(ln_b + c);
+  }
+
+  ws_dma_tile(x, ldx, r_begin, r_end - 1, lds + 2 * kWsPlane, wave, lane);     // raw tile 0 -> region 1
+  __syncthreads();
+  ws_split_tile(lds + 2 * kWsPlane, lds, tid);                                 // -> X planes in region 0
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    char* XP = lds + (t & 1) * 2 * kWsPlane;
+    char* HP = lds + ((t + 1) & 1) * 2 * kWsPlane;
+    const long row0 = r_begin + (long)t * kWsTile;
+    f32x16 o0, o1;                                   // GEMM2 accumulators: 64 rows x this wave's 32 output columns
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float4 rres[8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      // ---- GEMM1, hidden units [p*256 + wave*32, +32): D[i][j] = sum_k W1[i][k] X[j][k]
+      f32x16 h0, h1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+      {
+        // the weight fragments do not depend on the tile: without an opaque base hipcc hoists all four passes' loads
+        // out of the tile loop (512 live registers, 400+ spills)
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const uint4* w1q = w1p + opaque;
+        uint4 wh[16], wl[16];
+        const long base = (long)(p * 8 + wave) * 128 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          wh[ks] = w1q[(long)ks * 16 * 128 + base];
+          wl[ks] = w1q[(long)ks * 16 * 128 + base + 64];
+        }
+        const char* pa = XP + vi * kWsPitch + kb * 16;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const bf16x8 xh0 = *reinterpret_cast<const bf16x8*>(pa + ks * 32);
+          const bf16x8 xl0 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + ks * 32);
+          const bf16x8 xh1 = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch + ks * 32);
+          const bf16x8 xl1 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + 32 * kWsPitch + ks * 32);
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[ks]), bl = __builtin_bit_cast(bf16x8, wl[ks]);
+          h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xl0, h0, 0, 0, 0);
+          h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xl1, h1, 0, 0, 0);
+          h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, xh0, h0, 0, 0, 0);
+          h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, xh1, h1, 0, 0, 0);
+          h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xh0, h0, 0, 0, 0);
+          h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xh1, h1, 0, 0, 0);
+        }
+      }
+      // bias + ReLU + split; register group g of a lane = hidden units wave*32 + 8g + 4kb .. +3 of row (rt*32 + vi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bb = *reinterpret_cast<const float4*>(b1 + p * 256 + wave * 32 + 8 * g + 4 * kb);
+        unsigned h01, h23, l01, l23;
+        char* dst = HP + vi * kWsPitch + (wave * 32 + 8 * g + 4 * kb) * 2;
+        ws_split2(fmaxf(h0[4 * g] + bb.x, 0.f), fmaxf(h0[4 * g + 1] + bb.y, 0.f), h01, l01);
+        ws_split2(fmaxf(h0[4 * g + 2] + bb.z, 0.f), fmaxf(h0[4 * g + 3] + bb.w, 0.f), h23, l23);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(dst + kWsPlane) = make_uint2(l01, l23);
+        ws_split2(fmaxf(h1[4 * g] + bb.x, 0.f), fmaxf(h1[4 * g + 1] + bb.y, 0.f), h01, l01);
+        ws_split2(fmaxf(h1[4 * g + 2] + bb.z, 0.f), fmaxf(h1[4 * g + 3] + bb.w, 0.f), h23, l23);
+        *reinterpret_cast<uint2*>(dst + 32 * kWsPitch) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(dst + 32 * kWsPitch + kWsPlane) = make_uint2(l01, l23);
+      }
+      __syncthreads();                 // H half p complete; for p == 1 the X planes are dead from here
+      if (p == 1) {
+        if (t + 1 < ntiles) ws_dma_tile(x, ldx, row0 + kWsTile, r_end - 1, XP, wave, lane);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {           // the residual rows (= x itself) of the epilogue
+          long m = row0 + wave * 8 + rr;
+          if (m > r_end - 1) m = r_end - 1;
+          rres[rr] = *reinterpret_cast<const float4*>(x + m * ldx + c);
+        }
+      }
+      // ---- GEMM2, k = hidden units [p*256, +256): out[j][n] += sum_k H[j][k] W2[n][k], n in [wave*32, +32)
+      {
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const uint4* w2q = w2p + opaque;
+        uint4 wh[16], wl[16];
+        const long base = (long)wave * 128 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          wh[ks] = w2q[(long)(p * 16 + ks) * 8 * 128 + base];
+          wl[ks] = w2q[(long)(p * 16 + ks) * 8 * 128 + base + 64];
+        }
+        const char* pa = HP + vi * kWsPitch + kb * 16;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(pa + ks * 32);
+          const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + ks * 32);
+          const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch + ks * 32);
+          const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + 32 * kWsPitch + ks * 32);
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[ks]), bl = __builtin_bit_cast(bf16x8, wl[ks]);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, o1, 0, 0, 0);
+          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, o1, 0, 0, 0);
+        }
+      }
+      __syncthreads();                 // every wave is done reading H half p
+    }
+    // ---- epilogue through the H region: + b2 + x, LayerNorm, store
+    float* sO = reinterpret_cast<float*>(HP);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+      sO[row * kWsOLd + wave * 32 + vi] = o0[r];
+      sO[(row + 32) * kWsOLd + wave * 32 + vi] = o1[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;
+      const long m = row0 + row;
+      if (m >= r_end) break;                   // wave-uniform
+      float4 v = *reinterpret_cast<const float4*>(sO + row * kWsOLd + c);
+      v.x += b2v.x + rres[rr].x; v.y += b2v.y + rres[rr].y; v.z += b2v.z + rres[rr].z; v.w += b2v.w + rres[rr].w;
+      if (ln_g) {
+        const float mean = ws_wave_sum((v.x + v.y) + (v.z + v.w)) * (1.f / 256.f);
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        const float var = ws_wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.f / 256.f);
+        const float rstd = rsqrtf(var + ln_eps);
+        v.x = dx * rstd * gv.x + bev.x; v.y = dy * rstd * gv.y + bev.y;
+        v.z = dz * rstd * gv.z + bev.z; v.w = dw * rstd * gv.w + bev.w;
+      }
+      *reinterpret_cast<float4*>(out + m * ldo + c) = v;
+    }
+    if (t + 1 < ntiles) {
+      __syncthreads();                 // epilogue tile consumed; the next raw tile (in XP) landed
+      ws_split_tile(XP, HP, tid);      // -> X planes of tile t+1 in this tile's H region (roles swap)
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace occ
+
+extern "C" int occ_linear_ws_bf16x3_f32(const float* a, int64_t lda, int K, const void* weight_packed,
+                                        const float* bias, int act, const float* residual, int64_t ldres,
+                                        int residual_cols, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                        float* out, int64_t ldo, int M, int N, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(a && weight_packed && out, "linear_ws: null pointer argument");
+  OCC_CHECK_ARG(M > 0 && N > 0, "linear_ws: bad dimension (M=%d N=%d)", M, N);
+  OCC_CHECK_ARG(act == 0 || act == 1, "linear_ws: act must be 0 (none) or 1 (ReLU)");
+  OCC_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "linear_ws: ln_gamma and ln_beta go together");
+  OCC_CHECK_ARG(lda >= K && ldo >= N && (!residual || ldres >= residual_cols),
+                "linear_ws: leading dimension smaller than the row");
+  if (K != kWsK || N % 4 || lda % 4 || ldo % 4 || (residual && (ldres % 4 || residual_cols % 4)) ||
+      (ln_gamma && N > 256) || (reinterpret_cast<uintptr_t>(a) & 15)) {
+    set_error("linear_ws: no kernel for K=%d N=%d (need K == 256, N %% 4 == 0, 16-byte aligned rows, N <= 256 with "
+              "LayerNorm)", K, N);
+    return OCC_E_UNSUPPORTED;
+  }
+  const int ncg = (N + 255) / 256;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  // one block per CU and round: row ranges so that (row ranges x column groups) ~ the CU count
+  int nrb = cus / ncg;
+  if (nrb < 1) nrb = 1;
+  const int max_rb = (M + kWsTile - 1) / kWsTile;
+  if (nrb > max_rb) nrb = max_rb;
+  const int rows_per_block = (M + nrb - 1) / nrb;
+  nrb = (M + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(linear_ws_kernel, dim3((unsigned)nrb, (unsigned)ncg), dim3(512), 0,
+                     reinterpret_cast<hipStream_t>(stream), a, (long)lda,
+                     reinterpret_cast<const uint4*>(weight_packed), (N + 31) / 32, bias, act, residual, (long)ldres,
+                     residual ? residual_cols : 0, ln_gamma, ln_beta, ln_eps, out, (long)ldo, M, N, rows_per_block);
+  OCC_CHECK_LAUNCH("linear_ws");
+  return OCC_OK;
+}
+
+extern "C" int occ_ffn_ws_bf16x3_f32(const float* x, int64_t ldx, const void* w1_packed, const float* b1,
+                                     const void* w2_packed, const float* b2, const float* ln_gamma,
+                                     const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int C,
+                                     int hidden, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(x && w1_packed && b1 && w2_packed && b2 && out, "ffn_ws: null pointer argument");
+  OCC_CHECK_ARG(M > 0, "ffn_ws: bad dimension (M=%d)", M);
+  OCC_CHECK_ARG((ln_gamma == nullptr) == (ln_beta == nullptr), "ffn_ws: ln_gamma and ln_beta go together");
+  OCC_CHECK_ARG(ldx >= C && ldo >= C, "ffn_ws: leading dimension smaller than the row");
+  if (C != 256 || hidden != 512 || ldx % 4 || ldo % 4 || (reinterpret_cast<uintptr_t>(x) & 15)) {
+    set_error("ffn_ws: no kernel for C=%d hidden=%d (need C == 256, hidden == 512, 16-byte aligned rows)", C, hidden);
+    return OCC_E_UNSUPPORTED;
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  int nrb = cus;
+  const int max_rb = (M + kWsTile - 1) / kWsTile;
+  if (nrb > max_rb) nrb = max_rb;
+  const int rows_per_block = (M + nrb - 1) / nrb;
+  nrb = (M + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(ffn_ws_kernel, dim3((unsigned)nrb), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     (long)ldx, reinterpret_cast<const uint4*>(w1_packed), b1,
+                     reinterpret_cast<const uint4*>(w2_packed), b2, ln_gamma, ln_beta, ln_eps, out, (long)ldo, M,
+                     rows_per_block);
+  OCC_CHECK_LAUNCH("ffn_ws");
+  return OCC_OK;
+}

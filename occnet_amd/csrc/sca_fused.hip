@@ -167,10 +167,8 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
   static_assert(LP >= 8 && LP <= 32 && (LP & (LP - 1)) == 0, "L*P must be a power of two in [8,32]");
   constexpr int LPp = LP + 1;
   __shared__ __attribute__((aligned(16))) SampleParamB smem[kScaWaves * M * LPp];
-  // the camera-independent per-sample terms (softmax weight, normalised offset) wait in LDS, not in registers:
-  // live across the gather they push the kernel over the 168 VGPRs of three waves per SIMD (10 scratch spills =
-  // 100 MB of extra writes per launch)
-  __shared__ __attribute__((aligned(16))) float pre[kScaWaves][3][K][64];
+  // the camera-independent per-sample terms (softmax weight, normalised offset) stay in registers here: the fp16 gather
+  // has registers to spare (100 VGPRs), and without the 12 KB `pre` slab of the fp32 kernel four blocks fit a CU's LDS
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -212,9 +210,6 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     const float2 o = *reinterpret_cast<const float2*>(orow + 2 * idx);
     ox[k] = o.x / (float)lvW;
     oy[k] = o.y / (float)lvH;
-    pre[wave][0][k][lane] = aw[k];
-    pre[wave][1][k][lane] = ox[k];
-    pre[wave][2][k][lane] = oy[k];
   }
 
   // f32 rows: 8 lanes x 4 channels per head; fp16 rows: 4 lanes x 8 channels per head and two sample halves
@@ -233,7 +228,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
       const int z = (s % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
       const float2 rxy = *reinterpret_cast<const float2*>(rp + 2 * z);
       SampleParamB p;
-      const float aw_k = pre[wave][0][k][lane], ox_k = pre[wave][1][k][lane], oy_k = pre[wave][2][k][lane];
+      const float aw_k = aw[k], ox_k = ox[k], oy_k = oy[k];
       n_in += bilinear_setup_b(rxy.x + ox_k, rxy.y + oy_k, aw_k, lvH, lvW, lvS,
                                (unsigned)row_stride * EV, kOobOffset, true, p);
       sp[m * LPp + s] = p;
@@ -279,7 +274,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
   }
 }
 
-template <int L, int P, int WPS = 3, int DEPTH = 4>
+template <int L, int P, int WPS = 4, int DEPTH = 2>
 static int launch_sca_h(const void* value, const int64_t* shapes, const int64_t* lstart,
                         const float* offs, long offs_stride, const float* logits, long logits_stride,
                         const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
@@ -317,15 +312,20 @@ static int sca_dispatch(const void* value, bool halfv, const int64_t* spatial_sh
     set_error("sca_fused_forward: no fused kernel for M=%d D=%d", M, D);
     return OCC_E_UNSUPPORTED;
   }
-  // development switch (tools_dev/sca_probe.py): 1 = four waves per SIMD with a 2-sample window, 2 = three waves, 3-sample
+  // development switch (tools_dev/sca_probe.py): (waves per SIMD, samples in the rolling window)
   const char* hv_ = getenv("OCC_SCA_H_VARIANT");
   const int hvar = hv_ ? atoi(hv_) : 0;
-  if (halfv && L == 4 && P == 8 && hvar == 1)
-    return launch_sca_h<4, 8, 4, 2>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits,
-                                        (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st);
-  if (halfv && L == 4 && P == 8 && hvar == 2)
-    return launch_sca_h<4, 8, 3, 2>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits,
-                                        (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st);
+#define OCC_SCA_HVAR(ID, WPS, DEPTH)                                                                         \
+  if (halfv && L == 4 && P == 8 && hvar == ID)                                                                \
+    return launch_sca_h<4, 8, WPS, DEPTH>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
+                                          (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st);
+  OCC_SCA_HVAR(1, 4, 2)
+  OCC_SCA_HVAR(2, 3, 2)
+  OCC_SCA_HVAR(3, 6, 1)
+  OCC_SCA_HVAR(6, 8, 1)
+  OCC_SCA_HVAR(4, 5, 2)
+  OCC_SCA_HVAR(5, 3, 4)
+#undef OCC_SCA_HVAR
 #define OCC_SCA_CASE(LL, PP)                                                                       \
   if (L == LL && P == PP) {                                                                        \
     if (halfv)                                                                                     \

@@ -160,22 +160,16 @@ def point_sampling(ref_3d, lidar2img, ego2lidar, pc_range, img_h, img_w):
     return ref_cam, mask.view(torch.bool), vis
 
 
-# Which SCA gather kernel runs: 0 = query-major (round 1, csrc/sca_fused.hip), 1..3 = head-major
-# (csrc/sca_head.hip: 1 = no LDS staging, 2 / 3 = coarsest level staged in LDS with 8 / 6 waves per block).
-# bench.py's roofline names the kernel and only trusts a PMC traffic file measured on the same variant.
-SCA_KERNEL = int(os.environ.get("OCC_SCA_KERNEL", "0"))
-# OCC_SCA_VALUES=f16 (opt-in): the projected value maps are stored as fp16 and gathered by sca_head_h_kernel — half
-# the bytes through the texture path; the value elements are rounded to 11 significant bits (not the default)
-SCA_VALUES = os.environ.get("OCC_SCA_VALUES", "f32")
-_SCA_NAMES = {0: "sca_fused_kernel<4,8> (query-major)", 1: "sca_head_kernel<4,8,4,1,false> (head-major)",
-              2: "sca_head_kernel<4,8,8,2,true> (head-major, coarsest level in LDS)",
-              3: "sca_head_kernel<4,8,6,2,true> (head-major, coarsest level in LDS)"}
+# Storage type of the projected value maps the fused SCA gather reads: 'f16' (default for the fused inference path: one
+# head row of a pixel = 64 bytes = 4 lanes x 16 bytes, so a wave load fetches 16 rows instead of 8 — csrc/sca_fused.hip)
+# or 'f32' (OCC_SCA_VALUES=f32: the round-1/2 kernel, 8 lanes per 128-byte row).  Sampling arithmetic, attention weights
+# and accumulation are fp32 in both.
+SCA_VALUES = os.environ.get("OCC_SCA_VALUES", "f16")
 
 
-def sca_variant_name(kernel=None):
-    if kernel is None and SCA_VALUES == "f16":
-        return "sca_fused_h_kernel<4,8> (query-major, fp16 values)"
-    return _SCA_NAMES[SCA_KERNEL if kernel is None else kernel]
+def sca_variant_name():
+    return ("sca_fused_h_kernel<4,8> (query-major, fp16 value rows)" if SCA_VALUES == "f16"
+            else "sca_fused_kernel<4,8> (query-major, fp32 value rows)")
 
 
 def sca_value_bytes():
@@ -183,11 +177,10 @@ def sca_value_bytes():
 
 
 def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, ref_cam, vis_bits,
-                      num_heads, num_levels, num_points, order=None, stats=None, kernel=None, stage_pix=None):
-    """Fused SCA gather.  value (B*NC, S, M, D); offs (B, Nq, M*L*P*2) / logits (B, Nq, M*L*P) may
+                      num_heads, num_levels, num_points, order=None, stats=None):
+    """Fused SCA gather.  value (B*NC, S, M, D) float32 or float16; offs (B, Nq, M*L*P*2) / logits (B, Nq, M*L*P) may
     be column slices of one wider Linear output (last dim contiguous); ref_cam (NC,B,Nq,Z,2);
-    vis_bits (B,Nq) int32.  -> slots (B, Nq, M*D).  kernel: see SCA_KERNEL; stage_pix = H*W of the last level
-    (computed from spatial_shapes — one host sync — when not given)."""
+    vis_bits (B,Nq) int32.  -> slots (B, Nq, M*D) float32."""
     half = value.dtype == torch.float16
     if half:
         if not (value.is_cuda and value.is_contiguous()):
@@ -212,37 +205,12 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
         raise OccAmdError("sca_fused_forward: vis_bits must be contiguous int32 (B,Nq)")
     if order is not None and (order.dtype != torch.int32 or order.numel() != Nq):
         raise OccAmdError("sca_fused_forward: order must be int32 (Nq)")
-    kernel = SCA_KERNEL if kernel is None else int(kernel)
     slots = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
+    fn = _lib.lib().occ_sca_fused_forward_f16v if half else _lib.lib().occ_sca_fused_forward_f32
     with torch.cuda.device(value.device), _timed('sca_fused_forward'):
-        if half:
-            rc = _lib.lib().occ_sca_fused_forward_f16v(
-                ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
-                i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
-                ptr(order), ptr(slots), ptr(stats), i32(B), i32(NC), i32(S), i32(M), i32(D), i32(L),
-                i32(P), i32(Z), i32(Nq), stream_ptr(value.device))
-        elif kernel == 0:
-            rc = _lib.lib().occ_sca_fused_forward_f32(
-                ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
-                i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
-                ptr(order), ptr(slots), ptr(stats), i32(B), i32(NC), i32(S), i32(M), i32(D), i32(L),
-                i32(P), i32(Z), i32(Nq), stream_ptr(value.device))
-        else:
-            if stage_pix is None:
-                # H*W of the last level: from the host copy the plugin attaches to the shapes tensor, else one
-                # device->host read
-                hw = getattr(spatial_shapes, '_occ_hw', None)
-                if kernel < 2:
-                    stage_pix = 0
-                elif hw is not None:
-                    stage_pix = int(hw[-1][0]) * int(hw[-1][1])
-                else:
-                    stage_pix = S - int(level_start_index[-1])
-            rc = _lib.lib().occ_sca_head_forward_f32(
-                ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs),
-                i64(offs.stride(1)), ptr(logits), i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits),
-                ptr(order), ptr(slots), ptr(stats), i32(B), i32(NC), i32(S), i32(M), i32(D), i32(L),
-                i32(P), i32(Z), i32(Nq), i32(int(stage_pix)), i32(kernel), stream_ptr(value.device))
+        rc = fn(ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs), i64(offs.stride(1)), ptr(logits),
+                i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits), ptr(order), ptr(slots), ptr(stats), i32(B),
+                i32(NC), i32(S), i32(M), i32(D), i32(L), i32(P), i32(Z), i32(Nq), stream_ptr(value.device))
     _lib.check(rc, "sca_fused_forward")
     return slots
 
@@ -406,13 +374,11 @@ def _rows2d(name, t, k=None):
 # chain), 'bf16x3' = three bf16 MFMAs on hi/lo-split operands with f32 accumulation (relative error of a
 # product <= 2^-16; 2-3x faster).  The default can be overridden with OCC_LINEAR_PRECISION.
 LINEAR_PRECISION = os.environ.get("OCC_LINEAR_PRECISION", "bf16x3")
-# bf16x3 kernel: 'x3' (64-row blocks, weights global -> registers; default) or 'x3s' (round-2 experiment: 160-row
-# blocks, 32-k chunks, weights staged once per block in LDS — measured 0-25 % SLOWER on the encoder's shapes, both
-# kernels sit at ~3 TB/s of activation traffic: profiles/r02_linear_probe.txt)
-LINEAR_KERNEL = os.environ.get("OCC_LINEAR_KERNEL", "x3")
-# the encoder's FFN + LayerNorm as one kernel (csrc/ffn_fused.hip), OCC_FFN_FUSED=1; default: two Linear launches
-# (default off: measured 137 us against 111 us for the two launches on 40 000 rows — profiles/r02_linear_probe.txt)
-FFN_FUSED = os.environ.get("OCC_FFN_FUSED", "0") == "1"
+# bf16x3 kernel for the tall K == 256 GEMMs: 'ws' (default: weight-stationary persistent kernel, csrc/linear_ws.hip) or
+# 'x3' (OCC_LINEAR_KERNEL=x3: the round-1 64-row-block kernel, which every other shape takes anyway)
+LINEAR_KERNEL = os.environ.get("OCC_LINEAR_KERNEL", "ws")
+# the encoder's FFN + LayerNorm: 'ws' (default: one launch, csrc/linear_ws.hip) or 'two' (OCC_FFN=two: two Linear launches)
+FFN_KERNEL = os.environ.get("OCC_FFN", "ws")
 _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight (small LRU)
 
 
@@ -488,13 +454,14 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
 
 
 def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, ln=None,
-           precision=None):
+           precision=None, residual_cols=None):
     """out = LayerNorm(residual + act([a | a2 (+ a2_add)] @ weight^T + bias)) on the f32 matrix cores.
 
     a (…, K1); a2 / a2_add (…, K2) optional second K segment (+ addend); weight (N, K1+K2) and bias (N)
     in torch Linear layout; act None | 'relu'; residual (…, N); ln = (gamma, beta, eps) or an
-    nn.LayerNorm; precision 'f32' | 'bf16x3' (None = LINEAR_PRECISION).  -> (…, N) float32.  Raises
-    OccAmdUnsupported for shapes without an MFMA kernel."""
+    nn.LayerNorm; precision 'f32' | 'bf16x3' (None = LINEAR_PRECISION); residual_cols < N: residual has only that
+    many columns and is added to the first residual_cols outputs (weight-stationary kernel only).
+    -> (…, N) float32.  Raises OccAmdUnsupported for shapes without an MFMA kernel."""
     precision = precision or LINEAR_PRECISION
     if precision not in ("f32", "bf16x3"):
         raise OccAmdError(f"linear: unknown precision {precision!r}")
@@ -520,7 +487,7 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
             raise OccAmdError("linear: bias must have N entries")
     ldres = 0
     if residual is not None:
-        _, Mr, _, ldres = _rows2d("residual", residual, N)
+        _, Mr, _, ldres = _rows2d("residual", residual, N if residual_cols is None else int(residual_cols))
         if Mr != M:
             raise OccAmdError("linear: residual differs in rows")
     g = b = None
@@ -539,15 +506,22 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
     if not weight.is_contiguous():
         raise OccAmdError("linear: weight must be contiguous")
     wdev = linear_pack_weight_bf16x3(weight) if precision == "bf16x3" and (K1 + K2) % 16 == 0 else weight
-    if wdev is weight:
-        fn = _lib.lib().occ_linear_f32
-    elif LINEAR_KERNEL == "x3s" and K1 % 32 == 0 and K2 % 32 == 0:
-        fn = _lib.lib().occ_linear_bf16x3s_f32
-    else:
-        fn = _lib.lib().occ_linear_bf16x3_f32
     out = torch.empty(a.shape[:-1] + (N,), dtype=torch.float32, device=a.device)
     if _TIMING is not None and (_TIMING_ONLY is None or 'linear' in _TIMING_ONLY):
         _TIMING.setdefault('linear_flops', []).append(2.0 * M * N * (K1 + K2))
+    ws = (wdev is not weight and LINEAR_KERNEL == "ws" and K1 == 256 and K2 == 0 and M >= 1024
+          and not (ln is not None and N > 256))
+    if residual_cols is not None and not ws:
+        raise OccAmdUnsupported("linear: residual_cols needs the weight-stationary kernel (K == 256, M >= 1024)")
+    if ws:
+        with torch.cuda.device(a.device), _timed('linear'):
+            rc = _lib.lib().occ_linear_ws_bf16x3_f32(
+                ptr(a_), i64(lda1), i32(K1), ptr(wdev), ptr(bias), i32(1 if act == 'relu' else 0), ptr(residual),
+                i64(ldres), i32(N if residual_cols is None else int(residual_cols)), ptr(g), ptr(b),
+                f32(float(eps)), ptr(out), i64(N), i32(M), i32(N), stream_ptr(a.device))
+        _lib.check(rc, "linear_ws")
+        return out
+    fn = _lib.lib().occ_linear_f32 if wdev is weight else _lib.lib().occ_linear_bf16x3_f32
     with torch.cuda.device(a.device), _timed('linear'):
         rc = fn(ptr(a_), i64(lda1), i32(K1), ptr(a2), ptr(a2_add), i64(lda2), i32(K2), ptr(wdev),
                 ptr(bias), i32(1 if act == 'relu' else 0), ptr(residual), i64(ldres), ptr(g), ptr(b),
@@ -737,50 +711,39 @@ def linear_autograd(x, weight, bias=None, act=None):
     return torch.relu(y) if act == 'relu' else y
 
 
-_PACKED_FFN = {}        # (w1 ptr/version, w2 ptr/version, epoch) -> packed stream
-
-
-def ffn_fused(x, w1, b1, w2, b2, ln=None):
-    """LayerNorm(x + relu(x @ w1^T + b1) @ w2^T + b2) in ONE launch (csrc/ffn_fused.hip; hidden activations stay
-    in registers).  x (..., 256) fp32 with uniformly strided rows; w1 (512, 256), w2 (256, 512) Linear weights;
-    ln = (gamma, beta, eps) | nn.LayerNorm | None.  Raises OccAmdUnsupported for other sizes."""
+def ffn_ws(x, w1, b1, w2, b2, ln=None):
+    """LayerNorm(x + relu(x @ w1^T + b1) @ w2^T + b2) in ONE launch (csrc/linear_ws.hip: the hidden activations go
+    through LDS, never through HBM).  x (..., 256) fp32 with uniformly strided rows; w1 (512, 256), w2 (256, 512)
+    Linear weights (packed hi/lo once, cached); ln = (gamma, beta, eps) | nn.LayerNorm | None.  Raises
+    OccAmdUnsupported for other sizes."""
     x_, M, C, ldx = _rows2d("x", x)
     for n, t in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2)):
         _need_cuda_f32(n, t)
     hidden = w1.shape[0]
     if tuple(w1.shape) != (hidden, C) or tuple(w2.shape) != (C, hidden) or b1.numel() != hidden or b2.numel() != C:
-        raise OccAmdError("ffn_fused: inconsistent weight shapes")
+        raise OccAmdError("ffn_ws: inconsistent weight shapes")
     g = b = None
     eps = 0.0
     if ln is not None:
         if isinstance(ln, torch.nn.LayerNorm):
             if tuple(ln.normalized_shape) != (C,) or ln.weight is None or ln.bias is None:
-                raise OccAmdUnsupported("ffn_fused: LayerNorm must be affine over the C features")
+                raise OccAmdUnsupported("ffn_ws: LayerNorm must be affine over the C features")
             g, b, eps = ln.weight, ln.bias, ln.eps
         else:
             g, b, eps = ln
         _need_cuda_f32("ln_gamma", g)
         _need_cuda_f32("ln_beta", b)
-    key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version, str(w1.device), cache_epoch())
-    hit = _PACKED_FFN.get(key)
-    if hit is None:
-        packed = torch.empty(8 * C * hidden, dtype=torch.uint8, device=w1.device)   # two matrices x (hi + lo) bf16
-        with torch.cuda.device(w1.device):
-            rc = _lib.lib().occ_ffn_pack_weights_bf16x3(ptr(w1.contiguous()), ptr(w2.contiguous()), ptr(packed),
-                                                        i32(C), i32(hidden), stream_ptr(w1.device))
-        _lib.check(rc, "ffn_pack_weights")
-        if len(_PACKED_FFN) >= 64:
-            _PACKED_FFN.pop(next(iter(_PACKED_FFN)))
-        hit = (packed, w1, w2)              # the weights stay referenced: their addresses cannot be recycled
-        _PACKED_FFN[key] = hit
+    if C % 16 or hidden % 16 or not (w1.is_contiguous() and w2.is_contiguous()):
+        raise OccAmdUnsupported("ffn_ws: weights must be contiguous with C, hidden multiples of 16")
+    p1, p2 = linear_pack_weight_bf16x3(w1), linear_pack_weight_bf16x3(w2)
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     if _TIMING is not None and (_TIMING_ONLY is None or 'linear' in _TIMING_ONLY):
         _TIMING.setdefault('linear_flops', []).append(4.0 * M * C * hidden)
     with torch.cuda.device(x.device), _timed('linear'):
-        rc = _lib.lib().occ_ffn_fused_bf16x3_f32(ptr(x_), i64(ldx), ptr(hit[0]), ptr(b1), ptr(b2), ptr(g), ptr(b),
-                                                 f32(float(eps)), ptr(out), i64(C), i32(M), i32(C), i32(hidden),
-                                                 stream_ptr(x.device))
-    _lib.check(rc, "ffn_fused")
+        rc = _lib.lib().occ_ffn_ws_bf16x3_f32(ptr(x_), i64(ldx), ptr(p1), ptr(b1), ptr(p2), ptr(b2), ptr(g), ptr(b),
+                                              f32(float(eps)), ptr(out), i64(C), i32(M), i32(C), i32(hidden),
+                                              stream_ptr(x.device))
+    _lib.check(rc, "ffn_ws")
     return out
 
 

@@ -52,6 +52,29 @@ class BEVFormerOcc(BaseModule):
         self.video_test_mode = video_test_mode
         self.prev_frame_info = {'prev_bev': None, 'scene_token': None, 'prev_pos': 0, 'prev_angle': 0}
 
+    def train(self, mode=True):
+        if mode:    # parameters / BatchNorm statistics may change while training: re-check the folded plan's sources
+            object.__setattr__(self, '_plan_dirty', True)
+        return super().train(mode)
+
+    def _backbone_signature(self):
+        mods = [m for m in (getattr(self, 'img_backbone', None), getattr(self, 'img_neck', None)) if m is not None]
+        return tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+
+    def _current_plan(self):
+        """The folded inference backbone, rebuilt when its source parameters changed since the fold."""
+        plan = getattr(self, '_inference_backbone', None)
+        if plan is None:
+            return None
+        stale = plan.built_epoch != cache_epoch()
+        if not stale and getattr(self, '_plan_dirty', False):
+            stale = plan.signature != self._backbone_signature()
+            object.__setattr__(self, '_plan_dirty', self.training)
+        if stale:
+            self.enable_fused_backbone(**self._inference_backbone_args)
+            plan = self._inference_backbone
+        return plan
+
     @property
     def with_img_neck(self):
         return hasattr(self, 'img_neck') and self.img_neck is not None
@@ -69,11 +92,10 @@ class BEVFormerOcc(BaseModule):
         if img.dim() == 5:
             B, N, C, H, W = img.size()
             img = img.reshape(B * N, C, H, W)
-        plan = getattr(self, '_inference_backbone', None)
-        if plan is not None and not self.training and not torch.is_grad_enabled():
-            if plan.built_epoch != cache_epoch():     # parameters were reloaded / trained since the fold
-                self.enable_fused_backbone(**self._inference_backbone_args)
-                plan = self._inference_backbone
+        plan = None
+        if not self.training and not torch.is_grad_enabled():
+            plan = self._current_plan()     # refolded if the parameters were reloaded / trained since the fold
+        if plan is not None:
             img_feats = plan(img)       # BN-folded, NHWC, own bf16 kernels
         else:
             if self.use_grid_mask:
@@ -112,6 +134,7 @@ class BEVFormerOcc(BaseModule):
                                           fused_bottleneck=fused_bottleneck)
             plan.use_graph = use_graph
             plan.built_epoch = cache_epoch()
+            plan.signature = self._backbone_signature()
             object.__setattr__(self, '_inference_backbone', plan)   # not a sub-module: owns copies
         return self
 
@@ -126,11 +149,8 @@ class BEVFormerOcc(BaseModule):
         B, N, Hs, Ws, _ = img_u8.shape
         mean, std = img_norm_cfg['mean'], img_norm_cfg['std']
         to_rgb = bool(img_norm_cfg.get('to_rgb', True))
-        plan = getattr(self, '_inference_backbone', None)
-        if plan is not None and not self.training and getattr(plan, '_stem_fused', False):
-            if plan.built_epoch != cache_epoch():
-                self.enable_fused_backbone(**self._inference_backbone_args)
-                plan = self._inference_backbone
+        plan = None if self.training else self._current_plan()
+        if plan is not None and getattr(plan, '_stem_fused', False):
             feats, hw = plan.forward_u8(img_u8.reshape(B * N, Hs, Ws, 3), mean, std, to_rgb, size_divisor)
         else:
             x = img_u8.reshape(B * N, Hs, Ws, 3).float()

@@ -23,14 +23,11 @@ class BaseModule(nn.Module):
         super().__init__()
         self._is_init = False
         self.init_cfg = init_cfg
-        # parameters rewritten through load_state_dict (param.data.copy_: no _version bump) or a mode change
-        # (training updates, BatchNorm statistics) make every derived-weight cache stale: bump the epoch
+        # parameters rewritten through load_state_dict (param.data.copy_: no _version bump) make every derived-weight
+        # cache stale: bump the epoch.  train() / eval() do NOT: optimizer steps and BatchNorm statistics update their
+        # tensors in place (the _version every cache key carries), and obtain_history_bev flips the mode twice per
+        # training step (the bump refolded the backbone prefix plan and repacked every weight each step)
         self.register_load_state_dict_post_hook(_bump_cache_epoch)
-
-    def train(self, mode=True):
-        if mode != self.training:
-            _bump_cache_epoch()
-        return super().train(mode)
 
     def init_weights(self):
         for m in self.children():
@@ -143,9 +140,9 @@ class FFN(BaseModule):
                 and isinstance(self.dropout_layer, nn.Identity)):
             return None
         fc1, fc2 = self.layers[0][0], self.layers[1]
-        if identity is None and ext.LINEAR_PRECISION == "bf16x3" and ext.FFN_FUSED:
-            try:    # one launch, hidden activations in registers (embed 256 / hidden 512; else the two-launch form)
-                return ext.ffn_fused(x.contiguous(), fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln=post_norm)
+        if identity is None and ext.LINEAR_PRECISION == "bf16x3" and ext.FFN_KERNEL == "ws" and x.numel() >= 1024 * 256:
+            try:    # one launch, hidden activations through LDS (embed 256 / hidden 512; else the two-launch form)
+                return ext.ffn_ws(x.contiguous(), fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln=post_norm)
             except OccAmdUnsupported:
                 pass
         try:

@@ -209,8 +209,7 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                                              spatial_shapes=spatial_shapes,
                                              level_start_index=level_start_index,
                                              vis_bits=kwargs.get('vis_bits'),
-                                             bev_order=kwargs.get('bev_order_flat' if ext.SCA_KERNEL else
-                                                                  'bev_order'),
+                                             bev_order=kwargs.get('bev_order'),
                                              gather_stats=kwargs.get('gather_stats'),
                                              post_norm=post_norm)
                 if out is not None:
@@ -365,15 +364,12 @@ class BEVFormerEncoder(TransformerLayerSequence):
             self._pos_key, self._pos_src, self._pos_qm = key, bev_pos, bev_pos.permute(1, 0, 2).contiguous()
         return self._pos_qm
 
-    def _bev_order(self, bev_h, bev_w, device, flat=False):
-        """Query processing order of the gather kernels: 8x8 BEV tiles; `flat` = plain tile order (head-major SCA
-        kernels: a block = 8-query rows of consecutive tiles, the XCD is picked by the head), else the tile list
-        is additionally dealt over the 8 XCDs in 4-query blocks (query-major kernels)."""
-        sweep = os.environ.get("OCC_BEV_SWEEP", "raster")
-        key = (bev_h, bev_w, str(device), flat, sweep)
+    def _bev_order(self, bev_h, bev_w, device):
+        """Query processing order of the gather kernels: 8x8 BEV tiles, the tile list dealt over the 8 XCDs in
+        4-query blocks (one wave per query, four waves per block)."""
+        key = (bev_h, bev_w, str(device))
         if key not in self._order_cache:
-            order = bev_tile_order(bev_h, bev_w, n_xcd=1 if flat else 8, sweep=sweep)
-            self._order_cache[key] = torch.from_numpy(order).to(device)
+            self._order_cache[key] = torch.from_numpy(bev_tile_order(bev_h, bev_w, n_xcd=8)).to(device)
         return self._order_cache[key]
 
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
@@ -401,7 +397,6 @@ class BEVFormerEncoder(TransformerLayerSequence):
         else:
             hybird_ref_2d = hybrid_same
         extra = dict(vis_bits=vis_bits, bev_order=self._bev_order(bev_h, bev_w, bev_query.device),
-                     bev_order_flat=self._bev_order(bev_h, bev_w, bev_query.device, flat=True),
                      tsa_spatial_shapes=tsa_shapes, tsa_level_start_index=tsa_start)
         output = bev_query
         if _VPROJ_OVERLAP and hasattr(value, 'prefetch') and not torch.is_grad_enabled():

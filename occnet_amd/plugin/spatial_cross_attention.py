@@ -404,7 +404,7 @@ class SpatialCrossAttention(BaseModule):
                 slots = self._fused_slots(query, value, reference_points_cam, bev_mask,
                                           spatial_shapes, level_start_index,
                                           vis_bits=kwargs.get('vis_bits'),
-                                          order=kwargs.get('bev_order_flat' if ext.SCA_KERNEL else 'bev_order'),
+                                          order=kwargs.get('bev_order'),
                                           stats=kwargs.get('gather_stats'))
             except OccAmdUnsupported:
                 slots = None

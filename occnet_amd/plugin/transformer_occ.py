@@ -22,24 +22,53 @@ from .spatial_cross_attention import MSDeformableAttention3D, _require_device
 from .temporal_self_attention import TemporalSelfAttention
 
 
+_ROT_CACHE = {}
+
+
+def _rotation_source_index(H, W, angle_deg, center):
+    """For every output pixel of a nearest-neighbour rotation by angle_deg (counter-clockwise, degrees) about
+    `center` (x, y): the flat index of its source pixel, or -1 outside the map.  Evaluated ON THE HOST in float32 with
+    the affine-grid formulation torchvision's `rotate` uses (inverse rotation matrix about the centre -> normalised
+    sampling grid -> grid_sample(mode='nearest', align_corners=False)), by rotating an image of pixel indices: which
+    neighbour a near-tie coordinate rounds to then matches the reference's CPU path bit for bit.  (Evaluated on the
+    device, fused multiply-adds move a handful of the 40 000 coordinates across a rounding boundary: one wrong
+    source pixel is an O(1) error in the history BEV.)"""
+    import math
+    key = (H, W, float(angle_deg), float(center[0]), float(center[1]))
+    hit = _ROT_CACHE.get(key)
+    if hit is None:
+        cx, cy = center[0] - W * 0.5, center[1] - H * 0.5
+        rot = math.radians(-float(angle_deg))
+        cos, sin = math.cos(rot), math.sin(rot)
+        m = [cos, sin, 0.0, -sin, cos, 0.0]
+        m[2] += m[0] * (-cx) + m[1] * (-cy) + cx
+        m[5] += m[3] * (-cx) + m[4] * (-cy) + cy
+        theta = torch.tensor(m, dtype=torch.float32).view(1, 2, 3)
+        base = torch.empty(1, H, W, 3, dtype=torch.float32)
+        base[..., 0].copy_(torch.linspace(-W * 0.5 + 0.5, W * 0.5 + 0.5 - 1, steps=W))
+        base[..., 1].copy_(torch.linspace(-H * 0.5 + 0.5, H * 0.5 + 0.5 - 1, steps=H).unsqueeze(-1))
+        base[..., 2].fill_(1)
+        grid = base.view(1, H * W, 3).bmm(theta.transpose(1, 2) / torch.tensor([0.5 * W, 0.5 * H])).view(1, H, W, 2)
+        # pixel indices + 1 (exact in float32 below 2^24), zero padding marks "outside"
+        ids = torch.arange(1, H * W + 1, dtype=torch.float32).view(1, 1, H, W)
+        src = F.grid_sample(ids, grid, mode='nearest', padding_mode='zeros', align_corners=False).view(-1)
+        hit = src.to(torch.int64) - 1
+        if len(_ROT_CACHE) >= 16:
+            _ROT_CACHE.pop(next(iter(_ROT_CACHE)))
+        _ROT_CACHE[key] = hit
+    return hit
+
+
 def rotate_bev_nearest(bev, angle_deg, center):
     """Rotate a (C, H, W) BEV map by angle_deg (counter-clockwise, degrees) about `center` (x, y) in
     pixels, nearest-neighbour, zero fill — the operation the reference applies to the history BEV
-    with torchvision's `rotate(img, angle, center=rotate_center)` (transformer_occ.py:195-205)."""
-    import math
+    with torchvision's `rotate(img, angle, center=rotate_center)` (transformer_occ.py:195-205).  The source-pixel map
+    comes from the host (see _rotation_source_index); the device only gathers."""
     C, H, W = bev.shape
-    cx, cy = center[0] - W * 0.5, center[1] - H * 0.5
-    a = math.radians(-angle_deg)
-    cos, sin = math.cos(a), math.sin(a)
-    # output pixel (centred coords) -> source pixel: inverse rotation about (cx, cy)
-    xs = torch.arange(W, device=bev.device, dtype=bev.dtype) + 0.5 - W * 0.5
-    ys = torch.arange(H, device=bev.device, dtype=bev.dtype) + 0.5 - H * 0.5
-    gy, gx = torch.meshgrid(ys, xs, indexing='ij')
-    sx = cos * (gx - cx) + sin * (gy - cy) + cx
-    sy = -sin * (gx - cx) + cos * (gy - cy) + cy
-    grid = torch.stack((sx / (0.5 * W), sy / (0.5 * H)), -1)[None]
-    return F.grid_sample(bev[None], grid, mode='nearest', padding_mode='zeros',
-                         align_corners=False)[0]
+    assert H * W < (1 << 24)
+    src = _rotation_source_index(H, W, angle_deg, center).to(bev.device, non_blocking=True)
+    out = bev.reshape(C, H * W).index_select(1, src.clamp(min=0)) * (src >= 0).to(bev.dtype)
+    return out.view(C, H, W)
 
 
 class LazyFeatures:

@@ -92,7 +92,7 @@ def make_images(cfg=BASE, batch=1, seed=0, device="cpu"):
     return x.to(device)
 
 
-def bev_tile_order(bev_h, bev_w, tile_h=8, tile_w=8, n_xcd=8, waves_per_block=4, sweep='raster'):
+def bev_tile_order(bev_h, bev_w, tile_h=8, tile_w=8, n_xcd=8, waves_per_block=4):
     """Processing order of the BEV queries for the gather kernels (a permutation of arange(H*W)).
 
     Queries are visited in tile_h x tile_w tiles (neighbouring pillars project to neighbouring
@@ -101,25 +101,13 @@ def bev_tile_order(bev_h, bev_w, tile_h=8, tile_w=8, n_xcd=8, waves_per_block=4,
     1/8 of the tile list instead of every 8th tile.  Only locality depends on this, never results.
     """
     q = np.arange(bev_h * bev_w, dtype=np.int64).reshape(bev_h, bev_w)
-    tiles, centres = [], []
+    tiles = []
     for y0 in range(0, bev_h, tile_h):
         xs = range(0, bev_w, tile_w)
         if (y0 // tile_h) % 2:
             xs = reversed(list(xs))        # boustrophedon: consecutive tiles stay adjacent
         for x0 in xs:
             tiles.append(q[y0:y0 + tile_h, x0:x0 + tile_w].reshape(-1))
-            centres.append((min(y0 + tile_h, bev_h) + y0 - bev_h, min(x0 + tile_w, bev_w) + x0 - bev_w))
-    if sweep == 'polar':
-        # azimuth sweep around the ego (the grid centre): every BEV cell on one ray from a camera projects into the
-        # same image columns, so a raster walk re-fetches a camera's columns once per tile row crossing that ray;
-        # walking the tiles by azimuth (near to far inside an angular bin) touches each image column band once
-        cy, cx = np.asarray(centres, dtype=np.float64).T
-        ang = np.arctan2(cy, cx)
-        nbin = max(8, int(round(2 * np.pi * max(bev_h, bev_w) / (2.0 * tile_w))))     # ~ one tile wide at the rim
-        key = np.floor((ang + np.pi) / (2 * np.pi) * nbin).clip(0, nbin - 1) * 1e6 + np.hypot(cy, cx)
-        tiles = [tiles[i] for i in np.argsort(key, kind='stable')]
-    elif sweep != 'raster':
-        raise ValueError(f"unknown sweep {sweep!r}")
     flat = np.concatenate(tiles)
     n = flat.size
     nblk = (n + waves_per_block - 1) // waves_per_block

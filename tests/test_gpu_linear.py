@@ -25,20 +25,28 @@ CASES = [
     ("two_seg_noadd",  33,   32,  64,  36,  False, None,  False,  True,     False),
     ("k16_chunks",     50,   48,  16,  64,  True,  None,  True,   False,    False),
     ("one_row",        1,    256, 0,   256, True,  None,  False,  True,     True),
-    # 160-row blocks of the round-2 kernel: exact multiple, ragged tail, rows 128..159 of a block, > 1 column block
     ("m160",           160,  256, 0,   256, True,  None,  False,  True,     True),
     ("m481_tail",      481,  256, 256, 192, True,  None,  True,   False,    False),
     ("m130_n768",      130,  256, 0,   768, True,  'relu', False, False,    False),
     ("k512_n260",      200,  512, 0,   260, True,  None,  False,  True,     False),
+    # the weight-stationary kernel's domain (K == 256, M >= 1024): one / several column groups, idle waves (N = 192),
+    # ragged row ranges and tiles, every epilogue
+    ("ws_out_proj",    4099, 256, 0,   256, True,  None,  False,  True,     True),
+    ("ws_value_proj",  1031, 256, 0,   256, True,  None,  False,  False,    False),
+    ("ws_tsa_q_192",   2500, 256, 0,   192, False, None,  False,  True,     False),
+    ("ws_sca_q_768",   3001, 256, 0,   768, True,  None,  False,  False,    False),
+    ("ws_ffn1_relu",   20000, 256, 0,  512, True,  'relu', False, False,    False),
+    ("ws_n100_ln",     1500, 256, 0,   100, True,  'relu', False, True,     True),
 ]
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3/x3s"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3/x3"])
 @pytest.mark.parametrize("name,M,K1,K2,N,bias,act,addend,residual,ln", CASES, ids=[c[0] for c in CASES])
 def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, ln, precision, monkeypatch):
     from occnet_amd import ext
-    # "bf16x3" = the default kernel (x3), "bf16x3/x3s" = the LDS-shared-weights variant (K % 32 != 0 falls to x3)
-    monkeypatch.setattr(ext, "LINEAR_KERNEL", "x3s" if precision.endswith("/x3s") else "x3")
+    # "bf16x3" = the default dispatch (weight-stationary kernel for K == 256 and M >= 1024, else the 64-row-block
+    # kernel), "bf16x3/x3" = the 64-row-block kernel for every shape
+    monkeypatch.setattr(ext, "LINEAR_KERNEL", "x3" if precision.endswith("/x3") else "ws")
     precision = precision.split("/")[0]
     g = torch.Generator().manual_seed(50)
     a = _mk(g, M, K1)
@@ -177,10 +185,10 @@ def test_value_proj_bf16_multi_segment_single_launch():
         assert d < 3e-5
 
 
-@pytest.mark.parametrize("M,ln", [(1, True), (31, True), (128, True), (129, False), (1000, True), (4099, True)])
-def test_ffn_fused_matches_oracle(M, ln):
-    """csrc/ffn_fused.hip: LayerNorm(x + W2 relu(W1 x + b1) + b2) in one launch vs the float64 oracle chain
-    (mmcv FFN + nn.LayerNorm; reference encoder.py:377-404), ragged row counts."""
+@pytest.mark.parametrize("M,ln", [(1, True), (31, True), (128, True), (129, False), (1000, True), (4099, True), (40000, True)])
+def test_ffn_ws_matches_oracle(M, ln):
+    """csrc/linear_ws.hip ffn_ws_kernel: LayerNorm(x + W2 relu(W1 x + b1) + b2) in one launch vs the float64 oracle
+    chain (mmcv FFN + nn.LayerNorm; reference encoder.py:377-404), ragged row counts."""
     from occnet_amd import ext
     g = torch.Generator().manual_seed(70 + M)
     x = _mk(g, M, 256)
@@ -190,11 +198,11 @@ def test_ffn_fused_matches_oracle(M, ln):
     h = odense.linear_chain(x.double(), w1.double(), b1.double(), act='relu')
     ref = odense.linear_chain(h, w2.double(), b2.double(), residual=x.double(),
                               ln=None if lnp is None else (lnp[0].double(), lnp[1].double(), lnp[2]))
-    out = ext.ffn_fused(x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(),
-                        ln=None if lnp is None else (lnp[0].cuda(), lnp[1].cuda(), lnp[2]))
+    out = ext.ffn_ws(x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(),
+                     ln=None if lnp is None else (lnp[0].cuda(), lnp[1].cuda(), lnp[2]))
     torch.cuda.synchronize()
     d = float((out.cpu().double() - ref).abs().max())
-    print(f"ffn_fused M={M} ln={ln}: max|hip - oracle(f64)| = {d:.3e}")
+    print(f"ffn_ws M={M} ln={ln}: max|hip - oracle(f64)| = {d:.3e}")
     assert out.shape == (M, 256) and d < 2e-4
     # and against the two-launch form it replaces (same arithmetic, different summation order)
     two = ext.linear(ext.linear(x.cuda(), w1.cuda(), b1.cuda(), act='relu'), w2.cuda(), b2.cuda(),
@@ -202,7 +210,7 @@ def test_ffn_fused_matches_oracle(M, ln):
     assert float((out - two).abs().max()) < 1e-4
 
 
-def test_ffn_fused_asymmetric_weights_catch_layout_mistakes():
+def test_ffn_ws_asymmetric_weights_catch_layout_mistakes():
     """Structured weights: W1 picks input feature (u mod 256) for hidden unit u, W2 sums hidden units with
     distinct power-of-two-ish weights — any mistake in the fragment / permuted-k layout changes the result."""
     from occnet_amd import ext
@@ -213,7 +221,7 @@ def test_ffn_fused_asymmetric_weights_catch_layout_mistakes():
     w2 = ((torch.arange(256 * 512, dtype=torch.float32).reshape(256, 512) % 13) - 6.0) / 8.0
     b1, b2 = torch.zeros(512), torch.zeros(256)
     ref = x.double() + torch.relu(x.double() @ w1.double().T) @ w2.double().T
-    out = ext.ffn_fused(x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    out = ext.ffn_ws(x.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
     assert float((out.cpu().double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
 
 

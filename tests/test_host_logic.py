@@ -185,8 +185,10 @@ def test_train_step_goes_through_ddp_forward_world2():
 
 
 def test_cache_epoch_invalidation():
-    """derived-weight caches also key on an epoch that load_state_dict, a train()/eval()
-    change and invalidate_caches() bump (writes through param.data do not touch tensor._version)."""
+    """derived-weight caches also key on an epoch that load_state_dict and invalidate_caches()
+    bump (writes through param.data do not touch tensor._version).  ADVICE r2 (medium): a train()/eval() flip does
+    NOT bump it (obtain_history_bev flips twice per training step); in-place training updates are seen through
+    tensor._version, and the folded inference backbone re-checks its sources' signature after training mode."""
     import occnet_amd
     from occnet_amd.plugin.spatial_cross_attention import _CatLinearCache
     from occnet_amd.plugin.bricks import BaseModule
@@ -210,10 +212,48 @@ def test_cache_epoch_invalidation():
     assert occnet_amd.cache_epoch() > e
     e = occnet_amd.cache_epoch()
     m.train(False)
-    assert occnet_amd.cache_epoch() > e                         # mode change (trained weights, BN statistics)
-    e = occnet_amd.cache_epoch()
-    m.train(False)
-    assert occnet_amd.cache_epoch() == e                        # no change, no bump
+    m.train(True)
+    assert occnet_amd.cache_epoch() == e                        # mode flips do not invalidate anything ...
+    w2, _ = cache.get((m.a, m.b))
+    with torch.no_grad():
+        m.a.weight.add_(1.0)                                    # ... an in-place (optimizer-style) update does
+    w3, _ = cache.get((m.a, m.b))
+    assert w3 is not w2 and torch.equal(w3[:2], m.a.weight)
+
+
+def test_folded_plan_signature_rechecked_after_training_mode():
+    """The folded inference backbone holds COPIES of the backbone weights: after the detector has been in training
+    mode its (data_ptr, _version) signature is compared once; unchanged parameters keep the plan (the history-BEV
+    eval()/train() flip of every training step), changed ones rebuild it."""
+    from occnet_amd.plugin.bevformer_occ import BEVFormerOcc
+    det = BEVFormerOcc.__new__(BEVFormerOcc)
+    torch.nn.Module.__init__(det)
+    det.img_backbone = torch.nn.Conv2d(3, 4, 3)
+    built = []
+
+    class Plan:
+        pass
+
+    def enable(**kw):
+        import occnet_amd
+        plan = Plan()
+        plan.built_epoch, plan.signature = occnet_amd.cache_epoch(), det._backbone_signature()
+        built.append(plan)
+        object.__setattr__(det, '_inference_backbone', plan)
+    det.enable_fused_backbone = enable
+    object.__setattr__(det, '_inference_backbone_args', {})
+    enable()
+    det.eval()
+    assert det._current_plan() is built[0]
+    det.train()
+    det.eval()                                                  # mode flip, nothing trained
+    assert det._current_plan() is built[0] and len(built) == 1
+    det.train()
+    with torch.no_grad():
+        det.img_backbone.weight.mul_(0.5)                       # an optimizer step
+    det.eval()
+    assert det._current_plan() is built[1] and len(built) == 2
+    assert det._current_plan() is built[1]                      # clean again: no signature walk, no rebuild
 
 
 def test_grid_mask_follows_reference_rng_and_geometry():

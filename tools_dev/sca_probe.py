@@ -44,8 +44,9 @@ def timed(fn):
 
 ref = orig(v32, *a[1:], **k)
 ref16 = None
-for name, val, hv in (("f32 values (sca_fused_kernel)", v32, "0"), ("f16 values, 3 waves, window 4", v16, "0"),
-                      ("f16 values, 4 waves, window 2", v16, "1"), ("f16 values, 3 waves, window 2", v16, "2")):
+for name, val, hv in (("f32 values (sca_fused_kernel)", v32, "0"), ("f16 values, default (4 waves, window 2)", v16, "0"),
+                      ("f16 values, 6 waves, window 1", v16, "3"), ("f16 values, 8 waves, window 1", v16, "6"), ("f16 values, 5 waves, window 2", v16, "4"),
+                      ("f16 values, 3 waves, window 4", v16, "5"), ("f16 values, 3 waves, window 2", v16, "2")):
     os.environ["OCC_SCA_H_VARIANT"] = hv
     stats = torch.zeros(2, dtype=torch.int64, device=dev)
     out = orig(val, *a[1:], **k, stats=stats)

@@ -14,7 +14,7 @@
 //     (global_load_lds_dwordx4, no registers) while the matrix cores work on tile t, is split once per block into
 //     hi/lo bf16 planes (528-byte row pitch: conflict-free ds_read_b128 of the A fragments), and all 8 waves read
 //     the same planes;
-//   * the residual rows of tile t are requested before its k loop and are in registers when the epilogue needs them;
+//   * the residual rows of tile t are requested right after its k loop, under the epilogue's LDS transpose;
 //   * epilogue per tile through an LDS transpose (the planes' space): bias, ReLU, residual, two-pass LayerNorm by
 //     one wave per row, 16-byte stores.
 // A launch moves every input byte once and writes every output byte once; what is left is HBM time.
@@ -71,6 +71,40 @@ __device__ __forceinline__ void ws_split_tile(const char* raw, char* planes, int
   }
 }
 
+
+// k loop of one 32-row half tile against this wave's 32 columns: A fragments (hi, lo planes) read one k-step ahead,
+// three MFMAs per k-step on ONE accumulator (the co-resident wave of the SIMD fills the dependent-issue gaps).  One
+// accumulator tile at a time keeps the kernel inside 256 registers with the 128 weight registers AND a fragment
+// prefetch — with two tiles live hipcc had 8 registers left for fragments and waited out every LDS read.
+template <bool TRANSPOSED>
+__device__ __forceinline__ f32x16 ws_kloop32(const char* pa, const uint4 (&wh)[16], const uint4 (&wl)[16]) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  bf16x8 fh[2], fl[2];
+  fh[0] = *reinterpret_cast<const bf16x8*>(pa);
+  fl[0] = *reinterpret_cast<const bf16x8*>(pa + kWsPlane);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    if (ks + 1 < 16) {
+      fh[(ks + 1) & 1] = *reinterpret_cast<const bf16x8*>(pa + (ks + 1) * 32);
+      fl[(ks + 1) & 1] = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + (ks + 1) * 32);
+    }
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[ks]), bl = __builtin_bit_cast(bf16x8, wl[ks]);
+    const bf16x8 ah = fh[ks & 1], al = fl[ks & 1];
+    if (TRANSPOSED) {        // D = W . A^T (weights as the row operand)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc, 0, 0, 0);
+    } else {                 // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
 __global__ __launch_bounds__(512, 2) void linear_ws_kernel(
     const float* __restrict__ a, long lda, const uint4* __restrict__ wp, int NT32,
     const float* __restrict__ bias, int act, const float* __restrict__ residual, long ldres, int nres,
@@ -124,7 +158,18 @@ __global__ __launch_bounds__(512, 2) void linear_ws_kernel(
   for (int t = 0; t < ntiles; ++t) {
     const long row0 = r_begin + (long)t * kWsTile;
     if (t + 1 < ntiles) ws_dma_tile(a, lda, row0 + kWsTile, r_end - 1, raw, wave, lane);
-    // residual rows of this tile (8 per wave), requested now, consumed after the k loop
+    // the two 32-row halves one after the other; the results wait in registers until every wave has left the planes
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    if (live) {
+      const char* pa = planes + vi * kWsPitch + kb * 16;
+      acc0 = ws_kloop32<false>(pa, wh, wl);
+      acc1 = ws_kloop32<false>(pa + 32 * kWsPitch, wh, wl);
+    }
+    __syncthreads();                   // every wave is done with the planes (and the next tile's DMA has landed)
+    // residual rows of this tile (8 per wave): requested here, their latency hides under the transpose below — held
+    // across the k loop they cost the 32 registers the fragment prefetch needs
     float4 rres[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
@@ -133,29 +178,6 @@ __global__ __launch_bounds__(512, 2) void linear_ws_kernel(
       rres[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (res_live) rres[rr] = *reinterpret_cast<const float4*>(residual + m * ldres + n0 + c);
     }
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    if (live) {
-      const char* pa = planes + vi * kWsPitch + kb * 16;
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(pa + ks * 32);
-        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + ks * 32);
-        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch + ks * 32);
-        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + 32 * kWsPitch + ks * 32);
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[ks]), bl = __builtin_bit_cast(bf16x8, wl[ks]);
-        // term-major (small terms first), alternating the two accumulators: no back-to-back dependent MFMAs
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc1, 0, 0, 0);
-      }
-    }
-    __syncthreads();                   // every wave is done with the planes; next tile's DMA + residual rows landed
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
@@ -196,16 +218,113 @@ __global__ __launch_bounds__(512, 2) void linear_ws_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// The encoder's feed-forward block + the LayerNorm that follows it as ONE launch on the same structure:
+// The encoder's feed-forward block + the LayerNorm that follows it as ONE launch on the same tile machinery:
 //     out = LayerNorm( x + W2 . relu(W1 . x + b1) + b2 )          (C = 256, hidden = 512)
 // (mmcv FFN + norm, encoder.py:377-404, custom_base_transformer_layer.py:74-99).  Round 2's fused FFN kept the
 // hidden activations in registers at one wave per SIMD and lost to two launches; here the 64 x 512 hidden tile goes
 // through LDS in two halves and never reaches HBM (2 x 82 MB per layer).  Per 64-row tile, for hidden half p = 0, 1:
 //   GEMM1 (transposed: D = W1 . X^T, so a lane's four consecutive D registers are four consecutive hidden units of one
 //   row -> bias, ReLU, hi/lo split, 8-byte LDS stores straight into the A-operand planes of GEMM2), then
-//   GEMM2 accumulates out += H_p . W2[:, half p]^T.  Each of the four passes loads its 32 columns' weight fragments
-//   (128 VGPRs) from L2.  Two 67.5 KB LDS regions swap roles every tile: {X planes | H planes + epilogue tile}; the next
-//   tile's fp32 rows arrive by LDS-DMA in the X region as soon as the second GEMM1 pass has read it.
+//   GEMM2 accumulates out += H_p . W2[:, half p]^T.
+// The weights (1 MB of hi/lo fragments, too many for the register file) are a STREAM of 64 k-steps per tile — [W1 half
+// 0 | W2 half 0 | W1 half 1 | W2 half 1] x 16 — that runs through an 8-step register ring: the fragments of step s + 8
+// are requested from L2 right after the MFMAs of step s have consumed their slot, across phase and tile boundaries.
+// Two 67.5 KB LDS regions swap roles every tile: {X planes | H planes + epilogue tile}; the next tile's fp32 rows
+// arrive by LDS-DMA in the X region as soon as the second GEMM1 pass has read it.
+struct FfnRing { uint4 h[8], l[8]; };
+
+// fragments of stream step s (0..63 within a tile; the stream is periodic) of this wave's 32 columns: buffer loads with
+// a wave-uniform scalar offset per step and ONE vector offset (lane * 16) for the whole stream — as flat loads hipcc
+// built a 64-bit vector address per step and spilled them
+template <int S>
+__device__ __forceinline__ void ffn_ring_load(FfnRing& ring, __amdgpu_buffer_rsrc_t r1, __amdgpu_buffer_rsrc_t r2,
+                                              int wave_off1, int wave_off2, int lane16) {
+  constexpr int s = S & 63, ph = s >> 4, ks = s & 15, p = ph >> 1;
+  if ((ph & 1) == 0) {       // W1 (hidden 512, C 256): 16 column tiles of 32, 16 k-steps; uint4 index ks*2048 + (p*8+wave)*128
+    const int so = (ks * 2048 + p * 8 * 128) * 16 + wave_off1;
+    ring.h[S & 7] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, lane16, so, 0));
+    ring.l[S & 7] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, lane16 + 1024, so, 0));
+  } else {                   // W2 (C 256, hidden 512): 8 column tiles, 32 k-steps; uint4 index (p*16+ks)*1024 + wave*128
+    const int so = (p * 16 + ks) * 1024 * 16 + wave_off2;
+    ring.h[S & 7] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r2, lane16, so, 0));
+    ring.l[S & 7] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r2, lane16 + 1024, so, 0));
+  }
+}
+
+// one phase = 16 stream steps over the 64 rows of the planes at `pa` (both 32-row halves per step: independent
+// accumulators), A fragments read one step ahead
+template <int PH, bool TRANSPOSED>
+__device__ __forceinline__ void ffn_phase(const char* pa, FfnRing& ring, __amdgpu_buffer_rsrc_t r1,
+                                          __amdgpu_buffer_rsrc_t r2, int wo1, int wo2, int lane16, f32x16& a0,
+                                          f32x16& a1) {
+  bf16x8 fh0[2], fl0[2], fh1[2], fl1[2];
+  fh0[0] = *reinterpret_cast<const bf16x8*>(pa);
+  fl0[0] = *reinterpret_cast<const bf16x8*>(pa + kWsPlane);
+  fh1[0] = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch);
+  fl1[0] = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch + kWsPlane);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    constexpr int dummy = 0;
+    (void)dummy;
+    if (ks + 1 < 16) {
+      const int n = (ks + 1) & 1;
+      fh0[n] = *reinterpret_cast<const bf16x8*>(pa + (ks + 1) * 32);
+      fl0[n] = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + (ks + 1) * 32);
+      fh1[n] = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch + (ks + 1) * 32);
+      fl1[n] = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch + kWsPlane + (ks + 1) * 32);
+    }
+    const int c = ks & 1, slot = ks & 7;          // (PH*16 + ks) & 7 == ks & 7
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, ring.h[slot]), bl = __builtin_bit_cast(bf16x8, ring.l[slot]);
+    if (TRANSPOSED) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fl0[c], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fl1[c], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, fh0[c], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, fh1[c], a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fh0[c], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, fh1[c], a1, 0, 0, 0);
+    } else {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl0[c], bh, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl1[c], bh, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0[c], bl, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1[c], bl, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0[c], bh, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1[c], bh, a1, 0, 0, 0);
+    }
+    // the slot is free: request the fragments of stream step s + 8 (next phase / next tile included)
+    switch (ks) {
+#define OCC_FFN_NEXT(KS) case KS: ffn_ring_load<PH * 16 + KS + 8>(ring, r1, r2, wo1, wo2, lane16); break;
+      OCC_FFN_NEXT(0) OCC_FFN_NEXT(1) OCC_FFN_NEXT(2) OCC_FFN_NEXT(3) OCC_FFN_NEXT(4) OCC_FFN_NEXT(5)
+      OCC_FFN_NEXT(6) OCC_FFN_NEXT(7) OCC_FFN_NEXT(8) OCC_FFN_NEXT(9) OCC_FFN_NEXT(10) OCC_FFN_NEXT(11)
+      OCC_FFN_NEXT(12) OCC_FFN_NEXT(13) OCC_FFN_NEXT(14) OCC_FFN_NEXT(15)
+#undef OCC_FFN_NEXT
+    }
+    // pin the software pipeline: hipcc otherwise sinks every ring request down to its use (load, vmcnt(0), MFMA) — and a
+    // full sched_barrier here made it spill 290 registers.  Groups in program order per step:
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // the step's six MFMAs,
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // then the two ring requests for step s + 8,
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // then the four fragment reads of step s + 1
+  }
+}
+
+// GEMM1 result of hidden half P -> bias, ReLU, hi/lo split -> H planes (A operand of GEMM2)
+__device__ __forceinline__ void ffn_write_hidden(char* HP, const f32x16& h0, const f32x16& h1, const float* __restrict__ b1,
+                                                 int p, int wave, int vi, int kb) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {    // register group g of a lane = hidden units wave*32 + 8g + 4kb .. +3 of row rt*32 + vi
+    const float4 bb = *reinterpret_cast<const float4*>(b1 + p * 256 + wave * 32 + 8 * g + 4 * kb);
+    unsigned h01, h23, l01, l23;
+    char* dst = HP + vi * kWsPitch + (wave * 32 + 8 * g + 4 * kb) * 2;
+    ws_split2(fmaxf(h0[4 * g] + bb.x, 0.f), fmaxf(h0[4 * g + 1] + bb.y, 0.f), h01, l01);
+    ws_split2(fmaxf(h0[4 * g + 2] + bb.z, 0.f), fmaxf(h0[4 * g + 3] + bb.w, 0.f), h23, l23);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(dst + kWsPlane) = make_uint2(l01, l23);
+    ws_split2(fmaxf(h1[4 * g] + bb.x, 0.f), fmaxf(h1[4 * g + 1] + bb.y, 0.f), h01, l01);
+    ws_split2(fmaxf(h1[4 * g + 2] + bb.z, 0.f), fmaxf(h1[4 * g + 3] + bb.w, 0.f), h23, l23);
+    *reinterpret_cast<uint2*>(dst + 32 * kWsPitch) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(dst + 32 * kWsPitch + kWsPlane) = make_uint2(l01, l23);
+  }
+}
+
 __global__ __launch_bounds__(512, 2) void ffn_ws_kernel(
     const float* __restrict__ x, long ldx, const uint4* __restrict__ w1p, const float* __restrict__ b1,
     const uint4* __restrict__ w2p, const float* __restrict__ b2, const float* __restrict__ ln_g,
@@ -228,6 +347,13 @@ __global__ __launch_bounds__(512, 2) void ffn_ws_kernel(
   }
 
   ws_dma_tile(x, ldx, r_begin, r_end - 1, lds + 2 * kWsPlane, wave, lane);     // raw tile 0 -> region 1
+  const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(w1p, 512u * 256u * 4u), r2 = uniform_rsrc(w2p, 512u * 256u * 4u);
+  const int wo1 = wave * 128 * 16, wo2 = wave * 128 * 16, lane16 = lane * 16;
+  FfnRing ring;
+  ffn_ring_load<0>(ring, r1, r2, wo1, wo2, lane16); ffn_ring_load<1>(ring, r1, r2, wo1, wo2, lane16);
+  ffn_ring_load<2>(ring, r1, r2, wo1, wo2, lane16); ffn_ring_load<3>(ring, r1, r2, wo1, wo2, lane16);
+  ffn_ring_load<4>(ring, r1, r2, wo1, wo2, lane16); ffn_ring_load<5>(ring, r1, r2, wo1, wo2, lane16);
+  ffn_ring_load<6>(ring, r1, r2, wo1, wo2, lane16); ffn_ring_load<7>(ring, r1, r2, wo1, wo2, lane16);
   __syncthreads();
   ws_split_tile(lds + 2 * kWsPlane, lds, tid);                                 // -> X planes in region 0
   __syncthreads();
@@ -236,101 +362,32 @@ __global__ __launch_bounds__(512, 2) void ffn_ws_kernel(
     char* XP = lds + (t & 1) * 2 * kWsPlane;
     char* HP = lds + ((t + 1) & 1) * 2 * kWsPlane;
     const long row0 = r_begin + (long)t * kWsTile;
-    f32x16 o0, o1;                                   // GEMM2 accumulators: 64 rows x this wave's 32 output columns
+    const char* xa = XP + vi * kWsPitch + kb * 16;
+    const char* ha = HP + vi * kWsPitch + kb * 16;
+    f32x16 o0, o1, h0, h1;                           // o: GEMM2 accumulators, 64 rows x this wave's 32 output columns
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; h0[r] = 0.f; h1[r] = 0.f; }
+    ffn_phase<0, true>(xa, ring, r1, r2, wo1, wo2, lane16, h0, h1);                // GEMM1, hidden half 0
+    ffn_write_hidden(HP, h0, h1, b1, 0, wave, vi, kb);
+    __syncthreads();                                                           // H half 0 complete
+    ffn_phase<1, false>(ha, ring, r1, r2, wo1, wo2, lane16, o0, o1);               // GEMM2, k half 0
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
+    ffn_phase<2, true>(xa, ring, r1, r2, wo1, wo2, lane16, h0, h1);                // GEMM1, hidden half 1 (X planes: no hazard)
+    __syncthreads();                                                           // every wave is done reading H half 0 and X
+    ffn_write_hidden(HP, h0, h1, b1, 1, wave, vi, kb);
+    if (t + 1 < ntiles) ws_dma_tile(x, ldx, row0 + kWsTile, r_end - 1, XP, wave, lane);   // X region is dead: next raw tile
+    __syncthreads();                                                           // H half 1 complete
+    ffn_phase<3, false>(ha, ring, r1, r2, wo1, wo2, lane16, o0, o1);               // GEMM2, k half 1
+    __syncthreads();                                                           // every wave is done reading H half 1
+    // ---- epilogue through the H region: + b2 + x, LayerNorm, store
     float4 rres[8];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      // ---- GEMM1, hidden units [p*256 + wave*32, +32): D[i][j] = sum_k W1[i][k] X[j][k]
-      f32x16 h0, h1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { h0[r] = 0.f; h1[r] = 0.f; }
-      {
-        // the weight fragments do not depend on the tile: without an opaque base hipcc hoists all four passes' loads
-        // out of the tile loop (512 live registers, 400+ spills)
-        int opaque = 0;
-        asm volatile("" : "+s"(opaque));
-        const uint4* w1q = w1p + opaque;
-        uint4 wh[16], wl[16];
-        const long base = (long)(p * 8 + wave) * 128 + lane;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          wh[ks] = w1q[(long)ks * 16 * 128 + base];
-          wl[ks] = w1q[(long)ks * 16 * 128 + base + 64];
-        }
-        const char* pa = XP + vi * kWsPitch + kb * 16;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const bf16x8 xh0 = *reinterpret_cast<const bf16x8*>(pa + ks * 32);
-          const bf16x8 xl0 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + ks * 32);
-          const bf16x8 xh1 = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch + ks * 32);
-          const bf16x8 xl1 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + 32 * kWsPitch + ks * 32);
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[ks]), bl = __builtin_bit_cast(bf16x8, wl[ks]);
-          h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xl0, h0, 0, 0, 0);
-          h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xl1, h1, 0, 0, 0);
-          h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, xh0, h0, 0, 0, 0);
-          h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, xh1, h1, 0, 0, 0);
-          h0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xh0, h0, 0, 0, 0);
-          h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, xh1, h1, 0, 0, 0);
-        }
-      }
-      // bias + ReLU + split; register group g of a lane = hidden units wave*32 + 8g + 4kb .. +3 of row (rt*32 + vi)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bb = *reinterpret_cast<const float4*>(b1 + p * 256 + wave * 32 + 8 * g + 4 * kb);
-        unsigned h01, h23, l01, l23;
-        char* dst = HP + vi * kWsPitch + (wave * 32 + 8 * g + 4 * kb) * 2;
-        ws_split2(fmaxf(h0[4 * g] + bb.x, 0.f), fmaxf(h0[4 * g + 1] + bb.y, 0.f), h01, l01);
-        ws_split2(fmaxf(h0[4 * g + 2] + bb.z, 0.f), fmaxf(h0[4 * g + 3] + bb.w, 0.f), h23, l23);
-        *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(dst + kWsPlane) = make_uint2(l01, l23);
-        ws_split2(fmaxf(h1[4 * g] + bb.x, 0.f), fmaxf(h1[4 * g + 1] + bb.y, 0.f), h01, l01);
-        ws_split2(fmaxf(h1[4 * g + 2] + bb.z, 0.f), fmaxf(h1[4 * g + 3] + bb.w, 0.f), h23, l23);
-        *reinterpret_cast<uint2*>(dst + 32 * kWsPitch) = make_uint2(h01, h23);
-        *reinterpret_cast<uint2*>(dst + 32 * kWsPitch + kWsPlane) = make_uint2(l01, l23);
-      }
-      __syncthreads();                 // H half p complete; for p == 1 the X planes are dead from here
-      if (p == 1) {
-        if (t + 1 < ntiles) ws_dma_tile(x, ldx, row0 + kWsTile, r_end - 1, XP, wave, lane);
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {           // the residual rows (= x itself) of the epilogue
-          long m = row0 + wave * 8 + rr;
-          if (m > r_end - 1) m = r_end - 1;
-          rres[rr] = *reinterpret_cast<const float4*>(x + m * ldx + c);
-        }
-      }
-      // ---- GEMM2, k = hidden units [p*256, +256): out[j][n] += sum_k H[j][k] W2[n][k], n in [wave*32, +32)
-      {
-        int opaque = 0;
-        asm volatile("" : "+s"(opaque));
-        const uint4* w2q = w2p + opaque;
-        uint4 wh[16], wl[16];
-        const long base = (long)wave * 128 + lane;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          wh[ks] = w2q[(long)(p * 16 + ks) * 8 * 128 + base];
-          wl[ks] = w2q[(long)(p * 16 + ks) * 8 * 128 + base + 64];
-        }
-        const char* pa = HP + vi * kWsPitch + kb * 16;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(pa + ks * 32);
-          const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + ks * 32);
-          const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(pa + 32 * kWsPitch + ks * 32);
-          const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(pa + kWsPlane + 32 * kWsPitch + ks * 32);
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[ks]), bl = __builtin_bit_cast(bf16x8, wl[ks]);
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, o1, 0, 0, 0);
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, o1, 0, 0, 0);
-          o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, o1, 0, 0, 0);
-        }
-      }
-      __syncthreads();                 // every wave is done reading H half p
+    for (int rr = 0; rr < 8; ++rr) {               // the residual rows (= x itself), L2-warm: this tile came in by DMA
+      long m = row0 + wave * 8 + rr;
+      if (m > r_end - 1) m = r_end - 1;
+      rres[rr] = *reinterpret_cast<const float4*>(x + m * ldx + c);
     }
-    // ---- epilogue through the H region: + b2 + x, LayerNorm, store
     float* sO = reinterpret_cast<float*>(HP);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

@@ -95,7 +95,7 @@ def test_hires_full_size_fused_vs_library_ops():
     for k in ('bev_embed', 'occ', 'flow'):
         d = maxdiff(a[k], b[k])
         print(f"hires 400x400x32 {k}: fused vs library ops max diff = {d:.3e}")
-        assert d < 2e-4
+        assert d < 5e-4        # the fused path gathers fp16 value rows, the library path fp32 ones
 
 
 def test_bench_multi_rank_plumbing(tmp_path):

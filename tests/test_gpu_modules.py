@@ -150,7 +150,8 @@ def test_unfused_path_matches_fused():
     for k in ('bev_embed', 'occ', 'flow'):
         d1, d2 = maxdiff(a[k], b[k]), maxdiff(b[k], c[k])
         print(f"all-fused vs gather-fused {k}: {d1:.3e}; gather-fused vs unfused {k}: {d2:.3e}")
-        assert d1 < 2e-4 and d2 < 2e-4
+        # level (a) gathers fp16 value rows (the default), (b) and (c) fp32 ones: 11 significant bits on the values
+        assert d1 < 5e-4 and d2 < 2e-4
 
 
 def test_gather_stats_match_oracle_count():

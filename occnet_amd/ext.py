@@ -374,11 +374,13 @@ def _rows2d(name, t, k=None):
 # chain), 'bf16x3' = three bf16 MFMAs on hi/lo-split operands with f32 accumulation (relative error of a
 # product <= 2^-16; 2-3x faster).  The default can be overridden with OCC_LINEAR_PRECISION.
 LINEAR_PRECISION = os.environ.get("OCC_LINEAR_PRECISION", "bf16x3")
-# bf16x3 kernel for the tall K == 256 GEMMs: 'ws' (default: weight-stationary persistent kernel, csrc/linear_ws.hip) or
-# 'x3' (OCC_LINEAR_KERNEL=x3: the round-1 64-row-block kernel, which every other shape takes anyway)
-LINEAR_KERNEL = os.environ.get("OCC_LINEAR_KERNEL", "ws")
-# the encoder's FFN + LayerNorm: 'ws' (default: one launch, csrc/linear_ws.hip) or 'two' (OCC_FFN=two: two Linear launches)
-FFN_KERNEL = os.environ.get("OCC_FFN", "ws")
+# bf16x3 kernel for the tall K == 256 GEMMs: 'x3' (default: the 64-row-block kernel, csrc/linear_bf16x3.hip) or 'ws'
+# (OCC_LINEAR_KERNEL=ws: the weight-stationary persistent kernel, csrc/linear_ws.hip — measured 0-30 % SLOWER on the
+# encoder's shapes so far, profiles/r03_linear_probe.txt)
+LINEAR_KERNEL = os.environ.get("OCC_LINEAR_KERNEL", "x3")
+# the encoder's FFN + LayerNorm: 'two' (default: two Linear launches) or 'ws' (OCC_FFN=ws: one launch, csrc/linear_ws.hip
+# — measured 121 us against 103 us for the two launches so far)
+FFN_KERNEL = os.environ.get("OCC_FFN", "two")
 _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight (small LRU)
 
 

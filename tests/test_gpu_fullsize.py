@@ -224,6 +224,7 @@ def test_base_geometry_with_history():
     torch.nn.Module.__init__(det)
     det.pts_bbox_head = prod
     det.video_test_mode = True
+    det.eval()             # obtain_history_bev restores the mode it found: a bare nn.Module starts in training mode
     L = 3
     frames = [synthetic.make_features(g, seed=170 + i) for i in range(L + 1)]
     metas_list = [[]]

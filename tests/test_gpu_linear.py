@@ -40,13 +40,13 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3/x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3/ws"])
 @pytest.mark.parametrize("name,M,K1,K2,N,bias,act,addend,residual,ln", CASES, ids=[c[0] for c in CASES])
 def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, ln, precision, monkeypatch):
     from occnet_amd import ext
-    # "bf16x3" = the default dispatch (weight-stationary kernel for K == 256 and M >= 1024, else the 64-row-block
-    # kernel), "bf16x3/x3" = the 64-row-block kernel for every shape
-    monkeypatch.setattr(ext, "LINEAR_KERNEL", "x3" if precision.endswith("/x3") else "ws")
+    # "bf16x3" = the default 64-row-block kernel, "bf16x3/ws" = the weight-stationary persistent kernel where it applies
+    # (K == 256 and M >= 1024; every other shape falls to the default kernel)
+    monkeypatch.setattr(ext, "LINEAR_KERNEL", "ws" if precision.endswith("/ws") else "x3")
     precision = precision.split("/")[0]
     g = torch.Generator().manual_seed(50)
     a = _mk(g, M, K1)

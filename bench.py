@@ -28,6 +28,12 @@ line.  Extra objects on that line:
                scaled to the layer count.  The same oracle outputs are used to CHECK the HIP path at full
                size (`parity_max_abs_diff`, bound 1e-3): a 1-layer head with the oracle's weights on the GPU.
 
+Timing protocol: the K timed steps carry HIP events around the roofline kernel only (8 event records per step);
+`value_no_instrumentation` is a second barrier-bracketed pass of K steps with no events at all, and the per-kernel
+breakdown (`mfma_kernels`) comes from 3 further untimed steps.  `--history H` times BASELINE.json configs[2]: every
+sample is a queue of H history frames (obtain_history_bev: backbone + BEV encoder per frame, each attending to the rotated
+BEV of the frame before) followed by the current frame's full pass with that history.
+
 `python bench.py --gpus N` with no torchrun environment re-executes itself under torch.distributed.run with N
 ranks (the reference's tools/dist_train.sh:9-11 role); under torchrun it reads RANK/LOCAL_RANK/WORLD_SIZE.
 """
@@ -96,6 +102,10 @@ def parse():
                     help="infer only, experiment: samples dealt round-robin to this many HIP streams, so the backbone "
                          "of sample i+1 can run under the hot path of sample i (throughput, not latency; default 1 = "
                          "the metric as defined: one sample at a time)")
+    ap.add_argument("--history", type=int, default=0,
+                    help="BASELINE.json configs[2] (temporal self-attention with a real history): every sample = this many "
+                         "history frames through BEVFormerOcc.obtain_history_bev (reference bevformer_occ.py:159-178) + "
+                         "the current frame with prev_bev; 3 = the reference's 4-frame queue.  Default 0 = configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -131,10 +141,22 @@ class Stepper:
     NORM = dict(mean=[103.530, 116.280, 123.675], std=[1.0, 1.0, 1.0], to_rgb=False)   # bevformer_base_occ.py:14-15
 
     def __init__(self, model, geo, scope, backbone_dtype, device, seed, plan="autocast", graph=False,
-                 hot_feat_format="backbone", input_format="resident-f32"):
+                 hot_feat_format="backbone", input_format="resident-f32", history=0):
         from occnet_amd import synthetic
         self.model, self.scope, self.device = model, scope, device
         self.metas = synthetic.make_img_metas(geo, batch=1, seed=seed)
+        self.history = int(history)
+        if self.history:
+            # the queue's metas: frame 0 starts the scene, every later frame (and the current one) sees the ego yaw
+            # change of 1.5 degrees since its predecessor (can_bus[-1], transformer_occ.py:198)
+            self.hist_metas = [[]]
+            for i in range(self.history):
+                m = synthetic.make_img_metas(geo, batch=1, seed=seed + 1 + i)[0]
+                m['prev_bev_exists'] = i > 0
+                m['can_bus'][-1] = 1.5
+                self.hist_metas[0].append(m)
+            self.metas[0]['prev_bev_exists'] = True
+            self.metas[0]['can_bus'][-1] = 1.5
         self.autocast = False
         self.u8 = None
         if scope == "e2e" and hasattr(model, "img_backbone") and input_format == "u8-h2d":
@@ -150,6 +172,9 @@ class Stepper:
             self._upload(0)
         elif scope == "e2e" and hasattr(model, "img_backbone"):
             self.img = synthetic.make_images(geo, batch=1, seed=seed, device=device)
+            if self.history:    # (bs, len_queue, N, 3, H, W) history images, resident like the current frame
+                self.hist_img = torch.stack([synthetic.make_images(geo, batch=1, seed=seed + 1 + i, device=device)[0]
+                                             for i in range(self.history)], 0)[None]
             self.autocast = backbone_dtype == "bf16" and plan == "autocast"
             if plan == "folded":   # stock MIOpen ops, eval BN folded into the convolutions, NHWC
                 model.enable_fused_backbone(
@@ -167,6 +192,11 @@ class Stepper:
                     return f.reshape(B * N, C, h, w).to(torch.bfloat16).contiguous(
                         memory_format=torch.channels_last).view(B, N, C, h, w)
                 self.feats = [nhwc(f) for f in self.feats]
+            if self.history:    # per level (bs, len_queue, N, C, h, w): what extract_feat(len_queue=H) returns
+                hf = [synthetic.make_features(geo, batch=1, seed=seed + 1 + i, device=device) for i in range(self.history)]
+                if hot_feat_format == "backbone":
+                    hf = [[nhwc(f) for f in fr] for fr in hf]
+                self.hist_feats = hf
 
     def _upload(self, slot):
         u = self.u8
@@ -199,7 +229,16 @@ class Stepper:
                 feats = m.extract_feat(img=self.img, img_metas=self.metas)
         else:
             feats = self.feats
-        outs = m.pts_bbox_head(feats, self.metas, prev_bev=None, test=True)
+        prev_bev = None
+        if self.history:
+            if self.scope == "e2e":
+                prev_bev = m.obtain_history_bev(self.hist_img, self.hist_metas)
+            else:       # feature input: the same loop as obtain_history_bev on resident per-frame features
+                for i in range(self.history):
+                    if not self.hist_metas[0][i]['prev_bev_exists']:
+                        prev_bev = None
+                    prev_bev = m.pts_bbox_head(self.hist_feats[i], [self.hist_metas[0][i]], prev_bev, only_bev=True)
+        outs = m.pts_bbox_head(feats, self.metas, prev_bev=prev_bev, test=True)
         occ, flow = m.pts_bbox_head.get_occ(outs, self.metas)
         return occ, flow
 
@@ -387,6 +426,35 @@ def cpu_baseline(cfg, geo, device=None, thread_counts=None):
     return res
 
 
+def backbone_precision_leg(model, stepper):
+    """What the bf16 backbone plan (the benchmarked configuration) costs at the OUTPUT: the same images through the
+    folded bf16 NHWC plan and through the stock fp32 ResNet-50 + FPN modules, both into the same HIP hot path ->
+    max |difference| of the voxel logits / flow and the share of voxels whose decoded class changes.  (The backbone
+    is outside the hand-written scope; the 1e-3 parity bound is stated from the FPN maps onward.)"""
+    m = model
+    with torch.no_grad():
+        feats_b = m.extract_feat(img=stepper.img, img_metas=stepper.metas)
+        out_b = m.pts_bbox_head(feats_b, stepper.metas, prev_bev=None, test=True)
+        cls_b, _ = m.pts_bbox_head.get_occ(out_b, stepper.metas)
+        args = m._inference_backbone_args
+        m.enable_fused_backbone(dtype=None)                                   # stock modules, fp32
+        feats_f = m.extract_feat(img=stepper.img, img_metas=stepper.metas)
+        out_f = m.pts_bbox_head(feats_f, stepper.metas, prev_bev=None, test=True)
+        cls_f, _ = m.pts_bbox_head.get_occ(out_f, stepper.metas)
+        m.enable_fused_backbone(**args)
+    torch.cuda.synchronize()
+    fscale = max(float(f.float().abs().max()) for f in feats_f)
+    fdiff = max(float((a.float() - b.float()).abs().max()) for a, b in zip(feats_b, feats_f))
+    return {
+        "backbone_bf16_vs_fp32_max_abs_diff": {k: float((out_b[k].float() - out_f[k].float()).abs().max())
+                                               for k in ("occ", "flow")},
+        "backbone_bf16_vs_fp32_output_scale": {k: float(out_f[k].float().abs().max()) for k in ("occ", "flow")},
+        "backbone_bf16_vs_fp32_fpn_rel_diff": fdiff / max(fscale, 1e-30),
+        "backbone_bf16_vs_fp32_decoded_class_changes": float((cls_b != cls_f).float().mean()),
+        "note": "random-init ResNet-50 + FPN, bf16 folded plan vs the stock fp32 modules, same images, same HIP hot path",
+    }
+
+
 def _bench_parity(head_cfg, ora, feats, metas, out_o, device):
     """The HIP path at FULL base geometry against the oracle pass the baseline just timed: a 1-layer head built
     from the same config, loaded with the oracle's weights, same fp32 features (north star: <= 1e-3)."""
@@ -485,53 +553,82 @@ def main():
             args.scope = "hotpath"          # feature-input config (no image backbone): only the hot path exists
         stepper = Stepper(model, geo, args.scope, args.backbone_dtype, device, seed=rank,
                           plan=args.backbone_plan, graph=args.backbone_graph,
-                          hot_feat_format=args.hot_feat_format, input_format=args.input)
+                          hot_feat_format=args.hot_feat_format, input_format=args.input, history=args.history)
 
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         stepper()
     torch.cuda.synchronize()
     stats, da = gather_stats(model, stepper) if args.mode == "infer" else ([], None)
+    if args.history:    # every SCA module ran once per frame of the queue: counters per launch
+        stats = [(r // (1 + args.history), n // (1 + args.history)) for r, n in stats]
 
-    record = None if args.no_kernel_timing else ext.kernel_timing(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    step_events = []
-    # every instrumented kernel is timed in the first `detail` steps; after that only the roofline kernel (the
-    # SCA gather) keeps its two event records per launch — 78 records per step cost ~0.3 ms of queue time
-    detail = min(args.steps, 3)
+    def timed_pass(steps):
+        """barrier + synchronize, `steps` steps, synchronize + barrier; MAX over ranks -> seconds"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step_events = []
+        for step_i in range(steps):
+            if args.per_step:       # GPU-side time of every step (events on the current stream; no host sync)
+                e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            if lanes is not None:
+                with torch.cuda.stream(lanes[step_i % len(lanes)]):
+                    stepper()
+            else:
+                stepper()
+            if args.per_step:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                step_events.append((e0, e1))
+        torch.cuda.synchronize()
+        if args.per_step and rank == 0:
+            ms = [a.elapsed_time(b) for a, b in step_events]
+            print("per-step GPU ms: " + " ".join(f"{m:.2f}" for m in ms), file=sys.stderr)
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if share else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     lanes = None
     if args.streams > 1 and args.mode == "infer" and args.input == "resident-f32":
         lanes = [torch.cuda.Stream(device=device) for _ in range(args.streams)]
         for s_ in lanes:
             s_.wait_stream(torch.cuda.current_stream())
-    for step_i in range(args.steps):
-        if record is not None and step_i == detail:
-            ext.kernel_timing_only({"sca_fused_forward"})
-        if args.per_step:       # GPU-side time of every step (events on the current stream; no host sync)
-            e0 = torch.cuda.Event(enable_timing=True); e0.record()
-        if lanes is not None:
-            with torch.cuda.stream(lanes[step_i % len(lanes)]):
-                stepper()
-        else:
-            stepper()
-        if args.per_step:
-            e1 = torch.cuda.Event(enable_timing=True); e1.record()
-            step_events.append((e0, e1))
-    torch.cuda.synchronize()
-    if args.per_step and rank == 0:
-        ms = [a.elapsed_time(b) for a, b in step_events]
-        print("per-step GPU ms: " + " ".join(f"{m:.2f}" for m in ms), file=sys.stderr)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # THE timed region: K steps; the only instrumentation inside it is one HIP event pair around every launch of the
+    # roofline kernel (the SCA gather: 4 launches per frame pass)
+    record = None if args.no_kernel_timing else ext.kernel_timing(True)
+    if record is not None:
+        ext.kernel_timing_only({"sca_fused_forward"})
+    elapsed = timed_pass(args.steps)
     times = ext.kernel_times_ms(record) if record is not None else {}
     ext.kernel_timing(False)
+    # per-kernel breakdown: `detail` further, untimed steps with every instrumented launch timed
+    detail = 3
+    if record is not None:
+        rec2 = ext.kernel_timing(True)
+        for _ in range(detail):
+            stepper()
+        torch.cuda.synchronize()
+        for k, v in ext.kernel_times_ms(rec2).items():
+            if k != "sca_fused_forward":
+                times[k] = v
+        ext.kernel_timing(False)
+        # the same K steps once more with no events at all: what the instrumentation costs
+        elapsed_clean = timed_pass(args.steps)
+    else:
+        elapsed_clean = elapsed
+    # every rank's mean roofline-kernel launch time (a future multi-GPU run shows per-rank skew)
+    sca_rank_ms = None
+    if world > 1 and times.get("sca_fused_forward"):
+        mine = torch.tensor([sum(times["sca_fused_forward"]) / len(times["sca_fused_forward"])], dtype=torch.float64,
+                            device="cpu" if share else device)
+        allm = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        sca_rank_ms = [float(t.item()) for t in allm]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -543,10 +640,13 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
+            # second pass of the same K steps without any HIP events (the timed region carries 2 per SCA launch)
+            "value_no_instrumentation": world * args.steps / elapsed_clean,
             # hot path: fp32 storage and accumulation everywhere; encoder Linears / Conv3d per
             # ext.LINEAR_PRECISION / CONV3D_PRECISION (bf16x3 = hi/lo-split bf16 MFMA, 16 mantissa bits);
             # the image backbone (ResNet-50 + FPN, ~45 % of the step) runs in --backbone-dtype
-            "dtype": (("f32 hot path" if ext.LINEAR_PRECISION == "f32" else "f32 hot path (GEMM operands bf16x3-split)")
+            "dtype": (("f32 hot path" if ext.LINEAR_PRECISION == "f32" else "f32 hot path (GEMM operands bf16x3-split")
+                      + (", SCA value rows fp16)" if ext.SCA_VALUES == "f16" else ")")
                       + (f" + {args.backbone_dtype} backbone" if stepper.scope == "e2e" else "")),
             "data": "synthetic",
             "config": {
@@ -555,6 +655,12 @@ def main():
                              f"{geo['bev_w']}x{geo['bev_h']}x{model.pts_bbox_head.transformer.pillar_h} "
                              "voxels x (17 logits + 2 flow)" if stepper.scope == "e2e" else
                              "bevformer_base_occ hot path only: 4 FPN maps (6 cams) -> voxels"),
+                "history_frames": args.history,
+                "frames_per_sample": 1 + args.history,
+                "temporal": (None if not args.history else
+                             f"BASELINE configs[2]: {args.history} history frames through obtain_history_bev (backbone + "
+                             f"BEV encoder each, TSA on the rotated BEV of the frame before) + the current frame with "
+                             f"prev_bev; value counts SAMPLES (queues), frames/s = value x {1 + args.history}"),
                 "mode": args.mode, "scope": stepper.scope, "input": args.input if stepper.scope == "e2e" else None,
                 "samples_per_gpu": 1, "global_batch": world,
                 "parallelism": f"dp{world}", "streams": args.streams, "hot_path_dtype": "f32",
@@ -591,7 +697,11 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("kernel_variant") == ext.sca_variant_name():      # measured on the kernel that just ran
+                from occnet_amd import build as _b
+                # trusted only for the kernel SOURCE it was measured on (digest of sca_fused.hip + the csrc headers)
+                # and the same value-row type: an edited kernel reports traffic null until it is re-profiled
+                if (tj.get("source_digest") == _b.source_digest("sca_fused.hip")
+                        and tj.get("kernel_variant") == ext.sca_variant_name()):
                     traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
             out["roofline"] = {
                 "kernel": f"{ext.sca_variant_name()} (fused SCA deformable gather, {'f32' if ev == 4 else 'f16'} values)",
@@ -612,7 +722,8 @@ def main():
                 "traffic_over_compulsory": (traffic / compulsory) if traffic else None,
                 "algorithmic_bytes_per_launch": mean_bytes, "algorithmic_gbps": mean_bytes / sec / 1e9,
                 "algorithmic_over_hbm_peak": mean_bytes / sec / HBM_PEAK,
-                "launch_ms": mean_ms, "launches_timed": len(sca), "rows_R": [r for r, _ in stats],
+                "launch_ms": mean_ms, "launches_timed": len(sca), "launch_ms_per_rank": sca_rank_ms,
+                "rows_R": [r for r, _ in stats],
                 "n_in_corners": [n for _, n in stats],
             }
             tsa = times.get("tsa_fused_forward", [])
@@ -646,6 +757,8 @@ def main():
                 lin = times.get("linear", [])
                 if lin:
                     out["mfma_kernels"]["linear_ms_per_step"] = sum(lin) / detail
+                    out["mfma_kernels"]["linear_kernel"] = ext.LINEAR_KERNEL
+                    out["mfma_kernels"]["ffn_kernel"] = ext.FFN_KERNEL
                     fl = times.get("linear_flops", [])
                     if fl:
                         out["mfma_kernels"]["linear_precision"] = ext.LINEAR_PRECISION
@@ -657,6 +770,12 @@ def main():
                 raise                # a parity failure is not a measurement: fail loudly
             except Exception as e:  # the baseline must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            if (args.mode == "infer" and stepper.scope == "e2e" and getattr(stepper, "img", None) is not None
+                    and getattr(model, "_inference_backbone", None) is not None and args.backbone_dtype == "bf16"):
+                try:
+                    out["backbone_precision"] = backbone_precision_leg(model, stepper)
+                except Exception as e:
+                    out["backbone_precision"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -45,9 +45,10 @@ def _digest():
 
 
 def source_digest(*names):
-    """Digest of the named csrc files (+ every header): keys a measurement (e.g. profiles/sca_gather_traffic.json) to
-    the kernel source it was taken on."""
-    return _file_digest([os.path.join(CSRC, n) for n in names] + _headers())[:16]
+    """Digest of the named csrc files + the csrc headers (common.h): keys a measurement (e.g.
+    profiles/sca_gather_traffic.json) to the kernel source it was taken on."""
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    return _file_digest([os.path.join(CSRC, n) for n in names] + hdrs)[:16]
 
 
 def hipcc():

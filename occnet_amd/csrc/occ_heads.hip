@@ -136,11 +136,14 @@ __global__ __launch_bounds__(256) void occ_heads_kernel(
     if (occ_cls != nullptr && lane < valid) {
       float best = sm[lane * 33];
       int arg = 0;
+      bool nan = best != best;
       for (int ch = 1; ch < ncls; ++ch) {
         const float x = sm[lane * 33 + ch];
+        nan |= x != x;
         if (x > best) { best = x; arg = ch; }
       }
-      occ_cls[row0 + lane] = arg;
+      // a NaN logit makes the reference's whole softmax row NaN, whose argmax torch resolves to index 0
+      occ_cls[row0 + lane] = nan ? 0 : arg;
     }
     wave_lds_sync();
   }
@@ -292,11 +295,14 @@ __global__ __launch_bounds__(256, 2) void occ_heads_x3_kernel(
     if (occ_cls != nullptr && lane < valid) {     // decode: argmax of the logits, first index on ties (= torch)
       float best = sm[lane * 33];
       int arg = 0;
+      bool nan = best != best;
       for (int ch = 1; ch < ncls; ++ch) {
         const float x = sm[lane * 33 + ch];
+        nan |= x != x;
         if (x > best) { best = x; arg = ch; }
       }
-      occ_cls[row0 + lane] = arg;
+      // a NaN logit makes the reference's whole softmax row NaN, whose argmax torch resolves to index 0
+      occ_cls[row0 + lane] = nan ? 0 : arg;
     }
     wave_lds_sync();
   }

@@ -387,8 +387,11 @@ _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight
 def linear_pack_weight_bf16x3(weight):
     """(N, K) float32 Linear weight -> bf16 hi/lo split in MFMA fragment order
     packed[K/16][ceil(N/32)][hi, lo][lane][8] (int16 storage, columns zero-padded to a multiple of 32), cached."""
+    # temporaries (a transposed weight in a backward pass, a concatenation rebuilt every forward) are marked by their
+    # producer and packed without entering the cache: an entry keeps its tensor alive and can never hit again
+    no_cache = getattr(weight, '_occ_no_cache', False)
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device), cache_epoch())
-    hit = _PACKED_W.get(key)
+    hit = None if no_cache else _PACKED_W.get(key)
     if hit is not None:
         return hit[1]
     _need_cuda_f32("weight", weight)
@@ -398,6 +401,8 @@ def linear_pack_weight_bf16x3(weight):
         rc = _lib.lib().occ_linear_pack_weight_bf16x3(ptr(weight), ptr(packed), i32(N), i32(K),
                                                       stream_ptr(weight.device))
     _lib.check(rc, "linear_pack_weight_bf16x3")
+    if no_cache:
+        return packed
     if len(_PACKED_W) >= 256:
         _PACKED_W.pop(next(iter(_PACKED_W)))
     # the entry keeps the weight tensor alive: while it is cached its address cannot be recycled by
@@ -583,7 +588,9 @@ class LinearX3Function(torch.autograd.Function):
             gout = gout * (out > 0)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = linear(gout, weight.t().contiguous(), None, precision='bf16x3')
+            wt = weight.t().contiguous()
+            wt._occ_no_cache = True                 # a temporary: packed for this call only
+            gx = linear(gout, wt, None, precision='bf16x3')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = linear_wgrad(gout, x, with_bias=ctx.has_bias)
         return gx, gw, gb, None

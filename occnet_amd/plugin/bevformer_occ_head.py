@@ -82,7 +82,11 @@ class BEVFormerOccHead(BaseModule):
             mlvl_feats, bev_queries, None, self.bev_h, self.bev_w, grid_length=grid_length,
             bev_pos=bev_pos, reg_branches=None, cls_branches=None, img_metas=img_metas,
             prev_bev=prev_bev)
-        return {'bev_embed': bev_embed, 'occ': occ_outs, 'flow': flow_outs}
+        preds = {'bev_embed': bev_embed, 'occ': occ_outs, 'flow': flow_outs}
+        cls = getattr(occ_outs, '_occ_cls', None)
+        if cls is not None:     # the fused heads kernel decoded the classes in the same pass: an explicit entry
+            preds['occ_cls'] = cls
+        return preds
 
     def loss(self, voxel_semantics, voxel_flow, mask_camera, preds_dicts, gt_bboxes_ignore=None,
              img_metas=None):
@@ -107,7 +111,10 @@ class BEVFormerOccHead(BaseModule):
     def get_occ(self, preds_dicts, img_metas=None, rescale=False):
         """-> (class index per voxel (B, W, H, Z) int64, flow (B, W, H, Z, 2))."""
         occ = preds_dicts['occ']
-        cls = getattr(occ, '_occ_cls', None)          # written by the fused heads kernel for THIS logits tensor
+        # 'occ_cls' (argmax of the logits, first index on ties, 0 for a row with a NaN — what softmax(-1).argmax(-1)
+        # yields) is written by the fused heads kernel in the pass that writes `occ`; it is only valid while `occ` is
+        # unmodified: callers that edit the logits must drop the key
+        cls = preds_dicts.get('occ_cls')
         if cls is not None and cls.shape == occ.shape[:-1] and cls.device == occ.device:
             return cls, preds_dicts['flow']
         occ_score = occ.float().softmax(-1).argmax(-1)

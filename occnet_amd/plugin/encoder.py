@@ -403,15 +403,19 @@ class BEVFormerEncoder(TransformerLayerSequence):
             vps = [getattr(getattr(a, 'deformable_attention', None), 'value_proj', None)
                    for layer in self.layers for a in layer.attentions]
             value.prefetch([vp for vp in vps if vp is not None])
-        for lid, layer in enumerate(self.layers):
-            output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
-                           ref_3d=ref_3d, bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
-                           level_start_index=level_start_index,
-                           reference_points_cam=reference_points_cam, bev_mask=bev_mask,
-                           prev_bev=prev_bev, **extra, **kwargs)
-            bev_query = output
-            if self.return_intermediate:
-                intermediate.append(output)
+        try:
+            for lid, layer in enumerate(self.layers):
+                output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
+                               ref_3d=ref_3d, bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
+                               level_start_index=level_start_index,
+                               reference_points_cam=reference_points_cam, bev_mask=bev_mask,
+                               prev_bev=prev_bev, **extra, **kwargs)
+                bev_query = output
+                if self.return_intermediate:
+                    intermediate.append(output)
+        finally:
+            if hasattr(value, 'finish'):
+                value.finish()          # join the value-projection side stream, drop unconsumed projections
         if self.return_intermediate:
             return torch.stack(intermediate)
         return output

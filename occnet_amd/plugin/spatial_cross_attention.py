@@ -108,6 +108,7 @@ class MSDeformableAttention3D(BaseModule):
         (the concatenation is part of the graph, so both layers receive their gradients) -> (…, n_off + n_att)."""
         w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
         b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0)
+        w._occ_no_cache = True                  # rebuilt every forward: its packed form must not pile up in the cache
         return ext.linear_autograd(query, w, b)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,

@@ -202,9 +202,10 @@ class TemporalSelfAttention(BaseModule):
             # training: both query-side Linears as ONE differentiable GEMM (forward, dx and dW each once instead of
             # twice); the concatenation is part of the graph, so both layers receive their gradients
             n_off = self.sampling_offsets.out_features
+            wcat = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0)
+            wcat._occ_no_cache = True           # rebuilt every forward: its packed form must not pile up in the cache
             proj = ext.linear_autograd(
-                query, torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
-                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
+                query, wcat, torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
             sampling_offsets = proj[..., :n_off].reshape(
                 bs, num_query, self.num_heads, self.num_bev_queue, self.num_levels, self.num_points, 2)
             attention_weights = proj[..., n_off:].reshape(

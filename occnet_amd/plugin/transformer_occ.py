@@ -136,33 +136,40 @@ class LazyFeatures:
         """Start project() for several layers' value_proj modules on a side stream (the projections depend on the
         camera features only, not on the BEV queries, so they can run under the first layers' TSA / Linear kernels
         instead of serially before each gather).  project() later hands the tensor out after making the consuming
-        stream wait for the side stream's event.  OCC_VPROJ_OVERLAP=0 turns it off."""
+        stream wait for the side stream's event; finish() (the encoder calls it when the layer stack is done, also on
+        an exception) joins the side stream and drops whatever was never consumed.  OCC_VPROJ_OVERLAP=0 turns it off.
+        The derived operands (packed weight, per-(level, camera) bias: first-use caches) are built on the MAIN stream
+        before the fork, so no later main-stream reader can race their side-stream construction."""
         dev = self.mlvl_feats[0].device
         side = self._side_streams.get(str(dev))
         if side is None:
             side = self._side_streams[str(dev)] = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
-        side.wait_stream(main)                               # the feature maps (and cached biases) are ready
-        self._pending = {}
+        prepared = [(vp, ext.linear_pack_weight_bf16x3(vp.weight), self._group_bias(vp)) for vp in value_projs]
+        side.wait_stream(main)                               # the feature maps, packs and biases are ready
+        for r in self.rows:
+            r.record_stream(side)                            # read by side-stream kernels: keep them out of reuse
+        self._pending, self._side = {}, side
         with torch.cuda.stream(side):
-            for vp in value_projs:
-                out = self.project(vp)
+            for vp, _, gb in prepared:
+                out = self._launch(vp, gb)
                 out.record_stream(main)                      # consumed (and released) on the main stream
                 ev = torch.cuda.Event()
                 ev.record(side)
                 self._pending[id(vp)] = (out, ev)
 
-    def project(self, value_proj):
-        """value_proj(feat + embeds) for every camera pixel -> (bs*num_cam, sum hw, N) fp32 (fp16 in the opt-in
-        OCC_SCA_VALUES=f16 mode)."""
-        hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
-        if hit is not None:
-            torch.cuda.current_stream(hit[0].device).wait_event(hit[1])
-            return hit[0]
+    def finish(self):
+        """Join the side stream: projections that no layer consumed (a layer fell back to the unfused path, an
+        exception unwound the encoder) must not outlive their inputs' stream ordering."""
+        pending = getattr(self, '_pending', None)
+        if pending:
+            torch.cuda.current_stream(self.mlvl_feats[0].device).wait_stream(self._side)
+        self._pending = {}
+
+    def _group_bias(self, value_proj):
+        """per-(level, camera) bias = (cams_embeds + level_embeds) . W^T + b: constant while the parameters are,
+        cached on the projection module (the entry holds the parameters, so the keys stay unambiguous)"""
         w, b = value_proj.weight, value_proj.bias
-        n = w.shape[0]
-        # per-(level, camera) bias = (cams_embeds + level_embeds) . W^T + b: constant while the parameters are,
-        # cached on the projection module (the entry holds the parameters, so the keys stay unambiguous)
         o = self.owner
         srcs = (w, b, o.level_embeds, o.cams_embeds if o.use_cams_embeds else None)
         key = tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs) + (len(self.hw), cache_epoch())
@@ -172,14 +179,28 @@ class LazyFeatures:
             gb = emb.view(-1, self.c) @ w.t().float()
             if b is not None:
                 gb = gb + b.float()
-            hit = (key, gb.view(len(self.hw), self.num_cam, n).contiguous(), srcs)
+            hit = (key, gb.view(len(self.hw), self.num_cam, w.shape[0]).contiguous(), srcs)
             value_proj._occ_group_bias = hit
-        gb = hit[1]
+        return hit[1]
+
+    def _launch(self, value_proj, gb):
+        w = value_proj.weight
+        n = w.shape[0]
         out = torch.empty((self.bs * self.num_cam * self.total, n), device=w.device,
                           dtype=torch.float16 if ext.SCA_VALUES == "f16" else torch.float32)
         ext.value_proj_bf16(self.rows, w, gb, out, rows_per_group=[h * wd for h, wd in self.hw],
                             out_group_rows=self.total, out_row0=self.starts)
         return out.view(self.bs * self.num_cam, self.total, n)
+
+    def project(self, value_proj):
+        """value_proj(feat + embeds) for every camera pixel -> (bs*num_cam, sum hw, N) fp16 (fp32 with
+        OCC_SCA_VALUES=f32)."""
+        hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
+        if hit is not None:
+            torch.cuda.current_stream(hit[0].device).wait_event(hit[1])
+            return hit[0]
+        return self._launch(value_proj, self._group_bias(value_proj))
+
 
 @TRANSFORMER.register_module()
 class TransformerOcc(BaseModule):

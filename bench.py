@@ -758,7 +758,6 @@ def main():
                 if lin:
                     out["mfma_kernels"]["linear_ms_per_step"] = sum(lin) / detail
                     out["mfma_kernels"]["linear_kernel"] = ext.LINEAR_KERNEL
-                    out["mfma_kernels"]["ffn_kernel"] = ext.FFN_KERNEL
                     fl = times.get("linear_flops", [])
                     if fl:
                         out["mfma_kernels"]["linear_precision"] = ext.LINEAR_PRECISION

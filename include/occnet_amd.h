@@ -294,17 +294,6 @@ int occ_linear_ws_bf16x3_f32(const float* a, int64_t lda, int K, const void* wei
                              const float* residual, int64_t ldres, int residual_cols, const float* ln_gamma,
                              const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N, void* stream);
 
-/* The encoder's feed-forward block + its LayerNorm as ONE launch on the same structure (csrc/linear_ws.hip):
- *     out = LayerNorm( x + W2 . relu(W1 . x + b1) + b2 )
- * = mmcv FFN (Linear, ReLU, Linear, + identity) and the `norm` that follows it in the layer's operation_order
- * (P/bevformer/modules/encoder.py:377-404; custom_base_transformer_layer.py:74-99).  The 512-wide hidden activations
- * go through LDS in two halves and never reach HBM.  w1_packed = occ_linear_pack_weight_bf16x3(W1 (hidden, C)),
- * w2_packed = occ_linear_pack_weight_bf16x3(W2 (C, hidden)); ln_gamma / ln_beta both NULL = no LayerNorm.
- * Kernel exists for C = 256, hidden = 512; OCC_E_UNSUPPORTED otherwise (the caller runs two Linear launches). */
-int occ_ffn_ws_bf16x3_f32(const float* x, int64_t ldx, const void* w1_packed, const float* b1, const void* w2_packed,
-                          const float* b2, const float* ln_gamma, const float* ln_beta, float ln_eps, float* out,
-                          int64_t ldo, int M, int C, int hidden, void* stream);
-
 /* ------------------------------------------------------------------------------------------
  * Ray casting through an occupancy grid (RayIoU metric) — replaces the reference's `dvr.render_forward`
  * (tools/ray_iou/lib/dvr/dvr.cpp:68-72 binding, dvr.cu:70-388), called at

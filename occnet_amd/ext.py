@@ -378,9 +378,6 @@ LINEAR_PRECISION = os.environ.get("OCC_LINEAR_PRECISION", "bf16x3")
 # (OCC_LINEAR_KERNEL=ws: the weight-stationary persistent kernel, csrc/linear_ws.hip — measured 0-30 % SLOWER on the
 # encoder's shapes so far, profiles/r03_linear_probe.txt)
 LINEAR_KERNEL = os.environ.get("OCC_LINEAR_KERNEL", "x3")
-# the encoder's FFN + LayerNorm: 'two' (default: two Linear launches) or 'ws' (OCC_FFN=ws: one launch, csrc/linear_ws.hip
-# — measured 121 us against 103 us for the two launches so far)
-FFN_KERNEL = os.environ.get("OCC_FFN", "two")
 _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight (small LRU)
 
 
@@ -718,42 +715,6 @@ def linear_autograd(x, weight, bias=None, act=None):
         return LinearWgradFunction.apply(x, weight, bias)
     y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if act == 'relu' else y
-
-
-def ffn_ws(x, w1, b1, w2, b2, ln=None):
-    """LayerNorm(x + relu(x @ w1^T + b1) @ w2^T + b2) in ONE launch (csrc/linear_ws.hip: the hidden activations go
-    through LDS, never through HBM).  x (..., 256) fp32 with uniformly strided rows; w1 (512, 256), w2 (256, 512)
-    Linear weights (packed hi/lo once, cached); ln = (gamma, beta, eps) | nn.LayerNorm | None.  Raises
-    OccAmdUnsupported for other sizes."""
-    x_, M, C, ldx = _rows2d("x", x)
-    for n, t in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2)):
-        _need_cuda_f32(n, t)
-    hidden = w1.shape[0]
-    if tuple(w1.shape) != (hidden, C) or tuple(w2.shape) != (C, hidden) or b1.numel() != hidden or b2.numel() != C:
-        raise OccAmdError("ffn_ws: inconsistent weight shapes")
-    g = b = None
-    eps = 0.0
-    if ln is not None:
-        if isinstance(ln, torch.nn.LayerNorm):
-            if tuple(ln.normalized_shape) != (C,) or ln.weight is None or ln.bias is None:
-                raise OccAmdUnsupported("ffn_ws: LayerNorm must be affine over the C features")
-            g, b, eps = ln.weight, ln.bias, ln.eps
-        else:
-            g, b, eps = ln
-        _need_cuda_f32("ln_gamma", g)
-        _need_cuda_f32("ln_beta", b)
-    if C % 16 or hidden % 16 or not (w1.is_contiguous() and w2.is_contiguous()):
-        raise OccAmdUnsupported("ffn_ws: weights must be contiguous with C, hidden multiples of 16")
-    p1, p2 = linear_pack_weight_bf16x3(w1), linear_pack_weight_bf16x3(w2)
-    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    if _TIMING is not None and (_TIMING_ONLY is None or 'linear' in _TIMING_ONLY):
-        _TIMING.setdefault('linear_flops', []).append(4.0 * M * C * hidden)
-    with torch.cuda.device(x.device), _timed('linear'):
-        rc = _lib.lib().occ_ffn_ws_bf16x3_f32(ptr(x_), i64(ldx), ptr(p1), ptr(b1), ptr(p2), ptr(b2), ptr(g), ptr(b),
-                                              f32(float(eps)), ptr(out), i64(C), i32(M), i32(C), i32(hidden),
-                                              stream_ptr(x.device))
-    _lib.check(rc, "ffn_ws")
-    return out
 
 
 def dvr_render_forward(sigma, origin, points, tindex, grid=None, phase_name="test"):

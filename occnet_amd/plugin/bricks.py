@@ -140,11 +140,6 @@ class FFN(BaseModule):
                 and isinstance(self.dropout_layer, nn.Identity)):
             return None
         fc1, fc2 = self.layers[0][0], self.layers[1]
-        if identity is None and ext.LINEAR_PRECISION == "bf16x3" and ext.FFN_KERNEL == "ws" and x.numel() >= 1024 * 256:
-            try:    # one launch, hidden activations through LDS (embed 256 / hidden 512; else the two-launch form)
-                return ext.ffn_ws(x.contiguous(), fc1.weight, fc1.bias, fc2.weight, fc2.bias, ln=post_norm)
-            except OccAmdUnsupported:
-                pass
         try:
             h = ext.linear(x.contiguous(), fc1.weight, fc1.bias, act='relu')
             return ext.linear(h, fc2.weight, fc2.bias,

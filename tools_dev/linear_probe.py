@@ -50,16 +50,3 @@ for name, K1, K2, N, act, has_res, has_ln in SHAPES:
     line += f"  maxdiff {float((outs['x3'] - outs['ws']).abs().max()):.2e}  [{mb:.0f} MB, floor {mb / 6.3e3 * 1e3:.1f} us @6.3 TB/s]"
     print(line, flush=True)
 
-w1 = (torch.randn(512, 256, generator=g) / 16).to(dev); b1 = torch.randn(512, generator=g).to(dev)
-w2 = (torch.randn(256, 512, generator=g) / 22).to(dev); b2 = torch.randn(256, generator=g).to(dev)
-xx = torch.randn(M, 256, generator=g).to(dev)
-ln = (torch.ones(256, device=dev), torch.zeros(256, device=dev), 1e-5)
-res = {}
-for name, fn in (("ffn two launches (x3)", lambda: ext.linear(ext.linear(xx, w1, b1, act='relu'), w2, b2, residual=xx, ln=ln)),
-                 ("ffn two launches (ws + x3)", lambda: ext.linear(ext.linear(xx, w1, b1, act='relu'), w2, b2, residual=xx, ln=ln)),
-                 ("ffn_ws one launch", lambda: ext.ffn_ws(xx, w1, b1, w2, b2, ln=ln))):
-    ext.LINEAR_KERNEL = "x3" if "(x3)" in name else "ws"
-    ms, o = timed(fn)
-    res[name] = o
-    print(f"{name:30s} {ms * 1e3:7.1f} us", flush=True)
-print("maxdiff ffn_ws vs two launches:", float((res["ffn_ws one launch"] - res["ffn two launches (x3)"]).abs().max()))

@@ -739,17 +739,15 @@ def main():
                 ms = [sum(conv[0::2]) / (len(conv) // 2), sum(conv[1::2]) / (len(conv) // 2)]
                 # bf16x3 (default): 3 bf16 MFMAs per product -> priced against the dense bf16 peak with 3x the
                 # algorithmic flops; f32: v_mfma_f32_32x32x2_f32 against the f32 peak
-                x3 = ext.CONV3D_PRECISION == "bf16x3" and tr.middle_dims % 16 == 0 and tr.out_dim % 16 == 0
-                peak, mult = (2500.0, 3.0) if x3 else (157.3, 1.0)
+                def conv_entry(ms_, fl_, cin):   # the kernel follows the packed weight: bf16x3 needs Cin % 16 == 0
+                    x3 = ext.CONV3D_PRECISION == "bf16x3" and cin % 16 == 0
+                    peak, mult = (2500.0, 3.0) if x3 else (157.3, 1.0)
+                    return {"launch_ms": ms_, "precision": "bf16x3" if x3 else "f32", "tflops": fl_ / ms_ / 1e9,
+                            "mfma_tflops": mult * fl_ / ms_ / 1e9, "frac": mult * fl_ / ms_ / 1e9 / peak}
                 out["mfma_kernels"] = {
                     "peak_tflops_f32": 157.3, "peak_tflops_bf16": 2500.0,
-                    "conv3d_precision": "bf16x3" if x3 else "f32",
-                    "conv3d_lifter": {"launch_ms": ms[0], "tflops": fl[0] / ms[0] / 1e9,
-                                      "mfma_tflops": mult * fl[0] / ms[0] / 1e9,
-                                      "frac": mult * fl[0] / ms[0] / 1e9 / peak},
-                    "conv3d_2": {"launch_ms": ms[1], "tflops": fl[1] / ms[1] / 1e9,
-                                 "mfma_tflops": mult * fl[1] / ms[1] / 1e9,
-                                 "frac": mult * fl[1] / ms[1] / 1e9 / peak},
+                    "conv3d_lifter": conv_entry(ms[0], fl[0], tr.middle_dims),
+                    "conv3d_2": conv_entry(ms[1], fl[1], tr.out_dim),
                 }
                 hd = times.get("occ_heads", [])
                 if hd:
@@ -757,7 +755,6 @@ def main():
                 lin = times.get("linear", [])
                 if lin:
                     out["mfma_kernels"]["linear_ms_per_step"] = sum(lin) / detail
-                    out["mfma_kernels"]["linear_kernel"] = ext.LINEAR_KERNEL
                     fl = times.get("linear_flops", [])
                     if fl:
                         out["mfma_kernels"]["linear_precision"] = ext.LINEAR_PRECISION

@@ -284,17 +284,6 @@ int occ_linear_wgrad_bf16x3_f32(const float* dy, int64_t lddy, const float* x, i
                                 void* workspace, int64_t workspace_bytes, int M, int N, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Weight-stationary persistent form of occ_linear_bf16x3_f32 for the encoder's tall GEMMs with K == 256
- * (csrc/linear_ws.hip; same arithmetic, same packed weights, same reference call sites): one 8-wave block per CU keeps
- * its 32 columns' hi/lo fragments in registers for a contiguous range of rows, the rows stream through LDS by LDS-DMA
- * in 64-row tiles, every input byte is read once.  residual (M, residual_cols) is added to the first residual_cols
- * (multiple of 4, <= N) outputs only.  Needs K == 256, N % 4 == 0, 16-byte aligned rows, N <= 256 with LayerNorm;
- * OCC_E_UNSUPPORTED otherwise (the caller takes occ_linear_bf16x3_f32). */
-int occ_linear_ws_bf16x3_f32(const float* a, int64_t lda, int K, const void* weight_packed, const float* bias, int act,
-                             const float* residual, int64_t ldres, int residual_cols, const float* ln_gamma,
-                             const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N, void* stream);
-
-/* ------------------------------------------------------------------------------------------
  * Ray casting through an occupancy grid (RayIoU metric) — replaces the reference's `dvr.render_forward`
  * (tools/ray_iou/lib/dvr/dvr.cpp:68-72 binding, dvr.cu:70-388), called at
  * projects/mmdet3d_plugin/datasets/ray_metrics.py:116-123.

@@ -374,10 +374,6 @@ def _rows2d(name, t, k=None):
 # chain), 'bf16x3' = three bf16 MFMAs on hi/lo-split operands with f32 accumulation (relative error of a
 # product <= 2^-16; 2-3x faster).  The default can be overridden with OCC_LINEAR_PRECISION.
 LINEAR_PRECISION = os.environ.get("OCC_LINEAR_PRECISION", "bf16x3")
-# bf16x3 kernel for the tall K == 256 GEMMs: 'x3' (default: the 64-row-block kernel, csrc/linear_bf16x3.hip) or 'ws'
-# (OCC_LINEAR_KERNEL=ws: the weight-stationary persistent kernel, csrc/linear_ws.hip — measured 0-30 % SLOWER on the
-# encoder's shapes so far, profiles/r03_linear_probe.txt)
-LINEAR_KERNEL = os.environ.get("OCC_LINEAR_KERNEL", "x3")
 _PACKED_W = {}          # (data_ptr, version, shape) -> packed hi/lo bf16 weight (small LRU)
 
 
@@ -458,14 +454,13 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
 
 
 def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, ln=None,
-           precision=None, residual_cols=None):
+           precision=None):
     """out = LayerNorm(residual + act([a | a2 (+ a2_add)] @ weight^T + bias)) on the f32 matrix cores.
 
     a (…, K1); a2 / a2_add (…, K2) optional second K segment (+ addend); weight (N, K1+K2) and bias (N)
     in torch Linear layout; act None | 'relu'; residual (…, N); ln = (gamma, beta, eps) or an
-    nn.LayerNorm; precision 'f32' | 'bf16x3' (None = LINEAR_PRECISION); residual_cols < N: residual has only that
-    many columns and is added to the first residual_cols outputs (weight-stationary kernel only).
-    -> (…, N) float32.  Raises OccAmdUnsupported for shapes without an MFMA kernel."""
+    nn.LayerNorm; precision 'f32' | 'bf16x3' (None = LINEAR_PRECISION).  -> (…, N) float32.  Raises
+    OccAmdUnsupported for shapes without an MFMA kernel."""
     precision = precision or LINEAR_PRECISION
     if precision not in ("f32", "bf16x3"):
         raise OccAmdError(f"linear: unknown precision {precision!r}")
@@ -491,7 +486,7 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
             raise OccAmdError("linear: bias must have N entries")
     ldres = 0
     if residual is not None:
-        _, Mr, _, ldres = _rows2d("residual", residual, N if residual_cols is None else int(residual_cols))
+        _, Mr, _, ldres = _rows2d("residual", residual, N)
         if Mr != M:
             raise OccAmdError("linear: residual differs in rows")
     g = b = None
@@ -513,18 +508,6 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
     out = torch.empty(a.shape[:-1] + (N,), dtype=torch.float32, device=a.device)
     if _TIMING is not None and (_TIMING_ONLY is None or 'linear' in _TIMING_ONLY):
         _TIMING.setdefault('linear_flops', []).append(2.0 * M * N * (K1 + K2))
-    ws = (wdev is not weight and LINEAR_KERNEL == "ws" and K1 == 256 and K2 == 0 and M >= 1024
-          and not (ln is not None and N > 256))
-    if residual_cols is not None and not ws:
-        raise OccAmdUnsupported("linear: residual_cols needs the weight-stationary kernel (K == 256, M >= 1024)")
-    if ws:
-        with torch.cuda.device(a.device), _timed('linear'):
-            rc = _lib.lib().occ_linear_ws_bf16x3_f32(
-                ptr(a_), i64(lda1), i32(K1), ptr(wdev), ptr(bias), i32(1 if act == 'relu' else 0), ptr(residual),
-                i64(ldres), i32(N if residual_cols is None else int(residual_cols)), ptr(g), ptr(b),
-                f32(float(eps)), ptr(out), i64(N), i32(M), i32(N), stream_ptr(a.device))
-        _lib.check(rc, "linear_ws")
-        return out
     fn = _lib.lib().occ_linear_f32 if wdev is weight else _lib.lib().occ_linear_bf16x3_f32
     with torch.cuda.device(a.device), _timed('linear'):
         rc = fn(ptr(a_), i64(lda1), i32(K1), ptr(a2), ptr(a2_add), i64(lda2), i32(K2), ptr(wdev),

@@ -29,8 +29,7 @@ CASES = [
     ("m481_tail",      481,  256, 256, 192, True,  None,  True,   False,    False),
     ("m130_n768",      130,  256, 0,   768, True,  'relu', False, False,    False),
     ("k512_n260",      200,  512, 0,   260, True,  None,  False,  True,     False),
-    # the weight-stationary kernel's domain (K == 256, M >= 1024): one / several column groups, idle waves (N = 192),
-    # ragged row ranges and tiles, every epilogue
+    # the encoder's tall shapes: one / several column blocks, N = 192, ragged tails, every epilogue
     ("ws_out_proj",    4099, 256, 0,   256, True,  None,  False,  True,     True),
     ("ws_value_proj",  1031, 256, 0,   256, True,  None,  False,  False,    False),
     ("ws_tsa_q_192",   2500, 256, 0,   192, False, None,  False,  True,     False),
@@ -40,14 +39,10 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3/ws"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("name,M,K1,K2,N,bias,act,addend,residual,ln", CASES, ids=[c[0] for c in CASES])
 def test_linear_matches_oracle(name, M, K1, K2, N, bias, act, addend, residual, ln, precision, monkeypatch):
     from occnet_amd import ext
-    # "bf16x3" = the default 64-row-block kernel, "bf16x3/ws" = the weight-stationary persistent kernel where it applies
-    # (K == 256 and M >= 1024; every other shape falls to the default kernel)
-    monkeypatch.setattr(ext, "LINEAR_KERNEL", "ws" if precision.endswith("/ws") else "x3")
-    precision = precision.split("/")[0]
     g = torch.Generator().manual_seed(50)
     a = _mk(g, M, K1)
     a2 = _mk(g, M, K2) if K2 else None

@@ -1,3 +1,4 @@
+// LAB (not built into libocc_amd.so; see tools_dev/lab/README.md for the measurements that rejected it).
 // Weight-stationary persistent Linear for the encoder's tall-skinny GEMMs (M = 40 000 BEV queries, K = 256,
 // N = 192 / 256 / 512 / 768) on the gfx950 bf16 matrix cores, bf16x3 arithmetic (see linear_bf16x3.hip: hi/lo-split
 // operands, f32 accumulation, product error <= 2^-16) — same contract and call sites as occ_linear_bf16x3_f32

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Time the encoder's Linear shapes (M = 40 000): the 64-row-block kernel (x3) against the weight-stationary persistent
-kernel (ws), and the FFN as two launches against the one-launch ffn_ws.  usage: python tools_dev/linear_probe.py"""
+"""Time the encoder's Linear shapes (M = 40 000) on the default bf16x3 kernel.  (Round 3 compared it with the
+weight-stationary persistent kernel and a one-launch FFN, both now in tools_dev/lab: profiles/r03_linear_probe_ws_v*.txt.)
+usage: python tools_dev/linear_probe.py"""
 import os
 import sys
 import torch
@@ -42,11 +43,7 @@ for name, K1, K2, N, act, has_res, has_ln in SHAPES:
     line = f"{name:30s}"
     outs = {}
     mb = (M * (K1 + K2) + M * N + (M * N if has_res else 0)) * 4 / 1e6
-    for kern in ("x3", "ws"):
-        ext.LINEAR_KERNEL = kern
-        ms, o = timed(lambda: ext.linear(a, w, b, act=act, residual=res, ln=ln))
-        outs[kern] = o
-        line += f"  {kern}: {ms * 1e3:7.1f} us ({mb / ms / 1e3:5.2f} TB/s)"
-    line += f"  maxdiff {float((outs['x3'] - outs['ws']).abs().max()):.2e}  [{mb:.0f} MB, floor {mb / 6.3e3 * 1e3:.1f} us @6.3 TB/s]"
+    ms, o = timed(lambda: ext.linear(a, w, b, act=act, residual=res, ln=ln))
+    line += f"  {ms * 1e3:7.1f} us ({mb / ms / 1e3:5.2f} TB/s)  [{mb:.0f} MB, floor {mb / 6.3e3 * 1e3:.1f} us @6.3 TB/s]"
     print(line, flush=True)
 

@@ -328,6 +328,18 @@ int occ_value_proj_bf16_f16(int n_segments, const void* const* a, const int64_t*
                             const float* const* group_bias, int bias_groups, const void* weight_packed,
                             void* out, int64_t ldo, int K, int N, int64_t out_group_rows, void* stream);
 
+/* Several projections of the SAME rows in one launch — the four encoder layers' SCA value projections depend on the
+ * camera features only (spatial_cross_attention.py:366 in each of the 4 layers): weight_packed = pack of the
+ * (n_planes * plane_cols, K) stacked weights, group_bias[s] (bias_groups, n_planes * plane_cols); projection p writes
+ * plane p of `out` (planes plane_stride elements apart, rows of ldo elements, plane_cols columns; fp16 when out_f16) just
+ * as the single-projection calls above would.  The column blocks of a row block are dealt to one XCD back to back: the
+ * feature maps are read from HBM once instead of once per layer.  plane_cols % 256 == 0, otherwise OCC_E_UNSUPPORTED. */
+int occ_value_proj_bf16_planes(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
+                               const int64_t* rows_per_group, const int64_t* out_row0,
+                               const float* const* group_bias, int bias_groups, const void* weight_packed, void* out,
+                               int out_f16, int64_t ldo, int K, int n_planes, int plane_cols, int64_t plane_stride,
+                               int64_t out_group_rows, void* stream);
+
 /* ResNet stem in one launch (outside the hand-written hot path):
  *   out = max_pool2d(relu(conv2d(x, W 7x7, stride 2, pad 3) + bias), kernel 3, stride 2, pad 1)
  * x (batch, 3, H, W) f32 NCHW (rounded to bf16 while staged) ; weight_frag = occ_mfma_pack_b_frag_bf16 of the

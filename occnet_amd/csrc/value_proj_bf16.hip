@@ -46,12 +46,23 @@ struct VpSegments {
 template <int NT, int RT, bool OUTH>
 __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
     VpSegments seg, const uint4* __restrict__ wp, int bias_groups, void* __restrict__ out_, long ldo, int N,
-    int K, long out_group_rows) {
+    int K, long out_group_rows, int ncb, int plane_cols, long plane_stride) {
   float* __restrict__ out = reinterpret_cast<float*>(out_);
+  // (row block rb, column block n0).  One projection: the grid's x / y.  Stacked projections (ncb > 1, several layers'
+  // weights along N): the ncb column blocks of a row block must read its 32-64 KB of feature rows from the SAME L2, so
+  // they are dealt as linear id = (rb / 8) * 8 ncb + cb * 8 + rb % 8 — hardware block id % 8 picks the XCD, which is
+  // rb % 8 for all of them, and they are dispatched within 8 ncb blocks of each other: HBM sees the rows once.
+  int rb = (int)blockIdx.x, n0 = (int)blockIdx.y * (128 * NT);
+  if (ncb > 1) {
+    const int id = (int)blockIdx.x, grp = id / (8 * ncb), within = id % (8 * ncb);
+    rb = grp * 8 + (within & 7);
+    n0 = (within >> 3) * (128 * NT);
+    if (rb >= seg.first_block[kVpMaxSeg]) return;       // padding of the last group of 8 row blocks
+  }
   int si = 0;
 #pragma unroll
   for (int i = 1; i < kVpMaxSeg; ++i)
-    if (i < seg.n && (int)blockIdx.x >= seg.first_block[i]) si = i;
+    if (i < seg.n && rb >= seg.first_block[i]) si = i;
   const uint4* __restrict__ a = seg.a[si];
   const float* __restrict__ gbias = seg.gbias[si];
   const long M = seg.rows[si], rows_per_group = seg.rows_per_group[si], out_row0 = seg.out_row0[si];
@@ -63,8 +74,7 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
   __shared__ __attribute__((aligned(16))) char lds[STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kb = lane >> 5;
-  const long m0 = (long)((int)blockIdx.x - seg.first_block[si]) * BM;     // first_block counts BM-row blocks
-  const int n0 = blockIdx.y * BN;
+  const long m0 = (long)(rb - seg.first_block[si]) * BM;     // first_block counts BM-row blocks
   const int NT32 = (N + 31) / 32;
 
   f32x16 acc[RT][NT];
@@ -170,7 +180,9 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
           const float4 b = *reinterpret_cast<const float4*>(gbias + (g % bias_groups) * N + n0 + c);
           v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
-        const long eo = (g * out_group_rows + out_row0 + i) * ldo + n0 + c;
+        // column n lives in output plane n / plane_cols (one plane per stacked projection), column n % plane_cols
+        const int nn = n0 + c;
+        const long eo = (long)(nn / plane_cols) * plane_stride + (g * out_group_rows + out_row0 + i) * ldo + nn % plane_cols;
         if (OUTH) {
           const __half2 h01 = __floats2half2_rn(v.x, v.y), h23 = __floats2half2_rn(v.z, v.w);
           *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(out_) + eo) =
@@ -189,12 +201,15 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
                                   const int64_t* rows, const int64_t* rows_per_group,
                                   const int64_t* out_row0, const float* const* group_bias,
                                   int bias_groups, const void* weight_packed, void* out, int64_t ldo,
-                                  int K, int N, int64_t out_group_rows, bool out_f16, void* stream) {
+                                  int K, int N, int64_t out_group_rows, bool out_f16, void* stream,
+                                  int plane_cols = 0, int64_t plane_stride = 0) {
   using namespace occ;
   OCC_CHECK_ARG(a && lda && rows && rows_per_group && out_row0 && weight_packed && out,
                 "value_proj_bf16: null pointer argument");
   OCC_CHECK_ARG(n_segments > 0 && n_segments <= kVpMaxSeg, "value_proj_bf16: 1..%d segments", kVpMaxSeg);
-  OCC_CHECK_ARG(K > 0 && N > 0 && out_group_rows >= 0 && ldo >= N, "value_proj_bf16: bad dimension");
+  if (plane_cols <= 0) { plane_cols = N; plane_stride = 0; }
+  OCC_CHECK_ARG(K > 0 && N > 0 && out_group_rows >= 0 && ldo >= plane_cols && N % plane_cols == 0,
+                "value_proj_bf16: bad dimension");
   OCC_CHECK_ARG(!group_bias || bias_groups > 0, "value_proj_bf16: bias_groups must be positive");
   if (K % 32 || N % 4 || ldo % 4) {
     set_error("value_proj_bf16: no kernel for K=%d N=%d (need K %% 32 == 0, N %% 4 == 0, 16-byte aligned rows)",
@@ -229,10 +244,16 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
   seg.first_block[kVpMaxSeg] = (int)blocks;
   seg.n = n_segments;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // stacked projections (planes): the column blocks of a row block are dealt to one XCD (see the kernel)
+  const bool walk = plane_stride != 0 && plane_cols % 256 == 0;
+  const long groups8 = (blocks + 7) / 8;
 #define OCC_VP_LAUNCH__(NTT, BNN, RTT, HH)                                                          \
-  hipLaunchKernelGGL((value_proj_bf16_kernel<NTT, RTT, HH>), dim3((unsigned)blocks, (unsigned)((N + BNN - 1) / BNN)), \
+  hipLaunchKernelGGL((value_proj_bf16_kernel<NTT, RTT, HH>),                                        \
+                     walk ? dim3((unsigned)(groups8 * 8 * ((N + BNN - 1) / BNN)), 1)                \
+                          : dim3((unsigned)blocks, (unsigned)((N + BNN - 1) / BNN)),                \
                      dim3(256), 0, st, seg, reinterpret_cast<const uint4*>(weight_packed), bias_groups, out, \
-                     (long)ldo, N, K, (long)out_group_rows)
+                     (long)ldo, N, K, (long)out_group_rows, walk ? (N + BNN - 1) / BNN : 1, plane_cols, \
+                     (long)plane_stride)
 #define OCC_VP_LAUNCH_(NTT, BNN, RTT) do { if (out_f16) OCC_VP_LAUNCH__(NTT, BNN, RTT, true); else OCC_VP_LAUNCH__(NTT, BNN, RTT, false); } while (0)
 #define OCC_VP_LAUNCH(NTT, BNN) do { if (bm == 128) OCC_VP_LAUNCH_(NTT, BNN, 4); else OCC_VP_LAUNCH_(NTT, BNN, 2); } while (0)
   if (N <= 128) OCC_VP_LAUNCH(1, 128); else OCC_VP_LAUNCH(2, 256);
@@ -260,4 +281,26 @@ extern "C" int occ_value_proj_bf16_f16(int n_segments, const void* const* a, con
                                        int K, int N, int64_t out_group_rows, void* stream) {
   return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
                                 weight_packed, out, ldo, K, N, out_group_rows, true, stream);
+}
+
+// Several projections of the SAME rows in one launch (the four encoder layers' SCA value projections depend on the
+// camera features only): weight_packed = pack of the (n_planes * plane_cols, K) stacked weights, group_bias[s]
+// (bias_groups, n_planes * plane_cols); projection p writes plane p of `out` (plane_stride elements apart, rows of ldo
+// elements, plane_cols columns) exactly as occ_value_proj_bf16_f16 / _f32 would.  The column blocks of a row block run
+// on one XCD back to back, so the feature maps are read from HBM once instead of once per layer.  plane_cols % 256 == 0.
+extern "C" int occ_value_proj_bf16_planes(int n_segments, const void* const* a, const int64_t* lda,
+                                          const int64_t* rows, const int64_t* rows_per_group,
+                                          const int64_t* out_row0, const float* const* group_bias,
+                                          int bias_groups, const void* weight_packed, void* out, int out_f16,
+                                          int64_t ldo, int K, int n_planes, int plane_cols, int64_t plane_stride,
+                                          int64_t out_group_rows, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(n_planes > 0 && plane_cols > 0 && plane_stride > 0, "value_proj_bf16_planes: bad plane geometry");
+  if (plane_cols % 256) {
+    set_error("value_proj_bf16_planes: plane_cols=%d is not a multiple of 256", plane_cols);
+    return OCC_E_UNSUPPORTED;
+  }
+  return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
+                                weight_packed, out, ldo, K, n_planes * plane_cols, out_group_rows, out_f16 != 0, stream,
+                                plane_cols, plane_stride);
 }

@@ -453,6 +453,53 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
     return out
 
 
+_STACKED_VP = {}        # (weights' (ptr, version) ..., epoch) -> (stacked weight, its pack) of value_proj_bf16_planes
+
+
+def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, out_group_rows, out_row0):
+    """The same rows through SEVERAL projections in one launch (the encoder layers' SCA value projections):
+    out[p] = value_proj_bf16(a_list, weights[p], group_biases[p], ...) for every p, feature rows read from HBM once.
+    weights: list of P (N, K) fp32 Linear weights (N % 256 == 0); group_biases: list of P (S, G, N) fp32 or None;
+    out (P, rows, N) fp32 or fp16, contiguous."""
+    P, S = len(weights), len(a_list)
+    N, K = weights[0].shape
+    if any(tuple(w.shape) != (N, K) for w in weights) or N % 256:
+        raise OccAmdUnsupported("value_proj_bf16_planes: equal (N, K) weights with N % 256 == 0 needed")
+    out_half = out.dtype == torch.float16
+    if not (out.is_cuda and out.dim() == 3 and out.shape[0] == P and out.shape[2] == N and out.is_contiguous()
+            and (out_half or out.dtype == torch.float32)):
+        raise OccAmdError("value_proj_bf16_planes: out must be a contiguous (P, rows, N) fp32 / fp16 device tensor")
+    for a, rpg, r0 in zip(a_list, rows_per_group, out_row0):
+        if not (a.is_cuda and a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1 and a.shape[1] == K):
+            raise OccAmdUnsupported("value_proj_bf16_planes: every a must be a (M, K) bfloat16 device matrix with unit "
+                                    "column stride")
+        groups = (a.shape[0] + rpg - 1) // rpg
+        if (groups - 1) * out_group_rows + r0 + min(rpg, a.shape[0]) > out.shape[1]:
+            raise OccAmdError("value_proj_bf16_planes: output rows out of range")
+    key = tuple((w.data_ptr(), w._version) for w in weights) + (str(weights[0].device), cache_epoch())
+    hit = _STACKED_VP.get(key)
+    if hit is None:
+        stacked = torch.cat([w.detach() for w in weights], 0).contiguous()
+        stacked._occ_no_cache = True
+        if len(_STACKED_VP) >= 8:
+            _STACKED_VP.pop(next(iter(_STACKED_VP)))
+        hit = _STACKED_VP[key] = (stacked, linear_pack_weight_bf16x3(stacked), list(weights))
+    gb_ptrs, G, gb_keep = None, 0, None
+    if group_biases is not None and group_biases[0] is not None:
+        gb_keep = torch.cat(list(group_biases), 2).contiguous()                  # (S, G, P*N)
+        G = gb_keep.shape[1]
+        gb_ptrs = (ctypes.c_void_p * S)(*[gb_keep[s].data_ptr() for s in range(S)])
+    arr64 = lambda v: (ctypes.c_int64 * S)(*[int(x) for x in v])
+    a_ptrs = (ctypes.c_void_p * S)(*[a.data_ptr() for a in a_list])
+    with torch.cuda.device(out.device), _timed('value_proj'):
+        rc = _lib.lib().occ_value_proj_bf16_planes(
+            i32(S), a_ptrs, arr64([a.stride(0) for a in a_list]), arr64([a.shape[0] for a in a_list]),
+            arr64(rows_per_group), arr64(out_row0), gb_ptrs, i32(G), ptr(hit[1]), ptr(out), i32(1 if out_half else 0),
+            i64(N), i32(K), i32(P), i32(N), i64(out.stride(0)), i64(out_group_rows), stream_ptr(out.device))
+    _lib.check(rc, "value_proj_bf16_planes")
+    return out
+
+
 def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, ln=None,
            precision=None):
     """out = LayerNorm(residual + act([a | a2 (+ a2_add)] @ weight^T + bias)) on the f32 matrix cores.

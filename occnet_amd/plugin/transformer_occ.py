@@ -145,18 +145,38 @@ class LazyFeatures:
         if side is None:
             side = self._side_streams[str(dev)] = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
-        prepared = [(vp, ext.linear_pack_weight_bf16x3(vp.weight), self._group_bias(vp)) for vp in value_projs]
+        gbs = [self._group_bias(vp) for vp in value_projs]
+        stacked = (len(value_projs) > 1 and all(tuple(vp.weight.shape) == tuple(value_projs[0].weight.shape)
+                                                for vp in value_projs) and value_projs[0].weight.shape[0] % 256 == 0)
+        if not stacked:
+            for vp in value_projs:
+                ext.linear_pack_weight_bf16x3(vp.weight)
         side.wait_stream(main)                               # the feature maps, packs and biases are ready
         for r in self.rows:
             r.record_stream(side)                            # read by side-stream kernels: keep them out of reuse
         self._pending, self._side = {}, side
         with torch.cuda.stream(side):
-            for vp, _, gb in prepared:
-                out = self._launch(vp, gb)
-                out.record_stream(main)                      # consumed (and released) on the main stream
+            if stacked:
+                # ONE launch for all layers: every block projects its rows with all the layers' weights, the feature
+                # maps are read from HBM once (occ_value_proj_bf16_planes); layer l's values are plane l
+                n = value_projs[0].weight.shape[0]
+                out = torch.empty((len(value_projs), self.bs * self.num_cam * self.total, n), device=self.rows[0].device,
+                                  dtype=torch.float16 if ext.SCA_VALUES == "f16" else torch.float32)
+                ext.value_proj_bf16_planes(self.rows, [vp.weight for vp in value_projs], gbs, out,
+                                           rows_per_group=[h * wd for h, wd in self.hw], out_group_rows=self.total,
+                                           out_row0=self.starts)
+                out.record_stream(main)
                 ev = torch.cuda.Event()
                 ev.record(side)
-                self._pending[id(vp)] = (out, ev)
+                for l, vp in enumerate(value_projs):
+                    self._pending[id(vp)] = (out[l].view(self.bs * self.num_cam, self.total, n), ev)
+            else:
+                for vp, gb in zip(value_projs, gbs):
+                    out = self._launch(vp, gb)
+                    out.record_stream(main)                  # consumed (and released) on the main stream
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self._pending[id(vp)] = (out, ev)
 
     def finish(self):
         """Join the side stream: projections that no layer consumed (a layer fell back to the unfused path, an

@@ -180,6 +180,29 @@ def test_value_proj_bf16_multi_segment_single_launch():
         assert d < 3e-5
 
 
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16])
+def test_value_proj_planes_equals_separate_launches(out_dtype):
+    """occ_value_proj_bf16_planes (the four encoder layers' value projections in one launch, feature rows read once,
+    column blocks of a row block dealt to one XCD) is BIT-IDENTICAL to one occ_value_proj_bf16 launch per layer:
+    ragged segment sizes (the last group of 8 row blocks is padded), 3 cameras, 4 planes."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(12)
+    cams, K, N, P = 3, 256, 256, 4
+    hws = [1300, 333, 90, 20]
+    starts = [0, 1300, 1633, 1723]
+    total = sum(hws)
+    a_list = [torch.randn(cams * hw, K, generator=g).cuda().to(torch.bfloat16) for hw in hws]
+    ws = [(torch.randn(N, K, generator=g) / 16).cuda() for _ in range(P)]
+    gbs = [torch.randn(len(hws), cams, N, generator=g).cuda() for _ in range(P)]
+    out = torch.full((P, cams * total, N), float('nan'), device='cuda', dtype=out_dtype)
+    ext.value_proj_bf16_planes(a_list, ws, gbs, out, rows_per_group=hws, out_group_rows=total, out_row0=starts)
+    assert not torch.isnan(out.float()).any()
+    for p in range(P):
+        ref = torch.empty(cams * total, N, device='cuda', dtype=out_dtype)
+        ext.value_proj_bf16(a_list, ws[p], gbs[p], ref, rows_per_group=hws, out_group_rows=total, out_row0=starts)
+        assert torch.equal(out[p], ref), (p, float((out[p].float() - ref.float()).abs().max()))
+
+
 WGRAD_CASES = [
     # name,          M,      N,   K
     ("ffn1",         40000,  512, 256),

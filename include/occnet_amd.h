@@ -126,13 +126,6 @@ int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_stride, const
                               const float* ref_2d, const int32_t* order, float* out, int B, int Nq,
                               int bev_h, int bev_w, int M, int D, int P, void* stream);
 
-/* The same gather over fp16 value maps (value_bt_stride in fp16 elements), as written by occ_linear_bf16x3_f16: 4 lanes
- * x 16 bytes per head row, 16 instead of 32 loads per lane (csrc/tsa_fused.hip); arithmetic and accumulation fp32. */
-int occ_tsa_fused_forward_f16v(const void* value_f16, int64_t value_bt_stride, const float* offs,
-                               int64_t offs_stride, const float* logits, int64_t logits_stride,
-                               const float* ref_2d, const int32_t* order, float* out, int B, int Nq,
-                               int bev_h, int bev_w, int M, int D, int P, void* stream);
-
 /* ------------------------------------------------------------------------------------------
  * Multi-scale deformable attention, backward (mmcv op semantics).  Shapes as in the forward;
  *   grad_output (B, Lq, M*D) f32 in;  grad_value (B, S, M, D), grad_sampling_loc (B, Lq, M, L, P, 2),
@@ -254,13 +247,6 @@ int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2
                           int64_t lda2, int K2, const void* weight_packed, const float* bias, int act,
                           const float* residual, int64_t ldres, const float* ln_gamma,
                           const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N,
-                          void* stream);
-
-/* same arithmetic, output rows written as fp16 (ldo in fp16 elements): the projected value maps of the fp16-row gathers */
-int occ_linear_bf16x3_f16(const float* a1, int64_t lda1, int K1, const float* a2, const float* a2_add,
-                          int64_t lda2, int K2, const void* weight_packed, const float* bias, int act,
-                          const float* residual, int64_t ldres, const float* ln_gamma,
-                          const float* ln_beta, float ln_eps, void* out_f16, int64_t ldo, int M, int N,
                           void* stream);
 
 /* Training path of SpatialCrossAttention, query side (csrc/sca_prep.hip; reference spatial_cross_attention.py:338-373

@@ -19,7 +19,6 @@
 // per chunk, so the in-order vmcnt wait for chunk c never drains younger prefetches); blocks walk K in a
 // rotated order (L2 channel hot-spotting); epilogue (bias, ReLU, residual, two-pass LayerNorm) on row-major
 // rows through an LDS transpose.
-#include <hip/hip_fp16.h>
 #include "common.h"
 
 namespace occ {
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
     const float* __restrict__ a2add, long lda2, int K2, const uint4* __restrict__ wp,
     const float* __restrict__ bias, int act, const float* __restrict__ residual, long ldres,
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
-    float* __restrict__ out, long ldo, int M, int N, int out_half) {
+    float* __restrict__ out, long ldo, int M, int N) {
   constexpr int BM = 32 * RT, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
   constexpr int A_BYTES = BM * kXLD;                                 // one plane (hi or lo)
   // LDS: only the activation chunk (hi + lo planes), split and staged ONCE per block (double buffered, one
@@ -243,15 +242,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
         v.x = dx * rstd * gv.x + bev.x; v.y = dy * rstd * gv.y + bev.y;
         v.z = dz * rstd * gv.z + bev.z; v.w = dw * rstd * gv.w + bev.w;
       }
-      if (col_live) {
-        if (out_half) {      // fp16 rows (the TSA value maps of the fp16-row gather); ldo counts fp16 elements
-          const __half2 h01 = __floats2half2_rn(v.x, v.y), h23 = __floats2half2_rn(v.z, v.w);
-          *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(out) + m * ldo + n0 + c) =
-              make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-        } else {
-          *reinterpret_cast<float4*>(out + m * ldo + n0 + c) = v;
-        }
-      }
+      if (col_live) *reinterpret_cast<float4*>(out + m * ldo + n0 + c) = v;
     }
   }
 }
@@ -275,12 +266,12 @@ extern "C" int occ_linear_pack_weight_bf16x3(const float* weight, void* packed, 
   return OCC_OK;
 }
 
-static int linear_bf16x3_launch(const float* a1, int64_t lda1, int K1, const float* a2,
-                                const float* a2_add, int64_t lda2, int K2,
-                                const void* weight_packed, const float* bias, int act,
-                                const float* residual, int64_t ldres, const float* ln_gamma,
-                                const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M,
-                                int N, int out_half, void* stream) {
+extern "C" int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2,
+                                     const float* a2_add, int64_t lda2, int K2,
+                                     const void* weight_packed, const float* bias, int act,
+                                     const float* residual, int64_t ldres, const float* ln_gamma,
+                                     const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M,
+                                     int N, void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(a1 && weight_packed && out, "linear_bf16x3: null pointer argument");
   OCC_CHECK_ARG(M > 0 && N > 0 && K1 > 0 && K2 >= 0, "linear_bf16x3: bad dimension (M=%d N=%d K1=%d K2=%d)",
@@ -307,7 +298,7 @@ static int linear_bf16x3_launch(const float* a1, int64_t lda1, int K1, const flo
   hipLaunchKernelGGL((linear_bf16x3_kernel<NTT, RTT, ADDD>),                                        \
                      dim3((unsigned)((M + 32 * RTT - 1) / (32 * RTT)), (unsigned)((N + BNN - 1) / BNN)), \
                      dim3(256), 0, st, a1, (long)lda1, K1, a2, a2_add, (long)lda2, K2, wp, bias, act, \
-                     residual, (long)ldres, ln_gamma, ln_beta, ln_eps, out, (long)ldo, M, N, out_half)
+                     residual, (long)ldres, ln_gamma, ln_beta, ln_eps, out, (long)ldo, M, N)
 #define OCC_X3_LAUNCH(NTT, RTT, BNN)                                                                \
   do {                                                                                              \
     if (a2_add) OCC_X3_LAUNCH_(NTT, RTT, BNN, true); else OCC_X3_LAUNCH_(NTT, RTT, BNN, false);      \
@@ -321,26 +312,4 @@ static int linear_bf16x3_launch(const float* a1, int64_t lda1, int K1, const flo
 #undef OCC_X3_LAUNCH_
   OCC_CHECK_LAUNCH("linear_bf16x3");
   return OCC_OK;
-}
-
-extern "C" int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2,
-                                     const float* a2_add, int64_t lda2, int K2,
-                                     const void* weight_packed, const float* bias, int act,
-                                     const float* residual, int64_t ldres, const float* ln_gamma,
-                                     const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M,
-                                     int N, void* stream) {
-  return linear_bf16x3_launch(a1, lda1, K1, a2, a2_add, lda2, K2, weight_packed, bias, act, residual, ldres, ln_gamma,
-                              ln_beta, ln_eps, out, ldo, M, N, 0, stream);
-}
-
-// same arithmetic, output rows written as fp16 (ldo in fp16 elements): the projected TSA value maps of the fp16-row
-// gather (occ_tsa_fused_forward_f16v)
-extern "C" int occ_linear_bf16x3_f16(const float* a1, int64_t lda1, int K1, const float* a2,
-                                     const float* a2_add, int64_t lda2, int K2,
-                                     const void* weight_packed, const float* bias, int act,
-                                     const float* residual, int64_t ldres, const float* ln_gamma,
-                                     const float* ln_beta, float ln_eps, void* out_f16, int64_t ldo, int M,
-                                     int N, void* stream) {
-  return linear_bf16x3_launch(a1, lda1, K1, a2, a2_add, lda2, K2, weight_packed, bias, act, residual, ldres, ln_gamma,
-                              ln_beta, ln_eps, reinterpret_cast<float*>(out_f16), ldo, M, N, 1, stream);
 }

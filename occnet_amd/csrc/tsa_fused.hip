@@ -10,21 +10,14 @@
 // its head's 8 samples (32 x 16-byte loads per lane) from the two queue entries' value maps and
 // writes the mean.  When there is no history BEV the reference stacks the current BEV twice:
 // pass value_bt_stride = 0 and the two entries alias one projected buffer.
-//
-// HALFV (default for inference since round 3, like the SCA gather — see csrc/sca_fused.hip): fp16 value rows, one head
-// row of a pixel = 64 bytes = four lanes x 16 bytes; the wave's 16 lane groups are 8 heads x the 2 queue entries, every
-// lane accumulates 8 channels in fp32 (v_fma_mix_f32) over its entry's 4 samples (16 loads per lane instead of 32) and
-// the queue mean is one cross-lane add.  Both entries go through ONE buffer descriptor (the entry offset rides in the
-// per-lane byte offset), because a descriptor must be wave-uniform.
 #include "common.h"
 
 namespace occ {
 
 constexpr int kTsaWaves = 4;
 
-template <bool HALFV>
 __global__ __launch_bounds__(256) void tsa_fused_kernel(
-    const void* __restrict__ value_, long value_bt_stride, const float* __restrict__ offs,
+    const float* __restrict__ value, long value_bt_stride, const float* __restrict__ offs,
     long offs_stride, const float* __restrict__ logits, long logits_stride,
     const float* __restrict__ ref_2d, const int32_t* __restrict__ order, float* __restrict__ out,
     int B, int Nq, int bev_h, int bev_w) {
@@ -40,7 +33,6 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
   const int q = order ? order[r] : r;
   SampleParamB* sp = smem + wave * M * NSp;
   constexpr int row_stride = M * D;
-  constexpr unsigned EV = HALFV ? 2u : 4u;
 
   // lane = m*8 + t*4 + p : exactly the memory order of both Linear outputs
   const int m = lane >> 3, t = (lane >> 2) & 1;
@@ -57,49 +49,31 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
   // dummy load of row 0, no 0 * Inf)
   SampleParamB p;
   bilinear_setup_b(rf.x + o.x / (float)bev_w, rf.y + o.y / (float)bev_h, aw, bev_h, bev_w, 0,
-                   (unsigned)row_stride * EV, kOobOffset, true, p);
+                   (unsigned)row_stride * 4u, kOobOffset, true, p);
   sp[m * NSp + (lane & 7)] = p;
   wave_lds_sync();
 
-  const unsigned map_bytes = (unsigned)bev_h * (unsigned)bev_w * (unsigned)row_stride * EV;
-  if (HALFV) {
-    const char* value = reinterpret_cast<const char*>(value_);
-    const int gm = (lane >> 2) & 7, gt = lane >> 5, c8 = lane & 3;       // head, queue entry, 8-channel slice
-    const unsigned bt_bytes = (unsigned)(value_bt_stride * 2);
-    const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(value + (long)b * 2 * value_bt_stride * 2, bt_bytes + map_bytes);
-    const unsigned lane_off = (unsigned)(gm * D + c8 * 8) * 2u + (unsigned)gt * bt_bytes;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    gather_samples_buf_h<P, P>(rs, lane_off, sp + gm * NSp + gt * P, a0, a1);
-    a0.x += __shfl_xor(a0.x, 32); a0.y += __shfl_xor(a0.y, 32); a0.z += __shfl_xor(a0.z, 32); a0.w += __shfl_xor(a0.w, 32);
-    a1.x += __shfl_xor(a1.x, 32); a1.y += __shfl_xor(a1.y, 32); a1.z += __shfl_xor(a1.z, 32); a1.w += __shfl_xor(a1.w, 32);
-    if (gt == 0) {
-      float* dst = out + ((long)b * Nq + q) * row_stride + gm * D + c8 * 8;
-      *reinterpret_cast<float4*>(dst) = make_float4(a0.x * 0.5f, a0.y * 0.5f, a0.z * 0.5f, a0.w * 0.5f);
-      *reinterpret_cast<float4*>(dst + 4) = make_float4(a1.x * 0.5f, a1.y * 0.5f, a1.z * 0.5f, a1.w * 0.5f);
-    }
-  } else {
-    const float* value = reinterpret_cast<const float*>(value_);
-    const int g = lane >> 3, c4 = lane & 7;
-    const __amdgpu_buffer_rsrc_t r0 = uniform_rsrc(value + ((long)b * 2 + 0) * value_bt_stride, map_bytes);
-    const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(value + ((long)b * 2 + 1) * value_bt_stride, map_bytes);
-    const unsigned lane_off = (unsigned)(g * D + c4 * 4) * 4u;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    a0 = gather_samples_buf<4>(r0, lane_off, sp + g * NSp, P, a0);
-    a1 = gather_samples_buf<4>(r1, lane_off, sp + g * NSp + P, P, a1);
-    float4 o4 = make_float4((a0.x + a1.x) * 0.5f, (a0.y + a1.y) * 0.5f, (a0.z + a1.z) * 0.5f,
-                            (a0.w + a1.w) * 0.5f);
-    *reinterpret_cast<float4*>(out + ((long)b * Nq + q) * row_stride + g * D + c4 * 4) = o4;
-  }
+  const int g = lane >> 3, c4 = lane & 7;
+  const unsigned map_bytes = (unsigned)bev_h * (unsigned)bev_w * (unsigned)row_stride * 4u;
+  const __amdgpu_buffer_rsrc_t r0 = uniform_rsrc(value + ((long)b * 2 + 0) * value_bt_stride, map_bytes);
+  const __amdgpu_buffer_rsrc_t r1 = uniform_rsrc(value + ((long)b * 2 + 1) * value_bt_stride, map_bytes);
+  const unsigned lane_off = (unsigned)(g * D + c4 * 4) * 4u;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  a0 = gather_samples_buf<4>(r0, lane_off, sp + g * NSp, P, a0);
+  a1 = gather_samples_buf<4>(r1, lane_off, sp + g * NSp + P, P, a1);
+  float4 o4 = make_float4((a0.x + a1.x) * 0.5f, (a0.y + a1.y) * 0.5f, (a0.z + a1.z) * 0.5f,
+                          (a0.w + a1.w) * 0.5f);
+  *reinterpret_cast<float4*>(out + ((long)b * Nq + q) * row_stride + g * D + c4 * 4) = o4;
 }
 
 }  // namespace occ
 
-static int tsa_dispatch(const void* value, bool halfv, int64_t value_bt_stride,
-                        const float* offs, int64_t offs_stride,
-                        const float* logits, int64_t logits_stride,
-                        const float* ref_2d, const int32_t* order, float* out,
-                        int B, int Nq, int bev_h, int bev_w, int M, int D, int P,
-                        void* stream) {
+extern "C" int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_stride,
+                                         const float* offs, int64_t offs_stride,
+                                         const float* logits, int64_t logits_stride,
+                                         const float* ref_2d, const int32_t* order, float* out,
+                                         int B, int Nq, int bev_h, int bev_w, int M, int D, int P,
+                                         void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(value && offs && logits && ref_2d && out, "tsa_fused_forward: null pointer argument");
   OCC_CHECK_ARG(B > 0 && Nq > 0 && bev_h > 0 && bev_w > 0, "tsa_fused_forward: bad dimension");
@@ -115,38 +89,9 @@ static int tsa_dispatch(const void* value, bool halfv, int64_t value_bt_stride,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long waves = (long)B * Nq;
   const long blocks = (waves + kTsaWaves - 1) / kTsaWaves;
-  if (halfv) {
-    OCC_CHECK_ARG(value_bt_stride * 2 + (int64_t)bev_h * bev_w * M * D * 2 < (int64_t)kOobOffset,
-                  "tsa_fused_forward: queue entries too far apart for one descriptor");
-    hipLaunchKernelGGL(tsa_fused_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, value,
-                       (long)value_bt_stride, offs, (long)offs_stride, logits, (long)logits_stride,
-                       ref_2d, order, out, B, Nq, bev_h, bev_w);
-  } else {
-    hipLaunchKernelGGL(tsa_fused_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, value,
-                       (long)value_bt_stride, offs, (long)offs_stride, logits, (long)logits_stride,
-                       ref_2d, order, out, B, Nq, bev_h, bev_w);
-  }
+  hipLaunchKernelGGL(tsa_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, st, value,
+                     (long)value_bt_stride, offs, (long)offs_stride, logits, (long)logits_stride,
+                     ref_2d, order, out, B, Nq, bev_h, bev_w);
   OCC_CHECK_LAUNCH("tsa_fused_forward");
   return OCC_OK;
-}
-
-extern "C" int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_stride,
-                                         const float* offs, int64_t offs_stride,
-                                         const float* logits, int64_t logits_stride,
-                                         const float* ref_2d, const int32_t* order, float* out,
-                                         int B, int Nq, int bev_h, int bev_w, int M, int D, int P,
-                                         void* stream) {
-  return tsa_dispatch(value, false, value_bt_stride, offs, offs_stride, logits, logits_stride, ref_2d, order, out, B, Nq,
-                      bev_h, bev_w, M, D, P, stream);
-}
-
-// fp16 value maps (value_bt_stride in fp16 elements), as written by occ_linear_bf16x3_f16
-extern "C" int occ_tsa_fused_forward_f16v(const void* value_f16, int64_t value_bt_stride,
-                                          const float* offs, int64_t offs_stride,
-                                          const float* logits, int64_t logits_stride,
-                                          const float* ref_2d, const int32_t* order, float* out,
-                                          int B, int Nq, int bev_h, int bev_w, int M, int D, int P,
-                                          void* stream) {
-  return tsa_dispatch(value_f16, true, value_bt_stride, offs, offs_stride, logits, logits_stride, ref_2d, order, out, B,
-                      Nq, bev_h, bev_w, M, D, P, stream);
 }

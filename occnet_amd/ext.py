@@ -160,7 +160,7 @@ def point_sampling(ref_3d, lidar2img, ego2lidar, pc_range, img_h, img_w):
     return ref_cam, mask.view(torch.bool), vis
 
 
-# Storage type of the projected value maps the fused SCA and TSA gathers read: 'f16' (default for the fused inference path: one
+# Storage type of the projected value maps the fused SCA gather reads: 'f16' (default for the fused inference path: one
 # head row of a pixel = 64 bytes = 4 lanes x 16 bytes, so a wave load fetches 16 rows instead of 8 — csrc/sca_fused.hip)
 # or 'f32' (OCC_SCA_VALUES=f32: the round-1/2 kernel, 8 lanes per 128-byte row).  Sampling arithmetic, attention weights
 # and accumulation are fp32 in both.
@@ -217,15 +217,10 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
 
 def tsa_fused_forward(value, offs, logits, ref_2d, bev_h, bev_w, num_heads, num_points,
                       shared_queue=False, order=None):
-    """Fused TSA gather.  value (float32 or float16): (B*2, Nq, M, D), or (B, Nq, M, D) with shared_queue=True when both
+    """Fused TSA gather.  value: (B*2, Nq, M, D), or (B, Nq, M, D) with shared_queue=True when both
     queue entries are the same projected BEV (no history).  offs (B,Nq,M*2*P*2), logits
     (B,Nq,M*2*P), ref_2d (B*2,Nq,1,2).  -> (B, Nq, M*D)."""
-    half = value.dtype == torch.float16
-    if half:
-        if not (value.is_cuda and value.is_contiguous()):
-            raise OccAmdError("tsa_fused_forward: fp16 value must be a contiguous device tensor")
-    else:
-        _need_cuda_f32("value", value)
+    _need_cuda_f32("value", value)
     _need_cuda_f32("ref_2d", ref_2d)
     _need_cuda_f32("offs", offs, contiguous=False)
     _need_cuda_f32("logits", logits, contiguous=False)
@@ -253,9 +248,8 @@ def tsa_fused_forward(value, offs, logits, ref_2d, bev_h, bev_w, num_heads, num_
         if t.shape[-1] != w or t.stride(-1) != 1 or t.stride(0) != Nq * t.stride(1):
             raise OccAmdError(f"tsa_fused_forward: {n} must be (B,Nq,{w}) with unit inner stride")
     out = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
-    fn = _lib.lib().occ_tsa_fused_forward_f16v if half else _lib.lib().occ_tsa_fused_forward_f32
     with torch.cuda.device(value.device), _timed('tsa_fused_forward'):
-        rc = fn(
+        rc = _lib.lib().occ_tsa_fused_forward_f32(
             ptr(value), i64(stride), ptr(offs), i64(offs.stride(1)), ptr(logits),
             i64(logits.stride(1)), ptr(ref_2d), ptr(order), ptr(out), i32(B), i32(Nq), i32(bev_h),
             i32(bev_w), i32(M), i32(D), i32(P), stream_ptr(value.device))
@@ -507,13 +501,12 @@ def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, o
 
 
 def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, ln=None,
-           precision=None, out_dtype=None):
+           precision=None):
     """out = LayerNorm(residual + act([a | a2 (+ a2_add)] @ weight^T + bias)) on the f32 matrix cores.
 
     a (…, K1); a2 / a2_add (…, K2) optional second K segment (+ addend); weight (N, K1+K2) and bias (N)
     in torch Linear layout; act None | 'relu'; residual (…, N); ln = (gamma, beta, eps) or an
-    nn.LayerNorm; precision 'f32' | 'bf16x3' (None = LINEAR_PRECISION); out_dtype torch.float16: the rows are written
-    as fp16 (bf16x3 kernel only: the value maps of the fp16-row gathers).  -> (…, N) float32 (or float16).  Raises
+    nn.LayerNorm; precision 'f32' | 'bf16x3' (None = LINEAR_PRECISION).  -> (…, N) float32.  Raises
     OccAmdUnsupported for shapes without an MFMA kernel."""
     precision = precision or LINEAR_PRECISION
     if precision not in ("f32", "bf16x3"):
@@ -559,14 +552,10 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
     if not weight.is_contiguous():
         raise OccAmdError("linear: weight must be contiguous")
     wdev = linear_pack_weight_bf16x3(weight) if precision == "bf16x3" and (K1 + K2) % 16 == 0 else weight
-    half_out = out_dtype == torch.float16
-    if half_out and wdev is weight:
-        raise OccAmdUnsupported("linear: fp16 output needs the bf16x3 kernel")
-    out = torch.empty(a.shape[:-1] + (N,), dtype=torch.float16 if half_out else torch.float32, device=a.device)
+    out = torch.empty(a.shape[:-1] + (N,), dtype=torch.float32, device=a.device)
     if _TIMING is not None and (_TIMING_ONLY is None or 'linear' in _TIMING_ONLY):
         _TIMING.setdefault('linear_flops', []).append(2.0 * M * N * (K1 + K2))
-    fn = (_lib.lib().occ_linear_f32 if wdev is weight else
-          _lib.lib().occ_linear_bf16x3_f16 if half_out else _lib.lib().occ_linear_bf16x3_f32)
+    fn = _lib.lib().occ_linear_f32 if wdev is weight else _lib.lib().occ_linear_bf16x3_f32
     with torch.cuda.device(a.device), _timed('linear'):
         rc = fn(ptr(a_), i64(lda1), i32(K1), ptr(a2), ptr(a2_add), i64(lda2), i32(K2), ptr(wdev),
                 ptr(bias), i32(1 if act == 'relu' else 0), ptr(residual), i64(ldres), ptr(g), ptr(b),

@@ -250,8 +250,9 @@ class SpatialCrossAttention(BaseModule):
             else:
                 num_cams, l, bs, _ = value.shape
                 v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
-                half = ext.SCA_VALUES == "f16" and ext.LINEAR_PRECISION == "bf16x3"
-                v = ext.linear(v, da.value_proj.weight, da.value_proj.bias, out_dtype=torch.float16 if half else None)
+                v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
+                if ext.SCA_VALUES == "f16":
+                    v = v.half()
             v = v.view(bs * self.num_cams, l, da.num_heads, -1)
             w, b = da._qcat.get((da.sampling_offsets, da.attention_weights))
             lin = ext.linear(query.contiguous(), w, b)

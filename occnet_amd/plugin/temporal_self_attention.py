@@ -126,9 +126,7 @@ class TemporalSelfAttention(BaseModule):
                                  a2_add=None if query_pos is None else query_pos.contiguous())
             n_off = self.sampling_offsets.out_features
             vsrc = (value_first if shared else value).contiguous()
-            half = ext.SCA_VALUES == "f16" and ext.LINEAR_PRECISION == "bf16x3"       # fp16 value rows (default)
-            v = ext.linear(vsrc, self.value_proj.weight, self.value_proj.bias,
-                           out_dtype=torch.float16 if half else None)
+            v = ext.linear(vsrc, self.value_proj.weight, self.value_proj.bias)
             v = v.view(v.shape[0], num_query, self.num_heads, -1)
             out = ext.tsa_fused_forward(v, lin[..., :n_off], lin[..., n_off:],
                                         reference_points.float().contiguous(), bev_h, bev_w,

@@ -306,36 +306,6 @@ def test_sca_fp16_values_vs_fp32_values(feat_format, monkeypatch):
         assert maxdiff(half[k], exact[k]) > 0.0            # two different kernels really ran
 
 
-@pytest.mark.parametrize("shared", [False, True])
-def test_tsa_fp16_value_kernel_matches_fp32_kernel(shared):
-    """occ_tsa_fused_forward_f16v (4 lanes per fp16 head row, both queue entries through one descriptor) vs the fp32-row
-    kernel on the SAME (fp16-representable) values: fp32 accumulation noise only.  With a history (two value maps) and
-    without (one map aliased by both entries, value_bt_stride = 0); ragged tail, off-map samples."""
-    from occnet_amd import ext
-    B, bev_h, bev_w, M, D, P = 1, 37, 29, 8, 32, 4
-    Nq = bev_h * bev_w
-    gen = torch.Generator().manual_seed(8)
-    value = torch.randn((B if shared else 2 * B), Nq, M, D, generator=gen).half()
-    offs = torch.randn(B, Nq, M * 2 * P * 2, generator=gen) * 3
-    logits = torch.randn(B, Nq, M * 2 * P, generator=gen)
-    ref_2d = torch.rand(B * 2, Nq, 1, 2, generator=gen) * 1.1 - 0.05
-    args = (offs.cuda(), logits.cuda(), ref_2d.cuda(), bev_h, bev_w, M, P)
-    a = ext.tsa_fused_forward(value.cuda(), *args, shared_queue=shared)
-    b = ext.tsa_fused_forward(value.float().cuda(), *args, shared_queue=shared)
-    d = maxdiff(a, b)
-    print(f"TSA fp16-row kernel vs fp32-row kernel (shared={shared}): {d:.3e}")
-    assert a.shape == (B, Nq, M * D) and d < 1e-5
-
-
-def test_linear_fp16_output_is_the_rounded_fp32_output():
-    from occnet_amd import ext
-    gen = torch.Generator().manual_seed(9)
-    x = torch.randn(1500, 256, generator=gen).cuda()
-    w = (torch.randn(256, 256, generator=gen) / 16).cuda()
-    bb = torch.randn(256, generator=gen).cuda()
-    assert torch.equal(ext.linear(x, w, bb, out_dtype=torch.float16), ext.linear(x, w, bb).half())
-
-
 def test_fp16_value_kernels_in_isolation():
     """The two kernels of the fp16-value mode, separately: (a) the gather on fp16 values equals the fp32-value
     gather on the same (rounded) values to fp32 accumulation noise; (b) the fp16-output value projection equals

@@ -733,12 +733,16 @@ def main():
             head = model.pts_bbox_head
             tr = head.transformer
             conv = times.get("conv3d_bn_relu", [])
-            if conv and tr.use_3d and len(conv) % 2 == 0:
+            fused = times.get("conv3d_heads", [])          # second convolution + heads + decode as one launch
+            if conv and tr.use_3d and (fused or len(conv) % 2 == 0):
                 vox = head.bev_h * head.bev_w * tr.pillar_h
                 fl = [2.0 * vox * 27 * tr.middle_dims * tr.out_dim, 2.0 * vox * 27 * tr.out_dim * tr.out_dim]
-                ms = [sum(conv[0::2]) / (len(conv) // 2), sum(conv[1::2]) / (len(conv) // 2)]
-                # bf16x3 (default): 3 bf16 MFMAs per product -> priced against the dense bf16 peak with 3x the
-                # algorithmic flops; f32: v_mfma_f32_32x32x2_f32 against the f32 peak
+                if fused:
+                    ms = [sum(conv) / len(conv), sum(fused) / len(fused)]
+                    fl[1] += 2.0 * vox * (32 * 128 + 128 * 32)          # + the two MLP heads (padded to 32 outputs)
+                else:
+                    ms = [sum(conv[0::2]) / (len(conv) // 2), sum(conv[1::2]) / (len(conv) // 2)]
+
                 def conv_entry(ms_, fl_, cin):   # the kernel follows the packed weight: bf16x3 needs Cin % 16 == 0
                     x3 = ext.CONV3D_PRECISION == "bf16x3" and cin % 16 == 0
                     peak, mult = (2500.0, 3.0) if x3 else (157.3, 1.0)
@@ -747,7 +751,7 @@ def main():
                 out["mfma_kernels"] = {
                     "peak_tflops_f32": 157.3, "peak_tflops_bf16": 2500.0,
                     "conv3d_lifter": conv_entry(ms[0], fl[0], tr.middle_dims),
-                    "conv3d_2": conv_entry(ms[1], fl[1], tr.out_dim),
+                    ("conv3d_2_heads_decode_fused" if fused else "conv3d_2"): conv_entry(ms[1], fl[1], tr.out_dim),
                 }
                 hd = times.get("occ_heads", [])
                 if hd:

@@ -192,6 +192,23 @@ int occ_conv3d_bn_relu_bf16x3_f32(const float* in, const void* w_packed, const f
                                   int64_t out_stride_b, int64_t out_stride_y, int64_t out_stride_x, int relu,
                                   void* stream);
 
+/* Second decoder convolution + BatchNorm(eval) + ReLU + BOTH occupancy heads + the class decode in ONE kernel
+ * (csrc/conv3d_mfma.hip conv3d_heads_x3_kernel; reference transformer_occ.py:304-321, bevformer_occ_head.py:210-212):
+ * the (B, Y, X, Z, 32) activations of the second convolution never reach HBM.  in (B, Y, X, Z, Cin = 32) f32 (layout 0 of
+ * occ_conv3d_bn_relu_*), w_packed = occ_conv3d_pack_weight_bf16x3, scale / shift (32) as there; heads_packed =
+ * occ_conv3d_heads_pack(...) (occ_conv3d_heads_pack_bytes() bytes: the eight head tensors of occ_occ_heads_f32 as bf16
+ * hi/lo MFMA fragments + biases, C = 32, hidden = 64).  Outputs in the reference's (B, X, Y, Z, .) order:
+ * occ_out (.., num_classes), flow_out (.., 2), occ_cls_out (..) int64 or NULL — the same values occ_conv3d_bn_relu_bf16x3_f32
+ * (out (X, Y)-major) followed by occ_occ_heads_decode_f32(exact_f32 = 0) produce.  Z == 16, Cin == 32 only. */
+int64_t occ_conv3d_heads_pack_bytes(void);
+int occ_conv3d_heads_pack(const float* w1_occ, const float* b1_occ, const float* w2_occ, const float* b2_occ,
+                          const float* w1_flow, const float* b1_flow, const float* w2_flow, const float* b2_flow,
+                          void* packed, int C, int hidden, int num_classes, void* stream);
+int occ_conv3d_heads_decode_bf16x3_f32(const float* in, const void* w_packed, const float* scale, const float* shift,
+                                       const void* heads_packed, float* occ_out, float* flow_out,
+                                       int64_t* occ_cls_out, int B, int Z, int Y, int X, int Cin, int num_classes,
+                                       void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Occupancy heads on every voxel feature row:
  *   occ  = Linear(hidden, num_classes)( Softplus( Linear(C, hidden)(feat) ) )     (predicter)

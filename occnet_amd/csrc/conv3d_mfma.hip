@@ -51,7 +51,15 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
   constexpr int VS = G::VS, PS = G::PS, HX = G::HX, HY = G::HY, NACC = G::NACC, H2 = CH / 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
+  // XCD-aware tile order: hardware block b runs on XCD b % 8, each with a private L2.  Dealt linearly, the eight tiles
+  // of a row segment land on eight different L2s and every XCD fetches its own copy of the shared halos (PMC, round 2:
+  // 306 MB read for an 82 MB input).  Here XCD x walks the contiguous tile range [x*q + min(x, r), ...) — neighbours in
+  // space are neighbours in time on ONE L2 (bijective for any grid size: q = n / 8, r = n % 8).
+  int bid;
+  {
+    const int n = (int)gridDim.x, q = n >> 3, r = n & 7, x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    bid = x * q + (x < r ? x : r) + j;
+  }
   const int tx_i = bid % tiles_x;
   bid /= tiles_x;
   const int ty_i = bid % tiles_y;
@@ -237,7 +245,15 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(
   constexpr int VSB = G::VS * 4, PSB = G::PS * 4, HX = G::HX, HY = G::HY, NACC = G::NACC;   // bytes
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;
+  // XCD-aware tile order: hardware block b runs on XCD b % 8, each with a private L2.  Dealt linearly, the eight tiles
+  // of a row segment land on eight different L2s and every XCD fetches its own copy of the shared halos (PMC, round 2:
+  // 306 MB read for an 82 MB input).  Here XCD x walks the contiguous tile range [x*q + min(x, r), ...) — neighbours in
+  // space are neighbours in time on ONE L2 (bijective for any grid size: q = n / 8, r = n % 8).
+  int bid;
+  {
+    const int n = (int)gridDim.x, q = n >> 3, r = n & 7, x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    bid = x * q + (x < r ? x : r) + j;
+  }
   const int tx_i = bid % tiles_x;
   bid /= tiles_x;
   const int ty_i = bid % tiles_y;
@@ -442,6 +458,274 @@ static int launch_conv(const float* in, const float* wp, const float* scale, con
   return OCC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Second decoder convolution + BatchNorm + ReLU + BOTH occupancy heads + the class decode in ONE kernel (SURVEY.md §7
+// step 5: "heads fused on the same tile so the 640 000 x 32 activations never round-trip HBM"; reference
+// transformer_occ.py:304-321 + bevformer_occ_head.py:210-212).  The convolution is conv3d_bf16x3_kernel<Z, TY, TX, 0>
+// with the MFMA operands swapped — D = W . A^T, so a lane holds 16 output channels of ONE voxel: after scale / shift /
+// ReLU its registers 0-7 and 8-15, split into hi / lo bf16, ARE the two k-steps of the heads' first contraction
+// (k-slot j of lane half g = channel 16 s + 8 (j / 4) + 4 g + j % 4, the order the W1cat fragments are packed in) — no
+// LDS transpose, no HBM round trip.  The heads' fragments (32 KB, packed once by conv3d_heads_pack_kernel) replace the
+// halo in LDS once the taps are done; the rest is occ_heads_x3_kernel's body (csrc/occ_heads.hip) per 32-voxel tile.
+constexpr int kHeadsPackBytes = 16 * 1024 + 16 * 1024 + 128 * 4 + 32 * 4;
+
+__device__ __forceinline__ float cvh_softplus(float x) {        // torch.nn.Softplus(beta=1, threshold=20)
+  return x > 20.f ? x : fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x)));
+}
+__device__ __forceinline__ void cvh_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2_rne(x0, x1);
+  lo = pack_bf16x2_rne(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
+// [W1cat fragments [(a*2 + s)*2 + plane][lane][8] | W2cat fragments [(kk*2 + plane)][lane][8] | b1 (128 f32) | b2 (32 f32)]
+__global__ void conv3d_heads_pack_kernel(const float* __restrict__ w1o, const float* __restrict__ b1o,
+                                         const float* __restrict__ w2o, const float* __restrict__ b2o,
+                                         const float* __restrict__ w1f, const float* __restrict__ b1f,
+                                         const float* __restrict__ w2f, const float* __restrict__ b2f,
+                                         unsigned short* __restrict__ packed, int ncls) {
+  constexpr int C = 32, HID = 64;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < 4096) {
+    const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
+    const int m = l & 31, gg = l >> 5;
+    {   // W1cat: f = a*2 + s; k-slot (s, gg, j) stands for channel 16 s + 8 (j / 4) + 4 gg + j % 4 (the D-register order)
+      const int a = f >> 1, sk = f & 1, u = 32 * a + m, k = 16 * sk + 8 * (j >> 2) + 4 * gg + (j & 3);
+      const float w = u < HID ? w1o[u * C + k] : w1f[(u - HID) * C + k];
+      const unsigned short hi = bf16_rne(w), lo = bf16_rne(w - __uint_as_float((unsigned)hi << 16));
+      packed[((f * 2 + 0) * 64 + l) * 8 + j] = hi;
+      packed[((f * 2 + 1) * 64 + l) * 8 + j] = lo;
+    }
+    {   // W2cat: f = kk = 2a + ks; output row m, hidden unit u (occ_heads_x3_kernel's layout)
+      const int a = f >> 1, ks = f & 1, u = 32 * a + 16 * ks + 8 * (j >> 2) + 4 * gg + (j & 3);
+      float w = 0.f;
+      if (m < ncls) { if (u < HID) w = w2o[m * HID + u]; }
+      else if (m < ncls + 2) { if (u >= HID) w = w2f[(m - ncls) * HID + (u - HID)]; }
+      const unsigned short hi = bf16_rne(w), lo = bf16_rne(w - __uint_as_float((unsigned)hi << 16));
+      packed[8192 + ((f * 2 + 0) * 64 + l) * 8 + j] = hi;
+      packed[8192 + ((f * 2 + 1) * 64 + l) * 8 + j] = lo;
+    }
+  }
+  float* bp = reinterpret_cast<float*>(packed + 16384);
+  if (e < 128) bp[e] = e < HID ? b1o[e] : b1f[e - HID];
+  if (e < 32) bp[128 + e] = e < ncls ? b2o[e] : (e < ncls + 2 ? b2f[e - ncls] : 0.f);
+}
+
+template <int Z, int TY, int TX>
+__global__ __launch_bounds__(256) void conv3d_heads_x3_kernel(
+    const float* __restrict__ in, const uint4* __restrict__ wp, const float* __restrict__ scale,
+    const float* __restrict__ shift, const uint4* __restrict__ heads_pack, float* __restrict__ occ,
+    float* __restrict__ flow, long long* __restrict__ occ_cls, int Y, int X, int ncls, int tiles_x, int tiles_y) {
+  constexpr int CH = 16, Cin = 32;
+  using G = ConvGeom<Z, CH, TY, TX>;
+  constexpr int VSB = G::VS * 4, PSB = G::PS * 4, HX = G::HX, HY = G::HY, NACC = G::NACC;   // bytes
+  static_assert(G::LDS_FLOATS * 4 >= kHeadsPackBytes + 4 * 32 * 33 * 4, "the heads' fragments + transposes overlay the halo");
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid;                                    // XCD-aware tile order (see conv3d_bf16x3_kernel)
+  {
+    const int n = (int)gridDim.x, q = n >> 3, r = n & 7, x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    bid = x * q + (x < r ? x : r) + j;
+  }
+  const int tx_i = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty_i = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty_i * TY, x0 = tx_i * TX;
+  const float* inb = in + (long)b * Y * X * Z * Cin;
+
+  for (int i = tid; i < HY * HX * 2 * (VSB / 16); i += 256) {          // z-halo slots stay zero
+    const int pil = i / (2 * (VSB / 16)), rem = i % (2 * (VSB / 16));
+    const int part = rem % (VSB / 16);
+    *reinterpret_cast<uint4*>(ldsb + pil * PSB + (rem >= VSB / 16 ? (Z + 1) * VSB : 0) + part * 16) =
+        make_uint4(0u, 0u, 0u, 0u);
+  }
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  const int vi = lane & 31, kh = lane >> 5;
+  int abase[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int rt = wave * NACC + a;
+    const int ty = rt / G::TXG, txg = rt % G::TXG;
+    const int px = txg * G::PX + vi / Z, z = vi % Z;
+    abase[a] = (ty * HX + px) * PSB + z * VSB + kh * 16;
+  }
+  for (int p = 0; p < Cin / CH; ++p) {
+    if (p) __syncthreads();
+    {
+      constexpr int PARTS = CH / 4, ITEMS = HY * HX * Z * PARTS, ITERS = (ITEMS + 255) / 256;
+      float4 v[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int part = idx % PARTS, z = (idx / PARTS) % Z, pil = idx / (PARTS * Z);
+        const int gy = y0 + pil / HX - 1, gx = x0 + pil % HX - 1;
+        v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < ITEMS && gy >= 0 && gy < Y && gx >= 0 && gx < X)
+          v[it] = *reinterpret_cast<const float4*>(inb + (((long)gy * X + gx) * Z + z) * Cin + p * CH + part * 4);
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * 256;
+        const int part = idx % PARTS, z = (idx / PARTS) % Z, pil = idx / (PARTS * Z);
+        if (idx < ITEMS) {
+          unsigned h01, h23, l01, l23;
+          cvh_split2(v[it].x, v[it].y, h01, l01);
+          cvh_split2(v[it].z, v[it].w, h23, l23);
+          char* d = ldsb + pil * PSB + (z + 1) * VSB + part * 8;
+          *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(d + 32) = make_uint2(l01, l23);
+        }
+      }
+    }
+    __syncthreads();
+    const uint4* wq = wp + ((long)p * 27 * 2 * 2 + kh) * 32 + vi;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+      const int toff = (ky * HX + kx) * PSB + kz * VSB;
+      const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[(t * 2 + 0) * 64]);
+      const bf16x8 wl = __builtin_bit_cast(bf16x8, wq[(t * 2 + 1) * 64]);
+      bf16x8 ah[NACC], al[NACC];
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) {
+        ah[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff);
+        al[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff + 32);
+      }
+      // TRANSPOSED: weights are the row operand -> D[output channel][voxel]
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al[a], acc[a], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah[a], acc[a], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah[a], acc[a], 0, 0, 0);
+    }
+  }
+
+  // ---- the heads' operands replace the halo -------------------------------------------------------------------------
+  __syncthreads();
+  for (int i = tid; i < kHeadsPackBytes / 16; i += 256) reinterpret_cast<uint4*>(ldsb)[i] = heads_pack[i];
+  __syncthreads();
+  const bf16x8* W1 = reinterpret_cast<const bf16x8*>(ldsb) + lane;
+  const bf16x8* W2 = reinterpret_cast<const bf16x8*>(ldsb + 16384) + lane;
+  const float* b1s = reinterpret_cast<const float*>(ldsb + 32768);
+  const float* b2s = b1s + 128;
+  float* sm = reinterpret_cast<float*>(ldsb + kHeadsPackBytes) + wave * (32 * 33);
+  // BatchNorm (eval) scale / shift of this lane's 16 output channels: (r & 3) + 8 (r >> 2) + 4 kh
+  float4 scv[4], shv[4];
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    scv[q4] = *reinterpret_cast<const float4*>(scale + 8 * q4 + 4 * kh);
+    shv[q4] = *reinterpret_cast<const float4*>(shift + 8 * q4 + 4 * kh);
+  }
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    // conv tile a of this wave: 32 voxels = PX pillars x Z heights; lane's voxel vi
+    uint4 xh[2], xl[2];
+    {
+      float f[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        f[4 * q4 + 0] = fmaxf(fmaf(acc[a][4 * q4 + 0], scv[q4].x, shv[q4].x), 0.f);
+        f[4 * q4 + 1] = fmaxf(fmaf(acc[a][4 * q4 + 1], scv[q4].y, shv[q4].y), 0.f);
+        f[4 * q4 + 2] = fmaxf(fmaf(acc[a][4 * q4 + 2], scv[q4].z, shv[q4].z), 0.f);
+        f[4 * q4 + 3] = fmaxf(fmaf(acc[a][4 * q4 + 3], scv[q4].w, shv[q4].w), 0.f);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        cvh_split2(f[8 * s2 + 0], f[8 * s2 + 1], xh[s2].x, xl[s2].x); cvh_split2(f[8 * s2 + 2], f[8 * s2 + 3], xh[s2].y, xl[s2].y);
+        cvh_split2(f[8 * s2 + 4], f[8 * s2 + 5], xh[s2].z, xl[s2].z); cvh_split2(f[8 * s2 + 6], f[8 * s2 + 7], xh[s2].w, xl[s2].w);
+      }
+    }
+    f32x16 h[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[t][r] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8 bxh = __builtin_bit_cast(bf16x8, xh[s2]), bxl = __builtin_bit_cast(bf16x8, xl[s2]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[((t * 2 + s2) * 2 + 1) * 64], bxh, h[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[((t * 2 + s2) * 2 + 0) * 64], bxl, h[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) h[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[((t * 2 + s2) * 2 + 0) * 64], bxh, h[t], 0, 0, 0);
+    }
+    f32x16 o0, o1, o2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = o2[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 bb = *reinterpret_cast<const float4*>(b1s + 32 * t + 8 * q4 + 4 * kh);
+        const float t0 = h[t][4 * q4 + 0] + bb.x, t1 = h[t][4 * q4 + 1] + bb.y;
+        const float t2 = h[t][4 * q4 + 2] + bb.z, t3 = h[t][4 * q4 + 3] + bb.w;
+        if (t < 2) {
+          v[4 * q4 + 0] = cvh_softplus(t0); v[4 * q4 + 1] = cvh_softplus(t1);
+          v[4 * q4 + 2] = cvh_softplus(t2); v[4 * q4 + 3] = cvh_softplus(t3);
+        } else {
+          v[4 * q4 + 0] = fmaxf(t0, 0.f); v[4 * q4 + 1] = fmaxf(t1, 0.f);
+          v[4 * q4 + 2] = fmaxf(t2, 0.f); v[4 * q4 + 3] = fmaxf(t3, 0.f);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 hh, hl;
+        cvh_split2(v[8 * ks + 0], v[8 * ks + 1], hh.x, hl.x); cvh_split2(v[8 * ks + 2], v[8 * ks + 3], hh.y, hl.y);
+        cvh_split2(v[8 * ks + 4], v[8 * ks + 5], hh.z, hl.z); cvh_split2(v[8 * ks + 6], v[8 * ks + 7], hh.w, hl.w);
+        const int kk = 2 * t + ks;
+        const bf16x8 wh = W2[(kk * 2 + 0) * 64], wl = W2[(kk * 2 + 1) * 64];
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, __builtin_bit_cast(bf16x8, hh), o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, __builtin_bit_cast(bf16x8, hl), o1, 0, 0, 0);
+        o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, __builtin_bit_cast(bf16x8, hh), o2, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 bb = *reinterpret_cast<const float4*>(b2s + 8 * q4 + 4 * kh);
+      const float bq[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * q4 + i;
+        sm[vi * 33 + 8 * q4 + 4 * kh + i] = ((o0[r] + o1[r]) + o2[r]) + bq[i];
+      }
+    }
+    wave_lds_sync();
+    // output rows: voxel v of the tile = pillar (gy, gx0 + v / Z), height v % Z; outputs are (B, X, Y, Z, .)
+    const int rt = wave * NACC + a;
+    const int gy = y0 + rt / G::TXG, gx0 = x0 + (rt % G::TXG) * G::PX;
+    if (gy < Y) {
+      for (int e = lane; e < 32 * ncls; e += 64) {
+        const int v = e / ncls, ch = e - v * ncls, gx = gx0 + v / Z;
+        if (gx < X) occ[((((long)b * X + gx) * Y + gy) * Z + v % Z) * ncls + ch] = sm[v * 33 + ch];
+      }
+      {
+        const int v = lane >> 1, gx = gx0 + v / Z;
+        if (gx < X) flow[((((long)b * X + gx) * Y + gy) * Z + v % Z) * 2 + (lane & 1)] = sm[v * 33 + ncls + (lane & 1)];
+      }
+      if (occ_cls != nullptr && lane < 32) {      // decode: argmax of the logits, first index on ties, 0 for a NaN row
+        const int gx = gx0 + lane / Z;
+        float best = sm[lane * 33];
+        int arg = 0;
+        bool nan = best != best;
+        for (int ch = 1; ch < ncls; ++ch) {
+          const float x = sm[lane * 33 + ch];
+          nan |= x != x;
+          if (x > best) { best = x; arg = ch; }
+        }
+        if (gx < X) occ_cls[(((long)b * X + gx) * Y + gy) * Z + lane % Z] = nan ? 0 : arg;
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
 }  // namespace occ
 
 extern "C" int occ_conv3d_channel_block(int Cin) { return Cin % 16 == 0 ? 16 : (Cin % 8 == 0 ? 8 : 0); }
@@ -544,4 +828,55 @@ extern "C" int occ_conv3d_bn_relu_bf16x3_f32(const float* in, const void* w_pack
   OCC_CONV_CASE(4, 2, 16)
 #undef OCC_CONV_CASE
   return OCC_E_UNSUPPORTED;
+}
+
+extern "C" int occ_conv3d_heads_pack(const float* w1_occ, const float* b1_occ, const float* w2_occ, const float* b2_occ,
+                                     const float* w1_flow, const float* b1_flow, const float* w2_flow,
+                                     const float* b2_flow, void* packed, int C, int hidden, int num_classes,
+                                     void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(w1_occ && b1_occ && w2_occ && b2_occ && w1_flow && b1_flow && w2_flow && b2_flow && packed,
+                "conv3d_heads_pack: null pointer argument");
+  if (C != 32 || hidden != 64 || num_classes <= 0 || num_classes + 2 > 32) {
+    set_error("conv3d_heads_pack: no fused kernel for C=%d hidden=%d num_classes=%d", C, hidden, num_classes);
+    return OCC_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(conv3d_heads_pack_kernel, dim3(16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w1_occ,
+                     b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow,
+                     reinterpret_cast<unsigned short*>(packed), num_classes);
+  OCC_CHECK_LAUNCH("conv3d_heads_pack");
+  return OCC_OK;
+}
+
+extern "C" int64_t occ_conv3d_heads_pack_bytes(void) { return occ::kHeadsPackBytes; }
+
+extern "C" int occ_conv3d_heads_decode_bf16x3_f32(const float* in, const void* w_packed, const float* scale,
+                                                  const float* shift, const void* heads_packed, float* occ_out,
+                                                  float* flow_out, int64_t* occ_cls_out, int B, int Z, int Y, int X,
+                                                  int Cin, int num_classes, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(in && w_packed && scale && shift && heads_packed && occ_out && flow_out,
+                "conv3d_heads_decode: null pointer argument");
+  OCC_CHECK_ARG(B > 0 && Y > 0 && X > 0 && num_classes > 0, "conv3d_heads_decode: bad dimension");
+  OCC_CHECK_ARG((long)Y * X * Z * 32 < (1L << 31), "conv3d_heads_decode: one batch entry exceeds 2^31 elements");
+  if (Z != 16 || Cin != 32 || num_classes + 2 > 32) {
+    set_error("conv3d_heads_decode: no fused kernel for Z=%d Cin=%d num_classes=%d", Z, Cin, num_classes);
+    return OCC_E_UNSUPPORTED;
+  }
+  constexpr int TY = 2, TX = 8;
+  using G = ConvGeom<16, 16, TY, TX>;
+  const int tiles_x = (X + TX - 1) / TX, tiles_y = (Y + TY - 1) / TY;
+  const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+  auto k = conv3d_heads_x3_kernel<16, TY, TX>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) {
+    set_error("conv3d_heads_decode: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return OCC_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                     in, reinterpret_cast<const uint4*>(w_packed), scale, shift,
+                     reinterpret_cast<const uint4*>(heads_packed), occ_out, flow_out,
+                     reinterpret_cast<long long*>(occ_cls_out), Y, X, num_classes, tiles_x, tiles_y);
+  OCC_CHECK_LAUNCH("conv3d_heads_decode");
+  return OCC_OK;
 }

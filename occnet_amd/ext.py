@@ -320,6 +320,51 @@ def conv3d_bn_relu(x, w_packed, scale, shift, Z, Y, X, cin, cout, in_layout, out
     return out
 
 
+def conv3d_heads_pack(w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow):
+    """The eight head tensors (C = 32, hidden = 64) -> the operand buffer of conv3d_heads_decode (bf16 hi/lo MFMA
+    fragments + biases; uint8 tensor)."""
+    ts = (w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow, b2_flow)
+    for n, t in zip(("w1_occ", "b1_occ", "w2_occ", "b2_occ", "w1_flow", "b1_flow", "w2_flow", "b2_flow"), ts):
+        _need_cuda_f32(n, t)
+    hidden, C = w1_occ.shape
+    ncls = w2_occ.shape[0]
+    if (tuple(w1_flow.shape) != (hidden, C) or tuple(w2_occ.shape) != (ncls, hidden) or tuple(w2_flow.shape) != (2, hidden)
+            or b1_occ.numel() != hidden or b1_flow.numel() != hidden or b2_occ.numel() != ncls or b2_flow.numel() != 2):
+        raise OccAmdError("conv3d_heads_pack: inconsistent weight shapes")
+    lib = _lib.lib()
+    lib.occ_conv3d_heads_pack_bytes.restype = ctypes.c_int64
+    packed = torch.empty(int(lib.occ_conv3d_heads_pack_bytes()), dtype=torch.uint8, device=w1_occ.device)
+    with torch.cuda.device(w1_occ.device):
+        rc = lib.occ_conv3d_heads_pack(*[ptr(t) for t in ts], ptr(packed), i32(C), i32(hidden), i32(ncls),
+                                       stream_ptr(w1_occ.device))
+    _lib.check(rc, "conv3d_heads_pack")
+    return packed
+
+
+def conv3d_heads_decode(x, w_packed, scale, shift, heads_packed, Z, Y, X, num_classes):
+    """Second decoder convolution + BN(eval) + ReLU + both occupancy heads + argmax decode in one launch: x
+    (B, Y, X, Z, 32) fp32 -> occ (B, X, Y, Z, num_classes), flow (B, X, Y, Z, 2), occ_cls (B, X, Y, Z) int64 — what
+    conv3d_bn_relu(out_xy_major=True) + occ_heads(decode=True) produce, without the 82 MB round trip of the
+    convolution's output.  w_packed: conv3d_pack_weight (bf16x3); heads_packed: conv3d_heads_pack."""
+    for n, t in (("x", x), ("scale", scale), ("shift", shift)):
+        _need_cuda_f32(n, t)
+    if w_packed.dtype != torch.int16:
+        raise OccAmdUnsupported("conv3d_heads_decode: needs the bf16x3 packed weight")
+    B = x.shape[0]
+    cin = x.numel() // (B * Y * X * Z)
+    if x.numel() != B * Y * X * Z * cin or w_packed.numel() != 32 * cin * 27 * 2:
+        raise OccAmdError("conv3d_heads_decode: inconsistent shapes")
+    occ = torch.empty((B, X, Y, Z, num_classes), dtype=torch.float32, device=x.device)
+    flow = torch.empty((B, X, Y, Z, 2), dtype=torch.float32, device=x.device)
+    cls = torch.empty((B, X, Y, Z), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device), _timed('conv3d_heads'):
+        rc = _lib.lib().occ_conv3d_heads_decode_bf16x3_f32(
+            ptr(x), ptr(w_packed), ptr(scale), ptr(shift), ptr(heads_packed), ptr(occ), ptr(flow), ptr(cls), i32(B),
+            i32(Z), i32(Y), i32(X), i32(cin), i32(num_classes), stream_ptr(x.device))
+    _lib.check(rc, "conv3d_heads_decode")
+    return occ, flow, cls
+
+
 HEADS_PRECISION = os.environ.get("OCC_HEADS_PRECISION", "bf16x3")    # 'bf16x3' (default) or 'f32'
 
 

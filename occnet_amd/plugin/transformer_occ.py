@@ -10,6 +10,8 @@ Data layout: the flattened multi-camera key/value tensor is produced directly as
 256 channels contiguous — and handed to the encoder as a permuted VIEW in the reference's
 (num_cams, sum HW, bs, C) axis order, so SpatialCrossAttention's permute+reshape back is free.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -276,6 +278,7 @@ class TransformerOcc(BaseModule):
         self.init_layers()
         self.rotate_center = rotate_center
         self.use_fused_decoder = True     # flip to force the stock torch (MIOpen) decoder
+        self.fuse_heads = os.environ.get("OCC_DECODER_FUSE_HEADS", "1") == "1"   # conv3d_2 + heads + decode in one launch
         self.use_lazy_features = True     # bf16 NHWC maps go straight into the SCA value projection
         # autograd path only: dtype the MIOpen Conv3d decoder runs in under torch.autocast (None = fp32 as the
         # reference).  MIOpen's fp32 Conv3d backward costs 196 ms per step at 200x200x16, bf16 7 ms.
@@ -388,6 +391,15 @@ class TransformerOcc(BaseModule):
             self._dec_key, self._dec_pack = key, pack
         return self._dec_pack
 
+    def _heads_pack(self):
+        p, f = self.predicter, self.flow_predicter
+        ts = (p[0].weight, p[0].bias, p[2].weight, p[2].bias, f[0].weight, f[0].bias, f[2].weight, f[2].bias)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (cache_epoch(),)
+        if key != getattr(self, '_hp_key', None):
+            with torch.no_grad():
+                self._hp_key, self._hp_val = key, ext.conv3d_heads_pack(*[t.detach().float().contiguous() for t in ts])
+        return self._hp_val
+
     def _fused_decoder_ok(self, bev):
         if not (self.use_fused_decoder and self.use_3d and bev.is_cuda and bev.dtype == torch.float32):
             return False
@@ -416,9 +428,19 @@ class TransformerOcc(BaseModule):
         Z = self.pillar_h
         x = ext.conv3d_bn_relu(bev, w1, s1, t1, Z, bev_h, bev_w, self.middle_dims, self.out_dim,
                                in_layout=1)
+        p, f = self.predicter, self.flow_predicter
+        if (self.fuse_heads and Z == 16 and self.out_dim == 32 and w2.dtype == torch.int16
+                and ext.HEADS_PRECISION == "bf16x3" and p[0].weight.shape == (64, 32)):
+            # second convolution + heads + decode in ONE launch: its 82 MB of activations stay on chip
+            try:
+                occ, flow, cls = ext.conv3d_heads_decode(x, w2, s2, t2, self._heads_pack(), Z, bev_h, bev_w,
+                                                         p[2].weight.shape[0])
+                occ._occ_cls = cls
+                return occ, flow
+            except OccAmdUnsupported:
+                pass
         x = ext.conv3d_bn_relu(x, w2, s2, t2, Z, bev_h, bev_w, self.out_dim, self.out_dim,
                                in_layout=0, out_xy_major=True)
-        p, f = self.predicter, self.flow_predicter
         occ, flow, cls = ext.occ_heads(x, p[0].weight, p[0].bias, p[2].weight, p[2].bias,
                                        f[0].weight, f[0].bias, f[2].weight, f[2].bias, decode=True)
         # the decoded classes ride on the logits tensor OBJECT (BEVFormerOccHead.get_occ picks them up): the

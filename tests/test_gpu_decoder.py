@@ -137,3 +137,43 @@ def test_unsupported_shapes_raise_unsupported():
         ext.occ_heads(torch.randn(8, 16).cuda(), torch.randn(64, 16).cuda(), torch.randn(64).cuda(),
                       torch.randn(17, 64).cuda(), torch.randn(17).cuda(), torch.randn(64, 16).cuda(),
                       torch.randn(64).cuda(), torch.randn(2, 64).cuda(), torch.randn(2).cuda())
+
+
+@pytest.mark.parametrize("B,Y,X", [(1, 9, 21), (2, 7, 10), (1, 1, 1), (1, 16, 40)])
+def test_fused_conv_heads_decode_equals_two_launches(B, Y, X):
+    """occ_conv3d_heads_decode_bf16x3_f32 (second convolution + BN + ReLU + both heads + decode in one kernel; the
+    convolution's output never reaches HBM) vs the two launches it replaces — conv3d_bn_relu(out_xy_major) then
+    occ_heads(decode=True) — and vs the float64 oracle chain.  The fused kernel contracts the heads' first layer in a
+    permuted k order, so logits agree to fp32 summation noise; the decoded classes must be the argmax of ITS logits
+    bit for bit (first index on ties).  Ragged tiles (Y, X not multiples of the 2 x 8 block tile), batch 2."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(61)
+    Z, C, ncls = 16, 32, 17
+    x = torch.randn(B, Y, X, Z, C, generator=g)
+    w = torch.randn(C, C, 3, 3, 3, generator=g) * (2.0 / (C * 27)) ** 0.5
+    bn = _bn(C, g)
+    scale, shift = _fold(bn)
+    hw = dict(w1o=torch.randn(64, C, generator=g) / C ** 0.5, b1o=torch.randn(64, generator=g) * 0.1,
+              w2o=torch.randn(ncls, 64, generator=g) / 8, b2o=torch.randn(ncls, generator=g) * 0.1,
+              w1f=torch.randn(64, C, generator=g) / C ** 0.5, b1f=torch.randn(64, generator=g) * 0.1,
+              w2f=torch.randn(2, 64, generator=g) / 8, b2f=torch.randn(2, generator=g) * 0.1)
+    hc = [hw[k].cuda() for k in ("w1o", "b1o", "w2o", "b2o", "w1f", "b1f", "w2f", "b2f")]
+    wp = ext.conv3d_pack_weight(w.cuda(), precision="bf16x3")
+    pack = ext.conv3d_heads_pack(*hc)
+    occ, flow, cls = ext.conv3d_heads_decode(x.cuda(), wp, scale.cuda(), shift.cuda(), pack, Z, Y, X, ncls)
+    feat = ext.conv3d_bn_relu(x.cuda(), wp, scale.cuda(), shift.cuda(), Z, Y, X, C, C, in_layout=0, out_xy_major=True)
+    occ2, flow2, cls2 = ext.occ_heads(feat, *hc, decode=True, precision="bf16x3")
+    torch.cuda.synchronize()
+    assert occ.shape == (B, X, Y, Z, ncls) and flow.shape == (B, X, Y, Z, 2) and cls.shape == (B, X, Y, Z)
+    d_occ, d_flow = float((occ - occ2).abs().max()), float((flow - flow2).abs().max())
+    print(f"fused vs two launches ({B},{Y},{X}): occ {d_occ:.3e} flow {d_flow:.3e}")
+    assert d_occ < 2e-5 and d_flow < 2e-5
+    assert torch.equal(cls, occ.softmax(-1).argmax(-1))                      # decode == argmax of its own logits
+    # float64 oracle: conv + BN + ReLU, permute to (B, X, Y, Z, C), the two MLPs
+    ref = odec.conv3d_bn_relu(x.permute(0, 4, 3, 1, 2).double(), w.double(), *[t.double() for t in bn])
+    f64 = ref.permute(0, 4, 3, 2, 1)
+    o_ref = torch.nn.functional.linear(torch.nn.functional.softplus(torch.nn.functional.linear(f64, hw["w1o"].double(), hw["b1o"].double())), hw["w2o"].double(), hw["b2o"].double())
+    f_ref = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(f64, hw["w1f"].double(), hw["b1f"].double())), hw["w2f"].double(), hw["b2f"].double())
+    d1, d2 = float((occ.cpu().double() - o_ref).abs().max()), float((flow.cpu().double() - f_ref).abs().max())
+    print(f"fused vs oracle(f64): occ {d1:.3e} flow {d2:.3e}")
+    assert d1 < 2e-4 and d2 < 2e-4

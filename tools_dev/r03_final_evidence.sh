@@ -15,7 +15,7 @@ timeout 600 python bench.py --mode train --steps 6 --warmup 3 --no-cpu-baseline 
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_e2e -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing > $GRAFT_REPO_ROOT/gpurun_out/${T}_trace.log 2>&1)
 DB=$(find /tmp/prof_e2e -name "*.db" | head -1)
 python tools_dev/rocpd_summary.py $DB 60 --last-ms 60 > gpurun_out/${T}_e2e_kernel_trace_stats.txt 2>&1; head -24 gpurun_out/${T}_e2e_kernel_trace_stats.txt | cut -c1-150
-KR="sca_fused|tsa_fused|conv3d_mfma|conv3d_bf16x3|occ_heads|linear_bf16x3|linear_mfma|value_proj|point_sampling"
+KR="sca_fused|tsa_fused|conv3d_mfma|conv3d_bf16x3|conv3d_heads|occ_heads|linear_bf16x3|linear_mfma|value_proj|point_sampling"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TA_TA_BUSY_sum TA_BUSY_avr" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVES"; do
   i=$((i+1))

@@ -23,6 +23,7 @@
 // are what separates it from the 39 us of a plain bf16 -> fp32 widening copy of the same tensors; 128-row blocks
 // halve the former (102 us).  Pinning the prefetch with sched_barrier and an 8-chunk activation prefetch were
 // measured: no gain.
+#include <cstdlib>
 #include <hip/hip_fp16.h>
 #include "common.h"
 
@@ -195,6 +196,181 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
   }
 }
 
+
+// ---- activation-resident variant (K = 256, N % 256 == 0: the stacked SCA value projections) --------------------------
+// The tiled kernel above meets a block barrier every 32 k with two waves per SIMD: its weight loads, activation loads,
+// MFMAs and stores each cost 20-40 % of the launch when removed alone (ablation in the header) — they add up instead of
+// overlapping.  Here a block owns 128 rows for ALL N columns:
+//   * its 128 x 256 bf16 activation tile (64 KB) goes global -> LDS once, by LDS-DMA (no registers), 16-byte pieces
+//     XOR-swizzled by row so the MFMA A-fragment reads (ds_read_b128, row pitch 512 B) are bank-conflict-free;
+//   * after that ONE barrier the four waves never synchronise again: wave w walks the column passes (256 columns per
+//     pass, the wave's 64 of them as two 32-column tiles x four 32-row tiles = 8 accumulators), streaming its hi/lo
+//     weight fragments from L2 through a 4-deep register ring that runs ahead across k-steps AND across passes, so the
+//     epilogue of pass p (bias, fp16 rounding, 16 rows at a time through a 2 KB per-wave LDS scratch, 128-byte row
+//     segments stored) runs under the weight loads of pass p + 1 and under the other waves' MFMAs;
+//   * the feature rows are read from HBM exactly once per launch, whatever the number of stacked projections.
+constexpr int kVprRows = 128, kVprK = 256, kVprScratch = 2048;
+constexpr int kVprTileBytes = kVprRows * kVprK * 2;
+constexpr int kVprLdsBytes = kVprTileBytes + 4 * kVprScratch;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <bool OUTH>
+__global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
+    VpSegments seg, const uint4* __restrict__ wp, int bias_groups, void* __restrict__ out_, long ldo, int N,
+    long out_group_rows, int plane_cols, long plane_stride) {
+  extern __shared__ __attribute__((aligned(16))) char vlds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vi = lane & 31, kb = lane >> 5;
+  const int rb = (int)blockIdx.x;
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < kVpMaxSeg; ++i)
+    if (i < seg.n && rb >= seg.first_block[i]) si = i;
+  const uint4* __restrict__ a = seg.a[si];
+  const float* __restrict__ gbias = seg.gbias[si];
+  // row counts fit an int (the launcher checks): 32-bit index arithmetic keeps the scalar unit's divisions short
+  const int M = (int)seg.rows[si], rpg = (int)seg.rows_per_group[si];
+  const long out_row0 = seg.out_row0[si], lda8 = seg.lda8[si];
+  const int m0 = (rb - seg.first_block[si]) * kVprRows;
+  const int NT32 = N / 32, NP = N / 256;
+
+  // activation tile: DMA instruction j of wave w fills tile rows 2 (16 w + j) and + 1 (lanes 0-31 / 32-63); LDS slot s
+  // of row r holds the row's 16-byte piece s ^ (r & 31)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int r = (wave * 16 + j) * 2 + kb;
+    int m = m0 + r;
+    if (m >= M) m = M - 1;
+    __builtin_amdgcn_global_load_lds(a + (long)m * lda8 + (vi ^ (r & 31)), (lds_ptr_t)(vlds + (wave * 16 + j) * 1024), 16, 0, 0);
+  }
+
+  // weight ring: slot (step & 3) = {hi tile 0, lo tile 0, hi tile 1, lo tile 1} of flat step = pass * 16 + k-step
+  // (buffer loads: one lane-offset VGPR for all of them, the step's offset in an SGPR, hi/lo/tile in the immediate)
+  occ_u32x4 w[4][4];
+  const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(wp, (unsigned)(kVprK / 16) * (unsigned)NT32 * 2048u);
+  const int wv = (wave * 2 * 128 + lane) * 16;
+  const int kstep_bytes = NT32 * 2048;
+#define OCC_VPR_LOAD(SLOT, PASS, KS)                                                               \
+  {                                                                                               \
+    const int so = (KS) * kstep_bytes + (PASS) * (8 * 2048);                                      \
+    w[SLOT][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so, 0);                            \
+    w[SLOT][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 1024, so, 0);                     \
+    w[SLOT][2] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 2048, so, 0);                     \
+    w[SLOT][3] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 3072, so, 0);                     \
+  }
+  OCC_VPR_LOAD(0, 0, 0)
+  OCC_VPR_LOAD(1, 0, 1)
+  OCC_VPR_LOAD(2, 0, 2)
+  __syncthreads();                                  // the tile has landed (the barrier waits for the DMA)
+
+  // rows of this block may belong to two groups (camera images): g0 up to `boundary`, g0 + 1 from there
+  const int g0 = m0 / rpg;
+  const int boundary = min((g0 + 1) * rpg - m0, kVprRows);
+  const float* __restrict__ bias0 = gbias ? gbias + (long)(g0 % bias_groups) * N : nullptr;
+  const float* __restrict__ bias1 = gbias ? gbias + (long)((g0 + 1) % bias_groups) * N : nullptr;
+  char* scratch = vlds + kVprTileBytes + wave * kVprScratch;
+
+  // A fragments of k-step ks (the same for every pass): double buffered, read one step ahead
+  bf16x8 af[2][4];
+  // (slot of piece 2 ks + kb in row vi = (2 ks) ^ ((kb ^ vi) & 31): one XOR per step on an address the compiler cannot
+  // see through — it would otherwise keep all 16 steps' addresses in registers across the pass loop)
+  unsigned abase = (unsigned)(vi * 512 + ((kb ^ vi) & 31) * 16);
+#define OCC_VPR_AFRAG(BUF, KS)                                                                     \
+  {                                                                                               \
+    asm volatile("" : "+v"(abase));                                                               \
+    const char* ap = vlds + (abase ^ (unsigned)((KS) * 32));                                      \
+    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                              \
+      af[BUF][rt] = *reinterpret_cast<const bf16x8*>(ap + rt * (32 * 512));                       \
+  }
+  OCC_VPR_AFRAG(0, 0)
+#pragma unroll 1
+  for (int p = 0; p < NP; ++p) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
+    const int pn = p + 1 < NP ? p + 1 : p;           // the ring runs into the next pass (last pass: a harmless re-read)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks + 3 < 16) OCC_VPR_LOAD((ks + 3) & 3, p, ks + 3)
+      else OCC_VPR_LOAD((ks + 3) & 3, pn, ks + 3 - 16)
+      OCC_VPR_AFRAG((ks + 1) & 1, (ks + 1) & 15)
+      // small term first; 8 accumulators between the two MFMAs on one accumulator cover the result latency
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][rt], __builtin_bit_cast(bf16x8, w[ks & 3][2 * t + 1]),
+                                                               acc[rt][t], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][rt], __builtin_bit_cast(bf16x8, w[ks & 3][2 * t]),
+                                                               acc[rt][t], 0, 0, 0);
+      // pin the software pipeline (hipcc otherwise sinks every ring request down to its use: load, vmcnt(0), MFMA)
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // ring requests of step s + 3
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // A fragments of step s + 1
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+#undef OCC_VPR_AFRAG
+
+    // ---- epilogue of the pass: + group bias, RR rows at a time through the wave's scratch ----------------------------
+    constexpr int RR = OUTH ? 16 : 8, EB = OUTH ? 2 : 4, PPR = 64 * EB / 16;   // rows per round, bytes / element, pieces / row
+    const int nw = p * 256 + wave * 64;             // the wave's first column of this pass
+    float b0[2] = {0.f, 0.f}, b1[2] = {0.f, 0.f};
+    if (gbias) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { b0[t] = bias0[nw + t * 32 + vi]; b1[t] = bias1[nw + t * 32 + vi]; }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+      for (int rd = 0; rd < 32 / RR; ++rd) {
+#pragma unroll
+        for (int qq = 0; qq < RR / 8; ++qq) {
+          const int q4 = rd * (RR / 8) + qq;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int rloc = rt * 32 + 8 * q4 + 4 * kb + i;
+              const float v = acc[rt][t][4 * q4 + i] + (rloc >= boundary ? b1[t] : b0[t]);
+              const int e = (8 * qq + 4 * kb + i) * 64 + t * 32 + vi;
+              if (OUTH) reinterpret_cast<__half*>(scratch)[e] = __float2half_rn(v);
+              else reinterpret_cast<float*>(scratch)[e] = v;
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < RR * PPR / 64; ++j) {
+          const int row = lane / PPR + j * (64 / PPR), piece = lane % PPR;
+          const int rloc = rt * 32 + rd * RR + row;
+          const int m = m0 + rloc;
+          const uint4 v = *reinterpret_cast<const uint4*>(scratch + (row * PPR + piece) * 16);
+          if (m < M) {
+            const int g = rloc >= boundary ? g0 + 1 : g0;
+            const int n = nw + piece * (16 / EB);
+            const long eo = (long)(n / plane_cols) * plane_stride + ((long)g * out_group_rows + out_row0 + (m - g * rpg)) * ldo +
+                            n % plane_cols;
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out_) + eo * EB) = v;
+          }
+        }
+        wave_lds_sync();
+      }
+    }
+  }
+#undef OCC_VPR_LOAD
+}
+
 }  // namespace occ
 
 static int value_proj_bf16_launch(int n_segments, const void* const* a, const int64_t* lda,
@@ -221,7 +397,14 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
   // still gives every CU two blocks
   long total_rows = 0;
   for (int i = 0; i < n_segments; ++i) total_rows += rows[i];
-  const int bm = (total_rows / 128) * ((N + 255) / 256) >= 2L * 256 ? 128 : 64;
+  // the activation-resident kernel: K = 256, whole 256-column passes, at most two groups per 128-row block, and a
+  // plane never split inside a wave's 64 columns.  OCC_VPROJ_RESIDENT=0 (development switch) keeps the tiled kernel.
+  static const bool resident_on = [] { const char* e = getenv("OCC_VPROJ_RESIDENT"); return !(e && e[0] == '0'); }();
+  bool resident = resident_on && K == kVprK && N % 256 == 0 && plane_cols % 64 == 0 && ldo % 8 == 0 &&
+                  (plane_stride == 0 || plane_stride % 8 == 0);
+  for (int i = 0; i < n_segments && resident; ++i)
+    resident = rows_per_group[i] >= kVprRows && rows[i] < (1L << 30) && rows_per_group[i] < (1L << 30);
+  const int bm = resident ? kVprRows : (total_rows / 128) * ((N + 255) / 256) >= 2L * 256 ? 128 : 64;
   VpSegments seg;
   long blocks = 0;
   for (int i = 0; i < kVpMaxSeg; ++i) {
@@ -244,6 +427,24 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
   seg.first_block[kVpMaxSeg] = (int)blocks;
   seg.n = n_segments;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (resident) {
+    auto launch = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kVprLdsBytes);
+      if (e == hipSuccess)
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kVprLdsBytes, st, seg,
+                           reinterpret_cast<const uint4*>(weight_packed), bias_groups, out, (long)ldo, N,
+                           (long)out_group_rows, plane_cols, (long)plane_stride);
+      return e;
+    };
+    const hipError_t e = out_f16 ? launch(value_proj_resident_kernel<true>) : launch(value_proj_resident_kernel<false>);
+    if (e != hipSuccess) {
+      set_error("value_proj_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return OCC_E_LAUNCH;
+    }
+    OCC_CHECK_LAUNCH("value_proj_bf16");
+    return OCC_OK;
+  }
   // stacked projections (planes): the column blocks of a row block are dealt to one XCD (see the kernel)
   const bool walk = plane_stride != 0 && plane_cols % 256 == 0;
   const long groups8 = (blocks + 7) / 8;

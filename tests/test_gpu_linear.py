@@ -203,6 +203,64 @@ def test_value_proj_planes_equals_separate_launches(out_dtype):
         assert torch.equal(out[p], ref), (p, float((out[p].float() - ref.float()).abs().max()))
 
 
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("P", [1, 4])
+def test_value_proj_activation_resident_kernel(out_dtype, P):
+    """K = 256, N % 256 == 0, every group >= 128 rows: the activation-resident kernel (128-row tile in LDS by LDS-DMA, all
+    column passes without a barrier).  Ragged segments (last block of a segment partly past M; blocks that straddle two
+    camera groups, whose rows take different bias rows and land in different output blocks), bias table shorter than
+    the group count, P stacked projections.  Checked against float64 (fp16 output: against the float64 result rounded
+    to fp16, within one fp16 ulp) and — same rows plus one extra short segment, which sends the launch to the tiled
+    kernel — against the tiled kernel."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(13 + P)
+    cams, K, N, nb = 5, 256, 256, 3
+    hws = [1300, 333, 200, 129]
+    starts = [4, 1310, 1650, 1860]
+    total = 2020
+    a_list = [torch.randn(cams * hw, K, generator=g).cuda().to(torch.bfloat16) for hw in hws]
+    ws = [(torch.randn(N, K, generator=g) / 16).cuda() for _ in range(P)]
+    gbs = [torch.randn(len(hws), nb, N, generator=g).cuda() for _ in range(P)]
+    out = torch.full((P, cams * total, N), float('nan'), device='cuda', dtype=out_dtype)
+    if P == 1:
+        ext.value_proj_bf16(a_list, ws[0], gbs[0], out[0], rows_per_group=hws, out_group_rows=total, out_row0=starts)
+    else:
+        ext.value_proj_bf16_planes(a_list, ws, gbs, out, rows_per_group=hws, out_group_rows=total, out_row0=starts)
+    # the tiled kernel on the same rows: a fifth 20-row segment makes the launch ineligible for the resident kernel
+    a5 = a_list + [torch.randn(cams * 20, K, generator=g).cuda().to(torch.bfloat16)]
+    gb5 = [torch.cat([gb, torch.randn(1, nb, N, generator=g).cuda()]) for gb in gbs]
+    tiled = torch.full((P, cams * total, N), float('nan'), device='cuda', dtype=out_dtype)
+    if P == 1:
+        ext.value_proj_bf16(a5, ws[0], gb5[0], tiled[0], rows_per_group=hws + [20], out_group_rows=total,
+                            out_row0=starts + [1995])
+    else:
+        ext.value_proj_bf16_planes(a5, ws, gb5, tiled, rows_per_group=hws + [20], out_group_rows=total,
+                                   out_row0=starts + [1995])
+    written = torch.zeros(cams * total, dtype=torch.bool, device='cuda')
+    worst = worst_t = 0.0
+    for p in range(P):
+        o = out[p].view(cams, total, N)
+        t = tiled[p].view(cams, total, N)
+        for l, hw in enumerate(hws):
+            ref = (a_list[l].double() @ ws[p].double().t()).view(cams, hw, N) + \
+                gbs[p][l].double()[torch.arange(cams) % nb][:, None, :]
+            got = o[:, starts[l]:starts[l] + hw]
+            if out_dtype == torch.float16:
+                # one fp16 ulp of the float64 result (the kernel rounds an f32 sum that is within ~1e-5 of it)
+                ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14, device='cuda', dtype=torch.float64)).log2().floor().exp2() * 2.0 ** -10
+                assert bool(((got.double() - ref).abs() <= ulp).all())
+            else:
+                worst = max(worst, float((got.double() - ref).abs().max()))
+            worst_t = max(worst_t, float((got.double() - t[:, starts[l]:starts[l] + hw].double()).abs().max()))
+            if p == 0:
+                written.view(cams, total)[:, starts[l]:starts[l] + hw] = True
+    print(f"resident value projection P={P} {out_dtype}: max diff vs float64 {worst:.3e}, vs tiled kernel {worst_t:.3e}")
+    assert worst < 3e-5 and worst_t < (4e-3 if out_dtype == torch.float16 else 2e-5)
+    # nothing outside the groups' windows is touched
+    for p in range(P):
+        assert torch.isnan(out[p].float()[~written]).all() and not torch.isnan(out[p].float()[written]).any()
+
+
 WGRAD_CASES = [
     # name,          M,      N,   K
     ("ffn1",         40000,  512, 256),

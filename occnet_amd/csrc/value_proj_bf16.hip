@@ -206,10 +206,17 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
 //   * after that ONE barrier the four waves never synchronise again: wave w walks the column passes (256 columns per
 //     pass, the wave's 64 of them as two 32-column tiles x four 32-row tiles = 8 accumulators), streaming its hi/lo
 //     weight fragments from L2 through a 4-deep register ring that runs ahead across k-steps AND across passes, so the
-//     epilogue of pass p (bias, fp16 rounding, 16 rows at a time through a 2 KB per-wave LDS scratch, 128-byte row
-//     segments stored) runs under the weight loads of pass p + 1 and under the other waves' MFMAs;
+//     epilogue of pass p runs under the weight loads of pass p + 1 and under the other waves' MFMAs;
+//   * the MFMAs are TRANSPOSED (weights as the row operand): a lane ends up with 16 columns of ONE output row, four
+//     consecutive ones per register quad, so the epilogue is a packed convert + one ds_write_b64 per quad into a
+//     2.5 KB per-wave scratch and 16-byte row-segment stores out of it; the accumulators START at the group bias
+//     instead of zero, so there is no bias pass (first cut, lane = column: a convert, a select, an add and a 2-byte
+//     LDS write per element — 1 080 VALU instructions per pass beside 256 MFMAs, profiles/r03_vproj_resident_pmc.txt);
 //   * the feature rows are read from HBM exactly once per launch, whatever the number of stacked projections.
-constexpr int kVprRows = 128, kVprK = 256, kVprScratch = 2048;
+// Base shape (184 950 rows, four stacked 256-column projections, fp16 out): 0.40 ms tiled -> 0.22 ms (870 TFLOP/s of
+// bf16 MFMA work, profiles/r03_vproj_probe.txt).  Starting every other 256 blocks half a pass late (so that the two
+// blocks of a CU do not sit in the MFMA phase / the epilogue together) was measured: no change (r03_vproj_stagger.txt).
+constexpr int kVprRows = 128, kVprK = 256, kVprPitch = 80, kVprScratch = 32 * kVprPitch;
 constexpr int kVprTileBytes = kVprRows * kVprK * 2;
 constexpr int kVprLdsBytes = kVprTileBytes + 4 * kVprScratch;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -268,6 +275,9 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
   const int boundary = min((g0 + 1) * rpg - m0, kVprRows);
   const float* __restrict__ bias0 = gbias ? gbias + (long)(g0 % bias_groups) * N : nullptr;
   const float* __restrict__ bias1 = gbias ? gbias + (long)((g0 + 1) % bias_groups) * N : nullptr;
+  // output row of tile row r: orow0 + r (group g0) or orow1 + r (group g0 + 1)
+  const long orow0 = (long)g0 * out_group_rows + out_row0 + (m0 - g0 * rpg);
+  const long orow1 = orow0 + out_group_rows - rpg;
   char* scratch = vlds + kVprTileBytes + wave * kVprScratch;
 
   // A fragments of k-step ks (the same for every pass): double buffered, read one step ahead
@@ -285,13 +295,28 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
   OCC_VPR_AFRAG(0, 0)
 #pragma unroll 1
   for (int p = 0; p < NP; ++p) {
+    const int nw = p * 256 + wave * 64;              // the wave's first column of this pass
+    // D[column][row]: lane (vi, kb) holds row rt * 32 + vi, register 4 q + i = column 8 q + 4 kb + i of tile t.
+    // The accumulators start at the row's group bias.
     f32x16 acc[4][2];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int q = 0; q < 4; ++q) {
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+        if (gbias) {
+          c0 = *reinterpret_cast<const float4*>(bias0 + nw + t * 32 + 8 * q + 4 * kb);
+          c1 = *reinterpret_cast<const float4*>(bias1 + nw + t * 32 + 8 * q + 4 * kb);
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
+        for (int rt = 0; rt < 4; ++rt) {
+          const bool second = rt * 32 + vi >= boundary;
+          acc[rt][t][4 * q + 0] = second ? c1.x : c0.x;
+          acc[rt][t][4 * q + 1] = second ? c1.y : c0.y;
+          acc[rt][t][4 * q + 2] = second ? c1.z : c0.z;
+          acc[rt][t][4 * q + 3] = second ? c1.w : c0.w;
+        }
+      }
     const int pn = p + 1 < NP ? p + 1 : p;           // the ring runs into the next pass (last pass: a harmless re-read)
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
@@ -303,13 +328,13 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][rt], __builtin_bit_cast(bf16x8, w[ks & 3][2 * t + 1]),
+          acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t + 1]), af[ks & 1][rt],
                                                                acc[rt][t], 0, 0, 0);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][rt], __builtin_bit_cast(bf16x8, w[ks & 3][2 * t]),
+          acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t]), af[ks & 1][rt],
                                                                acc[rt][t], 0, 0, 0);
       // pin the software pipeline (hipcc otherwise sinks every ring request down to its use: load, vmcnt(0), MFMA)
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
@@ -321,53 +346,50 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
-#undef OCC_VPR_AFRAG
 
-    // ---- epilogue of the pass: + group bias, RR rows at a time through the wave's scratch ----------------------------
-    constexpr int RR = OUTH ? 16 : 8, EB = OUTH ? 2 : 4, PPR = 64 * EB / 16;   // rows per round, bytes / element, pieces / row
-    const int nw = p * 256 + wave * 64;             // the wave's first column of this pass
-    float b0[2] = {0.f, 0.f}, b1[2] = {0.f, 0.f};
-    if (gbias) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) { b0[t] = bias0[nw + t * 32 + vi]; b1[t] = bias1[nw + t * 32 + vi]; }
-    }
+    // ---- epilogue of the pass: CPR columns of a 32-row tile at a time through the wave's scratch (row pitch 80 B) ------
+    constexpr int EB = OUTH ? 2 : 4, CPR = OUTH ? 32 : 16;      // bytes / element, columns per round (64-byte row segments)
+    const int plane = nw / plane_cols, pcol = nw - plane * plane_cols;     // the wave's 64 columns lie in one plane
+    char* const obase = reinterpret_cast<char*>(out_) + ((long)plane * plane_stride + pcol) * EB;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
-      for (int rd = 0; rd < 32 / RR; ++rd) {
+      for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int qq = 0; qq < RR / 8; ++qq) {
-          const int q4 = rd * (RR / 8) + qq;
+        for (int rd = 0; rd < 32 / CPR; ++rd) {
+          if (OUTH) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int rloc = rt * 32 + 8 * q4 + 4 * kb + i;
-              const float v = acc[rt][t][4 * q4 + i] + (rloc >= boundary ? b1[t] : b0[t]);
-              const int e = (8 * qq + 4 * kb + i) * 64 + t * 32 + vi;
-              if (OUTH) reinterpret_cast<__half*>(scratch)[e] = __float2half_rn(v);
-              else reinterpret_cast<float*>(scratch)[e] = v;
+            for (int q = 0; q < 4; ++q) {
+              const __half2 h01 = __floats2half2_rn(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1]);
+              const __half2 h23 = __floats2half2_rn(acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]);
+              *reinterpret_cast<uint2*>(scratch + vi * kVprPitch + 16 * q + 8 * kb) =
+                  make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
             }
-        }
-        wave_lds_sync();
+          } else {
 #pragma unroll
-        for (int j = 0; j < RR * PPR / 64; ++j) {
-          const int row = lane / PPR + j * (64 / PPR), piece = lane % PPR;
-          const int rloc = rt * 32 + rd * RR + row;
-          const int m = m0 + rloc;
-          const uint4 v = *reinterpret_cast<const uint4*>(scratch + (row * PPR + piece) * 16);
-          if (m < M) {
-            const int g = rloc >= boundary ? g0 + 1 : g0;
-            const int n = nw + piece * (16 / EB);
-            const long eo = (long)(n / plane_cols) * plane_stride + ((long)g * out_group_rows + out_row0 + (m - g * rpg)) * ldo +
-                            n % plane_cols;
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(out_) + eo * EB) = v;
+            for (int qq = 0; qq < 2; ++qq) {
+              const int q = 2 * rd + qq;
+              *reinterpret_cast<float4*>(scratch + vi * kVprPitch + 32 * qq + 16 * kb) =
+                  make_float4(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1], acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]);
+            }
           }
+          wave_lds_sync();
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = (lane >> 2) + 16 * j, piece = lane & 3;
+            const int rloc = rt * 32 + row;
+            const uint4 v = *reinterpret_cast<const uint4*>(scratch + row * kVprPitch + piece * 16);
+            if (m0 + rloc < M) {
+              const long orow = (rloc >= boundary ? orow1 : orow0) + rloc;
+              *reinterpret_cast<uint4*>(obase + (orow * ldo + t * 32 + rd * CPR) * EB + piece * 16) = v;
+            }
+          }
+          wave_lds_sync();
         }
-        wave_lds_sync();
       }
     }
   }
+#undef OCC_VPR_AFRAG
 #undef OCC_VPR_LOAD
 }
 

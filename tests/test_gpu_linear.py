@@ -246,16 +246,16 @@ def test_value_proj_activation_resident_kernel(out_dtype, P):
                 gbs[p][l].double()[torch.arange(cams) % nb][:, None, :]
             got = o[:, starts[l]:starts[l] + hw]
             if out_dtype == torch.float16:
-                # one fp16 ulp of the float64 result (the kernel rounds an f32 sum that is within ~1e-5 of it)
+                # the kernel rounds to fp16 an f32 sum that is within 3e-5 of the float64 result: half an ulp + 3e-5
                 ulp = torch.maximum(ref.abs(), torch.tensor(2.0 ** -14, device='cuda', dtype=torch.float64)).log2().floor().exp2() * 2.0 ** -10
-                assert bool(((got.double() - ref).abs() <= ulp).all())
+                assert bool(((got.double() - ref).abs() <= 0.5 * ulp + 3e-5).all())
             else:
                 worst = max(worst, float((got.double() - ref).abs().max()))
             worst_t = max(worst_t, float((got.double() - t[:, starts[l]:starts[l] + hw].double()).abs().max()))
             if p == 0:
                 written.view(cams, total)[:, starts[l]:starts[l] + hw] = True
     print(f"resident value projection P={P} {out_dtype}: max diff vs float64 {worst:.3e}, vs tiled kernel {worst_t:.3e}")
-    assert worst < 3e-5 and worst_t < (4e-3 if out_dtype == torch.float16 else 2e-5)
+    assert worst < 3e-5 and worst_t < (1.6e-2 if out_dtype == torch.float16 else 2e-5)   # fp16: one ulp at |v| < 16
     # nothing outside the groups' windows is touched
     for p in range(P):
         assert torch.isnan(out[p].float()[~written]).all() and not torch.isnan(out[p].float()[written]).any()

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
   }
 }
 
+
 }  // namespace occ
 
 extern "C" int occ_linear_pack_weight_bf16x3(const float* weight, void* packed, int N, int K,

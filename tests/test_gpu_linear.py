@@ -36,6 +36,16 @@ CASES = [
     ("ws_sca_q_768",   3001, 256, 0,   768, True,  None,  False,  False,    False),
     ("ws_ffn1_relu",   20000, 256, 0,  512, True,  'relu', False, False,    False),
     ("ws_n100_ln",     1500, 256, 0,   100, True,  'relu', False, True,     True),
+    # taller cases (>= 8192 rows, ragged last block): one / two / three column blocks, N = 192 / 64 / 128, K = 512 from one
+    # or two segments (+ addend), every epilogue  (written for the activation-resident variant, tools_dev/lab/linear_x3r.hip)
+    ("xr_sca_q_768",   33001, 256, 0,  768, True,  None,  False,  False,    False),
+    ("xr_ffn1_relu",   8200, 256, 0,   512, True,  'relu', False, False,    False),
+    ("xr_out_proj_ln", 10001, 256, 0,  256, True,  None,  False,  True,     True),
+    ("xr_ffn2_ln",     9000, 512, 0,   256, True,  None,  False,  True,     True),
+    ("xr_tsa_q_hist",  8200, 256, 256, 192, True,  None,  True,   False,    False),
+    ("xr_tsa_q_res",   8255, 256, 0,   192, False, None,  False,  True,     False),
+    ("xr_n64_relu_res", 8193, 256, 0,  64,  True,  'relu', False, True,     False),
+    ("xr_n128_ln",     8300, 512, 0,   128, True,  'relu', False, True,     True),
 ]
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Time the encoder's Linear shapes (M = 40 000) on the default bf16x3 kernel.  (Round 3 compared it with the
-weight-stationary persistent kernel and a one-launch FFN, both now in tools_dev/lab: profiles/r03_linear_probe_ws_v*.txt.)
+"""Time the encoder's Linear shapes (M = 40 000) on the bf16x3 kernels; OCC_LINEAR_RESIDENT=0 in the environment keeps the
+tiled kernel (the switch is read once per process: run the script twice for an A/B).
 usage: python tools_dev/linear_probe.py"""
 import os
 import sys
@@ -13,6 +13,7 @@ M = int(os.environ.get("LIN_M", "40000"))
 SHAPES = [  # name, K1, K2, N, act, residual, ln
     ("tsa_value_proj 256->256", 256, 0, 256, None, False, False),
     ("tsa_query 256->192 +res", 256, 0, 192, None, True, False),
+    ("tsa_query 256+256->192 (history)", 256, 256, 192, None, False, False),
     ("out_proj 256->256 +res+LN", 256, 0, 256, None, True, True),
     ("sca_query 256->768", 256, 0, 768, None, False, False),
     ("ffn1 256->512 relu", 256, 0, 512, 'relu', False, False),
@@ -20,7 +21,7 @@ SHAPES = [  # name, K1, K2, N, act, residual, ln
 ]
 
 
-def timed(fn, n=30):
+def timed(fn, n=40):
     for _ in range(5):
         o = fn()
     evs = []
@@ -33,17 +34,26 @@ def timed(fn, n=30):
     return ms[len(ms) // 2], o
 
 
+kern = "tiled" if os.environ.get("OCC_LINEAR_RESIDENT", "1") == "0" else "resident"
 g = torch.Generator().manual_seed(0)
+total = 0.0
 for name, K1, K2, N, act, has_res, has_ln in SHAPES:
     a = torch.randn(M, K1, generator=g).to(dev)
+    a2 = torch.randn(M, K2, generator=g).to(dev) if K2 else None
     w = (torch.randn(N, K1 + K2, generator=g) * (K1 + K2) ** -0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev)
     res = torch.randn(M, N, generator=g).to(dev) if has_res else None
     ln = (torch.ones(N, device=dev), torch.zeros(N, device=dev), 1e-5) if has_ln else None
-    line = f"{name:30s}"
-    outs = {}
     mb = (M * (K1 + K2) + M * N + (M * N if has_res else 0)) * 4 / 1e6
-    ms, o = timed(lambda: ext.linear(a, w, b, act=act, residual=res, ln=ln))
-    line += f"  {ms * 1e3:7.1f} us ({mb / ms / 1e3:5.2f} TB/s)  [{mb:.0f} MB, floor {mb / 6.3e3 * 1e3:.1f} us @6.3 TB/s]"
-    print(line, flush=True)
-
+    ms, o = timed(lambda: ext.linear(a, w, b, a2=a2, act=act, residual=res, ln=ln))
+    ref = torch.nn.functional.linear((a if a2 is None else torch.cat([a, a2], 1))[:512].double(), w.double(), b.double())
+    if act:
+        ref = ref.relu()
+    if has_res:
+        ref = ref + res[:512].double()
+    if has_ln:
+        ref = torch.nn.functional.layer_norm(ref, (N,), ln[0].double(), ln[1].double(), 1e-5)
+    total += ms
+    print(f"{kern:8s} {name:34s} {ms * 1e3:7.1f} us ({mb / ms / 1e3:5.2f} TB/s)  maxdiff {float((o[:512].double() - ref).abs().max()):.2e}"
+          f"  [{mb:.0f} MB, floor {mb / 6.3e3 * 1e3:.1f} us @6.3 TB/s]", flush=True)
+print(f"{kern:8s} sum {total * 1e3:.1f} us", flush=True)

@@ -312,20 +312,8 @@ static int sca_dispatch(const void* value, bool halfv, const int64_t* spatial_sh
     set_error("sca_fused_forward: no fused kernel for M=%d D=%d", M, D);
     return OCC_E_UNSUPPORTED;
   }
-  // development switch (tools_dev/sca_probe.py): (waves per SIMD, samples in the rolling window)
-  const char* hv_ = getenv("OCC_SCA_H_VARIANT");
-  const int hvar = hv_ ? atoi(hv_) : 0;
-#define OCC_SCA_HVAR(ID, WPS, DEPTH)                                                                         \
-  if (halfv && L == 4 && P == 8 && hvar == ID)                                                                \
-    return launch_sca_h<4, 8, WPS, DEPTH>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
-                                          (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st);
-  OCC_SCA_HVAR(1, 4, 2)
-  OCC_SCA_HVAR(2, 3, 2)
-  OCC_SCA_HVAR(3, 6, 1)
-  OCC_SCA_HVAR(6, 8, 1)
-  OCC_SCA_HVAR(4, 5, 2)
-  OCC_SCA_HVAR(5, 3, 4)
-#undef OCC_SCA_HVAR
+  // (fp16 rows: 4 waves per SIMD with a 2-sample rolling window is the default; 3/2, 6/1, 5/2, 3/4 and 8/1 were measured
+  // through a development switch, since removed: profiles/r03_sca_probe_fp16_rows.txt)
 #define OCC_SCA_CASE(LL, PP)                                                                       \
   if (L == LL && P == PP) {                                                                        \
     if (halfv)                                                                                     \

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Time the SCA gather kernels on the REAL inputs of the base config (captured from one forward of the bench model's
 last layer) and check them against each other: the fp32-value kernel (sca_fused_kernel) against the fp16-value kernel
-(sca_fused_h_kernel; OCC_SCA_H_VARIANT 0 = 3 waves/SIMD + 4-sample window, 1 = 4 waves + 2-sample window, 2 = 3 waves
-+ 2-sample window), plus the value projection with fp32 / fp16 output.   usage: python tools_dev/sca_probe.py [iters]"""
+(sca_fused_h_kernel, 4 waves/SIMD + 2-sample rolling window; the other (waves, window) pairs were measured in round 3
+through a since-removed development switch: profiles/r03_sca_probe_fp16_rows.txt), plus the value projection with
+fp32 / fp16 output.   usage: python tools_dev/sca_probe.py [iters]"""
 import json
 import os
 import sys
@@ -44,10 +45,7 @@ def timed(fn):
 
 ref = orig(v32, *a[1:], **k)
 ref16 = None
-for name, val, hv in (("f32 values (sca_fused_kernel)", v32, "0"), ("f16 values, default (4 waves, window 2)", v16, "0"),
-                      ("f16 values, 6 waves, window 1", v16, "3"), ("f16 values, 8 waves, window 1", v16, "6"), ("f16 values, 5 waves, window 2", v16, "4"),
-                      ("f16 values, 3 waves, window 4", v16, "5"), ("f16 values, 3 waves, window 2", v16, "2")):
-    os.environ["OCC_SCA_H_VARIANT"] = hv
+for name, val in (("f32 values (sca_fused_kernel)", v32), ("f16 values (sca_fused_h_kernel, 4 waves, window 2)", v16)):
     stats = torch.zeros(2, dtype=torch.int64, device=dev)
     out = orig(val, *a[1:], **k, stats=stats)
     torch.cuda.synchronize()
@@ -57,7 +55,6 @@ for name, val, hv in (("f32 values (sca_fused_kernel)", v32, "0"), ("f16 values,
     print(json.dumps(dict(kernel=name, median_ms=med, min_ms=mn, maxdiff_vs_f32_kernel=float((out - ref).abs().max()),
                           maxdiff_vs_first_f16=None if ref16 is None else float((out - ref16).abs().max()),
                           rows=int(stats[0]), n_in=int(stats[1]))), flush=True)
-os.environ["OCC_SCA_H_VARIANT"] = "0"
 
 # the value projection that feeds it: fp32 vs fp16 output (LazyFeatures.project of the last layer's value_proj)
 tr = model.pts_bbox_head.transformer

@@ -103,6 +103,43 @@ def test_ddp_train_step_single_rank():
             dist.destroy_process_group()
 
 
+def test_history_bev_inside_training_keeps_the_derived_caches():
+    """obtain_history_bev flips a training model to eval() and back every step.  That must not
+    invalidate the derived-weight caches (packed Linear weights, folded positional terms, group biases): the epoch stays,
+    and a second call packs nothing new and reproduces the first call's BEV bit for bit."""
+    import occnet_amd
+    from occnet_amd import ext
+    from occnet_amd.plugin import Config, build_model, import_plugin
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs', 'occ_base_200x200x16.py'))
+    cfg.merge_from_dict({'model.pts_bbox_head.bev_h': 40, 'model.pts_bbox_head.bev_w': 40,
+                         'model.pts_bbox_head.positional_encoding.row_num_embed': 40,
+                         'model.pts_bbox_head.positional_encoding.col_num_embed': 40,
+                         'model.pts_bbox_head.transformer.rotate_center': [20, 20]})
+    import_plugin(cfg)
+    torch.manual_seed(0)
+    model = build_model(cfg.model)
+    model.init_weights()
+    device = torch.device('cuda', 0)
+    model = model.to(device).train()
+    geo = dict(synthetic.BASE, img_h=128, img_w=224)
+    frames = torch.stack([synthetic.make_images(geo, batch=1, seed=s, device=device) for s in (0, 1)], 1)
+    metas = []
+    for i in range(2):
+        m = synthetic.make_img_metas(geo, batch=1)[0]
+        m['prev_bev_exists'] = i > 0
+        metas.append(m)
+    metas_list = [{0: metas[0], 1: metas[1]}]
+    epoch0 = occnet_amd.cache_epoch()
+    bev1 = model.obtain_history_bev(frames, metas_list)
+    assert model.training                                   # mode restored
+    packs1, ptrs1 = len(ext._PACKED_W), set(ext._PACKED_W.keys())
+    bev2 = model.obtain_history_bev(frames, metas_list)
+    assert occnet_amd.cache_epoch() == epoch0
+    assert len(ext._PACKED_W) == packs1 and set(ext._PACKED_W.keys()) == ptrs1
+    assert torch.equal(bev1, bev2)
+
+
 def test_ddp_two_ranks_gradients_identical():
     """1-vs-N gradient equality: two DDP ranks with different samples end
     one training step with IDENTICAL gradients, equal to the mean of their rank-local gradients — with and

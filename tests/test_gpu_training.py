@@ -106,7 +106,8 @@ def test_ddp_train_step_single_rank():
 def test_history_bev_inside_training_keeps_the_derived_caches():
     """obtain_history_bev flips a training model to eval() and back every step.  That must not
     invalidate the derived-weight caches (packed Linear weights, folded positional terms, group biases): the epoch stays,
-    and a second call packs nothing new and reproduces the first call's BEV bit for bit."""
+    and a second call packs nothing new and reproduces the first call's BEV (the stock backbone runs on MIOpen, whose
+    solver choice may differ between the first and later calls: compared to 1e-3 of the BEV's scale)."""
     import occnet_amd
     from occnet_amd import ext
     from occnet_amd.plugin import Config, build_model, import_plugin
@@ -137,7 +138,7 @@ def test_history_bev_inside_training_keeps_the_derived_caches():
     bev2 = model.obtain_history_bev(frames, metas_list)
     assert occnet_amd.cache_epoch() == epoch0
     assert len(ext._PACKED_W) == packs1 and set(ext._PACKED_W.keys()) == ptrs1
-    assert torch.equal(bev1, bev2)
+    assert float((bev1 - bev2).abs().max()) <= 1e-3 * float(bev1.abs().max())
 
 
 def test_ddp_two_ranks_gradients_identical():

@@ -188,28 +188,49 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
   const int count = __builtin_popcount(own);
 
   // ---- camera-independent part: softmax(logits) and offsets / (W_l, H_l) ------------------
+  // lane = (head m = lane / 8, sample group sK = lane % 8) holds the K CONSECUTIVE samples s = sK K + k of its head: the
+  // logits / offsets arrive as one / two vector loads and the softmax is a K-term local reduction + 3 shuffle steps over
+  // the head's 8 lanes.  (One sample per (lane, k) with s = lane % LP — the fp32 kernel's map — costs 5 shuffle steps
+  // per max and per sum for each of the K registers: 40 cross-lane operations per query instead of 6; the prologue was
+  // 0.021 ms of the 0.19 ms launch, profiles/r03_sca_ablation.txt.)
   float aw[K], ox[K], oy[K];
-  // sample index s = (lane + 64 k) % LP does not depend on k (64 % LP == 0): one level per lane
-  static_assert(64 % LP == 0, "the lane's level must not depend on k");
-  const int lane_l = (lane % LP) / P;
+  static_assert(P % K == 0 && K * 8 == LP, "a lane's K samples share one level");
+  const int hm = lane >> 3, sK = lane & 7;
+  const int lane_l = (sK * K) / P;
   const int lvH = (int)shapes[2 * lane_l], lvW = (int)shapes[2 * lane_l + 1], lvS = (int)lstart[lane_l];
-  const float* lrow = logits + ((long)b * Nq + q) * logits_stride;
-  const float* orow = offs + ((long)b * Nq + q) * offs_stride;
+  {
+    const float* lp = logits + ((long)b * Nq + q) * logits_stride + hm * LP + sK * K;
+    const float* op = offs + ((long)b * Nq + q) * offs_stride + 2 * (hm * LP + sK * K);
+    float x[K], o[2 * K];
+    if constexpr (K == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(lp);
+      x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+      const float4 u0 = *reinterpret_cast<const float4*>(op), u1 = *reinterpret_cast<const float4*>(op + 4);
+      o[0] = u0.x; o[1] = u0.y; o[2] = u0.z; o[3] = u0.w; o[4] = u1.x; o[5] = u1.y; o[6] = u1.z; o[7] = u1.w;
+    } else {
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int idx = lane + 64 * k;  // = m*LP + s
-    float x = lrow[idx];
-    float mx = x;
+      for (int k = 0; k < K; ++k) {
+        x[k] = lp[k];
+        const float2 t = *reinterpret_cast<const float2*>(op + 2 * k);
+        o[2 * k] = t.x; o[2 * k + 1] = t.y;
+      }
+    }
+    float mx = x[0];
 #pragma unroll
-    for (int d = LP / 2; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-    const float e = expf(x - mx);
-    float sum = e;
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
 #pragma unroll
-    for (int d = LP / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    aw[k] = e / sum;
-    const float2 o = *reinterpret_cast<const float2*>(orow + 2 * idx);
-    ox[k] = o.x / (float)lvW;
-    oy[k] = o.y / (float)lvH;
+    for (int d = 4; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); sum += x[k]; }
+#pragma unroll
+    for (int d = 4; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      aw[k] = x[k] / sum;
+      ox[k] = o[2 * k] / (float)lvW;
+      oy[k] = o[2 * k + 1] / (float)lvH;
+    }
   }
 
   // f32 rows: 8 lanes x 4 channels per head; fp16 rows: 4 lanes x 8 channels per head and two sample halves
@@ -223,8 +244,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     const float* rp = ref_cam + (((long)c * B + b) * Nq + q) * Z * 2;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const int idx = lane + 64 * k;
-      const int m = idx / LP, s = idx % LP;
+      const int m = hm, s = sK * K + k;
       const int z = (s % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
       const float2 rxy = *reinterpret_cast<const float2*>(rp + 2 * z);
       SampleParamB p;

@@ -251,7 +251,9 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
       const float aw_k = aw[k], ox_k = ox[k], oy_k = oy[k];
       n_in += bilinear_setup_b(rxy.x + ox_k, rxy.y + oy_k, aw_k, lvH, lvW, lvS,
                                (unsigned)row_stride * EV, kOobOffset, true, p);
-      sp[m * LPp + s] = p;
+      // slot k * 8 + sK, not s: the 8 lanes of a head write consecutive 32-byte entries (conflict-free); the gather
+      // sums a head's LP entries, so their order in the slab is free
+      sp[m * LPp + k * 8 + sK] = p;
     }
     wave_lds_sync();
     // corners outside their map carry an out-of-range byte offset: the buffer load returns 0 without a request

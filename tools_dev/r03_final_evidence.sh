@@ -37,14 +37,15 @@ print("# L2hit = TCC_HIT/(TCC_HIT+TCC_MISS); L2missMB = TCC_MISS*128/1e6; L1req/
 print("# LDScf = SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE; wait / stall / active = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES;")
 print("# FETCH/WRITE_SIZE in KB as reported (gfx950: HBM read bytes = 2 x FETCH_SIZE x 1024)")
 print(f"{'kernel':44s} {'n':>4s} {'kcyc':>8s} {'Mfma':>6s} {'TA':>6s} {'L2hit':>6s} {'L2missMB':>9s} {'L1rq/ac':>8s} {'LDScf':>6s} {'wait':>5s} {'stall':>5s} {'activ':>5s} {'FETCH':>10s} {'WRITE':>10s}")
+div = lambda a, b: a / b if b else float('nan')
 for k, c in sorted(acc.items()):
     m = lambda n: c[n][1] / c[n][0] if n in c and c[n][0] else float('nan')
     dur = m('SQ_BUSY_CYCLES') / 32
     hit, miss = m('TCC_HIT_sum'), m('TCC_MISS_sum')
     wc = m('SQ_WAVE_CYCLES')
-    print(f"{k[:44]:44s} {c['SQ_BUSY_CYCLES'][0]:4d} {dur/1e3:8.1f} {m('SQ_VALU_MFMA_BUSY_CYCLES')/(dur*1024):6.3f} "
-          f"{m('TA_BUSY_avr')/dur:6.3f} {hit/(hit+miss):6.3f} {miss*128/1e6:9.1f} {m('TCP_TCC_READ_REQ_sum')/m('TCP_TOTAL_CACHE_ACCESSES_sum'):8.3f} "
-          f"{m('SQ_LDS_BANK_CONFLICT')/m('SQ_LDS_IDX_ACTIVE'):6.3f} {m('SQ_WAIT_ANY')/wc:5.2f} {m('SQ_WAIT_INST_ANY')/wc:5.2f} {m('SQ_ACTIVE_INST_ANY')/wc:5.2f} "
+    print(f"{k[:44]:44s} {c['SQ_BUSY_CYCLES'][0]:4d} {dur/1e3:8.1f} {div(m('SQ_VALU_MFMA_BUSY_CYCLES'), dur*1024):6.3f} "
+          f"{div(m('TA_BUSY_avr'), dur):6.3f} {div(hit, hit+miss):6.3f} {miss*128/1e6:9.1f} {div(m('TCP_TCC_READ_REQ_sum'), m('TCP_TOTAL_CACHE_ACCESSES_sum')):8.3f} "
+          f"{div(m('SQ_LDS_BANK_CONFLICT'), m('SQ_LDS_IDX_ACTIVE')):6.3f} {div(m('SQ_WAIT_ANY'), wc):5.2f} {div(m('SQ_WAIT_INST_ANY'), wc):5.2f} {div(m('SQ_ACTIVE_INST_ANY'), wc):5.2f} "
           f"{m('FETCH_SIZE'):10.0f} {m('WRITE_SIZE'):10.0f}")
 PY
 cat gpurun_out/${T}_pmc_derived.txt | cut -c1-190

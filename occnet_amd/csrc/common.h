@@ -222,42 +222,6 @@ __device__ __forceinline__ float4 gather_samples_buf(__amdgpu_buffer_rsrc_t rsrc
   return acc;
 }
 
-// gather_samples_buf as a ROLLING window over NS (compile-time) samples: the 4 corner loads of sample j + DEPTH are
-// requested right after sample j is consumed, so DEPTH * 4 loads stay in flight instead of batches that drain to zero.
-// The window loop is NOT unrolled (fully unrolled, hipcc hoists the parameter reads of later samples and spills).
-template <int NS>
-__device__ __forceinline__ float4 gather_samples_buf_roll(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
-                                                          const SampleParamB* sp, float4 acc) {
-  constexpr int DEPTH = NS < 4 ? NS : 4;
-  static_assert(NS % DEPTH == 0, "sample count must be a multiple of the window");
-  float4 v[DEPTH][4];
-#pragma unroll
-  for (int u = 0; u < DEPTH; ++u) {
-    const occ_u32x4 o = *reinterpret_cast<const occ_u32x4*>(sp[u].o);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[u][k] = buf_load16(rsrc, o[k] + lane_off);
-  }
-#pragma unroll 1
-  for (int j0 = 0; j0 + DEPTH < NS; j0 += DEPTH) {
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u) {
-      // the weights are read when the sample is consumed (their LDS latency hides under the wait for the rows): held
-      // from issue to consumption they cost 16 more live registers and the kernel its third wave per SIMD
-      const float4 w = *reinterpret_cast<const float4*>(sp[j0 + u].w);
-      const occ_u32x4 o = *reinterpret_cast<const occ_u32x4*>(sp[j0 + DEPTH + u].o);
-      fma4(acc, w.x, v[u][0]); fma4(acc, w.y, v[u][1]); fma4(acc, w.z, v[u][2]); fma4(acc, w.w, v[u][3]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[u][k] = buf_load16(rsrc, o[k] + lane_off);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < DEPTH; ++u) {
-    const float4 w = *reinterpret_cast<const float4*>(sp[NS - DEPTH + u].w);
-    fma4(acc, w.x, v[u][0]); fma4(acc, w.y, v[u][1]); fma4(acc, w.z, v[u][2]); fma4(acc, w.w, v[u][3]);
-  }
-  return acc;
-}
-
 // acc += w * (fp16 in the low / high half of `packed`): v_fma_mix_f32 widens the fp16 operand inside the FMA.  Written as
 // asm because hipcc only selects the mixed-precision FMA when f32 denormals are flushed (its default keeps them) and
 // otherwise emits a v_cvt_f32_f16 per value: twice the VALU work of the fp32 gather.  Pure VALU, register operands only:
@@ -276,7 +240,11 @@ __device__ __forceinline__ void fma8h(float4& acc, float4& acc2, float w, const 
   fma_mix_lo(acc2.x, w, h[2]); fma_mix_hi(acc2.y, w, h[2]); fma_mix_lo(acc2.z, w, h[3]); fma_mix_hi(acc2.w, w, h[3]);
 }
 
-// The same rolling window for fp16 value rows: a lane's 16 bytes are 8 channels (4 lanes per 64-byte head row).
+// Gather over fp16 value rows: a lane's 16 bytes are 8 channels (4 lanes per 64-byte head row).  ROLLING window over NS
+// (compile-time) samples: the 4 corner loads of sample j + DEPTH are requested right after sample j is consumed, so
+// DEPTH * 4 loads stay in flight instead of batches that drain to zero.  The window loop is NOT unrolled (fully unrolled,
+// hipcc hoists the parameter reads of later samples and spills); the weights are read when the sample is consumed (their
+// LDS latency hides under the wait for the rows; held from issue to consumption they cost 16 more live registers).
 template <int NS, int DEPTH_ = 4>
 __device__ __forceinline__ void gather_samples_buf_h(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
                                                      const SampleParamB* sp, float4& acc, float4& acc2) {

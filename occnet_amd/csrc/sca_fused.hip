@@ -14,18 +14,19 @@
 // wave (4 per lane) into LDS, then every 8-lane group gathers its head's 32 samples:
 // 128 x 16-byte loads per lane, 16 in flight.
 //
-// HALFV (default for inference since round 3): the projected value maps are stored as fp16 (value_proj_bf16's fp16
-// epilogue), so one head's 32 channels of one pixel are 64 bytes = FOUR lanes x 16 bytes.  The texture path retires
-// ~one 1 KB wave load per ~21 clocks whatever the lanes ask for (tools_dev/ta_probe.hip: 47-50 B/clk/CU for random
-// 128-byte rows, random 64-byte rows fetched 8 B per lane, and fully coalesced 1 KB alike), so the cost of a row is the
-// number of LANES it occupies: with 16 B per lane a wave instruction fetches 16 fp16 rows instead of 8 fp32 rows.
-// The wave's 16 lane-groups = 8 heads x 2 halves of the head's L*P samples; every lane keeps 8 fp32 accumulators
-// (v_fma_mix_f32 widens the fp16 operand inside the FMA) and the two halves meet in one cross-lane add at the end.
-// Round 2's fp16 experiment (sca_head_h_kernel) kept 8 lanes x 8 B per row — the same number of wave loads per row —
-// and measured no gain for exactly this reason.  Sampling arithmetic, weights and accumulation stay fp32; the value
-// elements carry 11 significant bits (end-to-end effect at full size: tests/test_gpu_fullsize.py, bench parity leg).
-// Both variants issue their loads as a ROLLING window (the loads of sample j + 4 are requested as soon as sample j is
-// consumed) instead of batches of 16 that drain to zero before the next batch is requested.
+// fp16 value rows (sca_fused_h_kernel, default for inference since round 3): the projected value maps are stored as fp16
+// (the value projection's fp16 epilogue), so one head's 32 channels of one pixel are 64 bytes = FOUR lanes x 16 bytes.
+// The texture path retires ~one 1 KB wave load per ~21 clocks whatever the lanes ask for (tools_dev/ta_probe.hip:
+// 47-50 B/clk/CU for random 128-byte rows, random 64-byte rows fetched 8 B per lane, and fully coalesced 1 KB alike), so
+// the cost of a row is the number of LANES it occupies: with 16 B per lane a wave instruction fetches 16 fp16 rows
+// instead of 8 fp32 rows.  The wave's 16 lane-groups = 8 heads x 2 halves of the head's L*P samples; every lane keeps 8
+// fp32 accumulators (v_fma_mix_f32 widens the fp16 operand inside the FMA) and the two halves meet in one cross-lane
+// add at the end.  Round 2's fp16 experiment kept 8 lanes x 8 B per row — the same number of wave loads per row — and
+// measured no gain for exactly this reason.  Sampling arithmetic, weights and accumulation stay fp32; the value elements
+// carry 11 significant bits (end-to-end effect at full size: tests/test_gpu_fullsize.py, bench parity leg).  Its loads
+// run through a ROLLING window (the loads of sample j + DEPTH are requested as soon as sample j is consumed) instead of
+// batches that drain to zero before the next batch is requested; its softmax keeps a head's consecutive samples in one
+// lane (6 cross-lane operations per query instead of 40).  The fp32-row kernel (sca_fused_kernel) is round 2's, unchanged.
 #include <stdlib.h>
 #include "common.h"
 
@@ -180,8 +181,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
   SampleParamB* sp = smem + wave * M * LPp;
 
   constexpr int row_stride = M * D;
-  constexpr bool HALFV = true;
-  constexpr unsigned EV = 2u;                              // bytes per value element
+  constexpr unsigned EV = 2u;                              // bytes per value element (fp16)
   const char* value = reinterpret_cast<const char*>(value_);
   const uint32_t vis = vis_bits[q];                       // batch 0's mask picks the cameras
   const uint32_t own = vis_bits[(long)b * Nq + q];        // this batch's mask gives the divisor
@@ -233,9 +233,8 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     }
   }
 
-  // f32 rows: 8 lanes x 4 channels per head; fp16 rows: 4 lanes x 8 channels per head and two sample halves
-  const int g = HALFV ? (lane >> 2) & 7 : lane >> 3, c4 = HALFV ? lane & 3 : lane & 7;
-  const int half = HALFV ? lane >> 5 : 0;
+  // gather map: 4 lanes x 8 channels per head row, the two halves of the wave take the two halves of a head's samples
+  const int g = (lane >> 2) & 7, c4 = lane & 3, half = lane >> 5;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
   unsigned n_in = 0, n_rows = 0;
 
@@ -260,30 +259,21 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     // (round 1 issued a dummy load of row 0 for them: 9 % of the rows through the texture path, and 0 * Inf)
     const __amdgpu_buffer_rsrc_t rsrc =
         uniform_rsrc(value + ((long)b * NC + c) * S * row_stride * EV, (unsigned)S * row_stride * EV);
-    if (HALFV)
-      gather_samples_buf_h<LP / 2, DEPTH>(rsrc, (unsigned)(g * D + c4 * 8) * 2u, sp + g * LPp + half * (LP / 2), acc,
-                                          acc2);
-    else
-      acc = gather_samples_buf<4>(rsrc, (unsigned)(g * D + c4 * 4) * 4u, sp + g * LPp, LP, acc);
+    gather_samples_buf_h<LP / 2, DEPTH>(rsrc, (unsigned)(g * D + c4 * 8) * 2u, sp + g * LPp + half * (LP / 2), acc, acc2);
     wave_lds_sync();  // WAR: next camera rewrites the LDS slab
     ++n_rows;
   }
 
   const float inv = (float)(count > 0 ? count : 1);
-  if (HALFV) {
-    // the two sample halves of a head sit 32 lanes apart
-    acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32);
-    acc.w += __shfl_xor(acc.w, 32);
-    acc2.x += __shfl_xor(acc2.x, 32); acc2.y += __shfl_xor(acc2.y, 32); acc2.z += __shfl_xor(acc2.z, 32);
-    acc2.w += __shfl_xor(acc2.w, 32);
-    if (half == 0) {
-      float* dst = slots + ((long)b * Nq + q) * row_stride + g * D + c4 * 8;
-      *reinterpret_cast<float4*>(dst) = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
-      *reinterpret_cast<float4*>(dst + 4) = make_float4(acc2.x / inv, acc2.y / inv, acc2.z / inv, acc2.w / inv);
-    }
-  } else {
-    float4 o4 = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
-    *reinterpret_cast<float4*>(slots + ((long)b * Nq + q) * row_stride + g * D + c4 * 4) = o4;
+  // the two sample halves of a head sit 32 lanes apart
+  acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32);
+  acc.w += __shfl_xor(acc.w, 32);
+  acc2.x += __shfl_xor(acc2.x, 32); acc2.y += __shfl_xor(acc2.y, 32); acc2.z += __shfl_xor(acc2.z, 32);
+  acc2.w += __shfl_xor(acc2.w, 32);
+  if (half == 0) {
+    float* dst = slots + ((long)b * Nq + q) * row_stride + g * D + c4 * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc2.x / inv, acc2.y / inv, acc2.z / inv, acc2.w / inv);
   }
 
   if (stats) {

@@ -68,6 +68,21 @@ def test_backbone_and_projection_entry_points_validate_without_gpu():
     assert lib.occ_value_proj_bf16_f32(*args(9, one, 64, 256)) == -1                              # > 8 segments
     assert lib.occ_value_proj_bf16_f32(*args(1, one, 48, 256)) == -3                              # K % 32
     assert lib.occ_value_proj_bf16_f32(*args(1, (ctypes.c_int64 * 1)(32), 64, 256)) == -1         # lda < K
+    # stacked projections (round 3): plane geometry
+    pargs = lambda n_planes, plane_cols, stride: (1, ptrs, one, one, one, zero, null, 0, p, p, 1, i64(256), 64, n_planes,
+                                                  plane_cols, i64(stride), i64(64), null)
+    assert lib.occ_value_proj_bf16_planes(*pargs(0, 256, 1 << 20)) == -1                          # no planes
+    assert lib.occ_value_proj_bf16_planes(*pargs(4, 256, 0)) == -1                                # plane stride
+    assert lib.occ_value_proj_bf16_planes(*pargs(4, 192, 1 << 20)) == -3                          # plane_cols % 256
+    assert b'plane_cols' in lib.occ_last_error()
+    # fused second convolution + heads + decode (round 3)
+    lib.occ_conv3d_heads_pack_bytes.restype = ctypes.c_int64
+    assert lib.occ_conv3d_heads_pack_bytes() == 16 * 1024 + 16 * 1024 + 128 * 4 + 32 * 4
+    hargs = lambda Z, Cin, ncls, occ=p: (p, p, p, p, p, occ, p, null, 1, Z, 4, 4, Cin, ncls, null)
+    assert lib.occ_conv3d_heads_decode_bf16x3_f32(*hargs(16, 32, 17, null)) == -1                 # null output
+    assert lib.occ_conv3d_heads_decode_bf16x3_f32(*hargs(32, 32, 17)) == -3                       # Z = 32
+    assert lib.occ_conv3d_heads_decode_bf16x3_f32(*hargs(16, 16, 17)) == -3                       # Cin = 16
+    assert lib.occ_conv3d_heads_decode_bf16x3_f32(*hargs(16, 32, 40)) == -3                       # > 30 classes
     with pytest.raises(_lib.OccAmdUnsupported):
         ext.conv1x1_pack_weight(torch.zeros(8, 32))
     with pytest.raises(_lib.OccAmdUnsupported):

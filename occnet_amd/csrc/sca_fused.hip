@@ -27,7 +27,13 @@
 // run through a ROLLING window (the loads of sample j + DEPTH are requested as soon as sample j is consumed) instead of
 // batches that drain to zero before the next batch is requested; its softmax keeps a head's consecutive samples in one
 // lane (6 cross-lane operations per query instead of 40).  The fp32-row kernel (sca_fused_kernel) is round 2's, unchanged.
-#include <stdlib.h>
+// PIXEL-PAIR LAYOUT of the fp16 maps: value_f16[b * NC + c][pix >> 1][head][pix & 1][32] — the two x-neighbours (2k, 2k + 1)
+// of one head share one 128-byte line (a 64-byte row alone is half a line: every corner cost a whole L1 miss for half
+// its bytes).  The wide PMC sweep (profiles/r03_pmc_wide_sca_linear.txt) shows what binds the gather: 65 % of its L1
+// line accesses miss, the TCP sits 51 % of the launch in PENDING stall (its outstanding-miss capacity / the 232-cycle
+// L2 round trip) and the TD 96 % busy.  With pairs the left / right corners of a sample hit the same line half the
+// time: L1 -> L2 requests 31.3 M -> 21.3 M per launch, 0.178 -> 0.156 ms (profiles/r03_sca_pair_layout.txt).  The
+// value projection's fp16 epilogue writes this layout (csrc/value_proj_bf16.hip); S must be even (padded).
 #include "common.h"
 
 namespace occ {
@@ -250,6 +256,10 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
       const float aw_k = aw[k], ox_k = ox[k], oy_k = oy[k];
       n_in += bilinear_setup_b(rxy.x + ox_k, rxy.y + oy_k, aw_k, lvH, lvW, lvS,
                                (unsigned)row_stride * EV, kOobOffset, true, p);
+      // pixel-pair layout (file header): byte offset pix * 512 -> (pix >> 1) * 1024 + (pix & 1) * 64; the out-of-range
+      // marker stays out of range
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) p.o[kk] = (p.o[kk] & ~1023u) | ((p.o[kk] >> 3) & 64u);
       // slot k * 8 + sK, not s: the 8 lanes of a head write consecutive 32-byte entries (conflict-free); the gather
       // sums a head's LP entries, so their order in the slab is free
       sp[m * LPp + k * 8 + sK] = p;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     // (round 1 issued a dummy load of row 0 for them: 9 % of the rows through the texture path, and 0 * Inf)
     const __amdgpu_buffer_rsrc_t rsrc =
         uniform_rsrc(value + ((long)b * NC + c) * S * row_stride * EV, (unsigned)S * row_stride * EV);
-    gather_samples_buf_h<LP / 2, DEPTH>(rsrc, (unsigned)(g * D + c4 * 8) * 2u, sp + g * LPp + half * (LP / 2), acc, acc2);
+    gather_samples_buf_h<LP / 2, DEPTH>(rsrc, (unsigned)(g * 128 + c4 * 16), sp + g * LPp + half * (LP / 2), acc, acc2);
     wave_lds_sync();  // WAR: next camera rewrites the LDS slab
     ++n_rows;
   }
@@ -316,6 +326,7 @@ static int sca_dispatch(const void* value, bool halfv, const int64_t* spatial_sh
                 "sca_fused_forward: bad dimension (B=%d NC=%d S=%d Nq=%d Z=%d L=%d P=%d)", B, NC, S,
                 Nq, Z, L, P);
   OCC_CHECK_ARG(P % Z == 0, "sca_fused_forward: num_points(%d) must be a multiple of Z(%d)", P, Z);
+  OCC_CHECK_ARG(!halfv || S % 2 == 0, "sca_fused_forward: fp16 value maps are stored in pixel pairs: S(%d) must be even", S);
   OCC_CHECK_ARG(offs_stride >= (int64_t)M * L * P * 2 && logits_stride >= (int64_t)M * L * P,
                 "sca_fused_forward: row strides smaller than a row");
   OCC_CHECK_ARG((long)S * M * D * 4 < (long)kOobOffset, "sca_fused_forward: value batch entry too large");

@@ -185,8 +185,14 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
         const int nn = n0 + c;
         const long eo = (long)(nn / plane_cols) * plane_stride + (g * out_group_rows + out_row0 + i) * ldo + nn % plane_cols;
         if (OUTH) {
+          // fp16 maps are the SCA gather's operand: pixel-PAIR layout [group][pix >> 1][head][pix & 1][32] (sca_fused.hip),
+          // pix = out_row0 + i, head = column / 32; rows are contiguous (ldo == plane_cols, checked by the launcher)
+          const long pix = out_row0 + i;
+          const int pc = nn % plane_cols;
+          const long ep = (long)(nn / plane_cols) * plane_stride + (g * out_group_rows + (pix & ~1L)) * ldo +
+                          (pc >> 5) * 64 + (pix & 1) * 32 + (pc & 31);
           const __half2 h01 = __floats2half2_rn(v.x, v.y), h23 = __floats2half2_rn(v.z, v.w);
-          *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(out_) + eo) =
+          *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(out_) + ep) =
               make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
         } else {
           *reinterpret_cast<float4*>(out + eo) = v;
@@ -278,6 +284,11 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
   // output row of tile row r: orow0 + r (group g0) or orow1 + r (group g0 + 1)
   const long orow0 = (long)g0 * out_group_rows + out_row0 + (m0 - g0 * rpg);
   const long orow1 = orow0 + out_group_rows - rpg;
+  // the same split into (first row of the group's block, pixel index inside it) for the fp16 pixel-pair layout
+  // (a group's block is < 2 GB: 32-bit offsets inside it)
+  const unsigned row_bytes = (unsigned)ldo * 2u;
+  const long gbytes0 = (long)g0 * out_group_rows * row_bytes, gbytes1 = gbytes0 + out_group_rows * row_bytes;
+  const int pix0 = (int)out_row0 + (m0 - g0 * rpg), pix1 = pix0 - rpg;
   char* scratch = vlds + kVprTileBytes + wave * kVprScratch;
 
   // A fragments of k-step ks (the same for every pass): double buffered, read one step ahead
@@ -349,8 +360,11 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
 
     // ---- epilogue of the pass: CPR columns of a 32-row tile at a time through the wave's scratch (row pitch 80 B) ------
     constexpr int EB = OUTH ? 2 : 4, CPR = OUTH ? 32 : 16;      // bytes / element, columns per round (64-byte row segments)
+    int elane = lane;                               // opaque per pass: the store offsets are recomputed here instead of
+    asm volatile("" : "+v"(elane));                 // living (spilled) across the k loop
     const int plane = nw / plane_cols, pcol = nw - plane * plane_cols;     // the wave's 64 columns lie in one plane
     char* const obase = reinterpret_cast<char*>(out_) + ((long)plane * plane_stride + pcol) * EB;
+    char* const pbase = reinterpret_cast<char*>(out_) + (long)plane * plane_stride * EB;     // plane base (pair layout)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
@@ -376,12 +390,21 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
           wave_lds_sync();
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const int row = (lane >> 2) + 16 * j, piece = lane & 3;
+            const int row = (elane >> 2) + 16 * j, piece = elane & 3;
             const int rloc = rt * 32 + row;
             const uint4 v = *reinterpret_cast<const uint4*>(scratch + row * kVprPitch + piece * 16);
             if (m0 + rloc < M) {
-              const long orow = (rloc >= boundary ? orow1 : orow0) + rloc;
-              *reinterpret_cast<uint4*>(obase + (orow * ldo + t * 32 + rd * CPR) * EB + piece * 16) = v;
+              if (OUTH) {
+                // pixel-pair layout of the fp16 maps (sca_fused.hip): [group][pix >> 1][head][pix & 1][32]; the wave's
+                // tile t is head (pcol + 32 t) / 32 of the plane, a 16-byte piece = 8 of its 32 channels
+                const bool second = rloc >= boundary;
+                const int pix = (second ? pix1 : pix0) + rloc;
+                const unsigned inb = (unsigned)(pix & ~1) * row_bytes + (unsigned)(((pcol >> 5) + t) * 128 + (pix & 1) * 64 + piece * 16);
+                *reinterpret_cast<uint4*>(pbase + (second ? gbytes1 : gbytes0) + inb) = v;
+              } else {
+                const long orow = (rloc >= boundary ? orow1 : orow0) + rloc;
+                *reinterpret_cast<uint4*>(obase + (orow * ldo + t * 32 + rd * CPR) * EB + piece * 16) = v;
+              }
             }
           }
           wave_lds_sync();
@@ -409,6 +432,10 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
   OCC_CHECK_ARG(K > 0 && N > 0 && out_group_rows >= 0 && ldo >= plane_cols && N % plane_cols == 0,
                 "value_proj_bf16: bad dimension");
   OCC_CHECK_ARG(!group_bias || bias_groups > 0, "value_proj_bf16: bias_groups must be positive");
+  // fp16 output = the SCA gather's pixel-pair layout: contiguous rows of whole 32-channel heads, even blocks
+  OCC_CHECK_ARG(!out_f16 || (ldo == plane_cols && plane_cols % 32 == 0 && out_group_rows % 2 == 0 &&
+                             out_group_rows * ldo * 2 < (1L << 31)),
+                "value_proj_bf16: fp16 output needs ldo == columns, columns %% 32 == 0 and an even out_group_rows");
   if (K % 32 || N % 4 || ldo % 4) {
     set_error("value_proj_bf16: no kernel for K=%d N=%d (need K %% 32 == 0, N %% 4 == 0, 16-byte aligned rows)",
               K, N);

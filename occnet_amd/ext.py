@@ -176,15 +176,43 @@ def sca_value_bytes():
     return 2 if SCA_VALUES == "f16" else 4
 
 
+def sca_pair_layout(value):
+    """(B*NC, S, M, D) fp16 value maps in row order -> the fused gather's pixel-PAIR order: a contiguous
+    (B*NC, S_pad, M, D) tensor, S_pad = S rounded up to even, whose memory is [b][pix >> 1][head][pix & 1][D] — the two
+    x-neighbours (2k, 2k+1) of one head share one 128-byte line (csrc/sca_fused.hip).  The value projection's fp16
+    outputs are written in this order directly; this helper is for tests and for maps that were projected in fp32."""
+    BN, S, M, D = value.shape
+    if S & 1:
+        value = torch.cat([value, value.new_zeros(BN, 1, M, D)], 1)
+    return value.reshape(BN, -1, 2, M, D).permute(0, 1, 3, 2, 4).contiguous().view(BN, -1, M, D)
+
+
+def sca_unpair_layout(value_pairs, S=None):
+    """Inverse of sca_pair_layout: pixel-pair-ordered (B*NC, S_pad, M, D) [or (B*NC * S_pad, M*D) with M = cols / 32]
+    -> row order, first S rows."""
+    BN, S_pad, M, D = value_pairs.shape
+    v = value_pairs.reshape(BN, S_pad // 2, M, 2, D).permute(0, 1, 3, 2, 4).reshape(BN, S_pad, M, D)
+    return v if S is None else v[:, :S]
+
+
 def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, ref_cam, vis_bits,
-                      num_heads, num_levels, num_points, order=None, stats=None):
+                      num_heads, num_levels, num_points, order=None, stats=None, value_layout="rows"):
     """Fused SCA gather.  value (B*NC, S, M, D) float32 or float16; offs (B, Nq, M*L*P*2) / logits (B, Nq, M*L*P) may
     be column slices of one wider Linear output (last dim contiguous); ref_cam (NC,B,Nq,Z,2);
-    vis_bits (B,Nq) int32.  -> slots (B, Nq, M*D) float32."""
+    vis_bits (B,Nq) int32.  -> slots (B, Nq, M*D) float32.
+    fp16 maps reach the kernel in pixel-pair order (sca_pair_layout): value_layout="pairs" says the tensor already is
+    (what value_proj_bf16 / value_proj_bf16_planes write into an fp16 output); "rows" (default) converts a row-ordered
+    fp16 tensor first (a copy: tests and the fp32-projection path only)."""
     half = value.dtype == torch.float16
     if half:
-        if not (value.is_cuda and value.is_contiguous()):
+        if value_layout not in ("rows", "pairs"):
+            raise OccAmdError(f"sca_fused_forward: unknown value_layout {value_layout!r}")
+        if not value.is_cuda:
             raise OccAmdError("sca_fused_forward: fp16 value must be a contiguous device tensor")
+        if value_layout == "rows":
+            value = sca_pair_layout(value)
+        if not value.is_contiguous() or value.shape[1] % 2:
+            raise OccAmdError("sca_fused_forward: pixel-pair fp16 value must be contiguous with an even number of rows")
     else:
         _need_cuda_f32("value", value)
     _need_cuda_f32("ref_cam", ref_cam)
@@ -452,7 +480,9 @@ def linear_pack_weight_bf16x3(weight):
 def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_rows, out_row0):
     """For every segment s (FPN level) and row m = g*rows_per_group[s] + i of a_list[s]:
         out[g*out_group_rows + out_row0[s] + i] = a_list[s][m] @ weight.T + group_bias[s][g % G]   (fp32 out),
-    all segments in one launch.  a_list[s] (M_s, K) bf16 with unit column stride (an NHWC feature map seen as
+    all segments in one launch.  An fp16 `out` is the fused SCA gather's operand and is written in its pixel-PAIR
+    order (sca_pair_layout: row r of a group's block lands at [r >> 1][head][r & 1][32]; out_group_rows must be even,
+    N a multiple of 32, rows contiguous) — read it back in row order with sca_unpair_layout.  a_list[s] (M_s, K) bf16 with unit column stride (an NHWC feature map seen as
     pixels x channels); weight (N, K) fp32 Linear weight (packed hi/lo once, cached); group_bias (S, G, N) fp32
     contiguous or None; out fp32 2-D (rows, N); rows_per_group / out_row0: one int per segment."""
     if isinstance(a_list, torch.Tensor):

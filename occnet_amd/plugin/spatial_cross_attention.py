@@ -244,16 +244,18 @@ class SpatialCrossAttention(BaseModule):
         if not isinstance(da, MSDeformableAttention3D):
             return None
         try:
+            layout = "rows"
             if hasattr(value, 'project'):      # LazyFeatures: bf16 NHWC maps, projected level by level
-                bs, l = value.bs, value.total
+                bs = value.bs
                 v = value.project(da.value_proj)
+                layout = "pairs" if v.dtype == torch.float16 else "rows"    # the projection's fp16 epilogue writes pairs
             else:
                 num_cams, l, bs, _ = value.shape
                 v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
                 v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
                 if ext.SCA_VALUES == "f16":
-                    v = v.half()
-            v = v.view(bs * self.num_cams, l, da.num_heads, -1)
+                    v = v.half()                                            # row order: the gather wrapper re-orders it
+            v = v.view(bs * self.num_cams, v.shape[1], da.num_heads, -1)
             w, b = da._qcat.get((da.sampling_offsets, da.attention_weights))
             lin = ext.linear(query.contiguous(), w, b)
             n_off = da.sampling_offsets.out_features
@@ -262,7 +264,7 @@ class SpatialCrossAttention(BaseModule):
             slots = ext.sca_fused_forward(v, spatial_shapes, level_start_index, lin[..., :n_off],
                                           lin[..., n_off:], reference_points_cam.float().contiguous(),
                                           vis_bits, da.num_heads, da.num_levels, da.num_points,
-                                          order=bev_order, stats=gather_stats)
+                                          order=bev_order, stats=gather_stats, value_layout=layout)
             return ext.linear(slots, self.output_proj.weight, self.output_proj.bias,
                               residual=query.contiguous(), ln=post_norm)
         except OccAmdUnsupported:

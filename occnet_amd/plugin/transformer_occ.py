@@ -162,16 +162,15 @@ class LazyFeatures:
                 # ONE launch for all layers: every block projects its rows with all the layers' weights, the feature
                 # maps are read from HBM once (occ_value_proj_bf16_planes); layer l's values are plane l
                 n = value_projs[0].weight.shape[0]
-                out = torch.empty((len(value_projs), self.bs * self.num_cam * self.total, n), device=self.rows[0].device,
-                                  dtype=torch.float16 if ext.SCA_VALUES == "f16" else torch.float32)
+                out = self._alloc(n, planes=len(value_projs))
                 ext.value_proj_bf16_planes(self.rows, [vp.weight for vp in value_projs], gbs, out,
-                                           rows_per_group=[h * wd for h, wd in self.hw], out_group_rows=self.total,
+                                           rows_per_group=[h * wd for h, wd in self.hw], out_group_rows=self.group_rows,
                                            out_row0=self.starts)
                 out.record_stream(main)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 for l, vp in enumerate(value_projs):
-                    self._pending[id(vp)] = (out[l].view(self.bs * self.num_cam, self.total, n), ev)
+                    self._pending[id(vp)] = (out[l].view(self.bs * self.num_cam, self.group_rows, n), ev)
             else:
                 for vp, gb in zip(value_projs, gbs):
                     out = self._launch(vp, gb)
@@ -205,18 +204,28 @@ class LazyFeatures:
             value_proj._occ_group_bias = hit
         return hit[1]
 
+    @property
+    def group_rows(self):
+        """rows of one camera's block in the projected maps: fp16 maps are stored in pixel PAIRS (ext.sca_pair_layout),
+        so an odd pixel count is padded by one (never written, never read: no sampling corner maps to it)"""
+        return self.total + (self.total & 1) if ext.SCA_VALUES == "f16" else self.total
+
+    def _alloc(self, n, planes=None):
+        rows = self.bs * self.num_cam * self.group_rows
+        return torch.empty((rows, n) if planes is None else (planes, rows, n), device=self.rows[0].device,
+                           dtype=torch.float16 if ext.SCA_VALUES == "f16" else torch.float32)
+
     def _launch(self, value_proj, gb):
         w = value_proj.weight
         n = w.shape[0]
-        out = torch.empty((self.bs * self.num_cam * self.total, n), device=w.device,
-                          dtype=torch.float16 if ext.SCA_VALUES == "f16" else torch.float32)
+        out = self._alloc(n)
         ext.value_proj_bf16(self.rows, w, gb, out, rows_per_group=[h * wd for h, wd in self.hw],
-                            out_group_rows=self.total, out_row0=self.starts)
-        return out.view(self.bs * self.num_cam, self.total, n)
+                            out_group_rows=self.group_rows, out_row0=self.starts)
+        return out.view(self.bs * self.num_cam, self.group_rows, n)
 
     def project(self, value_proj):
-        """value_proj(feat + embeds) for every camera pixel -> (bs*num_cam, sum hw, N) fp16 (fp32 with
-        OCC_SCA_VALUES=f32)."""
+        """value_proj(feat + embeds) for every camera pixel -> (bs*num_cam, sum hw, N) fp32 (OCC_SCA_VALUES=f32), or
+        (bs*num_cam, sum hw rounded up to even, N) fp16 in the gather's pixel-pair order (ext.sca_pair_layout)."""
         hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
         if hit is not None:
             torch.cuda.current_stream(hit[0].device).wait_event(hit[1])

@@ -342,7 +342,11 @@ def test_fp16_value_kernels_in_isolation():
     hw = [h * w for h, w in g['feat_shapes']]
     starts = [int(v) for v in start]
     o32 = torch.empty(NC * S, 256, device='cuda')
-    o16 = torch.empty(NC * S, 256, device='cuda', dtype=torch.float16)
+    Sp = S + (S & 1)                      # fp16 maps are written in pixel pairs: an even number of rows per camera
+    o16 = torch.zeros(NC * Sp, 256, device='cuda', dtype=torch.float16)
     ext.value_proj_bf16(rows, wgt, gb, o32, rows_per_group=hw, out_group_rows=S, out_row0=starts)
-    ext.value_proj_bf16(rows, wgt, gb, o16, rows_per_group=hw, out_group_rows=S, out_row0=starts)
-    assert torch.equal(o16, o32.half())
+    ext.value_proj_bf16(rows, wgt, gb, o16, rows_per_group=hw, out_group_rows=Sp, out_row0=starts)
+    back = ext.sca_unpair_layout(o16.view(NC, Sp, 8, 32), S)
+    assert torch.equal(back, o32.half().view(NC, S, 8, 32))
+    # and the pair order round-trips
+    assert torch.equal(ext.sca_unpair_layout(ext.sca_pair_layout(back), S), back)

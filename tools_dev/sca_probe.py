@@ -45,11 +45,13 @@ def timed(fn):
 
 ref = orig(v32, *a[1:], **k)
 ref16 = None
+v16 = ext.sca_pair_layout(v16)          # the kernel's operand order (what the value projection writes)
 for name, val in (("f32 values (sca_fused_kernel)", v32), ("f16 values (sca_fused_h_kernel, 4 waves, window 2)", v16)):
     stats = torch.zeros(2, dtype=torch.int64, device=dev)
-    out = orig(val, *a[1:], **k, stats=stats)
+    kk = dict(k, value_layout="pairs" if val is v16 else "rows")
+    out = orig(val, *a[1:], **kk, stats=stats)
     torch.cuda.synchronize()
-    med, mn = timed(lambda: orig(val, *a[1:], **k))
+    med, mn = timed(lambda: orig(val, *a[1:], **kk))
     if val is v16 and ref16 is None:
         ref16 = out
     print(json.dumps(dict(kernel=name, median_ms=med, min_ms=mn, maxdiff_vs_f32_kernel=float((out - ref).abs().max()),

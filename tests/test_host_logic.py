@@ -322,6 +322,31 @@ def test_folded_backbone_plan_on_cpu_matches_modules():
         assert rel < 2e-5, rel
 
 
+def test_sca_pixel_pair_layout_round_trip_and_addresses():
+    """ext.sca_pair_layout (host restatement of the order the value projection's fp16 epilogue writes and the fused gather
+    reads, csrc/sca_fused.hip): element (b, pix, head, d) lives at [b][pix >> 1][head][pix & 1][d]; odd pixel counts are
+    padded by one zero row; sca_unpair_layout inverts it."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(0)
+    for S in (6, 7, 31):
+        BN, M, D = 2, 8, 32
+        v = torch.randn(BN, S, M, D, generator=g).half()
+        p = ext.sca_pair_layout(v)
+        Sp = S + (S & 1)
+        assert p.shape == (BN, Sp, M, D) and p.is_contiguous()
+        flat = p.reshape(BN, -1)
+        for b, pix, m, d in ((0, 0, 0, 0), (1, S - 1, 7, 31), (0, 3, 2, 5), (1, 4, 5, 17)):
+            addr = ((pix >> 1) * M + m) * 2 * D + (pix & 1) * D + d
+            assert flat[b, addr] == v[b, pix, m, d]
+        if S & 1:       # the pad row is zero
+            assert float(ext.sca_unpair_layout(p)[:, S:].abs().max()) == 0.0
+        assert torch.equal(ext.sca_unpair_layout(p, S), v)
+        # the byte-offset transform the gather applies to a row-order offset pix * 512 (fp16, 8 heads x 32 channels)
+        for pix in range(S):
+            o = pix * 512
+            assert ((o & ~1023) | ((o >> 3) & 64)) == (pix >> 1) * 1024 + (pix & 1) * 64
+
+
 def test_lazy_features_only_for_backbone_format_inputs():
     from occnet_amd.plugin.transformer_occ import LazyFeatures
     f32 = [torch.zeros(1, 6, 256, 4, 5)]

@@ -676,7 +676,7 @@ def main():
             M, D = da.num_heads, da.embed_dims // da.num_heads
             S = M * da.num_levels * da.num_points
             n_layers = len(stats)
-            ev = ext.sca_value_bytes()                       # bytes per value element (4 = f32, 2 = f16 opt-in)
+            ev = ext.sca_value_bytes()                       # bytes per value element (2 = fp16 rows, the default; 4 = OCC_SCA_VALUES=f32)
             row_b = D * ev
             b_alg = [n_in * row_b + rows * S * 12 + rows * M * D * 4 for rows, n_in in stats]
             mean_ms = sum(sca) / len(sca)
@@ -713,9 +713,9 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "frac_hbm": (traffic / sec / HBM_PEAK) if traffic else None,
                 "frac_l1": l1_bytes / sec / L1_PEAK, "l1_bytes_per_launch": l1_bytes, "l1_peak_gbps": L1_PEAK / 1e9,
-                # what the TA/L1 path DELIVERS for this access shape (8 lanes x 16 B per 128-byte row, 16 loads in
-                # flight, 3 waves/SIMD) on cache-resident rows: 0.39 rows/clk/CU = 50 B/clk/CU, measured with
-                # tools_dev/ta_probe.hip (profiles/r02_ta_row_gather_probe_3waves.txt); rows from HBM: 0.091
+                # what the TA/L1 path DELIVERED in tools_dev/ta_probe.hip for 16-byte-per-lane row gathers on
+                # cache-resident rows (one 1 KB wave load per ~21 clocks = 50 B/clk/CU whatever the lanes ask for,
+                # profiles/r02_ta_row_gather_probe_3waves.txt; rows from HBM: 0.091 rows/clk/CU)
                 "l1_measured_peak_gbps": L1_MEASURED_PEAK / 1e9, "frac_l1_measured": l1_bytes / sec / L1_MEASURED_PEAK,
                 "compulsory_bytes": compulsory,
                 "compulsory_frac_hbm": compulsory / sec / HBM_PEAK,

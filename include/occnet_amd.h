@@ -269,6 +269,45 @@ int occ_linear_bf16x3_f32(const float* a1, int64_t lda1, int K1, const float* a2
                           const float* ln_beta, float ln_eps, float* out, int64_t ldo, int M, int N,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Row-local Linear CHAINS of a BEVFormerLayer, one launch each (csrc/linear_chain_x3.hip; bf16x3 arithmetic as
+ * occ_linear_bf16x3_f32; embed_dims = 256).  A 64-row block keeps the LayerNorm'd tile in LDS as the next Linear's
+ * operand; the weights of all stages of a chain are ONE buffer in consumption order:
+ *   occ_linear_chain_pack_bf16x3(W (N, K)) -> for every 256-row group of W: [K/16][8 tiles][hi | lo][lane][8 bf16]
+ *   (rows beyond N are zero), occ_linear_chain_packed_bytes(N, K) bytes; the caller concatenates the packs of the stages.
+ *
+ * occ_linear_ln_chain_bf16x3_f32 — "program A":   y = LayerNorm(a.W1^T + b1 + residual)      (N = K = 256)
+ *                                                 z = act2(y.W2^T + b2)                      (n2 columns, n2 % 32 == 0)
+ *   w_chain = [pack(W1) | pack(W2)], bias_chain = [b1 (256) | b2 zero-padded to ceil(n2 / 256) * 256].
+ *   Call sites replaced: TemporalSelfAttention.output_proj + residual (temporal_self_attention.py:266-272) + the layer's
+ *   first LayerNorm (encoder.py:377-404 `norm`) + MSDeformableAttention3D.sampling_offsets | attention_weights
+ *   (spatial_cross_attention.py:334-341) — z is what occ_sca_fused_forward_* reads.
+ *
+ * occ_encoder_ffn_chain_bf16x3_f32 — "program B": x2 = LayerNorm1(a.Wo^T + bo + residual)
+ *                                                 y  = LayerNorm2(relu(x2.W1^T + b1).W2^T + b2 + x2)   (hidden = 512)
+ *                                   optional tail: zq = y.Wq^T + q_term (nq <= 256 columns, nq % 64 == 0),
+ *                                                  zv = y.Wv^T + bv     (256 columns)
+ *   w_chain = [pack(Wo) | pack(W1) | pack(W2) | pack(Wq) | pack(Wv)] (the last two only with a tail),
+ *   bias_chain = [bo | b1 (512) | b2 | 256 zeros | bv].  zq == zv == NULL: no tail.  `y` doubles as scratch (x2 is parked
+ *   in the block's own rows before y is written).
+ *   Call sites replaced: SpatialCrossAttention.output_proj + residual (spatial_cross_attention.py:173-175), the second
+ *   LayerNorm, mmcv FFN (custom_base_transformer_layer.py:144-160) + the third LayerNorm, and — tail — the NEXT layer's
+ *   TemporalSelfAttention sampling_offsets | attention_weights on cat([query, query + pos]) (temporal_self_attention.py
+ *   :197-209; without history Wq = W[:, :256] + W[:, 256:], q_term = pos.W[:, 256:]^T + b) and its value_proj (:198).
+ */
+int64_t occ_linear_chain_packed_bytes(int N, int K);
+int occ_linear_chain_pack_bf16x3(const float* weight, void* packed, int N, int K, void* stream);
+int occ_linear_ln_chain_bf16x3_f32(const float* a, int64_t lda, const float* residual, int64_t ldres,
+                                   const void* w_chain, const float* bias_chain, const float* ln_gamma,
+                                   const float* ln_beta, float ln_eps, float* y, int64_t ldy, float* z,
+                                   int64_t ldz, int n2, int act2, int M, void* stream);
+int occ_encoder_ffn_chain_bf16x3_f32(const float* a, int64_t lda, const float* residual, int64_t ldres,
+                                     const void* w_chain, const float* bias_chain, const float* ln1_gamma,
+                                     const float* ln1_beta, float ln1_eps, const float* ln2_gamma,
+                                     const float* ln2_beta, float ln2_eps, float* y, int64_t ldy,
+                                     const float* q_term, int64_t ldq_term, float* zq, int64_t ldzq, int nq,
+                                     float* zv, int64_t ldzv, int M, void* stream);
+
 /* Training path of SpatialCrossAttention, query side (csrc/sca_prep.hip; reference spatial_cross_attention.py:338-373
  * applied to the per-camera rebatched rows): from proj (B, Q, >= 3*M*L*P) = [sampling_offsets | attention_weights]
  * Linear outputs per BEV query, row_to_query (R) (-1 = padded row) and the rebatched reference points ref_rb

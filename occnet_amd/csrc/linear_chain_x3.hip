@@ -1,0 +1,484 @@
+// Row-local Linear CHAINS of a BEVFormerLayer in one launch each, on the gfx950 bf16 matrix cores ("bf16x3", the
+// arithmetic of linear_bf16x3.hip: hi/lo bf16 split of both operands, three MFMAs per product, f32 accumulation).
+//
+// Every dense op between two gathers of the encoder acts on the same rows (reference: encoder.py:377-404,
+// spatial_cross_attention.py:173-175,334-341, temporal_self_attention.py:197-209,266-272, mmcv FFN).  As seven separate
+// launches per layer they move 882 MB per layer and run as one partial wave of blocks each, so load, MFMA and store
+// phases add up instead of overlapping (profiles/r03_linear_ablation.txt).  Two programs replace six of the seven:
+//
+//   program A (after the TSA gather):   y = LN(a.Wo^T + bo + res)                            -> x1
+//                                       z = y.Wq^T + bq        (sampling_offsets | attention_weights of the SCA, N = 768)
+//   program B (after the SCA gather):   x2 = LN(a.Wo^T + bo + res)
+//                                       h  = relu(x2.W1^T + b1)                              (512 hidden columns)
+//                                       y  = LN(h.W2^T + b2 + x2)                            -> x3, the layer output
+//                                       z  = [y.Wsum^T + term | y.Wv^T + bv]                 (optional: the NEXT layer's TSA
+//                                            query Linears with the positional term folded in, and its value projection)
+//
+// A block owns 64 rows for ALL columns of every stage.  The stage input is a 64 x 256 tile in LDS as hi and lo bf16
+// planes (64 KB, 16-byte pieces XOR-swizzled by row: conflict-free ds_read_b128 of the MFMA fragments); the four waves
+// each own 64 of the 256 output columns of a pass (2 x 2 accumulator tiles) and stream their hi/lo weight fragments
+// from L2 through a 4-deep register ring that runs ahead ACROSS stage boundaries (the weights of all stages are one
+// buffer in consumption order, 16 KB per k-step), so a stage's first MFMA never waits for a weight.  The MFMAs are
+// issued transposed (weights as the row operand): a lane ends up with 4 consecutive columns of one row per register
+// quad, which is at once (i) the float4 of the row-major global store, (ii) the 8-byte half of a 16-byte LDS piece of
+// the next stage's operand tile and (iii) a layout in which bias / residual are accumulator INITIAL VALUES and the
+// LayerNorm statistics are a lane-local sum + one shuffle + a 4-wave exchange through 2 KB of LDS.  The LayerNorm'd
+// tile never leaves the CU between the Linears; the FFN's hidden activation exists only as accumulator registers and
+// as the LDS tile (half of it at a time).  x2, the FFN's residual, is parked in the block's own rows of `y` (written
+// and re-read by the same lane, overwritten by x3 at the end).  Two blocks per CU (66 KB of LDS, <= 256 registers):
+// one block's epilogues run under the other's MFMAs.
+#include "common.h"
+
+namespace occ {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kChRows = 64;                       // rows per block
+constexpr int kChPlane = kChRows * 512;           // one bf16 plane of the operand tile: 64 rows x 256 k
+constexpr int kChRed = 2 * kChPlane;              // LayerNorm exchange: float[2][4][64]
+constexpr int kChLds = kChRed + 2 * 4 * kChRows * 4;
+constexpr int kChStepBytes = 16384;               // weights of one k-step (16 k) of one 256-column pass: 8 tiles x (hi, lo) x 1 KB
+
+struct ChainArgs {
+  const float* a; long lda;                       // stage input rows (M, 256)
+  const float* res; long ldres;                   // residual of the first LayerNorm (M, 256)
+  const uint4* wp; unsigned wbytes;               // chain weights in consumption order
+  const float* bias;                              // chain biases, 256 per pass (layout: see the launchers)
+  const float* ln1_g; const float* ln1_b; float eps1;
+  const float* ln2_g; const float* ln2_b; float eps2;
+  float* y; long ldy;                             // LayerNorm output rows (A: x1, B: x3 — and B's x2 parking space)
+  int npass;                                      // 256-column passes of the tail stage
+  int act;                                        // 1: ReLU on the tail outputs
+  const float* term; long ldterm; int term_cols;  // added to tail columns < term_cols (or NULL)
+  float* z1; long ldz1; int n1;                   // tail columns [0, n1) -> z1
+  float* z2; long ldz2; int off2; int n2;         // tail columns [off2, off2 + n2) -> z2 (column - off2)
+  int M;
+};
+
+__device__ __forceinline__ void ch_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2_rne(x0, x1);
+  lo = pack_bf16x2_rne(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
+// (N rows of a (N, K) f32 weight) -> chain order: for every 256-row group g: packed[g][K/16][8 tiles][hi | lo][lane][8 bf16]
+// (rows beyond N are zero), i.e. 16 KB per k-step: exactly what one flat ring step of a pass fetches
+__global__ void linear_chain_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, long n_elem,
+                                         int K, int N) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one (hi, lo) pair per thread
+  if (idx >= n_elem) return;
+  const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+  const long rest = idx >> 9;                                       // (group, k-step, tile)
+  const int tile = (int)(rest & 7);
+  const long gk = rest >> 3;
+  const int KS = K / 16;
+  const int ks = (int)(gk % KS), grp = (int)(gk / KS);
+  const int n = grp * 256 + tile * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
+  unsigned short hi = 0, lo = 0;
+  if (n < N) {
+    const float x = w[(long)n * K + k];
+    hi = bf16_rne(x);
+    lo = bf16_rne(x - __uint_as_float((unsigned)hi << 16));
+  }
+  unsigned short* dst = packed + ((rest * 2) * 64 + lane) * 8 + j;
+  dst[0] = hi;
+  dst[64 * 8] = lo;
+}
+
+// ---- building blocks (all indices compile-time: the arrays stay in registers) ------------------------------------------
+
+#define OCC_CH_LOAD(SLOT, STEP)                                                                    \
+  {                                                                                                \
+    const int so = (STEP) * kChStepBytes;                                                          \
+    w[SLOT][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so, 0);                             \
+    w[SLOT][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 1024, so, 0);                      \
+    w[SLOT][2] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 2048, so, 0);                      \
+    w[SLOT][3] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 3072, so, 0);                      \
+  }
+
+// operand fragments of k-step KS: piece 2 KS + kb of rows vi and 32 + vi, both planes (slot of piece p in row r = p ^ (r & 31))
+#define OCC_CH_AFRAG(BUF, KS)                                                                      \
+  {                                                                                                \
+    asm volatile("" : "+v"(abase));                                                                \
+    const char* ap = tl + (abase ^ (unsigned)((KS) * 32));                                         \
+    af[BUF][0][0] = *reinterpret_cast<const bf16x8*>(ap);                                          \
+    af[BUF][1][0] = *reinterpret_cast<const bf16x8*>(ap + 32 * 512);                               \
+    af[BUF][0][1] = *reinterpret_cast<const bf16x8*>(ap + kChPlane);                               \
+    af[BUF][1][1] = *reinterpret_cast<const bf16x8*>(ap + kChPlane + 32 * 512);                    \
+  }
+
+// one 256-column pass over the K = 256 tile: 16 k-steps, flat ring steps step0 .. step0 + 15 (requests run 3 ahead)
+__device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][4], const __amdgpu_buffer_rsrc_t wr,
+                                         const int wv, const int step0, const char* tl, unsigned& abase) {
+  bf16x8 af[2][2][2];                               // [buffer][row tile][plane hi, lo]
+  OCC_CH_AFRAG(0, 0)
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    OCC_CH_LOAD((ks + 3) & 3, step0 + ks + 3)
+    OCC_CH_AFRAG((ks + 1) & 1, (ks + 1) & 15)
+    // D[column][row] (weights as the row operand); small terms first, term-major over the four accumulators
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t]), af[ks & 1][rt][1],
+                                                             acc[rt][t], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t + 1]), af[ks & 1][rt][0],
+                                                             acc[rt][t], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t]), af[ks & 1][rt][0],
+                                                             acc[rt][t], 0, 0, 0);
+    // pin the software pipeline (hipcc otherwise sinks every ring request down to its use: load, vmcnt(0), MFMA)
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // ring requests of step s + 3
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // operand fragments of step s + 1
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  }
+}
+
+// accumulators <- bias[column] (+ src[row][column]): register 4 q + i of tile (rt, t) = row rt * 32 + vi, column
+// c0 + 32 t + 8 q + 4 kb + i.  `rows` = this lane's two (clamped) global rows.
+__device__ __forceinline__ void ch_init(f32x16 (&acc)[2][2], const float* __restrict__ bias, const float* src, long ld,
+                                        const long (&rows)[2], int c0, int kb) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + 32 * t + 8 * q + 4 * kb;
+      const float4 b = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src) s = *reinterpret_cast<const float4*>(src + rows[rt] * ld + c);
+        acc[rt][t][4 * q + 0] = s.x + b.x;
+        acc[rt][t][4 * q + 1] = s.y + b.y;
+        acc[rt][t][4 * q + 2] = s.z + b.z;
+        acc[rt][t][4 * q + 3] = s.w + b.w;
+      }
+    }
+}
+
+// register quads -> the operand tile (hi / lo planes): piece 8 wave + 4 t + q of row rt * 32 + vi, half kb
+__device__ __forceinline__ void ch_to_tile(const f32x16 (&acc)[2][2], char* tl, int wave, int vi, int kb) {
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned h01, h23, l01, l23;
+        ch_split2(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1], h01, l01);
+        ch_split2(acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3], h23, l23);
+        char* p = tl + (rt * 32 + vi) * 512 + (((8 * wave + 4 * t + q) ^ vi) & 31) * 16 + kb * 8;
+        *reinterpret_cast<uint2*>(p) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(p + kChPlane) = make_uint2(l01, l23);
+      }
+}
+
+// LayerNorm over the 256 columns of every row, in place in the accumulators (two passes: mean, then squared deviations)
+__device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, const float* __restrict__ g,
+                                             const float* __restrict__ b, float eps, int wave, int vi, int kb) {
+  float s[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += acc[rt][t][r];
+    v += __shfl_xor(v, 32);
+    s[rt] = v;
+    if (kb == 0) red[wave * kChRows + rt * 32 + vi] = v;
+  }
+  __syncthreads();          // also: every wave is past its k loop, the operand tile may be rewritten after this point
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int r = rt * 32 + vi;
+    const float mean = ((red[r] + red[kChRows + r]) + (red[2 * kChRows + r] + red[3 * kChRows + r])) * (1.f / 256.f);
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float d = acc[rt][t][k] - mean;
+        acc[rt][t][k] = d;
+        v = fmaf(d, d, v);
+      }
+    v += __shfl_xor(v, 32);
+    if (kb == 0) red[4 * kChRows + wave * kChRows + r] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int r = rt * 32 + vi;
+    const float* rr = red + 4 * kChRows;
+    s[rt] = rsqrtf(((rr[r] + rr[kChRows + r]) + (rr[2 * kChRows + r] + rr[3 * kChRows + r])) * (1.f / 256.f) + eps);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = wave * 64 + 32 * t + 8 * q + 4 * kb;
+      const float4 gv = *reinterpret_cast<const float4*>(g + c);
+      const float4 bv = *reinterpret_cast<const float4*>(b + c);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[rt][t][4 * q + 0] = fmaf(acc[rt][t][4 * q + 0] * s[rt], gv.x, bv.x);
+        acc[rt][t][4 * q + 1] = fmaf(acc[rt][t][4 * q + 1] * s[rt], gv.y, bv.y);
+        acc[rt][t][4 * q + 2] = fmaf(acc[rt][t][4 * q + 2] * s[rt], gv.z, bv.z);
+        acc[rt][t][4 * q + 3] = fmaf(acc[rt][t][4 * q + 3] * s[rt], gv.w, bv.w);
+      }
+    }
+}
+
+// register quads -> row-major global rows (column c0 + 32 t + 8 q + 4 kb of row rows[rt]); rows beyond M are skipped
+__device__ __forceinline__ void ch_store(const f32x16 (&acc)[2][2], float* dst, long ld, const long (&rows)[2],
+                                         const bool (&live)[2], int c0, int kb, bool t0_on, bool t1_on, bool relu) {
+  // c0 = column of `dst` that receives the wave's first column
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1], acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]);
+        if (relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (live[rt] && (t == 0 ? t0_on : t1_on))
+          *reinterpret_cast<float4*>(dst + rows[rt] * ld + c0 + 32 * t + 8 * q + 4 * kb) = v;
+      }
+}
+
+__device__ __forceinline__ void ch_relu(f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][t][r] = fmaxf(acc[rt][t][r], 0.f);
+}
+
+// PROG 0: program A, PROG 1: program B (file header)
+template <int PROG>
+__global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char tl[];
+  float* red = reinterpret_cast<float*>(tl + kChRed);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int vi = lane & 31, kb = lane >> 5;
+  const long m0 = (long)blockIdx.x * kChRows;
+  const int M = p.M;
+
+  // weight ring: slot (step & 3) = {hi tile 0, lo tile 0, hi tile 1, lo tile 1} of the wave's 64 columns of flat step
+  occ_u32x4 w[4][4];
+  const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(p.wp, p.wbytes);
+  const int wv = (wave * 4096) + lane * 16;
+  OCC_CH_LOAD(0, 0)
+  OCC_CH_LOAD(1, 1)
+  OCC_CH_LOAD(2, 2)
+
+  // this lane's two rows (clamped for the loads)
+  long rows[2];
+  bool live[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const long r = m0 + rt * 32 + vi;
+    live[rt] = r < M;
+    rows[rt] = live[rt] ? r : (long)M - 1;
+  }
+
+  // ---- stage input: 64 rows x 256 f32 -> hi / lo planes (a wave instruction = one whole row, 1 KB) ----------------------
+  {
+    float4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = j * 4 + wave;
+      long m = m0 + row;
+      if (m >= M) m = (long)M - 1;
+      v[j] = *reinterpret_cast<const float4*>(p.a + m * p.lda + lane * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = j * 4 + wave;
+      unsigned h01, h23, l01, l23;
+      ch_split2(v[j].x, v[j].y, h01, l01);
+      ch_split2(v[j].z, v[j].w, h23, l23);
+      char* q = tl + row * 512 + (((lane >> 1) ^ row) & 31) * 16 + (lane & 1) * 8;
+      *reinterpret_cast<uint2*>(q) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(q + kChPlane) = make_uint2(l01, l23);
+    }
+  }
+  unsigned abase = (unsigned)(vi * 512 + ((kb ^ vi) & 31) * 16);
+
+  // ---- stage 1: output_proj + bias + residual -> LayerNorm -------------------------------------------------------------
+  f32x16 acc[2][2];
+  ch_init(acc, p.bias, p.res, p.ldres, rows, wave * 64, kb);
+  __syncthreads();
+  ch_kloop(acc, w, wr, wv, 0, tl, abase);
+  ch_layernorm(acc, red, p.ln1_g, p.ln1_b, p.eps1, wave, vi, kb);
+  ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false);       // A: x1.  B: x2 parked in its own rows of y
+  ch_to_tile(acc, tl, wave, vi, kb);
+  __syncthreads();
+  int step = 16;
+  int bias_off = 256;
+
+  if constexpr (PROG == 1) {
+    // ---- FFN: both hidden halves from the x2 tile (registers), then the second Linear over the two K halves ------------
+    f32x16 ha[2][2], hb[2][2];
+    ch_init(ha, p.bias + 256, nullptr, 0, rows, wave * 64, kb);
+    ch_kloop(ha, w, wr, wv, 16, tl, abase);
+    ch_relu(ha);
+    ch_init(hb, p.bias + 512, nullptr, 0, rows, wave * 64, kb);
+    ch_kloop(hb, w, wr, wv, 32, tl, abase);
+    ch_relu(hb);
+    __syncthreads();                                // every wave has read the x2 tile for the last time
+    ch_to_tile(ha, tl, wave, vi, kb);
+    __syncthreads();                                // (also keeps the x2 reload below from being hoisted over ha's last use)
+    ch_init(acc, p.bias + 768, p.y, p.ldy, rows, wave * 64, kb);       // b2 + x2 (this lane's own stores)
+    ch_kloop(acc, w, wr, wv, 48, tl, abase);
+    __syncthreads();
+    ch_to_tile(hb, tl, wave, vi, kb);
+    __syncthreads();
+    ch_kloop(acc, w, wr, wv, 64, tl, abase);
+    ch_layernorm(acc, red, p.ln2_g, p.ln2_b, p.eps2, wave, vi, kb);
+    ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false);     // x3
+    if (p.npass > 0) {
+      ch_to_tile(acc, tl, wave, vi, kb);
+      __syncthreads();
+    }
+    step = 80;
+    bias_off = 1024;
+  }
+
+  // ---- tail stage: npass passes of 256 columns over the LayerNorm'd tile -----------------------------------------------
+#pragma unroll 1
+  for (int ps = 0; ps < p.npass; ++ps) {
+    const int c0 = ps * 256 + wave * 64;            // the wave's first tail column of this pass
+    const bool tm = p.term != nullptr && c0 < p.term_cols;          // term_cols is a multiple of 64: whole waves
+    ch_init(acc, p.bias + bias_off, tm ? p.term : nullptr, p.ldterm, rows, c0, kb);
+    ch_kloop(acc, w, wr, wv, step + ps * 16, tl, abase);
+    // the wave's two 32-column tiles go to z1 (columns < n1) or z2 (columns in [off2, off2 + n2)) or nowhere (padding)
+    const int ca = c0, cb = c0 + 32;
+    const bool a1 = ca < p.n1, b1 = cb < p.n1;
+    const bool a2 = ca >= p.off2 && ca < p.off2 + p.n2, b2 = cb >= p.off2 && cb < p.off2 + p.n2;
+    if (a1 || b1) ch_store(acc, p.z1, p.ldz1, rows, live, c0, kb, a1, b1, p.act != 0);
+    if (a2 || b2) ch_store(acc, p.z2, p.ldz2, rows, live, c0 - p.off2, kb, a2, b2, p.act != 0);
+  }
+}
+
+#undef OCC_CH_LOAD
+#undef OCC_CH_AFRAG
+
+}  // namespace occ
+
+extern "C" int64_t occ_linear_chain_packed_bytes(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return (int64_t)((N + 255) / 256) * 256 * K * 4;
+}
+
+extern "C" int occ_linear_chain_pack_bf16x3(const float* weight, void* packed, int N, int K, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(weight && packed, "linear_chain_pack_bf16x3: null pointer argument");
+  OCC_CHECK_ARG(N > 0 && K > 0, "linear_chain_pack_bf16x3: bad dimension");
+  if (K % 16) {
+    set_error("linear_chain_pack_bf16x3: K=%d is not a multiple of 16", K);
+    return OCC_E_UNSUPPORTED;
+  }
+  const long n = (long)((N + 255) / 256) * 256 * K;       // (hi, lo) pairs incl. the zero rows
+  hipLaunchKernelGGL(linear_chain_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), weight, reinterpret_cast<unsigned short*>(packed), n, K, N);
+  OCC_CHECK_LAUNCH("linear_chain_pack_bf16x3");
+  return OCC_OK;
+}
+
+namespace {
+template <int PROG>
+int chain_launch(const occ::ChainArgs& args, hipStream_t st, const char* what) {
+  using namespace occ;
+  auto kern = linear_chain_x3_kernel<PROG>;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kChLds);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
+    return OCC_E_LAUNCH;
+  }
+  const unsigned blocks = (unsigned)((args.M + kChRows - 1) / kChRows);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), kChLds, st, args);
+  OCC_CHECK_LAUNCH(what);
+  return OCC_OK;
+}
+}  // namespace
+
+extern "C" int occ_linear_ln_chain_bf16x3_f32(const float* a, int64_t lda, const float* residual, int64_t ldres,
+                                              const void* w_chain, const float* bias_chain, const float* ln_gamma,
+                                              const float* ln_beta, float ln_eps, float* y, int64_t ldy, float* z,
+                                              int64_t ldz, int n2, int act2, int M, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(a && residual && w_chain && bias_chain && ln_gamma && ln_beta && y && z,
+                "linear_ln_chain: null pointer argument");
+  OCC_CHECK_ARG(M > 0 && n2 > 0 && (act2 == 0 || act2 == 1), "linear_ln_chain: bad dimension (M=%d n2=%d act2=%d)", M, n2, act2);
+  OCC_CHECK_ARG(lda >= 256 && ldres >= 256 && ldy >= 256 && ldz >= n2, "linear_ln_chain: leading dimension smaller than the row");
+  if (n2 % 32 || lda % 4 || ldres % 4 || ldy % 4 || ldz % 4) {
+    set_error("linear_ln_chain: n2=%d must be a multiple of 32 and all rows 16-byte aligned", n2);
+    return OCC_E_UNSUPPORTED;
+  }
+  ChainArgs g = {};
+  g.a = a; g.lda = lda; g.res = residual; g.ldres = ldres;
+  g.npass = (n2 + 255) / 256;
+  g.wp = reinterpret_cast<const uint4*>(w_chain);
+  g.wbytes = (unsigned)(16 + 16 * g.npass) * (unsigned)kChStepBytes;
+  g.bias = bias_chain;
+  g.ln1_g = ln_gamma; g.ln1_b = ln_beta; g.eps1 = ln_eps;
+  g.y = y; g.ldy = ldy;
+  g.act = act2;
+  g.z1 = z; g.ldz1 = ldz; g.n1 = n2;
+  g.z2 = nullptr; g.ldz2 = 0; g.off2 = 0; g.n2 = 0;
+  g.M = M;
+  return chain_launch<0>(g, reinterpret_cast<hipStream_t>(stream), "linear_ln_chain");
+}
+
+extern "C" int occ_encoder_ffn_chain_bf16x3_f32(const float* a, int64_t lda, const float* residual, int64_t ldres,
+                                                const void* w_chain, const float* bias_chain, const float* ln1_gamma,
+                                                const float* ln1_beta, float ln1_eps, const float* ln2_gamma,
+                                                const float* ln2_beta, float ln2_eps, float* y, int64_t ldy,
+                                                const float* q_term, int64_t ldq_term, float* zq, int64_t ldzq, int nq,
+                                                float* zv, int64_t ldzv, int M, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(a && residual && w_chain && bias_chain && ln1_gamma && ln1_beta && ln2_gamma && ln2_beta && y,
+                "encoder_ffn_chain: null pointer argument");
+  OCC_CHECK_ARG(M > 0, "encoder_ffn_chain: bad dimension (M=%d)", M);
+  const bool tail = zq != nullptr || zv != nullptr;
+  OCC_CHECK_ARG(!tail || (zq && zv && nq > 0 && nq <= 256), "encoder_ffn_chain: the tail needs zq, zv and 0 < nq <= 256");
+  OCC_CHECK_ARG(lda >= 256 && ldres >= 256 && ldy >= 256 && (!tail || (ldzq >= nq && ldzv >= 256 && (!q_term || ldq_term >= nq))),
+                "encoder_ffn_chain: leading dimension smaller than the row");
+  if (lda % 4 || ldres % 4 || ldy % 4 || (tail && (nq % 64 || ldzq % 4 || ldzv % 4 || ldq_term % 4))) {
+    set_error("encoder_ffn_chain: nq=%d must be a multiple of 64 and all rows 16-byte aligned", nq);
+    return OCC_E_UNSUPPORTED;
+  }
+  ChainArgs g = {};
+  g.a = a; g.lda = lda; g.res = residual; g.ldres = ldres;
+  g.npass = tail ? 2 : 0;
+  g.wp = reinterpret_cast<const uint4*>(w_chain);
+  g.wbytes = (unsigned)(80 + 16 * g.npass) * (unsigned)kChStepBytes;
+  g.bias = bias_chain;
+  g.ln1_g = ln1_gamma; g.ln1_b = ln1_beta; g.eps1 = ln1_eps;
+  g.ln2_g = ln2_gamma; g.ln2_b = ln2_beta; g.eps2 = ln2_eps;
+  g.y = y; g.ldy = ldy;
+  g.act = 0;
+  g.term = tail ? q_term : nullptr; g.ldterm = ldq_term; g.term_cols = nq;
+  g.z1 = zq; g.ldz1 = ldzq; g.n1 = tail ? nq : 0;
+  g.z2 = zv; g.ldz2 = ldzv; g.off2 = 256; g.n2 = tail ? 256 : 0;
+  g.M = M;
+  return chain_launch<1>(g, reinterpret_cast<hipStream_t>(stream), "encoder_ffn_chain");
+}

@@ -639,6 +639,168 @@ def linear(a, weight, bias=None, a2=None, a2_add=None, act=None, residual=None, 
     return out
 
 
+# ---- row-local Linear chains (csrc/linear_chain_x3.hip) ---------------------------------------------------------------
+# OCC_LINEAR_CHAIN=0 keeps the encoder on one launch per Linear (the round-3 path); the chain kernels need
+# embed_dims = 256 and the bf16x3 precision mode
+LINEAR_CHAIN = os.environ.get("OCC_LINEAR_CHAIN", "1") != "0"
+_CHAIN_PACKS = {}       # identity key of the stage weights / biases -> (sources kept alive, packed buffer)
+
+
+def _ident(t):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape))
+
+
+def linear_chain_pack(weights):
+    """[(N_i, K_i) float32 weights in consumption order] -> one int16 buffer: every weight packed by
+    occ_linear_chain_pack_bf16x3 (256-row groups, 16 KB per k-step, zero rows beyond N), concatenated.  Cached on the
+    weights' identities (address, version) and the cache epoch."""
+    key = ("w",) + tuple(_ident(w) for w in weights) + (str(weights[0].device), cache_epoch())
+    hit = _CHAIN_PACKS.get(key)
+    if hit is not None:
+        return hit[1]
+    lib = _lib.lib()
+    lib.occ_linear_chain_packed_bytes.restype = ctypes.c_int64
+    sizes = []
+    for w in weights:
+        _need_cuda_f32("weight", w)
+        if w.dim() != 2 or w.shape[1] % 16:
+            raise OccAmdUnsupported("linear_chain_pack: weights must be (N, K) with K % 16 == 0")
+        sizes.append(int(lib.occ_linear_chain_packed_bytes(i32(w.shape[0]), i32(w.shape[1]))) // 2)
+    packed = torch.empty(sum(sizes), dtype=torch.int16, device=weights[0].device)
+    off = 0
+    with torch.cuda.device(packed.device):
+        for w, n in zip(weights, sizes):
+            rc = lib.occ_linear_chain_pack_bf16x3(ptr(w), ctypes.c_void_p(packed.data_ptr() + off * 2), i32(w.shape[0]),
+                                                  i32(w.shape[1]), stream_ptr(packed.device))
+            _lib.check(rc, "linear_chain_pack_bf16x3")
+            off += n
+    if len(_CHAIN_PACKS) >= 128:
+        _CHAIN_PACKS.pop(next(iter(_CHAIN_PACKS)))
+    _CHAIN_PACKS[key] = (list(weights), packed)      # the sources stay referenced: their addresses cannot be recycled
+    return packed
+
+
+def _chain_bias(parts, device):
+    """[(bias tensor or None, padded length)] -> one float32 vector (zeros where a bias is None / beyond its length)."""
+    key = ("b",) + tuple((_ident(b), n) for b, n in parts) + (str(device), cache_epoch())
+    hit = _CHAIN_PACKS.get(key)
+    if hit is not None:
+        return hit[1]
+    out = torch.zeros(sum(n for _, n in parts), dtype=torch.float32, device=device)
+    off = 0
+    for b, n in parts:
+        if b is not None:
+            _need_cuda_f32("bias", b)
+            out[off:off + b.numel()] = b.detach().reshape(-1)
+        off += n
+    if len(_CHAIN_PACKS) >= 128:
+        _CHAIN_PACKS.pop(next(iter(_CHAIN_PACKS)))
+    _CHAIN_PACKS[key] = ([b for b, _ in parts], out)
+    return out
+
+
+def _ln_params(ln, n=256):
+    if isinstance(ln, torch.nn.LayerNorm):
+        if tuple(ln.normalized_shape) != (n,) or ln.weight is None or ln.bias is None:
+            raise OccAmdUnsupported("linear chain: LayerNorm must be affine over the 256 outputs")
+        g, b, eps = ln.weight, ln.bias, ln.eps
+    else:
+        g, b, eps = ln
+    _need_cuda_f32("ln_gamma", g)
+    _need_cuda_f32("ln_beta", b)
+    if g.numel() != n or b.numel() != n:
+        raise OccAmdUnsupported("linear chain: LayerNorm must span the 256 outputs")
+    return g, b, float(eps)
+
+
+def _chain_rows(name, t):
+    t_, M, K, ld = _rows2d(name, t)
+    if K != 256:
+        raise OccAmdUnsupported(f"linear chain: {name} must have 256 columns (embed_dims = 256), got {K}")
+    return t_, M, ld
+
+
+def _chain_time(flops):
+    if _TIMING is not None and (_TIMING_ONLY is None or 'linear' in _TIMING_ONLY):
+        _TIMING.setdefault('linear_flops', []).append(float(flops))
+
+
+def linear_ln_chain(a, residual, w1, b1, ln, w2, b2, act2=None):
+    """Program A of csrc/linear_chain_x3.hip in ONE launch:  y = LayerNorm(a @ w1^T + b1 + residual),
+    z = act2(y @ w2^T + b2).  a, residual (…, 256) float32 device tensors; w1 (256, 256); w2 (n2, 256) with
+    n2 % 32 == 0; ln = nn.LayerNorm(256) or (gamma, beta, eps); act2 None | 'relu'.  -> (y (…, 256), z (…, n2)).
+    Raises OccAmdUnsupported for other shapes (the caller keeps occ `linear`)."""
+    if LINEAR_PRECISION != "bf16x3":
+        raise OccAmdUnsupported("linear chain: bf16x3 precision mode only")
+    a_, M, lda = _chain_rows("a", a)
+    r_, Mr, ldres = _chain_rows("residual", residual)
+    if Mr != M:
+        raise OccAmdError("linear_ln_chain: residual differs in rows")
+    if tuple(w1.shape) != (256, 256) or w2.dim() != 2 or w2.shape[1] != 256 or w2.shape[0] % 32:
+        raise OccAmdUnsupported("linear_ln_chain: w1 must be (256, 256) and w2 (n2 % 32 == 0, 256)")
+    if act2 not in (None, 'relu'):
+        raise OccAmdError("linear_ln_chain: act2 must be None or 'relu'")
+    g, b, eps = _ln_params(ln)
+    n2 = w2.shape[0]
+    wp = linear_chain_pack([w1, w2])
+    bias = _chain_bias([(b1, 256), (b2, (n2 + 255) // 256 * 256)], a.device)
+    y = torch.empty(a.shape[:-1] + (256,), dtype=torch.float32, device=a.device)
+    z = torch.empty(a.shape[:-1] + (n2,), dtype=torch.float32, device=a.device)
+    _chain_time(2.0 * M * 256 * (256 + n2))
+    with torch.cuda.device(a.device), _timed('linear'):
+        rc = _lib.lib().occ_linear_ln_chain_bf16x3_f32(
+            ptr(a_), i64(lda), ptr(r_), i64(ldres), ptr(wp), ptr(bias), ptr(g), ptr(b), f32(eps), ptr(y), i64(256),
+            ptr(z), i64(n2), i32(n2), i32(1 if act2 == 'relu' else 0), i32(M), stream_ptr(a.device))
+    _lib.check(rc, "linear_ln_chain")
+    return y, z
+
+
+def encoder_ffn_chain(a, residual, wo, bo, ln1, w1, b1, w2, b2, ln2, tail=None):
+    """Program B of csrc/linear_chain_x3.hip in ONE launch:
+        x2 = LayerNorm1(a @ wo^T + bo + residual);  y = LayerNorm2(relu(x2 @ w1^T + b1) @ w2^T + b2 + x2)
+    and, with tail = (wq (nq, 256), q_term (…, nq) or None, wv (256, 256), bv):  zq = y @ wq^T + q_term,
+    zv = y @ wv^T + bv.  a, residual (…, 256); wo (256, 256); w1 (512, 256); w2 (256, 512).
+    -> (y, zq, zv)  (zq = zv = None without a tail).  Raises OccAmdUnsupported for other shapes."""
+    if LINEAR_PRECISION != "bf16x3":
+        raise OccAmdUnsupported("linear chain: bf16x3 precision mode only")
+    a_, M, lda = _chain_rows("a", a)
+    r_, Mr, ldres = _chain_rows("residual", residual)
+    if Mr != M:
+        raise OccAmdError("encoder_ffn_chain: residual differs in rows")
+    if tuple(wo.shape) != (256, 256) or tuple(w1.shape) != (512, 256) or tuple(w2.shape) != (256, 512):
+        raise OccAmdUnsupported("encoder_ffn_chain: needs output_proj (256, 256) and a 256 -> 512 -> 256 FFN")
+    g1, be1, eps1 = _ln_params(ln1)
+    g2, be2, eps2 = _ln_params(ln2)
+    weights = [wo, w1, w2]
+    biases = [(bo, 256), (b1, 512), (b2, 256)]
+    zq = zv = q_term = None
+    nq, ldq = 0, 0
+    if tail is not None:
+        wq, q_term, wv, bv = tail
+        nq = wq.shape[0]
+        if wq.dim() != 2 or wq.shape[1] != 256 or nq > 256 or nq % 64 or tuple(wv.shape) != (256, 256):
+            raise OccAmdUnsupported("encoder_ffn_chain: tail needs wq (nq <= 256, nq % 64 == 0, 256) and wv (256, 256)")
+        if q_term is not None:
+            _, Mq, _, ldq = _rows2d("q_term", q_term, nq)
+            if Mq != M:
+                raise OccAmdError("encoder_ffn_chain: q_term differs in rows")
+        weights += [wq, wv]
+        biases += [(None, 256), (bv, 256)]
+        zq = torch.empty(a.shape[:-1] + (nq,), dtype=torch.float32, device=a.device)
+        zv = torch.empty(a.shape[:-1] + (256,), dtype=torch.float32, device=a.device)
+    wp = linear_chain_pack(weights)
+    bias = _chain_bias(biases, a.device)
+    y = torch.empty(a.shape[:-1] + (256,), dtype=torch.float32, device=a.device)
+    _chain_time(2.0 * M * 256 * (256 + 512 + 512 + (nq + 256 if tail is not None else 0)))
+    with torch.cuda.device(a.device), _timed('linear'):
+        rc = _lib.lib().occ_encoder_ffn_chain_bf16x3_f32(
+            ptr(a_), i64(lda), ptr(r_), i64(ldres), ptr(wp), ptr(bias), ptr(g1), ptr(be1), f32(eps1), ptr(g2),
+            ptr(be2), f32(eps2), ptr(y), i64(256), ptr(q_term), i64(ldq), ptr(zq), i64(nq), i32(nq), ptr(zv),
+            i64(256), i32(M), stream_ptr(a.device))
+    _lib.check(rc, "encoder_ffn_chain")
+    return y, zq, zv
+
+
 def linear_wgrad(dy, x, with_bias=True):
     """Weight / bias gradient of out = x @ W^T + b on the bf16x3 matrix-core kernel (csrc/linear_wgrad.hip):
     dW (N, K) = dy^T @ x, db (N) = dy.sum(rows).  dy (…, N), x (…, K) float32 device tensors with the same leading

@@ -243,6 +243,54 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
         return query
 
 
+    def forward_chain(self, query, value, bev_pos=None, ref_2d=None, bev_h=None, bev_w=None,
+                      reference_points_cam=None, spatial_shapes=None, level_start_index=None, prev_bev=None,
+                      tsa_pre=None, next_tsa=None, **kwargs):
+        """Inference form of the whole layer on TWO Linear launches (csrc/linear_chain_x3.hip) around the two fused
+        gathers: [TSA gather] -> output_proj + LN + the SCA's query Linears -> [SCA gather] -> output_proj + LN + FFN +
+        LN (+ the NEXT layer's TSA query Linears and value projection when `next_tsa` is given and there is no
+        history BEV).  `tsa_pre` = that tail of the previous layer.  -> (output, tail for the next layer or None);
+        raises OccAmdUnsupported when a shape has no chain kernel (the caller then runs forward())."""
+        tsa, sca = self.attentions
+        ffn = self.ffns[0]
+        bs = query.shape[0]
+        if not tsa._fusable(ref_2d):
+            raise ext.OccAmdUnsupported("forward_chain: TSA shape without a fused gather")
+        q = query.contiguous()
+        attn = tsa.fused_gather(q, prev_bev, bev_pos, ref_2d, bev_h, bev_w, kwargs.get('bev_order'), pre=tsa_pre)
+        wq, bq = sca.query_linear_operands()
+        x1, lin = ext.linear_ln_chain(attn, q, tsa.output_proj.weight, tsa.output_proj.bias, self.norms[0], wq, bq)
+        slots = sca.fused_gather(lin, value, reference_points_cam, kwargs.get('bev_mask'), spatial_shapes,
+                                 level_start_index, kwargs.get('vis_bits'), kwargs.get('bev_order'),
+                                 kwargs.get('gather_stats'))
+        tail = None
+        if next_tsa is not None and prev_bev is None and bs == 1 and bev_pos is not None:
+            tail = next_tsa.chain_tail(bev_pos)
+        fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
+        out, zq, zv = ext.encoder_ffn_chain(slots, x1, sca.output_proj.weight, sca.output_proj.bias, self.norms[1],
+                                            fc1.weight, fc1.bias, fc2.weight, fc2.bias, self.norms[2], tail=tail)
+        return out, (None if tail is None else (zq, zv))
+
+
+def _chain_layer_ok(layer):
+    """True when `layer` is the base-config BEVFormerLayer the chain kernels cover: post-norm TSA -> LN -> SCA -> LN ->
+    FFN -> LN with embed_dims 256 and a plain 256 -> 512 -> 256 ReLU FFN."""
+    from .bricks import FFN
+    from .spatial_cross_attention import SpatialCrossAttention
+    from .temporal_self_attention import TemporalSelfAttention
+    if not isinstance(layer, BEVFormerLayer) or not layer.use_fused or layer.embed_dims != 256:
+        return False
+    if tuple(layer.operation_order) != ('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm'):
+        return False
+    tsa, sca = layer.attentions
+    ffn = layer.ffns[0]
+    return (type(tsa) is TemporalSelfAttention and type(sca) is SpatialCrossAttention and tsa.use_fused
+            and sca.use_fused and all(isinstance(n, nn.LayerNorm) for n in layer.norms)
+            and isinstance(ffn, FFN) and ffn.num_fcs == 2 and ffn.add_identity
+            and isinstance(ffn.layers[0][1], nn.ReLU) and isinstance(ffn.dropout_layer, nn.Identity)
+            and ffn.feedforward_channels == 512 and sca.query_linear_operands() is not None)
+
+
 class TransformerLayerSequence(BaseModule):
     """mmcv TransformerLayerSequence: `layers` = num_layers deep copies of the layer cfg."""
 
@@ -403,13 +451,33 @@ class BEVFormerEncoder(TransformerLayerSequence):
             vps = [getattr(getattr(a, 'deformable_attention', None), 'value_proj', None)
                    for layer in self.layers for a in layer.attentions]
             value.prefetch([vp for vp in vps if vp is not None])
+        # inference: the row-local Linear chains of a layer as two launches (BEVFormerLayer.forward_chain)
+        chain = (ext.LINEAR_CHAIN and ext.LINEAR_PRECISION == "bf16x3" and not self.training and not args
+                 and bev_query.dtype == torch.float32 and value is not None
+                 and not (torch.is_grad_enabled() and (bev_query.requires_grad or any(
+                     p.requires_grad for p in self.parameters()))))
+        chain_ok = [chain and _chain_layer_ok(layer) for layer in self.layers]
+        tsa_pre = None
         try:
             for lid, layer in enumerate(self.layers):
-                output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
-                               ref_3d=ref_3d, bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
-                               level_start_index=level_start_index,
-                               reference_points_cam=reference_points_cam, bev_mask=bev_mask,
-                               prev_bev=prev_bev, **extra, **kwargs)
+                output = None
+                if chain_ok[lid]:
+                    nxt = self.layers[lid + 1].attentions[0] if lid + 1 < len(self.layers) and chain_ok[lid + 1] else None
+                    try:
+                        output, tsa_pre = layer.forward_chain(
+                            bev_query, value, bev_pos=bev_pos, ref_2d=hybird_ref_2d, bev_h=bev_h, bev_w=bev_w,
+                            reference_points_cam=reference_points_cam, spatial_shapes=spatial_shapes,
+                            level_start_index=level_start_index, prev_bev=prev_bev, tsa_pre=tsa_pre, next_tsa=nxt,
+                            bev_mask=bev_mask, gather_stats=kwargs.get('gather_stats'), **extra)
+                    except ext.OccAmdUnsupported:
+                        output, tsa_pre = None, None
+                if output is None:
+                    tsa_pre = None
+                    output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
+                                   ref_3d=ref_3d, bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
+                                   level_start_index=level_start_index,
+                                   reference_points_cam=reference_points_cam, bev_mask=bev_mask,
+                                   prev_bev=prev_bev, **extra, **kwargs)
                 bev_query = output
                 if self.return_intermediate:
                     intermediate.append(output)

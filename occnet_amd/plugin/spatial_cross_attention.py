@@ -233,6 +233,39 @@ class SpatialCrossAttention(BaseModule):
                                      da.num_heads, da.num_levels, da.num_points, order=order,
                                      stats=stats)
 
+    def query_linear_operands(self):
+        """(weight (n_off + n_att, C), bias) of the two query-side Linears as one GEMM, or None when the deformable
+        attention is not the MSDeformableAttention3D the fused gather implements."""
+        da = self.deformable_attention
+        if not isinstance(da, MSDeformableAttention3D):
+            return None
+        return da._qcat.get((da.sampling_offsets, da.attention_weights))
+
+    def fused_gather(self, lin, value, reference_points_cam=None, bev_mask=None, spatial_shapes=None,
+                     level_start_index=None, vis_bits=None, bev_order=None, gather_stats=None):
+        """Value projection + fused SCA gather for the query-side Linear outputs `lin` (bs, nq, n_off + n_att)
+        -> slots (bs, nq, C) BEFORE output_proj.  Raises OccAmdUnsupported."""
+        da = self.deformable_attention
+        layout = "rows"
+        if hasattr(value, 'project'):      # LazyFeatures: bf16 NHWC maps, projected level by level
+            bs = value.bs
+            v = value.project(da.value_proj)
+            layout = "pairs" if v.dtype == torch.float16 else "rows"    # the projection's fp16 epilogue writes pairs
+        else:
+            num_cams, l, bs, _ = value.shape
+            v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
+            v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
+            if ext.SCA_VALUES == "f16":
+                v = v.half()                                            # row order: the gather wrapper re-orders it
+        v = v.view(bs * self.num_cams, v.shape[1], da.num_heads, -1)
+        n_off = da.sampling_offsets.out_features
+        if vis_bits is None:
+            vis_bits = pack_vis_bits(bev_mask)
+        return ext.sca_fused_forward(v, spatial_shapes, level_start_index, lin[..., :n_off],
+                                     lin[..., n_off:], reference_points_cam.float().contiguous(),
+                                     vis_bits, da.num_heads, da.num_levels, da.num_points,
+                                     order=bev_order, stats=gather_stats, value_layout=layout)
+
     def forward_fused(self, query, value, reference_points_cam=None, bev_mask=None,
                       spatial_shapes=None, level_start_index=None, vis_bits=None, bev_order=None,
                       gather_stats=None, post_norm=None):
@@ -240,31 +273,13 @@ class SpatialCrossAttention(BaseModule):
         pixels, the query-side Linears, output_proj + residual + the layer's following LayerNorm as one
         epilogue) around the fused gather.  -> LayerNorm(output_proj(slots) + query), or None when a
         shape has no fused kernel."""
-        da = self.deformable_attention
-        if not isinstance(da, MSDeformableAttention3D):
+        wb = self.query_linear_operands()
+        if wb is None:
             return None
         try:
-            layout = "rows"
-            if hasattr(value, 'project'):      # LazyFeatures: bf16 NHWC maps, projected level by level
-                bs = value.bs
-                v = value.project(da.value_proj)
-                layout = "pairs" if v.dtype == torch.float16 else "rows"    # the projection's fp16 epilogue writes pairs
-            else:
-                num_cams, l, bs, _ = value.shape
-                v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
-                v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
-                if ext.SCA_VALUES == "f16":
-                    v = v.half()                                            # row order: the gather wrapper re-orders it
-            v = v.view(bs * self.num_cams, v.shape[1], da.num_heads, -1)
-            w, b = da._qcat.get((da.sampling_offsets, da.attention_weights))
-            lin = ext.linear(query.contiguous(), w, b)
-            n_off = da.sampling_offsets.out_features
-            if vis_bits is None:
-                vis_bits = pack_vis_bits(bev_mask)
-            slots = ext.sca_fused_forward(v, spatial_shapes, level_start_index, lin[..., :n_off],
-                                          lin[..., n_off:], reference_points_cam.float().contiguous(),
-                                          vis_bits, da.num_heads, da.num_levels, da.num_points,
-                                          order=bev_order, stats=gather_stats, value_layout=layout)
+            lin = ext.linear(query.contiguous(), wb[0], wb[1])
+            slots = self.fused_gather(lin, value, reference_points_cam, bev_mask, spatial_shapes,
+                                      level_start_index, vis_bits, bev_order, gather_stats)
             return ext.linear(slots, self.output_proj.weight, self.output_proj.bias,
                               residual=query.contiguous(), ln=post_norm)
         except OccAmdUnsupported:

@@ -98,23 +98,25 @@ class TemporalSelfAttention(BaseModule):
             self._fold_key, self._fold_src, self._fold_val = key, (w, b, query_pos), (w_sum, pos_term)
         return self._fold_val
 
-    def forward_fused(self, query, value=None, query_pos=None, reference_points=None, bev_h=None,
-                      bev_w=None, bev_order=None, post_norm=None):
-        """Inference form with every dense op on the MFMA Linear kernel: the cat([value, query+pos])
-        feeding the offset/weight Linears is read as two K segments, output_proj + residual + the
-        layer's following LayerNorm are one epilogue.  Same arguments/semantics as forward() (value
-        None = no history).  -> LayerNorm(output_proj(attn) + query), or None when a shape has no
-        fused kernel (the caller then takes forward())."""
-        if not (self.batch_first and self.num_levels == 1 and self.num_bev_queue == 2
-                and reference_points is not None and reference_points.shape[-1] == 2):
-            return None
+    def _fusable(self, reference_points):
+        return (self.batch_first and self.num_levels == 1 and self.num_bev_queue == 2
+                and reference_points is not None and reference_points.shape[-1] == 2)
+
+    def fused_gather(self, query, value=None, query_pos=None, reference_points=None, bev_h=None, bev_w=None,
+                     bev_order=None, pre=None):
+        """The gather half of forward_fused: both query Linears, the value projection and the fused TSA gather
+        -> (bs, num_query, C) BEFORE output_proj.  `pre` = (lin, v): the two Linear outputs already computed by the
+        previous layer's chain kernel (ext.encoder_ffn_chain tail; no-history case only).  Raises OccAmdUnsupported."""
         bs, num_query, c = query.shape
         shared = value is None
         if shared and bs > 1:   # interleaved (b0,b0,b1,b1,..) stack, as in forward()
             value = torch.stack([query, query], 1).reshape(bs * 2, num_query, c)
             shared = False
-        value_first = query if shared else value[:bs]
-        try:
+        n_off = self.sampling_offsets.out_features
+        if pre is not None and shared:
+            lin, v = pre
+        else:
+            value_first = query if shared else value[:bs]
             w, b = self._qcat.get((self.sampling_offsets, self.attention_weights))
             if shared and query_pos is not None:
                 # no history: cat([q, q + pos]) @ W^T + b = q @ (Wa + Wb)^T + (pos @ Wb^T + b); the
@@ -124,14 +126,32 @@ class TemporalSelfAttention(BaseModule):
             else:
                 lin = ext.linear(value_first.contiguous(), w, b, a2=query.contiguous(),
                                  a2_add=None if query_pos is None else query_pos.contiguous())
-            n_off = self.sampling_offsets.out_features
             vsrc = (value_first if shared else value).contiguous()
             v = ext.linear(vsrc, self.value_proj.weight, self.value_proj.bias)
-            v = v.view(v.shape[0], num_query, self.num_heads, -1)
-            out = ext.tsa_fused_forward(v, lin[..., :n_off], lin[..., n_off:],
-                                        reference_points.float().contiguous(), bev_h, bev_w,
-                                        self.num_heads, self.num_points, shared_queue=shared,
-                                        order=bev_order)
+        v = v.view(v.shape[0], num_query, self.num_heads, -1)
+        return ext.tsa_fused_forward(v, lin[..., :n_off], lin[..., n_off:],
+                                     reference_points.float().contiguous(), bev_h, bev_w,
+                                     self.num_heads, self.num_points, shared_queue=shared,
+                                     order=bev_order)
+
+    def chain_tail(self, query_pos):
+        """Operands with which the PREVIOUS layer's chain kernel computes this layer's query Linears and value
+        projection (no history, bs = 1): (w_sum (n, C), pos_term (bs, nq, n), value_proj.weight, value_proj.bias)."""
+        w, b = self._qcat.get((self.sampling_offsets, self.attention_weights))
+        w_sum, pos_term = self._folded_query_weights(w, b, query_pos)
+        return w_sum, pos_term, self.value_proj.weight, self.value_proj.bias
+
+    def forward_fused(self, query, value=None, query_pos=None, reference_points=None, bev_h=None,
+                      bev_w=None, bev_order=None, post_norm=None):
+        """Inference form with every dense op on the MFMA Linear kernel: the cat([value, query+pos])
+        feeding the offset/weight Linears is read as two K segments, output_proj + residual + the
+        layer's following LayerNorm are one epilogue.  Same arguments/semantics as forward() (value
+        None = no history).  -> LayerNorm(output_proj(attn) + query), or None when a shape has no
+        fused kernel (the caller then takes forward())."""
+        if not self._fusable(reference_points):
+            return None
+        try:
+            out = self.fused_gather(query, value, query_pos, reference_points, bev_h, bev_w, bev_order)
             return ext.linear(out, self.output_proj.weight, self.output_proj.bias,
                               residual=query.contiguous(), ln=post_norm)
         except OccAmdUnsupported:

@@ -380,3 +380,91 @@ def test_x3linear_module_is_a_state_dict_compatible_linear():
         y0 = m(x)
     assert y0.grad_fn is None
     assert float((y - y0).abs().max()) < 1e-3
+
+
+# ---- row-local Linear chains (csrc/linear_chain_x3.hip) vs the float64 oracle of the same op sequence ---------------
+
+def _chain_inputs(g, M, n2):
+    s = (1.0 / 256) ** 0.5
+    t = dict(a=_mk(g, M, 256), res=_mk(g, M, 256), w1=_mk(g, 256, 256, scale=s), b1=_mk(g, 256, scale=0.1),
+             ln_g=torch.rand(256, generator=g) + 0.5, ln_b=_mk(g, 256, scale=0.1),
+             w2=_mk(g, n2, 256, scale=s), b2=_mk(g, n2, scale=0.1))
+    return t
+
+
+@pytest.mark.parametrize("M,n2,act2", [(64, 768, None), (1, 256, None), (77, 768, None), (4099, 768, None),
+                                       (333, 512, 'relu'), (130, 192, None), (40000, 768, None)])
+def test_linear_ln_chain_matches_oracle(M, n2, act2):
+    """Program A: LayerNorm(a W1^T + b1 + res) and act2(y W2^T + b2) — asymmetric random operands, ragged last
+    block, one / two / three tail passes, a tail narrower than a pass."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(61)
+    t = _chain_inputs(g, M, n2)
+    d = {k: v.double() for k, v in t.items()}
+    y_ref = odense.linear_chain(d['a'], d['w1'], d['b1'], residual=d['res'], ln=(d['ln_g'], d['ln_b'], 1e-5))
+    z_ref = odense.linear_chain(y_ref, d['w2'], d['b2'], act=act2)
+    c = {k: v.cuda() for k, v in t.items()}
+    y, z = ext.linear_ln_chain(c['a'], c['res'], c['w1'], c['b1'], (c['ln_g'], c['ln_b'], 1e-5), c['w2'], c['b2'],
+                               act2=act2)
+    torch.cuda.synchronize()
+    dy = float((y.cpu().double() - y_ref).abs().max())
+    dz = float((z.cpu().double() - z_ref).abs().max())
+    print(f"chain A M={M} n2={n2}: max|y - oracle| = {dy:.3e}, max|z - oracle| = {dz:.3e}")
+    assert y.shape == (M, 256) and z.shape == (M, n2)
+    assert dy < 2e-4 and dz < 2e-4
+    # and against the one-launch-per-Linear path it replaces (same arithmetic class)
+    y1 = ext.linear(c['a'], c['w1'], c['b1'], residual=c['res'], ln=(c['ln_g'], c['ln_b'], 1e-5))
+    z1 = ext.linear(y1, c['w2'], c['b2'], act=act2)
+    assert float((y - y1).abs().max()) < 1e-4 and float((z - z1).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("M,tail,term", [(64, False, False), (77, True, True), (1, True, False), (4099, True, True),
+                                         (40000, True, True), (40000, False, False)])
+def test_encoder_ffn_chain_matches_oracle(M, tail, term):
+    """Program B: output_proj + LN, FFN (512 hidden) + LN, and the optional tail (192 query columns with a per-row
+    term + 256 value columns)."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(62)
+    s = (1.0 / 256) ** 0.5
+    t = dict(a=_mk(g, M, 256), res=_mk(g, M, 256), wo=_mk(g, 256, 256, scale=s), bo=_mk(g, 256, scale=0.1),
+             g1=torch.rand(256, generator=g) + 0.5, be1=_mk(g, 256, scale=0.1),
+             w1=_mk(g, 512, 256, scale=s), b1=_mk(g, 512, scale=0.1),
+             w2=_mk(g, 256, 512, scale=(1.0 / 512) ** 0.5), b2=_mk(g, 256, scale=0.1),
+             g2=torch.rand(256, generator=g) + 0.5, be2=_mk(g, 256, scale=0.1),
+             wq=_mk(g, 192, 256, scale=s), qt=_mk(g, M, 192), wv=_mk(g, 256, 256, scale=s), bv=_mk(g, 256, scale=0.1))
+    d = {k: v.double() for k, v in t.items()}
+    x2 = odense.linear_chain(d['a'], d['wo'], d['bo'], residual=d['res'], ln=(d['g1'], d['be1'], 1e-5))
+    h = odense.linear_chain(x2, d['w1'], d['b1'], act='relu')
+    y_ref = odense.linear_chain(h, d['w2'], d['b2'], residual=x2, ln=(d['g2'], d['be2'], 1e-5))
+    c = {k: v.cuda() for k, v in t.items()}
+    tl = (c['wq'], c['qt'] if term else None, c['wv'], c['bv']) if tail else None
+    y, zq, zv = ext.encoder_ffn_chain(c['a'], c['res'], c['wo'], c['bo'], (c['g1'], c['be1'], 1e-5), c['w1'], c['b1'],
+                                      c['w2'], c['b2'], (c['g2'], c['be2'], 1e-5), tail=tl)
+    torch.cuda.synchronize()
+    dy = float((y.cpu().double() - y_ref).abs().max())
+    print(f"chain B M={M} tail={tail}: max|y - oracle| = {dy:.3e}")
+    assert y.shape == (M, 256) and dy < 3e-4
+    if tail:
+        zq_ref = odense.linear_chain(y_ref, d['wq'], None, residual=d['qt'] if term else None)
+        zv_ref = odense.linear_chain(y_ref, d['wv'], d['bv'])
+        dq = float((zq.cpu().double() - zq_ref).abs().max())
+        dv = float((zv.cpu().double() - zv_ref).abs().max())
+        print(f"   max|zq - oracle| = {dq:.3e}, max|zv - oracle| = {dv:.3e}")
+        assert zq.shape == (M, 192) and zv.shape == (M, 256) and dq < 3e-4 and dv < 3e-4
+    else:
+        assert zq is None and zv is None
+
+
+def test_linear_chain_rejects_other_shapes():
+    from occnet_amd import ext
+    from occnet_amd._lib import OccAmdUnsupported
+    a = torch.zeros(8, 128, device='cuda')
+    w = torch.zeros(128, 128, device='cuda')
+    with pytest.raises(OccAmdUnsupported):
+        ext.linear_ln_chain(a, a, w, None, (torch.ones(128, device='cuda'), torch.zeros(128, device='cuda'), 1e-5), w, None)
+    a = torch.zeros(8, 256, device='cuda')
+    w = torch.zeros(256, 256, device='cuda')
+    ln = (torch.ones(256, device='cuda'), torch.zeros(256, device='cuda'), 1e-5)
+    with pytest.raises(OccAmdUnsupported):      # FFN hidden != 512
+        ext.encoder_ffn_chain(a, a, w, None, ln, torch.zeros(1024, 256, device='cuda'), None,
+                              torch.zeros(256, 1024, device='cuda'), None, ln)

@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""Time the row-local Linear chains of one encoder layer (M = 40 000): the chain kernels (csrc/linear_chain_x3.hip)
+against the one-launch-per-Linear sequence they replace, same operands, ABAB in one process.
+usage: python tools_dev/chain_probe.py"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from occnet_amd import ext   # noqa: E402
+
+dev = torch.device("cuda", 0)
+M = int(os.environ.get("LIN_M", "40000"))
+g = torch.Generator().manual_seed(0)
+R = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+s256, s512 = 256 ** -0.5, 512 ** -0.5
+a, res = R(M, 256), R(M, 256)
+wo, bo = R(256, 256, sc=s256), R(256, sc=0.1)
+ln1 = (torch.rand(256, generator=g).to(dev) + 0.5, R(256, sc=0.1), 1e-5)
+ln2 = (torch.rand(256, generator=g).to(dev) + 0.5, R(256, sc=0.1), 1e-5)
+wq, bq = R(768, 256, sc=s256), R(768, sc=0.1)
+w1, b1 = R(512, 256, sc=s256), R(512, sc=0.1)
+w2, b2 = R(256, 512, sc=s512), R(256, sc=0.1)
+wt, qt = R(192, 256, sc=s256), R(M, 192)
+wv, bv = R(256, 256, sc=s256), R(256, sc=0.1)
+
+
+def timed(fn, n=30):
+    for _ in range(4):
+        o = fn()
+    evs = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); o = fn(); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = sorted(x.elapsed_time(y) for x, y in evs)
+    return ms[len(ms) // 2] * 1e3, o
+
+
+def sep_a():
+    y = ext.linear(a, wo, bo, residual=res, ln=ln1)
+    return y, ext.linear(y, wq, bq)
+
+
+def sep_b(tail=True):
+    x2 = ext.linear(a, wo, bo, residual=res, ln=ln1)
+    h = ext.linear(x2, w1, b1, act='relu')
+    y = ext.linear(h, w2, b2, residual=x2, ln=ln2)
+    if not tail:
+        return y, None, None
+    return y, ext.linear(y, wt, None, residual=qt), ext.linear(y, wv, bv)
+
+
+def md(x, y):
+    return float((x - y).abs().max())
+
+
+for rnd in range(2):
+    t_sa, o_sa = timed(sep_a)
+    t_ca, o_ca = timed(lambda: ext.linear_ln_chain(a, res, wo, bo, ln1, wq, bq))
+    t_sb, o_sb = timed(sep_b)
+    t_cb, o_cb = timed(lambda: ext.encoder_ffn_chain(a, res, wo, bo, ln1, w1, b1, w2, b2, ln2, tail=(wt, qt, wv, bv)))
+    t_sb0, o_sb0 = timed(lambda: sep_b(False))
+    t_cb0, o_cb0 = timed(lambda: ext.encoder_ffn_chain(a, res, wo, bo, ln1, w1, b1, w2, b2, ln2))
+    fa = 2.0 * M * 256 * (256 + 768) * 3
+    fb = 2.0 * M * 256 * (256 + 512 + 512 + 192 + 256) * 3
+    print(f"round {rnd}: program A  separate (2 launches) {t_sa:7.1f} us   chain {t_ca:7.1f} us ({fa / t_ca / 1e6:6.0f} TFLOP/s bf16 issued)"
+          f"   max|dy| {md(o_sa[0], o_ca[0]):.1e} max|dz| {md(o_sa[1], o_ca[1]):.1e}", flush=True)
+    print(f"round {rnd}: program B  separate (5 launches) {t_sb:7.1f} us   chain {t_cb:7.1f} us ({fb / t_cb / 1e6:6.0f} TFLOP/s bf16 issued)"
+          f"   max|dy| {md(o_sb[0], o_cb[0]):.1e} max|dzq| {md(o_sb[1], o_cb[1]):.1e} max|dzv| {md(o_sb[2], o_cb[2]):.1e}", flush=True)
+    print(f"round {rnd}: program B without tail  separate (3 launches) {t_sb0:7.1f} us   chain {t_cb0:7.1f} us   max|dy| {md(o_sb0[0], o_cb0[0]):.1e}",
+          flush=True)

@@ -280,16 +280,14 @@ def gather_stats(model, stepper):
     from occnet_amd.plugin import SpatialCrossAttention
     scas = [m for m in model.modules() if isinstance(m, SpatialCrossAttention)]
     stats = [torch.zeros(2, dtype=torch.int64, device=stepper.device) for _ in scas]
-    originals = [(s.forward, s.forward_fused) for s in scas]
-    wrap = lambda f, st: (lambda *a, **k: f(*a, **{**k, 'gather_stats': st}))
-    for s, st, (f, ff) in zip(scas, stats, originals):
-        s.forward, s.forward_fused = wrap(f, st), wrap(ff, st)
+    for s, st in zip(scas, stats):
+        s.gather_stats = st
     try:
         stepper()
         torch.cuda.synchronize()
     finally:
         for s in scas:
-            del s.forward, s.forward_fused      # drop the instance attributes: class methods again
+            s.gather_stats = None
     da = scas[0].deformable_attention
     return [tuple(int(v) for v in st.cpu().tolist()) for st in stats], da
 

@@ -136,14 +136,17 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
         acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t]), af[ks & 1][rt][0],
                                                              acc[rt][t], 0, 0, 0);
     // pin the software pipeline (hipcc otherwise sinks every ring request down to its use: load, vmcnt(0), MFMA)
+    // (the operand fragments of step s + 1 are requested in the FIRST half of step s: the next step opens with the
+    // MFMAs that read the fragment requested last)
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // operand fragments of step s + 1
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // ring requests of step s + 3
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // operand fragments of step s + 1
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
   }
 }
 

@@ -212,6 +212,9 @@ class SpatialCrossAttention(BaseModule):
         self.output_proj = X3Linear(embed_dims, embed_dims)
         self.batch_first = batch_first
         self.use_fused = True          # flip to force the unfused (reference-shaped) HIP path
+        # optional int64[2] device tensor: the fused gather adds (visible rows, in-map corners) of every launch to it
+        # (bench.py's roofline leg, tests) — an attribute, so it reaches the gather on every fused path
+        self.gather_stats = None
         self.init_weight()
 
     def init_weight(self):
@@ -228,6 +231,8 @@ class SpatialCrossAttention(BaseModule):
         offs, logits = da.query_linears(query.float())
         if vis_bits is None:
             vis_bits = pack_vis_bits(bev_mask)
+        if stats is None:
+            stats = self.gather_stats
         return ext.sca_fused_forward(v, spatial_shapes, level_start_index, offs, logits,
                                      reference_points_cam.float().contiguous(), vis_bits,
                                      da.num_heads, da.num_levels, da.num_points, order=order,
@@ -246,6 +251,8 @@ class SpatialCrossAttention(BaseModule):
         """Value projection + fused SCA gather for the query-side Linear outputs `lin` (bs, nq, n_off + n_att)
         -> slots (bs, nq, C) BEFORE output_proj.  Raises OccAmdUnsupported."""
         da = self.deformable_attention
+        if gather_stats is None:
+            gather_stats = self.gather_stats
         layout = "rows"
         if hasattr(value, 'project'):      # LazyFeatures: bf16 NHWC maps, projected level by level
             bs = value.bs

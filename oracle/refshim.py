@@ -4,9 +4,10 @@ The reference hot path is pure Python but imports mmcv / mmdet / mmdet3d / torch
 top level and its package __init__ chain JIT-compiles a CUDA extension, so it cannot
 be imported as a package here.  This shim
   * registers stub modules for those third-party names in sys.modules (registries, BaseModule,
-    init helpers, no-op fp16 decorators, FFN / ConvModule / LearnedPositionalEncoding / losses taken
-    from occnet_amd.plugin.bricks — restatements of mmcv/mmdet behaviour, SURVEY.md Appendix B.3-B.5 —
-    and `multi_scale_deformable_attn_pytorch` from oracle/msda.py, Appendix B.1);
+    init helpers, no-op fp16 decorators, FFN / ConvModule / LearnedPositionalEncoding / losses from
+    oracle/thirdparty.py — the oracle's own restatements of mmcv/mmdet behaviour, SURVEY.md Appendix B.3-B.5,
+    independent of the product package since round 4 — and `multi_scale_deformable_attn_pytorch` from
+    oracle/msda.py, Appendix B.1);
   * creates empty package objects for `projects.mmdet3d_plugin...` whose __path__ points into
     /root/reference, so `importlib` executes the reference's module FILES (spatial_cross_attention.py,
     temporal_self_attention.py, encoder.py, custom_base_transformer_layer.py, transformer_occ.py,
@@ -46,9 +47,8 @@ def _pkg(name, path):
 
 def install():
     """Install the stubs and return a namespace with the reference classes + builders."""
-    from occnet_amd.plugin import bricks as pb
-    from occnet_amd.plugin.config import ConfigDict
-    from occnet_amd.plugin.registry import Registry, build_from_cfg
+    from oracle import thirdparty as pb          # NOT the product's bricks: the product must not define the golden
+    from oracle.thirdparty import ConfigDict, Registry, build_from_cfg
     from oracle import model as om
     from oracle.msda import multi_scale_deformable_attn_pytorch
 
@@ -295,8 +295,8 @@ def install_metrics():
 # Third-party leaves restated (none of them is under /root/reference): mmcv.impad / impad_to_multiple / imnormalize
 # (mmcv/image/geometric.py, photometric.py: bottom/right constant padding; `(img - mean) * (1 / std)` in float32 with
 # optional BGR->RGB), mmcv.load (pickle), pyquaternion.Quaternion.rotation_matrix and
-# nuscenes.utils.geometry_utils.transform_matrix (taken from occnet_amd.io — the goldens compare those two leaves with
-# themselves, as with FFN / ConvModule above), NuScenesDataset (attribute holder), tqdm (real), cv2 (unused here).
+# nuscenes.utils.geometry_utils.transform_matrix (oracle/thirdparty.py, independent of occnet_amd.io since round 4),
+# NuScenesDataset (attribute holder), tqdm (real), cv2 (unused here).
 # nuscenes_occ.py does `from ....tools.ray_iou.ego_pose_extractor import EgoPoseDataset` — a relative import that climbs
 # above `projects`; the files are therefore mounted under a synthetic top-level package `occref` = /root/reference.
 def install_datasets():
@@ -305,8 +305,8 @@ def install_datasets():
     import pickle
     import numpy as np
     import torch.utils.cpp_extension as cpp_ext
-    from occnet_amd import io as oio
-    from occnet_amd.plugin.registry import Registry
+    from oracle import thirdparty as oio         # oracle-owned restatements (not occnet_amd.io)
+    from oracle.thirdparty import Registry
 
     PIPELINES, DATASETS = Registry('pipeline'), Registry('dataset')
 

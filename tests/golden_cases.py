@@ -44,6 +44,9 @@ FULL_CASES = {
     # history BEV rotated by can_bus[-1] = 7.5 degrees about (100, 100): TSA's two-value, rotated-history branch
     'base_full_hist': dict(seed=22, batch=1, prev=True, angle=7.5,
                            geometry=dict(synthetic.BASE, num_points=8, num_layers=1)),
+    # the BENCHMARKED depth (round 4): all four encoder layers of the base config
+    'base_full_4layer': dict(seed=23, batch=1, prev=False, angle=0.0,
+                             geometry=dict(synthetic.BASE, num_points=8, num_layers=4)),
 }
 FULL_STRIDE = 997            # prime, coprime to every tensor dimension: the subsample walks all axes
 FULL_KEYS = ('bev_embed', 'occ', 'flow', 'layer0_tsa_out', 'layer0_sca_out')

@@ -185,7 +185,7 @@ def test_images_to_voxels_fp32_backbone():
 
 
 # ---- pinned to the reference at the benchmarked geometry (VERDICT r2 missing #2, #3) -------------------------------
-@pytest.mark.parametrize('name', ['base_full_nohist', 'base_full_hist'])
+@pytest.mark.parametrize('name', ['base_full_nohist', 'base_full_hist', 'base_full_4layer'])
 def test_product_matches_reference_golden_at_base_geometry(name):
     """HIP head vs tests/golden/base_full_*.npz: digests of what the reference's OWN module files produced at
     40 000 queries / 6 x 30 825 keys / max_len ~ 9 900 / 106 camera-less queries, one layer, without and with a

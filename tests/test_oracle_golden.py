@@ -71,3 +71,71 @@ def test_oracle_matches_reference_golden_at_base_geometry(name):
         assert tuple(out[k].shape) == tuple(int(v) for v in gold[f'{k}_shape'])
         sub, slab = compare_digest(k, out[k], gold, 2e-5)
         print(f'{name}/{k}: subsample max diff {sub:.2e}, slab mean diff {slab:.2e}')
+
+
+def test_thirdparty_restatements_agree():
+    """oracle/thirdparty.py (the leaves refshim runs the reference's files on since round 4) and the product's own
+    restatements (occnet_amd.plugin.bricks, occnet_amd.io) are two independent implementations of the same mmcv / mmdet
+    / pyquaternion / nuscenes-devkit behaviour: same state_dict keys, bit-identical outputs on seeded inputs."""
+    import numpy as np
+    import torch
+    from occnet_amd import io as pio
+    from occnet_amd.plugin import bricks as pb
+    from oracle import thirdparty as tp
+    g = torch.Generator().manual_seed(5)
+    # FFN (mmcv): keys, identity handling, dropout inert in eval
+    kw = dict(embed_dims=32, feedforward_channels=64, num_fcs=2, ffn_drop=0.1, act_cfg=dict(type='ReLU', inplace=True))
+    a, b = pb.FFN(**kw).eval(), tp.FFN(**kw).eval()
+    assert sorted(a.state_dict()) == sorted(b.state_dict()) == ['layers.0.0.bias', 'layers.0.0.weight', 'layers.1.bias',
+                                                                'layers.1.weight']
+    b.load_state_dict(a.state_dict())
+    x, idt = torch.randn(3, 7, 32, generator=g), torch.randn(3, 7, 32, generator=g)
+    with torch.no_grad():
+        assert torch.equal(a(x), b(x)) and torch.equal(a(x, idt), b(x, idt))
+        assert torch.equal(b(x), x + b.layers(x))
+    # ConvModule (mmcv) as transformer_occ.py:106-126 builds it: Conv3d + BN3d + ReLU, no conv bias
+    kw = dict(kernel_size=3, stride=1, padding=1, bias=False, conv_cfg=dict(type='Conv3d'), norm_cfg=dict(type='BN3d'),
+              act_cfg=dict(type='ReLU', inplace=True))
+    a, b = pb.ConvModule(4, 6, **kw).eval(), tp.ConvModule(4, 6, **kw).eval()
+    assert sorted(a.state_dict()) == sorted(b.state_dict()) and 'conv.bias' not in a.state_dict() \
+        and 'bn.running_var' in a.state_dict()
+    sd = a.state_dict()
+    sd['bn.running_mean'] = torch.randn(6, generator=g) * 0.1
+    sd['bn.running_var'] = torch.rand(6, generator=g) + 0.5
+    a.load_state_dict(sd), b.load_state_dict(sd)
+    v = torch.randn(2, 4, 5, 6, 7, generator=g)
+    with torch.no_grad():
+        assert torch.equal(a(v), b(v)) and float(b(v).min()) >= 0.0
+    # LearnedPositionalEncoding (mmdet)
+    a, b = pb.LearnedPositionalEncoding(8, 5, 6), tp.LearnedPositionalEncoding(8, 5, 6)
+    b.load_state_dict(a.state_dict())
+    m = torch.zeros(2, 5, 6)
+    assert torch.equal(a(m), b(m)) and tuple(b(m).shape) == (2, 16, 5, 6)
+    assert torch.equal(b(m)[0, :8, 3, 2], b.col_embed.weight[2]) and torch.equal(b(m)[1, 8:, 3, 2], b.row_embed.weight[3])
+    # losses (mmdet)
+    logits, lab = torch.randn(50, 17, generator=g), torch.randint(0, 17, (50,), generator=g)
+    assert torch.equal(pb.CrossEntropyLoss(loss_weight=1.0)(logits, lab), tp.CrossEntropyLoss(loss_weight=1.0)(logits, lab))
+    w = torch.rand(50, generator=g)
+    assert torch.equal(pb.CrossEntropyLoss()(logits, lab, weight=w, avg_factor=13.0),
+                       tp.CrossEntropyLoss()(logits, lab, weight=w, avg_factor=13.0))
+    p, t = torch.randn(40, 2, generator=g), torch.randn(40, 2, generator=g)
+    assert torch.equal(pb.L1Loss(loss_weight=0.25)(p, t), tp.L1Loss(loss_weight=0.25)(p, t))
+    # quaternion / homogeneous transform (pyquaternion, nuscenes-devkit): two formulations, agreement to 1e-15
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        q, tr = rng.normal(size=4), rng.normal(size=3)
+        assert np.abs(pio.quaternion_rotation_matrix(q) - tp.quaternion_rotation_matrix(q)).max() < 1e-14
+        for inv in (False, True):
+            assert np.abs(pio.transform_matrix(tr, q, inverse=inv) - tp.transform_matrix(tr, q, inverse=inv)).max() < 1e-14
+    r = tp.quaternion_rotation_matrix([0.5, 0.5, 0.5, 0.5])      # 120 degrees about (1,1,1): x -> y -> z -> x
+    assert np.abs(r @ np.array([1.0, 0, 0]) - np.array([0, 1.0, 0])).max() < 1e-15
+
+
+def test_refshim_does_not_import_product_leaves():
+    """The goldens' third-party leaves come from oracle/thirdparty.py, not from the product package."""
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ('refshim.py', 'thirdparty.py'):
+        with open(os.path.join(here, 'oracle', name)) as f:
+            lines = [l for l in f if ('import' in l and 'occnet_amd' in l and not l.lstrip().startswith('#'))]
+        assert lines == [], (name, lines)

@@ -55,7 +55,17 @@ def md(x, y):
     return float((x - y).abs().max())
 
 
-for rnd in range(2):
+# block-count sweep: 16 384 rows = 256 blocks (one per CU, alone), 32 768 = 512 (two per CU, one full round),
+# 40 000 = 625 (1.22 rounds: the encoder's shape)
+if os.environ.get("CHAIN_SWEEP", "1") == "1":
+    for m in (16384, 32768, 40000, 65536):
+        aa, rr, qq = a[:m] if m <= M else R(m, 256), res[:m] if m <= M else R(m, 256), qt[:m] if m <= M else R(m, 192)
+        ta, _ = timed(lambda: ext.linear_ln_chain(aa, rr, wo, bo, ln1, wq, bq))
+        tb, _ = timed(lambda: ext.encoder_ffn_chain(aa, rr, wo, bo, ln1, w1, b1, w2, b2, ln2, tail=(wt, qq, wv, bv)))
+        print(f"rows {m:6d} ({(m + 63) // 64:5d} blocks): program A {ta:7.1f} us ({ta / m * 1e3:6.3f} ns/row)   program B {tb:7.1f} us "
+              f"({tb / m * 1e3:6.3f} ns/row)", flush=True)
+
+for rnd in range(int(os.environ.get("CHAIN_ROUNDS", "2"))):
     t_sa, o_sa = timed(sep_a)
     t_ca, o_ca = timed(lambda: ext.linear_ln_chain(a, res, wo, bo, ln1, wq, bq))
     t_sb, o_sb = timed(sep_b)

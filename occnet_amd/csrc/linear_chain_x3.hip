@@ -27,6 +27,7 @@
 // as the LDS tile (half of it at a time).  x2, the FFN's residual, is parked in the block's own rows of `y` (written
 // and re-read by the same lane, overwritten by x3 at the end).  Two blocks per CU (66 KB of LDS, <= 256 registers):
 // one block's epilogues run under the other's MFMAs.
+#include <stdlib.h>
 #include "common.h"
 
 namespace occ {
@@ -96,27 +97,40 @@ __global__ void linear_chain_pack_kernel(const float* __restrict__ w, unsigned s
     w[SLOT][3] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 3072, so, 0);                      \
   }
 
-// operand fragments of k-step KS: piece 2 KS + kb of rows vi and 32 + vi, both planes (slot of piece p in row r = p ^ (r & 31))
-#define OCC_CH_AFRAG(BUF, KS)                                                                      \
+// operand fragments of (physical) k-step KK — wave-uniform, run time: piece 2 KK + kb of rows vi and 32 + vi, both planes
+// (slot of piece p in row r = p ^ (r & 31))
+#define OCC_CH_AFRAG(BUF, KK)                                                                      \
   {                                                                                                \
-    asm volatile("" : "+v"(abase));                                                                \
-    const char* ap = tl + (abase ^ (unsigned)((KS) * 32));                                         \
-    af[BUF][0][0] = *reinterpret_cast<const bf16x8*>(ap);                                          \
-    af[BUF][1][0] = *reinterpret_cast<const bf16x8*>(ap + 32 * 512);                               \
+    const char* ap = tl + (abase ^ (unsigned)((KK) * 32));                                         \
+    /* lo planes first: the step's first MFMAs (small term wh . al) read them */                   \
     af[BUF][0][1] = *reinterpret_cast<const bf16x8*>(ap + kChPlane);                               \
     af[BUF][1][1] = *reinterpret_cast<const bf16x8*>(ap + kChPlane + 32 * 512);                    \
+    af[BUF][0][0] = *reinterpret_cast<const bf16x8*>(ap);                                          \
+    af[BUF][1][0] = *reinterpret_cast<const bf16x8*>(ap + 32 * 512);                               \
   }
 
-// one 256-column pass over the K = 256 tile: 16 k-steps, flat ring steps step0 .. step0 + 15 (requests run 3 ahead)
+// one 256-column pass over the K = 256 tile: 16 k-steps, flat ring steps step0 .. step0 + 15 (requests run 3 ahead).
+// Every block walks the 16 k-steps in an order ROTATED by `rot` (a GEMM's k order is free): the blocks of an XCD start
+// together and run the same program, so without it all 64 of them request the same 16 KB of weights at the same time —
+// 4 096 line requests into the few L2 channels that hold that chunk while the others idle (round 4, call 2: one block
+// per CU alone took ~1 000 clocks per k-step, two took twice that: the L2 request rate of a hot channel, not MFMA, not
+// L1 bandwidth).  With the rotation the resident blocks are spread over all 16 chunks of a pass at any time.
+template <int ABL = 0>
 __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][4], const __amdgpu_buffer_rsrc_t wr,
-                                         const int wv, const int step0, const char* tl, unsigned& abase) {
+                                         const int wv, const int step0, const char* tl, const unsigned abase, const int rot) {
   bf16x8 af[2][2][2];                               // [buffer][row tile][plane hi, lo]
-  OCC_CH_AFRAG(0, 0)
+  OCC_CH_AFRAG(0, rot & 15)
+  // the group sequence below is matched to instructions in program order: without this leading group the four reads
+  // above fill step 0's fragment groups and EVERY step's reads slide one step late — issued right before their use
+  // (that is what the first cuts of this kernel did: rocprofv3 round 4 call 2, 56 % of the wave cycles issue-stalled)
+  if (ABL == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
-    OCC_CH_LOAD((ks + 3) & 3, step0 + ks + 3)
-    OCC_CH_AFRAG((ks + 1) & 1, (ks + 1) & 15)
+    if (!(ABL & 4) || ks == 0) OCC_CH_AFRAG((ks + 1) & 1, (ks + 1 + rot) & 15)
+    // logical step ks + 3 of this pass, or step ks + 3 - 16 of the next one (the ring runs across stage boundaries)
+    if (!(ABL & 1)) OCC_CH_LOAD((ks + 3) & 3, step0 + (ks + 3 < 16 ? 0 : 16) + ((ks + 3 + rot) & 15))
     // D[column][row] (weights as the row operand); small terms first, term-major over the four accumulators
+    if (!(ABL & 2)) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -135,18 +149,26 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
       for (int t = 0; t < 2; ++t)
         acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t]), af[ks & 1][rt][0],
                                                              acc[rt][t], 0, 0, 0);
-    // pin the software pipeline (hipcc otherwise sinks every ring request down to its use: load, vmcnt(0), MFMA)
-    // (the operand fragments of step s + 1 are requested in the FIRST half of step s: the next step opens with the
-    // MFMAs that read the fragment requested last)
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // operand fragments of step s + 1
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    } else {
+      // ablation: keep the operands alive without the matrix pipe
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" :: "v"(w[ks & 3][t]));
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) { asm volatile("" :: "v"(af[ks & 1][rt][0])); asm volatile("" :: "v"(af[ks & 1][rt][1])); }
+    }
+    if (ABL == 0) {
+    // pin the software pipeline (hipcc otherwise sinks every ring request down to its use: load, vmcnt(0), MFMA).  The
+    // operand fragments of step s + 1 are requested at the TOP of step s, lo planes first: the next step opens with the
+    // MFMAs that read them
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // operand fragments of step s + 1 (lo planes)
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // (hi planes)
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // ring requests of step s + 3
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    }
   }
 }
 
@@ -274,7 +296,7 @@ __device__ __forceinline__ void ch_relu(f32x16 (&acc)[2][2]) {
 }
 
 // PROG 0: program A, PROG 1: program B (file header)
-template <int PROG>
+template <int PROG, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs p) {
   extern __shared__ __attribute__((aligned(16))) char tl[];
   float* red = reinterpret_cast<float*>(tl + kChRed);
@@ -287,9 +309,11 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
   occ_u32x4 w[4][4];
   const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(p.wp, p.wbytes);
   const int wv = (wave * 4096) + lane * 16;
-  OCC_CH_LOAD(0, 0)
-  OCC_CH_LOAD(1, 1)
-  OCC_CH_LOAD(2, 2)
+  // k-step rotation of this block: blocks b, b + 8, b + 16, .. share an XCD
+  const int rot = (int)(blockIdx.x >> 3) & 15;
+  OCC_CH_LOAD(0, rot)
+  OCC_CH_LOAD(1, (rot + 1) & 15)
+  OCC_CH_LOAD(2, (rot + 2) & 15)
 
   // this lane's two rows (clamped for the loads)
   long rows[2];
@@ -301,7 +325,8 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
     rows[rt] = live[rt] ? r : (long)M - 1;
   }
 
-  // ---- stage input: 64 rows x 256 f32 -> hi / lo planes (a wave instruction = one whole row, 1 KB) ----------------------
+  // ---- stage input: 64 rows x 256 f32 -> hi / lo planes (a wave instruction = one whole row, 1 KB)
+  f32x16 acc[2][2];
   {
     float4 v[16];
 #pragma unroll
@@ -322,13 +347,11 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
       *reinterpret_cast<uint2*>(q + kChPlane) = make_uint2(l01, l23);
     }
   }
-  unsigned abase = (unsigned)(vi * 512 + ((kb ^ vi) & 31) * 16);
-
   // ---- stage 1: output_proj + bias + residual -> LayerNorm -------------------------------------------------------------
-  f32x16 acc[2][2];
   ch_init(acc, p.bias, p.res, p.ldres, rows, wave * 64, kb);
+  const unsigned abase = (unsigned)(vi * 512 + ((kb ^ vi) & 31) * 16);
   __syncthreads();
-  ch_kloop(acc, w, wr, wv, 0, tl, abase);
+  ch_kloop<ABL>(acc, w, wr, wv, 0, tl, abase, rot);
   ch_layernorm(acc, red, p.ln1_g, p.ln1_b, p.eps1, wave, vi, kb);
   ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false);       // A: x1.  B: x2 parked in its own rows of y
   ch_to_tile(acc, tl, wave, vi, kb);
@@ -340,20 +363,20 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
     // ---- FFN: both hidden halves from the x2 tile (registers), then the second Linear over the two K halves ------------
     f32x16 ha[2][2], hb[2][2];
     ch_init(ha, p.bias + 256, nullptr, 0, rows, wave * 64, kb);
-    ch_kloop(ha, w, wr, wv, 16, tl, abase);
+    ch_kloop<ABL>(ha, w, wr, wv, 16, tl, abase, rot);
     ch_relu(ha);
     ch_init(hb, p.bias + 512, nullptr, 0, rows, wave * 64, kb);
-    ch_kloop(hb, w, wr, wv, 32, tl, abase);
+    ch_kloop<ABL>(hb, w, wr, wv, 32, tl, abase, rot);
     ch_relu(hb);
     __syncthreads();                                // every wave has read the x2 tile for the last time
     ch_to_tile(ha, tl, wave, vi, kb);
     __syncthreads();                                // (also keeps the x2 reload below from being hoisted over ha's last use)
     ch_init(acc, p.bias + 768, p.y, p.ldy, rows, wave * 64, kb);       // b2 + x2 (this lane's own stores)
-    ch_kloop(acc, w, wr, wv, 48, tl, abase);
+    ch_kloop<ABL>(acc, w, wr, wv, 48, tl, abase, rot);
     __syncthreads();
     ch_to_tile(hb, tl, wave, vi, kb);
     __syncthreads();
-    ch_kloop(acc, w, wr, wv, 64, tl, abase);
+    ch_kloop<ABL>(acc, w, wr, wv, 64, tl, abase, rot);
     ch_layernorm(acc, red, p.ln2_g, p.ln2_b, p.eps2, wave, vi, kb);
     ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false);     // x3
     if (p.npass > 0) {
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
     const int c0 = ps * 256 + wave * 64;            // the wave's first tail column of this pass
     const bool tm = p.term != nullptr && c0 < p.term_cols;          // term_cols is a multiple of 64: whole waves
     ch_init(acc, p.bias + bias_off, tm ? p.term : nullptr, p.ldterm, rows, c0, kb);
-    ch_kloop(acc, w, wr, wv, step + ps * 16, tl, abase);
+    ch_kloop<ABL>(acc, w, wr, wv, step + ps * 16, tl, abase, rot);
     // the wave's two 32-column tiles go to z1 (columns < n1) or z2 (columns in [off2, off2 + n2)) or nowhere (padding)
     const int ca = c0, cb = c0 + 32;
     const bool a1 = ca < p.n1, b1 = cb < p.n1;
@@ -407,9 +430,17 @@ extern "C" int occ_linear_chain_pack_bf16x3(const float* weight, void* packed, i
 
 namespace {
 template <int PROG>
-int chain_launch(const occ::ChainArgs& args, hipStream_t st, const char* what) {
+int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what) {
   using namespace occ;
-  auto kern = linear_chain_x3_kernel<PROG>;
+  // development switch (timing only, results wrong by construction): OCC_CHAIN_ABLATE = 1 no weight loads in the k loops,
+  // 2 no MFMAs, 4 no operand-fragment reads
+  static const int abl = [] { const char* e = getenv("OCC_CHAIN_ABLATE"); return e ? atoi(e) : 0; }();
+  const ChainArgs& args = args_in;
+  void (*kern)(const ChainArgs) = linear_chain_x3_kernel<PROG, 0>;
+  if (PROG == 0 && abl == 1) kern = linear_chain_x3_kernel<0, 1>;
+  if (PROG == 0 && abl == 2) kern = linear_chain_x3_kernel<0, 2>;
+  if (PROG == 0 && abl == 4) kern = linear_chain_x3_kernel<0, 4>;
+  if (PROG == 0 && abl == 3) kern = linear_chain_x3_kernel<0, 3>;
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kChLds);
   if (e != hipSuccess) {

@@ -45,8 +45,15 @@ def _pkg(name, path):
     return m
 
 
+_INSTALLED = None
+
+
 def install():
-    """Install the stubs and return a namespace with the reference classes + builders."""
+    """Install the stubs and return a namespace with the reference classes + builders (idempotent: the reference's
+    modules register themselves into the registries of the FIRST call when they are imported)."""
+    global _INSTALLED
+    if _INSTALLED is not None:
+        return _INSTALLED
     from oracle import thirdparty as pb          # NOT the product's bricks: the product must not define the golden
     from oracle.thirdparty import ConfigDict, Registry, build_from_cfg
     from oracle import model as om
@@ -190,7 +197,7 @@ def install():
     head = importlib.import_module('projects.mmdet3d_plugin.bevformer.dense_heads.bevformer_occ_head')
     for m in (sca, tsa, enc, trf, head):
         assert m.__file__.startswith(REF_ROOT), m.__file__
-    return types.SimpleNamespace(
+    _INSTALLED = types.SimpleNamespace(
         SpatialCrossAttention=sca.SpatialCrossAttention,
         MSDeformableAttention3D=sca.MSDeformableAttention3D,
         TemporalSelfAttention=tsa.TemporalSelfAttention,
@@ -198,6 +205,7 @@ def install():
         TransformerOcc=trf.TransformerOcc, BEVFormerOccHead=head.BEVFormerOccHead,
         build_head=lambda cfg: build_from_cfg(cfg, HEADS),
         files=[m.__file__ for m in (sca, tsa, enc, trf, head)])
+    return _INSTALLED
 
 
 # ------------------------------------------------------------------------------------------------------------

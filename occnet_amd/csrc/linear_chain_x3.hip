@@ -55,6 +55,7 @@ struct ChainArgs {
   float* z1; long ldz1; int n1;                   // tail columns [0, n1) -> z1
   float* z2; long ldz2; int off2; int n2;         // tail columns [off2, off2 + n2) -> z2 (column - off2)
   int M;
+  int dbg;                                        // development: 1 = skip the row stores, 2 = non-temporal row stores
 };
 
 __device__ __forceinline__ void ch_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
@@ -117,7 +118,8 @@ __global__ void linear_chain_pack_kernel(const float* __restrict__ w, unsigned s
 // L1 bandwidth).  With the rotation the resident blocks are spread over all 16 chunks of a pass at any time.
 template <int ABL = 0>
 __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][4], const __amdgpu_buffer_rsrc_t wr,
-                                         const int wv, const int step0, const char* tl, const unsigned abase, const int rot) {
+                                         const int wv, const int step0, const int next0, const char* tl, const unsigned abase,
+                                         const int rot) {
   bf16x8 af[2][2][2];                               // [buffer][row tile][plane hi, lo]
   OCC_CH_AFRAG(0, rot & 15)
   // the group sequence below is matched to instructions in program order: without this leading group the four reads
@@ -127,8 +129,9 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     if (!(ABL & 4) || ks == 0) OCC_CH_AFRAG((ks + 1) & 1, (ks + 1 + rot) & 15)
-    // logical step ks + 3 of this pass, or step ks + 3 - 16 of the next one (the ring runs across stage boundaries)
-    if (!(ABL & 1)) OCC_CH_LOAD((ks + 3) & 3, step0 + (ks + 3 < 16 ? 0 : 16) + ((ks + 3 + rot) & 15))
+    // logical step ks + 3 of this pass, or step ks + 3 - 16 of the k loop that follows (first step next0: the ring runs
+    // across stage — and, in the persistent kernel, tile — boundaries)
+    if (!(ABL & 1)) OCC_CH_LOAD((ks + 3) & 3, (ks + 3 < 16 ? step0 : next0) + ((ks + 3 + rot) & 15))
     // D[column][row] (weights as the row operand); small terms first, term-major over the four accumulators
     if (!(ABL & 2)) {
 #pragma unroll
@@ -269,7 +272,7 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, co
 
 // register quads -> row-major global rows (column c0 + 32 t + 8 q + 4 kb of row rows[rt]); rows beyond M are skipped
 __device__ __forceinline__ void ch_store(const f32x16 (&acc)[2][2], float* dst, long ld, const long (&rows)[2],
-                                         const bool (&live)[2], int c0, int kb, bool t0_on, bool t1_on, bool relu) {
+                                         const bool (&live)[2], int c0, int kb, bool t0_on, bool t1_on, bool relu, int dbg = 0) {
   // c0 = column of `dst` that receives the wave's first column
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -281,8 +284,15 @@ __device__ __forceinline__ void ch_store(const f32x16 (&acc)[2][2], float* dst, 
         if (relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (live[rt] && (t == 0 ? t0_on : t1_on))
-          *reinterpret_cast<float4*>(dst + rows[rt] * ld + c0 + 32 * t + 8 * q + 4 * kb) = v;
+        if (live[rt] && (t == 0 ? t0_on : t1_on)) {
+          float4* o = reinterpret_cast<float4*>(dst + rows[rt] * ld + c0 + 32 * t + 8 * q + 4 * kb);
+          if (dbg == 0) *o = v;
+          else if (dbg == 2) {
+            typedef float occ_f32x4 __attribute__((ext_vector_type(4)));
+            const occ_f32x4 vv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(vv, reinterpret_cast<occ_f32x4*>(o));
+          }
+        }
       }
 }
 
@@ -351,9 +361,9 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
   ch_init(acc, p.bias, p.res, p.ldres, rows, wave * 64, kb);
   const unsigned abase = (unsigned)(vi * 512 + ((kb ^ vi) & 31) * 16);
   __syncthreads();
-  ch_kloop<ABL>(acc, w, wr, wv, 0, tl, abase, rot);
+  ch_kloop<ABL>(acc, w, wr, wv, 0, (0) + 16, tl, abase, rot);
   ch_layernorm(acc, red, p.ln1_g, p.ln1_b, p.eps1, wave, vi, kb);
-  ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false);       // A: x1.  B: x2 parked in its own rows of y
+  ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false, p.dbg);       // A: x1.  B: x2 parked in its own rows of y
   ch_to_tile(acc, tl, wave, vi, kb);
   __syncthreads();
   int step = 16;
@@ -363,22 +373,22 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
     // ---- FFN: both hidden halves from the x2 tile (registers), then the second Linear over the two K halves ------------
     f32x16 ha[2][2], hb[2][2];
     ch_init(ha, p.bias + 256, nullptr, 0, rows, wave * 64, kb);
-    ch_kloop<ABL>(ha, w, wr, wv, 16, tl, abase, rot);
+    ch_kloop<ABL>(ha, w, wr, wv, 16, (16) + 16, tl, abase, rot);
     ch_relu(ha);
     ch_init(hb, p.bias + 512, nullptr, 0, rows, wave * 64, kb);
-    ch_kloop<ABL>(hb, w, wr, wv, 32, tl, abase, rot);
+    ch_kloop<ABL>(hb, w, wr, wv, 32, (32) + 16, tl, abase, rot);
     ch_relu(hb);
     __syncthreads();                                // every wave has read the x2 tile for the last time
     ch_to_tile(ha, tl, wave, vi, kb);
     __syncthreads();                                // (also keeps the x2 reload below from being hoisted over ha's last use)
     ch_init(acc, p.bias + 768, p.y, p.ldy, rows, wave * 64, kb);       // b2 + x2 (this lane's own stores)
-    ch_kloop<ABL>(acc, w, wr, wv, 48, tl, abase, rot);
+    ch_kloop<ABL>(acc, w, wr, wv, 48, (48) + 16, tl, abase, rot);
     __syncthreads();
     ch_to_tile(hb, tl, wave, vi, kb);
     __syncthreads();
-    ch_kloop<ABL>(acc, w, wr, wv, 64, tl, abase, rot);
+    ch_kloop<ABL>(acc, w, wr, wv, 64, (64) + 16, tl, abase, rot);
     ch_layernorm(acc, red, p.ln2_g, p.ln2_b, p.eps2, wave, vi, kb);
-    ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false);     // x3
+    ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false, p.dbg);     // x3
     if (p.npass > 0) {
       ch_to_tile(acc, tl, wave, vi, kb);
       __syncthreads();
@@ -393,15 +403,16 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
     const int c0 = ps * 256 + wave * 64;            // the wave's first tail column of this pass
     const bool tm = p.term != nullptr && c0 < p.term_cols;          // term_cols is a multiple of 64: whole waves
     ch_init(acc, p.bias + bias_off, tm ? p.term : nullptr, p.ldterm, rows, c0, kb);
-    ch_kloop<ABL>(acc, w, wr, wv, step + ps * 16, tl, abase, rot);
+    ch_kloop<ABL>(acc, w, wr, wv, step + ps * 16, (step + ps * 16) + 16, tl, abase, rot);
     // the wave's two 32-column tiles go to z1 (columns < n1) or z2 (columns in [off2, off2 + n2)) or nowhere (padding)
     const int ca = c0, cb = c0 + 32;
     const bool a1 = ca < p.n1, b1 = cb < p.n1;
     const bool a2 = ca >= p.off2 && ca < p.off2 + p.n2, b2 = cb >= p.off2 && cb < p.off2 + p.n2;
-    if (a1 || b1) ch_store(acc, p.z1, p.ldz1, rows, live, c0, kb, a1, b1, p.act != 0);
-    if (a2 || b2) ch_store(acc, p.z2, p.ldz2, rows, live, c0 - p.off2, kb, a2, b2, p.act != 0);
+    if (a1 || b1) ch_store(acc, p.z1, p.ldz1, rows, live, c0, kb, a1, b1, p.act != 0, p.dbg);
+    if (a2 || b2) ch_store(acc, p.z2, p.ldz2, rows, live, c0 - p.off2, kb, a2, b2, p.act != 0, p.dbg);
   }
 }
+
 
 #undef OCC_CH_LOAD
 #undef OCC_CH_AFRAG
@@ -432,10 +443,13 @@ namespace {
 template <int PROG>
 int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what) {
   using namespace occ;
-  // development switch (timing only, results wrong by construction): OCC_CHAIN_ABLATE = 1 no weight loads in the k loops,
-  // 2 no MFMAs, 4 no operand-fragment reads
+  // OCC_CHAIN_ABLATE (program A, timing only — results wrong by construction): 1 no weight loads in the k loops,
+  // 2 no MFMAs, 4 no operand-fragment reads; OCC_CHAIN_DBG: 1 no row stores, 2 non-temporal row stores
   static const int abl = [] { const char* e = getenv("OCC_CHAIN_ABLATE"); return e ? atoi(e) : 0; }();
-  const ChainArgs& args = args_in;
+  static const int dbg = [] { const char* e = getenv("OCC_CHAIN_DBG"); return e ? atoi(e) : 0; }();
+  ChainArgs args = args_in;
+  args.dbg = dbg;
+  const int ntiles = (args.M + kChRows - 1) / kChRows;
   void (*kern)(const ChainArgs) = linear_chain_x3_kernel<PROG, 0>;
   if (PROG == 0 && abl == 1) kern = linear_chain_x3_kernel<0, 1>;
   if (PROG == 0 && abl == 2) kern = linear_chain_x3_kernel<0, 2>;
@@ -447,8 +461,7 @@ int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what
     set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
     return OCC_E_LAUNCH;
   }
-  const unsigned blocks = (unsigned)((args.M + kChRows - 1) / kChRows);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), kChLds, st, args);
+  hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), kChLds, st, args);
   OCC_CHECK_LAUNCH(what);
   return OCC_OK;
 }

@@ -65,6 +65,19 @@ if os.environ.get("CHAIN_SWEEP", "1") == "1":
         print(f"rows {m:6d} ({(m + 63) // 64:5d} blocks): program A {ta:7.1f} us ({ta / m * 1e3:6.3f} ns/row)   program B {tb:7.1f} us "
               f"({tb / m * 1e3:6.3f} ns/row)", flush=True)
 
+# memory floor of program A's traffic with stock streaming kernels: y = a + res (read 2 x 41 MB, write 41 MB), z = three
+# copies of y (read 41 MB, write 123 MB) — 246 MB like the chain (which reads y from LDS, not from memory)
+if os.environ.get("CHAIN_FLOOR", "1") == "1":
+    zbuf = torch.empty(M, 768, device=dev)
+    def floor_a():
+        y = torch.add(a, res)
+        zbuf.view(M, 3, 256).copy_(y.view(M, 1, 256).expand(M, 3, 256))
+        return y
+    t_f, _ = timed(floor_a)
+    t_add, _ = timed(lambda: torch.add(a, res))
+    print(f"memory floor, program A traffic (torch add + 3-way copy): {t_f:7.1f} us   (add alone {t_add:6.1f} us = "
+          f"{3 * M * 1024 / t_add / 1e6:5.2f} TB/s)", flush=True)
+
 for rnd in range(int(os.environ.get("CHAIN_ROUNDS", "2"))):
     t_sa, o_sa = timed(sep_a)
     t_ca, o_ca = timed(lambda: ext.linear_ln_chain(a, res, wo, bo, ln1, wq, bq))

@@ -24,9 +24,12 @@ line.  Extra objects on that line:
   cpu_baseline the CPU oracle (restated reference path, torch fp32) on a bounded sample of the same
                workload, rank 0 at N=1 only: thread-count sweep on one camera's share of the SCA
                deformable-attention call (1 warm-up + 3 runs, median), per-op seconds (A1 SCA call, A2 TSA
-               call, A9 decoder) and one encoder layer + the rest of the path at the best thread count,
-               scaled to the layer count.  The same oracle outputs are used to CHECK the HIP path at full
-               size (`parity_max_abs_diff`, bound 1e-3): a 1-layer head with the oracle's weights on the GPU.
+               call, A9 decoder) and ONE full sample — every encoder layer timed, nothing extrapolated — at
+               the best thread count.  The same oracle outputs CHECK the HIP path at full size, all layers
+               (`parity_max_abs_diff`, bound 1e-3): the same head with the oracle's weights on the GPU.
+  value_fp32_conformant / fp32_conformant   the same images -> voxels step with the backbone at the reference's
+               precision (stock fp32 modules) and its own images -> voxels parity figure against the host.
+  extra        short passes of the hot path alone, `--history 3` (configs[2]) and the 400x400x32 grid (configs[4]).
 
 Timing protocol: the K timed steps carry HIP events around the roofline kernel only (8 event records per step);
 `value_no_instrumentation` is a second barrier-bracketed pass of K steps with no events at all, and the per-kernel
@@ -107,6 +110,8 @@ def parse():
                          "history frames through BEVFormerOcc.obtain_history_bev (reference bevformer_occ.py:159-178) + "
                          "the current frame with prev_bev; 3 = the reference's 4-frame queue.  Default 0 = configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short hot-path / --history 3 / hi-res passes reported under `extra`")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -299,15 +304,15 @@ def _median(v):
 
 def cpu_baseline(cfg, geo, device=None, thread_counts=None):
     """The CPU oracle (oracle/model.py = the restated reference path, torch fp32; `kind: "port"`) on a bounded
-    sample of the bench workload, backbone excluded (the oracle starts at the FPN maps).
+    sample of the bench workload, backbone excluded (the oracle starts at the FPN maps): ONE sample through the
+    WHOLE hot path — all encoder layers are timed, nothing is extrapolated (round 3 timed one layer and scaled).
 
-    1. one encoder layer (of `n_layers`) + everything outside the layer stack (feature flatten, reference points,
-       lifter, Conv3d decoder, heads) at a moderate thread count, recording the inputs of the two deformable-
-       attention calls (A1 = SCA use, A2 = TSA use, SURVEY.md §8a) and the decoder (A9);
+    1. a first full pass at a moderate thread count, recording the inputs of the two deformable-attention calls of
+       layer 0 (A1 = SCA use, A2 = TSA use, SURVEY.md §8a) and of the decoder (A9);
     2. thread sweep (SURVEY.md §8d; 1 warm-up + 3 runs, median) on ONE camera's share of the A1 call;
     3. A1 (all cameras), A2 and A9 at the best thread count: 1 warm-up + 3 runs, median -> per_op_seconds;
-    4. the pass of step 1 again at the best thread count -> `value` (scaled to n_layers);
-    5. with `device`: the same 1-layer head on the HIP path with the oracle's weights and inputs ->
+    4. the full pass again at the best thread count -> `value`;
+    5. with `device`: the same head (all layers) on the HIP path with the oracle's weights and inputs ->
        parity_max_abs_diff (full base geometry: 40 000 queries x 6 cameras x 30 825 keys)."""
     import copy
     import oracle.model as om
@@ -317,7 +322,6 @@ def cpu_baseline(cfg, geo, device=None, thread_counts=None):
     hc = json.loads(json.dumps(hc))          # plain dicts
     hc.pop("type")
     n_layers = hc["transformer"]["encoder"]["num_layers"]
-    hc["transformer"]["encoder"]["num_layers"] = 1
     hc["transformer"]["encoder"]["transformerlayers"]["operation_order"] = tuple(
         hc["transformer"]["encoder"]["transformerlayers"]["operation_order"])
     torch.manual_seed(0)
@@ -334,26 +338,27 @@ def cpu_baseline(cfg, geo, device=None, thread_counts=None):
     if thread_counts is None:
         thread_counts = sorted({t for t in (8, 32, 64, cores) if t <= cores})
 
-    layer = ora.transformer.encoder.layers[0]
+    layers = list(ora.transformer.encoder.layers)
     decoder = ora.transformer.decoder
     rec = {}
 
     def run_once():
-        """One pass; returns (outputs, seconds total, seconds in the layer) and records op inputs/timings."""
-        t = {"layer": 0.0, "msda": [], "dec": 0.0}
+        """One full pass; returns (outputs, seconds total, per-part seconds) and records op inputs."""
+        t = {"layers": [0.0] * len(layers), "dec": 0.0}
         calls = []
-        orig_layer, orig_msda, orig_dec = layer.forward, om.multi_scale_deformable_attn_pytorch, decoder.forward
+        orig_fwd = [l.forward for l in layers]
+        orig_msda, orig_dec = om.multi_scale_deformable_attn_pytorch, decoder.forward
 
-        def layer_fwd(*a, **k):
-            t0 = time.perf_counter()
-            out = orig_layer(*a, **k)
-            t["layer"] += time.perf_counter() - t0
-            return out
+        def wrap_layer(i):
+            def fwd(*a, **k):
+                t0 = time.perf_counter()
+                out = orig_fwd[i](*a, **k)
+                t["layers"][i] += time.perf_counter() - t0
+                return out
+            return fwd
 
         def msda(*a):
-            t0 = time.perf_counter()
             out = orig_msda(*a)
-            t["msda"].append(time.perf_counter() - t0)
             calls.append(a)
             return out
 
@@ -363,16 +368,19 @@ def cpu_baseline(cfg, geo, device=None, thread_counts=None):
             out = orig_dec(x)
             t["dec"] += time.perf_counter() - t0
             return out
-        layer.forward, om.multi_scale_deformable_attn_pytorch, decoder.forward = layer_fwd, msda, dec_fwd
+        for i, l in enumerate(layers):
+            l.forward = wrap_layer(i)
+        om.multi_scale_deformable_attn_pytorch, decoder.forward = msda, dec_fwd
         try:
             with torch.no_grad():
                 t0 = time.perf_counter()
                 out = ora(feats, metas)
                 total = time.perf_counter() - t0
         finally:
-            layer.forward, om.multi_scale_deformable_attn_pytorch = orig_layer, orig_msda
-            decoder.forward = orig_dec
-        rec["calls"] = calls
+            for l, f in zip(layers, orig_fwd):
+                l.forward = f
+            om.multi_scale_deformable_attn_pytorch, decoder.forward = orig_msda, orig_dec
+        rec["calls"] = calls[:2]                    # layer 0: TSA first, then SCA
         return out, total, t
 
     def timed(fn, runs=3):
@@ -387,7 +395,7 @@ def cpu_baseline(cfg, geo, device=None, thread_counts=None):
     t_start = time.perf_counter()
     torch.set_num_threads(min(32, cores))
     out, total0, t0 = run_once()
-    tsa_args, sca_args = rec["calls"][0], rec["calls"][1]      # layer order: TSA first, then SCA
+    tsa_args, sca_args = rec["calls"][0], rec["calls"][1]
     one_cam = (sca_args[0][:1], sca_args[1], sca_args[2][:1], sca_args[3][:1])
     sweep = {}
     with torch.no_grad():
@@ -402,26 +410,132 @@ def cpu_baseline(cfg, geo, device=None, thread_counts=None):
             "A9_conv3d_decoder": timed(lambda: decoder(rec["dec_in"])),
         }
     out, total, t = run_once()
-    t_rest = total - t["layer"]
-    t_sample = t["layer"] * n_layers + t_rest
+    t_layers = sum(t["layers"])
     res = {
-        "value": 1.0 / t_sample, "unit": "samples/s", "cores": best, "kind": "port",
+        "value": 1.0 / total, "unit": "samples/s", "cores": best, "kind": "port",
         "host_cores_available": cores,
-        "sample": (f"oracle hot path (FPN features -> voxels, backbone excluded), one sample, torch fp32 CPU, "
-                   f"{best} threads (best of the sweep): 1 of {n_layers} encoder layers timed "
-                   f"({t['layer']:.2f} s) x{n_layers} + rest of the path ({t_rest:.2f} s)"),
-        "seconds_per_sample": t_sample,
+        "sample": (f"oracle hot path (FPN features -> voxels, backbone excluded), ONE sample, torch fp32 CPU, "
+                   f"{best} threads (best of the sweep): all {n_layers} encoder layers timed "
+                   f"({', '.join(f'{x:.2f}' for x in t['layers'])} s) + rest of the path ({total - t_layers:.2f} s); "
+                   f"nothing extrapolated"),
+        "seconds_per_sample": total,
+        "encoder_layer_seconds": t["layers"],
         "thread_sweep_seconds_A1_one_camera": {str(k): v for k, v in sweep.items()},
         "per_op_seconds": per_op,
         "per_op_note": "1 warm-up + 3 runs, median, at the best thread count; A1/A2 = the two "
-                       "multi_scale_deformable_attn_pytorch calls of one layer, A9 = 2x(Conv3d+BN3d+ReLU)",
+                       "multi_scale_deformable_attn_pytorch calls of layer 0, A9 = 2x(Conv3d+BN3d+ReLU)",
         "first_pass_seconds": total0, "first_pass_threads": min(32, cores),
         "baseline_wall_seconds": None,
     }
     if device is not None:
-        res.update(_bench_parity(hc, ora, feats, metas, out, device))
+        res.update(_bench_parity(hc, ora, feats, metas, out, device, n_layers))
     res["baseline_wall_seconds"] = time.perf_counter() - t_start
     return res
+
+
+def fp32_conformant_leg(model, stepper, cfg, steps=5):
+    """The same images -> voxels workload with the backbone at the REFERENCE's precision (stock fp32 ResNet-50 + FPN
+    modules, bevformer_base_occ.py:44-66) in front of the same HIP hot path: its throughput, and its own parity
+    figure — images -> voxels on the GPU against images -> voxels on the host (the same stock fp32 backbone modules on
+    CPU + the CPU oracle head with the model's weights); north star bound 1e-3.  The headline `value` runs the bf16
+    backbone plan (`backbone_precision` says what that costs at the output)."""
+    import copy
+    import oracle.model as om
+    m = model
+    args = m._inference_backbone_args
+    res = {}
+    try:
+        m.enable_fused_backbone(dtype=None)                                   # stock modules, fp32
+        with torch.no_grad():
+            for _ in range(2):
+                stepper()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                stepper()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            feats = m.extract_feat(img=stepper.img, img_metas=stepper.metas)
+            out_p = m.pts_bbox_head(feats, stepper.metas, prev_bev=None, test=True)
+            out_p = {k: out_p[k].float().cpu() for k in ("bev_embed", "occ", "flow")}
+        res.update(value=steps / el, unit="samples/s", ms_per_step=el / steps * 1e3, steps=steps,
+                   backbone="stock torch ResNet-50 + FPN modules, fp32 (MIOpen), NCHW")
+        # host side of the parity figure
+        t0 = time.perf_counter()
+        hc = json.loads(json.dumps(cfg.model.pts_bbox_head.to_dict() if hasattr(cfg.model.pts_bbox_head, "to_dict")
+                                   else dict(cfg.model.pts_bbox_head)))
+        hc.pop("type")
+        hc["transformer"]["encoder"]["transformerlayers"]["operation_order"] = tuple(
+            hc["transformer"]["encoder"]["transformerlayers"]["operation_order"])
+        ora = om.BEVFormerOccHead(**hc).eval()
+        ora.load_state_dict({k: v.detach().cpu() for k, v in m.pts_bbox_head.state_dict().items()}, strict=True)
+        cpu = copy.copy(m)                          # shallow: only the backbone / neck are replaced by host copies
+        bb, nk = copy.deepcopy(m.img_backbone).cpu().float().eval(), copy.deepcopy(m.img_neck).cpu().float().eval()
+        torch.set_num_threads(min(64, os.cpu_count() or 1))
+        with torch.no_grad():
+            img = stepper.img.detach().cpu()
+            B, N, C, H, W = img.shape
+            fm = nk(bb(img.reshape(B * N, C, H, W)))
+            feats_c = [f.view(B, N, f.shape[1], f.shape[2], f.shape[3]) for f in fm]
+            out_o = ora(feats_c, stepper.metas)
+        diffs, scales = {}, {}
+        for k in ("bev_embed", "occ", "flow"):
+            scales[k] = max(1.0, float(out_o[k].abs().max()))
+            diffs[k] = float((out_p[k].double() - out_o[k].double()).abs().max())
+        res.update(parity_max_abs_diff=diffs, parity_output_scale=scales,
+                   parity_max_rel_diff=max(diffs[k] / scales[k] for k in diffs), parity_bound=1e-3,
+                   parity_case="images -> voxels, all encoder layers: GPU (fp32 stock backbone + HIP hot path) vs host "
+                               "(the same fp32 backbone modules on CPU + the CPU oracle head, same weights)",
+                   parity_host_seconds=time.perf_counter() - t0)
+    finally:
+        m.enable_fused_backbone(**args)
+    return res
+
+
+def extra_legs(args, cfg, model, geo, device):
+    """Short driver-witnessed passes of the other BASELINE.json configurations, same process, same box: the hot path
+    alone (FPN maps -> voxels), configs[2] (`--history 3`: the reference's 4-frame temporal queue) and configs[4]
+    (400 x 400 x 32 grid, hot path).  Each: 2 warm-up + `n` timed steps between device synchronisations."""
+    def run(stepper, n):
+        with torch.no_grad():
+            for _ in range(2):
+                stepper()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                stepper()
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"value": n / el, "unit": "samples/s", "ms_per_step": el / n * 1e3, "steps": n}
+    out = {}
+    try:
+        st = Stepper(model, geo, "hotpath", args.backbone_dtype, device, seed=0, hot_feat_format="backbone")
+        out["hotpath"] = dict(run(st, 20), workload="bevformer_base_occ hot path only: 4 bf16 NHWC FPN maps (6 cams) -> voxels")
+        del st
+    except Exception as e:
+        out["hotpath"] = {"error": repr(e)}
+    try:
+        if getattr(model, "img_backbone", None) is not None:
+            st = Stepper(model, geo, "e2e", args.backbone_dtype, device, seed=0, plan=args.backbone_plan, history=3)
+            r = run(st, 5)
+            out["history3"] = dict(r, frames_per_s=r["value"] * 4,
+                                   workload="BASELINE configs[2]: 3 history frames through obtain_history_bev + the current "
+                                            "frame with prev_bev, images -> voxels; value counts 4-frame queues")
+            del st
+    except Exception as e:
+        out["history3"] = {"error": repr(e)}
+    try:
+        hp = os.path.join(ROOT, "configs", "occ_hires_400x400x32.py")
+        if os.path.exists(hp) and os.path.abspath(args.config) != hp:
+            cfg2, model2, geo2 = build(hp, device)
+            st = Stepper(model2, geo2, "hotpath", args.backbone_dtype, device, seed=0, hot_feat_format="backbone")
+            out["hires_400x400x32_hotpath"] = dict(run(st, 6), workload="BASELINE configs[4]: 400x400x32 voxel grid, hot path "
+                                                                          "(4 bf16 NHWC FPN maps -> voxels)")
+            del st, model2
+            torch.cuda.empty_cache()
+    except Exception as e:
+        out["hires_400x400x32_hotpath"] = {"error": repr(e)}
+    return out
 
 
 def backbone_precision_leg(model, stepper):
@@ -453,9 +567,10 @@ def backbone_precision_leg(model, stepper):
     }
 
 
-def _bench_parity(head_cfg, ora, feats, metas, out_o, device):
-    """The HIP path at FULL base geometry against the oracle pass the baseline just timed: a 1-layer head built
-    from the same config, loaded with the oracle's weights, same fp32 features (north star: <= 1e-3)."""
+def _bench_parity(head_cfg, ora, feats, metas, out_o, device, n_layers):
+    """The HIP path at FULL base geometry against the oracle pass the baseline just timed: the same head (all
+    encoder layers) built from the same config, loaded with the oracle's weights, same fp32 features (north star:
+    <= 1e-3)."""
     from occnet_amd.plugin import build_head
     cfgp = json.loads(json.dumps(head_cfg))
     cfgp["type"] = "BEVFormerOccHead"
@@ -473,7 +588,7 @@ def _bench_parity(head_cfg, ora, feats, metas, out_o, device):
     if not worst < 1e-3:
         raise AssertionError(f"bench parity check failed: HIP path differs from the oracle by {diffs}")
     return {"parity_max_abs_diff": diffs, "parity_bound": 1e-3,
-            "parity_case": "1 encoder layer + lifter + Conv3d decoder + heads, full base geometry, fp32 features"}
+            "parity_case": f"{n_layers} encoder layers + lifter + Conv3d decoder + heads, full base geometry, fp32 features"}
 
 
 def main():
@@ -705,9 +820,14 @@ def main():
                 "kernel": f"{ext.sca_variant_name()} (fused SCA deformable gather, {'f32' if ev == 4 else 'f16'} values)",
                 # rocprofv3 PMC (profiles/): texture addresser busy most of the launch, L2 hit ~0.8, HBM-side
                 # traffic a fraction of peak -> the binding resource is the L1/TA row-gather path, not HBM
-                "bound": "l1/ta",
+                "bound": ("l1/ta row-gather path, not hbm: frac_alg > 1 because SURVEY.md 8(d)'s algorithmic bytes are LOGICAL "
+                          "gather bytes — every fp16 value row is re-used ~28x per launch out of L2 / the 256 MiB Infinity "
+                          "Cache (a layer's maps are 95 MB), so HBM moves `traffic`, a fraction of them; `frac` is the "
+                          "physical HBM figure"),
                 "achieved": (traffic / sec / 1e9) if traffic else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": (traffic / sec / HBM_PEAK) if traffic else None,
+                # SURVEY.md 8(d) under its own name: B_alg / t_kernel / 8.0e12 (B_alg = N_in*d*e_v + R*S*12 + R*256*4)
+                "achieved_alg": mean_bytes / sec / 1e9, "frac_alg": mean_bytes / sec / HBM_PEAK,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "frac_hbm": (traffic / sec / HBM_PEAK) if traffic else None,
                 "frac_l1": l1_bytes / sec / L1_PEAK, "l1_bytes_per_launch": l1_bytes, "l1_peak_gbps": L1_PEAK / 1e9,
@@ -774,6 +894,16 @@ def main():
                     out["backbone_precision"] = backbone_precision_leg(model, stepper)
                 except Exception as e:
                     out["backbone_precision"] = {"error": repr(e)}
+                if not args.history:
+                    try:
+                        leg = fp32_conformant_leg(model, stepper, cfg)
+                        out["value_fp32_conformant"] = leg.get("value")
+                        out["fp32_conformant"] = leg
+                    except Exception as e:
+                        out["value_fp32_conformant"] = None
+                        out["fp32_conformant"] = {"error": repr(e)}
+        if world == 1 and args.mode == "infer" and not args.no_extras and not args.history and stepper.scope == "e2e":
+            out["extra"] = extra_legs(args, cfg, model, geo, device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

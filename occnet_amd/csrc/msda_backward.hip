@@ -395,7 +395,8 @@ constexpr int kReplayCap = 2048;
 
 __global__ __launch_bounds__(1024) void msda_bwd_scan_kernel(int* __restrict__ counts, int* __restrict__ cursor,
                                                              int n, int4* __restrict__ work,
-                                                             int* __restrict__ work_count) {
+                                                             int* __restrict__ work_count, int cap) {
+  // cap = kReplayCap, or INT_MAX in the deterministic mode (bins are never split: one block owns a bin)
   __shared__ int part[1024];
   __shared__ int wpart[1024];
   const int tid = threadIdx.x;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(1024) void msda_bwd_scan_kernel(int* __restrict__ c
   for (int i = lo; i < hi; ++i) {
     const int c = counts[i];
     sum += c;
-    wsum += (c + kReplayCap - 1) / kReplayCap;
+    wsum += c > 0 ? (c - 1) / cap + 1 : 0;
   }
   part[tid] = sum;
   wpart[tid] = wsum;
@@ -424,9 +425,9 @@ __global__ __launch_bounds__(1024) void msda_bwd_scan_kernel(int* __restrict__ c
     const int c = counts[i];
     counts[i] = run;
     cursor[i] = run;
-    const int nw = (c + kReplayCap - 1) / kReplayCap;
+    const int nw = c > 0 ? (c - 1) / cap + 1 : 0;
     for (int k = 0; k < nw; ++k)
-      work[wrun + k] = make_int4(i, run + k * kReplayCap, min(run + c, run + (k + 1) * kReplayCap), nw > 1);
+      work[wrun + k] = make_int4(i, run + k * cap, k + 1 < nw ? run + (k + 1) * cap : run + c, nw > 1);
     wrun += nw;
     run += c;
   }
@@ -531,6 +532,78 @@ __global__ __launch_bounds__(256) void msda_bwd_replay_kernel(
       o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += sum.w;
       *dst = o;
     }
+  }
+}
+
+// ---- deterministic mode (OCC_MSDA_BWD_DETERMINISTIC=1) ---------------------------------------------------------------
+// The default replay is not bit-reproducible: the position of an item inside its bin follows the integer-atomic slot
+// order of the fill pass, so the fp32 summation order changes from run to run, and the pieces of a split bin are
+// combined with float atomics.  Here the sums are made ORDER-INDEPENDENT instead of the order fixed: every
+// contribution g * w (one fp32 product, the same in every run) is converted to 64-bit fixed point — scaled by a power
+// of two taken from max |grad_output| of the launch, 40 fraction bits below it, 22 bits of headroom for the item count
+// of a bin — and accumulated with integer adds, which commute; bins are not split (one block owns a bin), the total is
+// converted back once.  Resolution 2^-40 of the largest output gradient: finer than the fp32 accumulation it replaces.
+// Slower (a hot coarse-level bin is replayed by one block): an opt-in for reproducible training runs, the contract of
+// the reference's caller-zeroed plain accumulation (multi_scale_deformable_attn_function.py:146-163).
+__global__ void msda_bwd_maxabs_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = fabsf(x[i]);
+    if (v < 3.0e38f) m = fmaxf(m, v);                  // Inf / NaN gradients do not set the scale
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bits
+}
+
+__global__ __launch_bounds__(256) void msda_bwd_replay_det_kernel(
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lstart, const int4* __restrict__ work,
+    const int* __restrict__ work_count, const BwdItem* __restrict__ items, const float* __restrict__ grad_out,
+    float* __restrict__ grad_value, int S, int M, int L, int Lq, int bins_per_bm) {
+  constexpr int D = 32;
+  extern __shared__ long long acc_d[];                 // [8 half-waves][(kBinPix + 1) * D]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ch = lane & 31;
+  if ((int)blockIdx.x >= work_count[0]) return;
+  const int4 wk = work[blockIdx.x];
+  const long bin_g = wk.x;
+  const int beg = wk.y, end = wk.z;
+  const int hw = wave * 2 + half;
+  long long* acc = acc_d + hw * (kBinPix + 1) * D;
+#pragma unroll
+  for (int i = 0; i <= kBinPix; ++i) acc[i * D + ch] = 0;
+  const long bm = bin_g / bins_per_bm;
+  int bl = (int)(bin_g - bm * bins_per_bm);
+  const int m = (int)(bm % M);
+  const long b = bm / M;
+  int l = 0, HW = 0;
+  for (; l < L; ++l) {
+    HW = (int)shapes[2 * l] * (int)shapes[2 * l + 1];
+    const int nb = (HW + kBinPix - 1) / kBinPix;
+    if (bl < nb) break;
+    bl -= nb;
+  }
+  if (l >= L) return;
+  const float mx = __uint_as_float((unsigned)work_count[1]);           // max |grad_output| of the launch
+  int e = 0;
+  if (mx > 0.f) (void)frexpf(mx, &e);                                  // mx < 2^e
+  const double scale = ldexp(1.0, 40 - e), inv = ldexp(1.0, e - 40);
+  const float* go = grad_out + (b * Lq * (long)M + m) * D + ch;
+  for (int idx = beg + hw; idx < end; idx += 8) {
+    const BwdItem it = items[idx];
+    const float g = go[(long)(it.qpl >> 5) * M * D];
+    const int pl = it.qpl & 31;
+    acc[pl * D + ch] += __double2ll_rn((double)(g * it.w0) * scale);
+    acc[(pl + 1) * D + ch] += __double2ll_rn((double)(g * it.w1) * scale);
+  }
+  __syncthreads();
+  const int p0 = bl * kBinPix, np = min(kBinPix, HW - p0);
+  const long st = lstart[l];
+  for (int i = tid; i < np * D; i += 256) {
+    const int px = i >> 5, c = i & 31;
+    long long sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += acc_d[k * (kBinPix + 1) * D + px * D + c];
+    grad_value[((b * S + st + p0 + px) * M + m) * D + c] += (float)((double)sum * inv);     // the bin's only writer
   }
 }
 
@@ -642,7 +715,8 @@ extern "C" int64_t occ_ms_deform_attn_backward_workspace_bytes(int B, int S, int
 // the ~0.7-0.9 GB per SCA call at the base config neither bypass nor compete with that pool.  workspace == NULL:
 // the library allocates with hipMallocAsync; if that fails it falls back to the float-atomic kernel (~4x slower) and
 // says so ONCE on stderr.  grad_value's summation order inside a 32-pixel bin follows integer-atomic slot order:
-// the last bits of grad_value are not reproducible run to run (as with mmcv's atomicAdd).
+// the last bits of grad_value are not reproducible run to run (as with mmcv's atomicAdd) — unless
+// OCC_MSDA_BWD_DETERMINISTIC=1 (D == 32): order-independent fixed-point accumulation, bit-identical runs.
 extern "C" int occ_ms_deform_attn_backward_ws_f32(
     const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
     const float* sampling_loc, const float* attn_weight, const float* grad_output, float* grad_value,
@@ -666,6 +740,9 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
     const dim3 grid1((unsigned)((threads + 255) / 256));
     // atomic-free grad_value (file header): per-sample gradients + flags, count, scan, fill, replay
     static const bool use_atomics = getenv("OCC_MSDA_BWD_ATOMICS") != nullptr;
+    // read per call (tests switch it inside one process): bit-reproducible grad_value, see msda_bwd_replay_det_kernel
+    const char* det_env = getenv("OCC_MSDA_BWD_DETERMINISTIC");
+    const bool deterministic = det_env != nullptr && det_env[0] == '1';
     const BwdWsLayout w = bwd_ws_layout(B, S, M, L, Lq, P);
     char* ws = nullptr;
     bool own = false;
@@ -712,7 +789,7 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
                            attn_weight, flags, counts, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
       }
       hipLaunchKernelGGL(msda_bwd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, cursor, (int)w.n_bins, work,
-                         work_count);
+                         work_count, deterministic ? 0x7fffffff : kReplayCap);
       if (block_bins) {
         hipLaunchKernelGGL(msda_bwd_bin_block_kernel<true>, dim3((unsigned)grid_b), dim3(kBinBlockThreads), lds_b,
                            st, spatial_shapes, sampling_loc, attn_weight, flags, cursor, items, M, L, Lq, P,
@@ -721,13 +798,35 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
         hipLaunchKernelGGL(msda_bwd_bin_kernel<true>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
                            attn_weight, flags, cursor, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
       }
-      hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)w.work_cap), dim3(256), 0, st,
-                         spatial_shapes, level_start_index, work, work_count, items, grad_output, grad_value, S, M,
-                         L, Lq, w.bins_per_bm);
+      if (deterministic) {
+        const size_t lds_d = (size_t)8 * (kBinPix + 1) * 32 * sizeof(long long);
+        hipError_t ed = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_replay_det_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+        if (ed == hipSuccess) ed = hipMemsetAsync(work_count + 1, 0, sizeof(int), st);
+        if (ed != hipSuccess) {
+          if (own) (void)hipFreeAsync(ws, st);
+          set_error("ms_deform_attn_backward: deterministic mode set-up failed: %s", hipGetErrorString(ed));
+          return OCC_E_LAUNCH;
+        }
+        hipLaunchKernelGGL(msda_bwd_maxabs_kernel, dim3(1024), dim3(256), 0, st, grad_output, n_items * 32,
+                           reinterpret_cast<unsigned*>(work_count + 1));
+        hipLaunchKernelGGL(msda_bwd_replay_det_kernel, dim3((unsigned)w.work_cap), dim3(256), lds_d, st,
+                           spatial_shapes, level_start_index, work, work_count, items, grad_output, grad_value, S, M,
+                           L, Lq, w.bins_per_bm);
+      } else {
+        hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)w.work_cap), dim3(256), 0, st,
+                           spatial_shapes, level_start_index, work, work_count, items, grad_output, grad_value, S, M,
+                           L, Lq, w.bins_per_bm);
+      }
       if (own) (void)hipFreeAsync(ws, st);
     } else {
       if (own && ws) (void)hipFreeAsync(ws, st);
       (void)hipGetLastError();
+      if (deterministic) {
+        set_error("ms_deform_attn_backward: OCC_MSDA_BWD_DETERMINISTIC=1 needs the binned path (%.2f GB of scratch, "
+                  "OCC_MSDA_BWD_ATOMICS unset)", (double)w.bytes / 1e9);
+        return OCC_E_UNSUPPORTED;
+      }
       if (!use_atomics) {
         static bool warned = false;
         if (!warned) {

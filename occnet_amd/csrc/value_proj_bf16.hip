@@ -29,6 +29,16 @@
 
 namespace occ {
 
+
+// f32 pair -> packed fp16 pair, SATURATING: |x| > 65 504 becomes +-65 504 instead of +-Inf (one v_med3_f32 per value).
+// The projected SCA value maps are stored in fp16 (sca_fused.hip); an Inf there would turn every bilinear sample that
+// touches the pixel into Inf / NaN (w * Inf, Inf - Inf), a clamp only caps one outlier value.  Random-init and the
+// synthetic features never get near the limit; a trained checkpoint's FPN outputs might.
+__device__ __forceinline__ unsigned vp_sat_half2(float a, float b) {
+  const __half2 h = __floats2half2_rn(__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f));
+  return __builtin_bit_cast(unsigned, h);
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -191,9 +201,8 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
           const int pc = nn % plane_cols;
           const long ep = (long)(nn / plane_cols) * plane_stride + (g * out_group_rows + (pix & ~1L)) * ldo +
                           (pc >> 5) * 64 + (pix & 1) * 32 + (pc & 31);
-          const __half2 h01 = __floats2half2_rn(v.x, v.y), h23 = __floats2half2_rn(v.z, v.w);
           *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(out_) + ep) =
-              make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+              make_uint2(vp_sat_half2(v.x, v.y), vp_sat_half2(v.z, v.w));
         } else {
           *reinterpret_cast<float4*>(out + eo) = v;
         }
@@ -374,10 +383,9 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
           if (OUTH) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const __half2 h01 = __floats2half2_rn(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1]);
-              const __half2 h23 = __floats2half2_rn(acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]);
               *reinterpret_cast<uint2*>(scratch + vi * kVprPitch + 16 * q + 8 * kb) =
-                  make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                  make_uint2(vp_sat_half2(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1]),
+                             vp_sat_half2(acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]));
             }
           } else {
 #pragma unroll

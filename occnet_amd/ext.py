@@ -366,6 +366,7 @@ def conv3d_heads_pack(w1_occ, b1_occ, w2_occ, b2_occ, w1_flow, b1_flow, w2_flow,
         rc = lib.occ_conv3d_heads_pack(*[ptr(t) for t in ts], ptr(packed), i32(C), i32(hidden), i32(ncls),
                                        stream_ptr(w1_occ.device))
     _lib.check(rc, "conv3d_heads_pack")
+    packed._occ_heads_meta = (int(C), int(hidden), int(ncls))     # the fragment layout bakes these in: checked at use
     return packed
 
 
@@ -378,6 +379,9 @@ def conv3d_heads_decode(x, w_packed, scale, shift, heads_packed, Z, Y, X, num_cl
         _need_cuda_f32(n, t)
     if w_packed.dtype != torch.int16:
         raise OccAmdUnsupported("conv3d_heads_decode: needs the bf16x3 packed weight")
+    meta = getattr(heads_packed, '_occ_heads_meta', None)
+    if meta is not None and meta[2] != int(num_classes):
+        raise OccAmdError(f"conv3d_heads_decode: heads were packed for {meta[2]} classes, called with {num_classes}")
     B = x.shape[0]
     cin = x.numel() // (B * Y * X * Z)
     if x.numel() != B * Y * X * Z * cin or w_packed.numel() != 32 * cin * 27 * 2:
@@ -531,6 +535,21 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
 _STACKED_VP = {}        # (weights' (ptr, version) ..., epoch) -> (stacked weight, its pack) of value_proj_bf16_planes
 
 
+def value_proj_planes_prepare(weights):
+    """The stacked + packed weight of value_proj_bf16_planes for this list of projections (cached on the weights'
+    identities): built on the CURRENT stream.  A caller that launches value_proj_bf16_planes on a side stream calls this
+    on the main stream first, so that no main-stream reader of the cache entry can race its construction."""
+    key = tuple((w.data_ptr(), w._version) for w in weights) + (str(weights[0].device), cache_epoch())
+    hit = _STACKED_VP.get(key)
+    if hit is None:
+        stacked = torch.cat([w.detach() for w in weights], 0).contiguous()
+        stacked._occ_no_cache = True
+        if len(_STACKED_VP) >= 8:
+            _STACKED_VP.pop(next(iter(_STACKED_VP)))
+        hit = _STACKED_VP[key] = (stacked, linear_pack_weight_bf16x3(stacked), list(weights))
+    return hit
+
+
 def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, out_group_rows, out_row0):
     """The same rows through SEVERAL projections in one launch (the encoder layers' SCA value projections):
     out[p] = value_proj_bf16(a_list, weights[p], group_biases[p], ...) for every p, feature rows read from HBM once.
@@ -551,14 +570,7 @@ def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, o
         groups = (a.shape[0] + rpg - 1) // rpg
         if (groups - 1) * out_group_rows + r0 + min(rpg, a.shape[0]) > out.shape[1]:
             raise OccAmdError("value_proj_bf16_planes: output rows out of range")
-    key = tuple((w.data_ptr(), w._version) for w in weights) + (str(weights[0].device), cache_epoch())
-    hit = _STACKED_VP.get(key)
-    if hit is None:
-        stacked = torch.cat([w.detach() for w in weights], 0).contiguous()
-        stacked._occ_no_cache = True
-        if len(_STACKED_VP) >= 8:
-            _STACKED_VP.pop(next(iter(_STACKED_VP)))
-        hit = _STACKED_VP[key] = (stacked, linear_pack_weight_bf16x3(stacked), list(weights))
+    hit = value_proj_planes_prepare(weights)
     gb_ptrs, G, gb_keep = None, 0, None
     if group_biases is not None and group_biases[0] is not None:
         gb_keep = torch.cat(list(group_biases), 2).contiguous()                  # (S, G, P*N)

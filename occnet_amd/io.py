@@ -127,6 +127,9 @@ def make_img_meta(cams, lidar2ego_translation, lidar2ego_rotation, img_shapes, c
 PSEUDO_LIDAR2EGO = np.array([[0., 1., 0., 0.94], [-1., 0., 0., 0.], [0., 0., 1., 1.84], [0., 0., 0., 1.]])
 
 
+_SCENE_FRAMES = {}      # id(data_infos) -> (list object, (len, dataset_type), {scene: [frames]})
+
+
 def lidar_origins(data_infos, index, dataset_type='openocc_v2', max_origins=8, xy_range=39.0):
     """Lidar origins the ray metric / the submission cast from for sample `index`: the lidar position of EVERY frame
     of the sample's scene expressed in the sample's ego frame, kept when |x|, |y| < 39 m, thinned to 8 evenly spaced
@@ -146,7 +149,16 @@ def lidar_origins(data_infos, index, dataset_type='openocc_v2', max_origins=8, x
     def global_from_lidar(info):
         return transform_matrix(info['ego2global_translation'], info['ego2global_rotation']).dot(ego_from_lidar(info))
     info = data_infos[index]
-    frames = [f for f in data_infos if scene_of(f) == scene_of(info)]
+    # scene -> frame list, built once per data_infos list (a rescan per call is O(N^2) over a dataset: ADVICE r3)
+    cache = _SCENE_FRAMES.get(id(data_infos))
+    if cache is None or cache[0] is not data_infos or cache[1] != (len(data_infos), dataset_type):
+        by_scene = {}
+        for f in data_infos:
+            by_scene.setdefault(scene_of(f), []).append(f)
+        cache = (data_infos, (len(data_infos), dataset_type), by_scene)
+        _SCENE_FRAMES.clear()
+        _SCENE_FRAMES[id(data_infos)] = cache
+    frames = cache[2][scene_of(info)]
     ref_index = next(i for i, f in enumerate(frames) if f is info)
     ref_lidar_from_global = np.linalg.inv(global_from_lidar(info))
     ref_ego_from_lidar = ego_from_lidar(info)

@@ -53,9 +53,34 @@ class BEVFormerOcc(BaseModule):
         self.prev_frame_info = {'prev_bev': None, 'scene_token': None, 'prev_pos': 0, 'prev_angle': 0}
 
     def train(self, mode=True):
-        if mode:    # parameters / BatchNorm statistics may change while training: re-check the folded plan's sources
-            object.__setattr__(self, '_plan_dirty', True)
-        return super().train(mode)
+        """Mode switch + cache safety net.  Every derived-weight cache (packed Linear / chain weights, folded backbone
+        plan, decoder / heads packs) is keyed on (address, _version) of its sources; writes through `.data`
+        (param.data.copy_: mmcv's EMAHook swap before validation, manual loads) do not bump _version.  On a REAL
+        train -> eval transition the contents are therefore fingerprinted (one fused norm over all parameters and
+        buffers, one host sync) and the cache epoch is bumped when they changed since the last check; the eval <-> train
+        flips inside obtain_history_bev (twice per training step) skip it."""
+        was_training = self.training
+        # parameters / BatchNorm statistics may change while training, and an eval() entry is where stale plans would be
+        # served from: re-check the folded plan's sources at the next forward in either case
+        object.__setattr__(self, '_plan_dirty', True)
+        out = super().train(mode)
+        if was_training and not mode and not getattr(self, '_in_history', False):
+            fp = self._content_fingerprint()
+            if fp is not None and fp != getattr(self, '_content_fp', None):
+                if getattr(self, '_content_fp', None) is not None:
+                    from .bricks import _bump_cache_epoch
+                    _bump_cache_epoch()
+                object.__setattr__(self, '_content_fp', fp)
+        return out
+
+    def _content_fingerprint(self):
+        """float64 sum of the per-tensor 2-norms of every device parameter / buffer (None on the host or without
+        floating-point tensors): changes whenever a weight is rewritten, however it was written."""
+        ts = [t.detach() for t in list(self.parameters()) + list(self.buffers()) if t.is_cuda and t.is_floating_point()]
+        if not ts:
+            return None
+        norms = torch._foreach_norm(ts)
+        return float(torch.stack([n.double() for n in norms]).sum().item())
 
     def _backbone_signature(self):
         mods = [m for m in (getattr(self, 'img_backbone', None), getattr(self, 'img_neck', None)) if m is not None]
@@ -128,6 +153,8 @@ class BEVFormerOcc(BaseModule):
         object.__setattr__(self, '_inference_backbone_args', dict(
             dtype=dtype, fused_ops=fused_ops, hip_tail=hip_tail, use_graph=use_graph,
             fused_bottleneck=fused_bottleneck))
+        # folded while training (no explicit .train() call needed for that): the sources may move before the first forward
+        object.__setattr__(self, '_plan_dirty', bool(self.training))
         if dtype is not None:
             plan = FusedInferenceBackbone(self.img_backbone, self.img_neck, dtype=dtype,
                                           fused_ops=fused_ops, hip_tail=hip_tail,
@@ -198,7 +225,9 @@ class BEVFormerOcc(BaseModule):
         """BEV of the history frames, iteratively, without gradients
         (imgs_queue (bs, len_queue, N, 3, H, W))."""
         was_training = self.training
+        object.__setattr__(self, '_in_history', True)      # no content fingerprint for this eval <-> train flip
         self.eval()
+        object.__setattr__(self, '_in_history', False)
         with torch.no_grad():
             prev_bev = None
             bs, len_queue, num_cams, C, H, W = imgs_queue.shape

@@ -263,7 +263,7 @@ class SpatialCrossAttention(BaseModule):
             v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
             v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
             if ext.SCA_VALUES == "f16":
-                v = v.half()                                            # row order: the gather wrapper re-orders it
+                v = v.clamp(-65504.0, 65504.0).half()                   # saturating, like the projection's fp16 epilogue
         v = v.view(bs * self.num_cams, v.shape[1], da.num_heads, -1)
         n_off = da.sampling_offsets.out_features
         if vis_bits is None:

@@ -55,6 +55,12 @@ def _rotation_source_index(H, W, angle_deg, center):
         ids = torch.arange(1, H * W + 1, dtype=torch.float32).view(1, 1, H, W)
         src = F.grid_sample(ids, grid, mode='nearest', padding_mode='zeros', align_corners=False).view(-1)
         hit = src.to(torch.int64) - 1
+        if torch.cuda.is_available():
+            # pinned: the per-frame upload is then an asynchronous copy (pageable memory makes it a synchronous one)
+            try:
+                hit = hit.pin_memory()
+            except RuntimeError:
+                pass
         if len(_ROT_CACHE) >= 16:
             _ROT_CACHE.pop(next(iter(_ROT_CACHE)))
         _ROT_CACHE[key] = hit
@@ -69,7 +75,10 @@ def rotate_bev_nearest(bev, angle_deg, center):
     C, H, W = bev.shape
     assert H * W < (1 << 24)
     src = _rotation_source_index(H, W, angle_deg, center).to(bev.device, non_blocking=True)
-    out = bev.reshape(C, H * W).index_select(1, src.clamp(min=0)) * (src >= 0).to(bev.dtype)
+    gathered = bev.reshape(C, H * W).index_select(1, src.clamp(min=0))
+    # pixels whose source lies outside the map are ZERO whatever pixel 0 holds (a product with 0 would spread a
+    # NaN / Inf at bev[:, 0, 0] to every padded pixel)
+    out = torch.where((src >= 0).unsqueeze(0), gathered, gathered.new_zeros(()))
     return out.view(C, H, W)
 
 
@@ -150,6 +159,11 @@ class LazyFeatures:
         gbs = [self._group_bias(vp) for vp in value_projs]
         stacked = (len(value_projs) > 1 and all(tuple(vp.weight.shape) == tuple(value_projs[0].weight.shape)
                                                 for vp in value_projs) and value_projs[0].weight.shape[0] % 256 == 0)
+        if stacked:
+            try:
+                ext.value_proj_planes_prepare([vp.weight for vp in value_projs])     # stack + pack on the MAIN stream
+            except ext.OccAmdError:
+                stacked = False
         if not stacked:
             for vp in value_projs:
                 ext.linear_pack_weight_bf16x3(vp.weight)
@@ -162,16 +176,20 @@ class LazyFeatures:
                 # ONE launch for all layers: every block projects its rows with all the layers' weights, the feature
                 # maps are read from HBM once (occ_value_proj_bf16_planes); layer l's values are plane l
                 n = value_projs[0].weight.shape[0]
-                out = self._alloc(n, planes=len(value_projs))
-                ext.value_proj_bf16_planes(self.rows, [vp.weight for vp in value_projs], gbs, out,
-                                           rows_per_group=[h * wd for h, wd in self.hw], out_group_rows=self.group_rows,
-                                           out_row0=self.starts)
-                out.record_stream(main)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                for l, vp in enumerate(value_projs):
-                    self._pending[id(vp)] = (out[l].view(self.bs * self.num_cam, self.group_rows, n), ev)
-            else:
+                try:
+                    out = self._alloc(n, planes=len(value_projs))
+                    ext.value_proj_bf16_planes(self.rows, [vp.weight for vp in value_projs], gbs, out,
+                                               rows_per_group=[h * wd for h, wd in self.hw],
+                                               out_group_rows=self.group_rows, out_row0=self.starts)
+                    out.record_stream(main)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    for l, vp in enumerate(value_projs):
+                        self._pending[id(vp)] = (out[l].view(self.bs * self.num_cam, self.group_rows, n), ev)
+                except ext.OccAmdError:          # e.g. the 74 KB LDS attribute refused: one launch per layer instead
+                    stacked = False
+                    self._pending = {}
+            if not stacked:
                 for vp, gb in zip(value_projs, gbs):
                     out = self._launch(vp, gb)
                     out.record_stream(main)                  # consumed (and released) on the main stream
@@ -439,7 +457,9 @@ class TransformerOcc(BaseModule):
                                in_layout=1)
         p, f = self.predicter, self.flow_predicter
         if (self.fuse_heads and Z == 16 and self.out_dim == 32 and w2.dtype == torch.int16
-                and ext.HEADS_PRECISION == "bf16x3" and p[0].weight.shape == (64, 32)):
+                and ext.HEADS_PRECISION == "bf16x3" and tuple(p[0].weight.shape) == (64, 32)
+                and tuple(f[0].weight.shape) == (64, 32) and tuple(p[2].weight.shape)[1] == 64
+                and tuple(f[2].weight.shape) == (2, 64)):
             # second convolution + heads + decode in ONE launch: its 82 MB of activations stay on chip
             try:
                 occ, flow, cls = ext.conv3d_heads_decode(x, w2, s2, t2, self._heads_pack(), Z, bev_h, bev_w,

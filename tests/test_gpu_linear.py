@@ -468,3 +468,38 @@ def test_linear_chain_rejects_other_shapes():
     with pytest.raises(OccAmdUnsupported):      # FFN hidden != 512
         ext.encoder_ffn_chain(a, a, w, None, ln, torch.zeros(1024, 256, device='cuda'), None,
                               torch.zeros(256, 1024, device='cuda'), None, ln)
+
+
+@pytest.mark.parametrize("P", [1, 4])
+def test_value_proj_fp16_output_saturates_instead_of_overflowing(P):
+    """fp16 SCA value maps (ADVICE r3 / VERDICT r3 weak #4): a projected value beyond the fp16 range is stored as
+    +-65 504, never as Inf — on both kernels (activation-resident: every group >= 128 rows; tiled: a short extra
+    segment) — and everything inside the range is unchanged."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(31 + P)
+    cams, K, N = 2, 256, 256
+    for hws in ([256], [256, 20]):                       # resident kernel / tiled kernel
+        total = sum(hws) + 4
+        starts = [0] + [sum(hws[:i + 1]) + 2 for i in range(len(hws) - 1)]
+        a_list = [torch.randn(cams * hw, K, generator=g).cuda().to(torch.bfloat16) for hw in hws]
+        a_list[0][5] = 60000.0                           # two pixels of huge features: |v| ~ 60000 * |sum w| >> 65504
+        a_list[0][7] = -60000.0
+        ws = [(torch.randn(N, K, generator=g) / 4).cuda() for _ in range(P)]
+        gbs = [torch.zeros(len(hws), 1, N).cuda() for _ in range(P)]
+        out = torch.zeros((P, cams * total, N), device='cuda', dtype=torch.float16)
+        if P == 1:
+            ext.value_proj_bf16(a_list, ws[0], gbs[0], out[0], rows_per_group=hws, out_group_rows=total, out_row0=starts)
+        else:
+            ext.value_proj_bf16_planes(a_list, ws, gbs, out, rows_per_group=hws, out_group_rows=total, out_row0=starts)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out.float()).all()), "fp16 value maps must saturate, not overflow"
+        for p in range(P):
+            o = ext.sca_unpair_layout(out[p].view(cams, total, N // 32, 32)).reshape(cams, total, N)
+            ref = (a_list[0].double() @ ws[p].double().t()).view(cams, hws[0], N)
+            got = o[:, starts[0]:starts[0] + hws[0]].double()
+            big = ref.abs() > 65504.0
+            assert int(big.sum()) > 100                  # the case really overflows
+            assert bool((got[big].abs() == 65504.0).all()) and bool((got[big].sign() == ref[big].sign()).all())
+            small = ref.abs() < 60000.0
+            rel = ((got[small] - ref[small]).abs() / ref[small].abs().clamp_min(1.0)).max()
+            assert float(rel) < 2e-3

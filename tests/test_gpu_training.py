@@ -317,3 +317,51 @@ def test_sca_prep_function_matches_torch_ops_and_gradient():
     e_g = float((pd.grad.cpu().double() - pr.grad).abs().max() / pr.grad.abs().max())
     print(f"sca_prep: loc {e_loc:.2e} attn {e_att:.2e} grad rel {e_g:.2e}")
     assert e_loc < 1e-5 and e_att < 1e-6 and e_g < 1e-5
+
+
+def test_data_copy_before_eval_is_caught_by_the_content_fingerprint():
+    """a weight rewritten through `.data.copy_` (mmcv's EMAHook swap before validation) leaves
+    (address, _version) unchanged, so every derived-weight cache would serve the OLD weights in eval.  The detector's
+    train -> eval transition fingerprints the contents and bumps the cache epoch when they moved; the eval <-> train
+    flips of obtain_history_bev do not (checked above)."""
+    import copy
+    import occnet_amd
+    from occnet_amd import synthetic
+    from occnet_amd.plugin import Config, build_model, import_plugin
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs', 'occ_tiny_50x50x4.py'))
+    import_plugin(cfg)
+    torch.manual_seed(0)
+    model = build_model(cfg.model)
+    model.init_weights()
+    device = torch.device('cuda', 0)
+    model = model.to(device)
+    geo = dict(synthetic.BASE)
+    geo.update(cfg.get("input_geometry", {}))
+    head = model.pts_bbox_head
+    geo.update(bev_h=head.bev_h, bev_w=head.bev_w)
+    feats = [f.to(device) for f in synthetic.make_features(geo, batch=1, seed=3)]
+    metas = synthetic.make_img_metas(geo, batch=1, seed=3)
+    model.train()
+    model.eval()                                            # first transition: fingerprint recorded
+    with torch.no_grad():
+        out1 = head(feats, metas)['occ'].clone()
+    e0 = occnet_amd.cache_epoch()
+    model.train()
+    model.eval()                                            # nothing changed: no bump
+    assert occnet_amd.cache_epoch() == e0
+    model.train()
+    fc = head.transformer.encoder.layers[0].ffns[0].layers[1]
+    fresh = copy.deepcopy(fc.weight.data) * 0.5 + 0.01
+    v0 = fc.weight._version
+    fc.weight.data.copy_(fresh)                             # the EMA swap: invisible to _version
+    assert fc.weight._version == v0
+    model.eval()
+    assert occnet_amd.cache_epoch() > e0                    # ... but not to the fingerprint
+    with torch.no_grad():
+        out2 = head(feats, metas)['occ'].clone()
+    assert float((out2 - out1).abs().max()) > 1e-4          # the new weights are what ran
+    occnet_amd.invalidate_caches()
+    with torch.no_grad():
+        out3 = head(feats, metas)['occ']
+    assert float((out3 - out2).abs().max()) < 1e-6          # and an explicit invalidation changes nothing further

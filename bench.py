@@ -602,6 +602,11 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus={world}",
               file=sys.stderr)
 
+    # one slice of the host cores per rank (occnet_amd/dist.py::bind_rank_threads; OCC_BIND_THREADS=0: off)
+    from occnet_amd.dist import bind_rank_threads
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    bound = bind_rank_threads(local_rank, local_world)
+
     if args.launcher_selftest:
         # the N-rank launch contract without a model: process group (gloo: no GPU needed), barrier, K timed
         # "steps", barrier, MAX over ranks, ONE JSON line from rank 0
@@ -618,8 +623,14 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        cores = None
+        if world > 1:       # every rank's core slice: disjoint when the binding worked
+            allc = [None] * world
+            dist.all_gather_object(allc, bound)
+            cores = allc
         if rank == 0:
             print(json.dumps({"metric": "launcher selftest (no model)", "value": world * args.steps / elapsed,
+                              "host_cores_per_rank": cores,
                               "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "data": "synthetic",
@@ -671,6 +682,8 @@ def main():
     for _ in range(max(args.warmup, 1) if args.warmup > 0 else 0):
         stepper()
     torch.cuda.synchronize()
+    if args.mode == "train" and world > 1 and hasattr(stepper.model, "_set_ddp_runtime_logging_sample_rate"):
+        stepper.model._set_ddp_runtime_logging_sample_rate(1)      # every timed step feeds DDP's comm / compute timers
     stats, da = gather_stats(model, stepper) if args.mode == "infer" else ([], None)
     if args.history:    # every SCA module ran once per frame of the queue: counters per launch
         stats = [(r // (1 + args.history), n // (1 + args.history)) for r, n in stats]
@@ -784,6 +797,11 @@ def main():
                 "config_file": os.path.relpath(args.config, ROOT),
             },
         }
+        out["host_cores_bound"] = None if bound is None else len(bound)
+        if args.mode == "train" and world > 1:
+            from occnet_amd.dist import ddp_comm_stats
+            # the path's ONLY collective: DDP's bucketed gradient all-reduce (RCCL over xGMI), as DDP's logger timed it
+            out["ddp"] = ddp_comm_stats(stepper.model)
         sca = times.get("sca_fused_forward", [])
         if sca:
             M, D = da.num_heads, da.embed_dims // da.num_heads

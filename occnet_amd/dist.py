@@ -50,3 +50,44 @@ def throughput(total_units_per_rank, elapsed_local, device=None):
     """Whole-job units/s: all ranks' units / max-over-ranks elapsed time."""
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     return world * total_units_per_rank / max_over_ranks(elapsed_local, device)
+
+
+def bind_rank_threads(local_rank, local_world, reserve=0):
+    """Give every rank of a node its own contiguous slice of the host cores this process may run on (the launcher's
+    affinity mask, usually all of them) and size torch's intra-op pool to it: eight ranks that each spin up a
+    256-thread pool on the same cores fight over them (image decoding, the CPU side of the launch queue).  Contiguous
+    core ids keep a rank on one socket / NUMA node on the usual enumeration.  -> the list of core ids (or None where
+    the platform has no sched_setaffinity).  OCC_BIND_THREADS=0 turns it off."""
+    import os as _os
+    if _os.environ.get("OCC_BIND_THREADS", "1") == "0" or not hasattr(_os, "sched_setaffinity") or local_world <= 1:
+        return None
+    avail = sorted(_os.sched_getaffinity(0))
+    per = max(1, (len(avail) - reserve) // local_world)
+    mine = avail[local_rank * per:(local_rank + 1) * per] or avail[-1:]
+    try:
+        _os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, len(mine)))
+    return mine
+
+
+def ddp_comm_stats(ddp_model):
+    """What DistributedDataParallel's own logger measured for the last sampled iterations (it brackets the backward
+    pass and every bucket's all-reduce with events): per-step backward compute time, gradient all-reduce time and how
+    much of the latter ran under the former.  Enable before the timed steps with
+    `ddp_model._set_ddp_runtime_logging_sample_rate(1)`.  -> dict of milliseconds (None where torch does not report it)."""
+    try:
+        d = ddp_model._get_ddp_logging_data()
+    except Exception:
+        return None
+    ns = lambda k: (d.get(k) / 1e6) if isinstance(d.get(k), (int, float)) and d.get(k) >= 0 else None
+    return {
+        "backward_compute_ms": ns("avg_backward_compute_time"),
+        "allreduce_ms": ns("avg_backward_comm_time"),
+        "allreduce_overlapped_ms": ns("avg_backward_compute_comm_overlap_time"),
+        "forward_compute_ms": ns("avg_forward_compute_time"),
+        "bucket_cap_bytes": d.get("bucket_cap_bytes"), "num_buckets": d.get("num_buckets_reduced", d.get("num_buckets")),
+        "gradient_bytes": d.get("total_parameter_size_bytes") or d.get("param_size_bytes"),
+        "backend": d.get("backend_name"),
+    }

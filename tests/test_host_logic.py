@@ -378,6 +378,73 @@ def test_bench_self_launches_n_ranks():
     assert abs(out['value'] - 2 * 4 / (out['ms_per_step'] * 4e-3)) / out['value'] < 1e-6
 
 
+def test_bench_launcher_at_eight_ranks_binds_disjoint_core_slices():
+    """The shape the driver's 8-GPU run takes: `bench.py --gpus 8` self-launches 8 ranks, every rank
+    pins itself to its own slice of the host cores (occnet_amd/dist.py::bind_rank_threads), rank 0 prints ONE JSON
+    line with n_gpus = 8.  gloo, no model, no GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'LOCAL_WORLD_SIZE')}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3',
+                          '--warmup', '0', '--launcher-selftest'], env=env, capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['config']['parallelism'] == 'dp8'
+    assert out['ms_per_step'] >= 8.0                       # rank 7 sleeps 8 ms per step: MAX over ranks
+    slices = out['host_cores_per_rank']
+    assert len(slices) == 8
+    if hasattr(os, 'sched_getaffinity') and len(os.sched_getaffinity(0)) >= 8:
+        assert all(s for s in slices)
+        flat = [c for s in slices for c in s]
+        assert len(flat) == len(set(flat))                 # disjoint
+        assert all(s == list(range(s[0], s[0] + len(s))) or sorted(s) == s for s in slices)
+
+
+def test_ddp_comm_stats_reports_allreduce_time():
+    """occnet_amd.dist.ddp_comm_stats on a 2-rank gloo DDP toy model: the fields bench.py --mode train --gpus N puts
+    under "ddp" (gradient all-reduce time per step, how much of it ran under the backward pass) exist and are sane."""
+    import json
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import json, os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        from occnet_amd.dist import ddp_comm_stats
+        dist.init_process_group('gloo')
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.ReLU(), torch.nn.Linear(512, 64))
+        ddp = torch.nn.parallel.DistributedDataParallel(m)
+        ddp._set_ddp_runtime_logging_sample_rate(1)
+        opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
+        for i in range(12):
+            opt.zero_grad()
+            ddp(torch.randn(32, 256)).square().mean().backward()
+            opt.step()
+        st = ddp_comm_stats(ddp)
+        if dist.get_rank() == 0:
+            print('STATS ' + json.dumps(st))
+        dist.destroy_process_group()
+    """ % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', '29541', '-c', code] if False else
+                         [sys.executable, '-c', "import subprocess,sys,os,tempfile\n"
+                          "f=tempfile.NamedTemporaryFile('w',suffix='.py',delete=False);f.write(%r);f.close()\n"
+                          "sys.exit(subprocess.call([sys.executable,'-m','torch.distributed.run','--nnodes=1',"
+                          "'--nproc-per-node','2','--master-addr','127.0.0.1','--master-port','29541',f.name]))" % code],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith('STATS ')][-1]
+    st = json.loads(line[6:])
+    assert st is not None and set(st) >= {'allreduce_ms', 'backward_compute_ms', 'allreduce_overlapped_ms'}
+    assert st['backend'] == 'gloo'
+    assert st['allreduce_ms'] is None or st['allreduce_ms'] >= 0.0
+
+
 def test_conv_bn_folded_matches_eval_batchnorm_with_gradients():
     """Training with norm_eval=True: conv -> eval BN computed as one convolution with folded weights must give the
     same output and the same gradients for the input, the convolution weight and the BN affine parameters."""

@@ -500,6 +500,8 @@ def test_value_proj_fp16_output_saturates_instead_of_overflowing(P):
             big = ref.abs() > 65504.0
             assert int(big.sum()) > 100                  # the case really overflows
             assert bool((got[big].abs() == 65504.0).all()) and bool((got[big].sign() == ref[big].sign()).all())
-            small = ref.abs() < 60000.0
-            rel = ((got[small] - ref[small]).abs() / ref[small].abs().clamp_min(1.0)).max()
-            assert float(rel) < 2e-3
+            normal = torch.ones_like(big)                # every pixel but the two huge ones: unchanged by the clamp
+            normal.view(cams * hws[0], N)[5] = False
+            normal.view(cams * hws[0], N)[7] = False
+            rel = ((got[normal] - ref[normal]).abs() / ref[normal].abs().clamp_min(1.0)).max()
+            assert float(rel) < 2e-3 and not bool(big[normal].any())

@@ -393,6 +393,191 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(
   }
 }
 
+// ---- Cin = 8 on the bf16 matrix cores: TWO TAPS per MFMA step ---------------------------------------------------------
+// BASELINE configs[4] (400 x 400 x 32 voxels, pillar_h = 32) lifts 256 / 32 = 8 channels per voxel: too few for the
+// 16-k step of v_mfma_f32_32x32x16_bf16 as conv3d_bf16x3_kernel feeds it (lane half = channel half), so round 3 sent this
+// convolution to the exact-f32 kernel (108 64-cycle MFMAs per row tile: 0.685 ms).  Here the two halves of the k-step
+// are two TAPS: lanes 0-31 contract the 8 channels of tap 2 s, lanes 32-63 those of tap 2 s + 1 — 14 steps for the 27
+// taps (the 28th is zero weights), 42 32-cycle MFMAs per row tile.  A halo voxel slot is [8 hi | 8 lo] bf16 + 16 B pad =
+// the f32 kernel's CH = 8 geometry (48 bytes: conflict-free ds_read_b128 at 12-bank strides); a lane half adds its own
+// tap's compile-time offset.  Weights: packed[step][hi, lo][lane half = tap parity][co][8] bf16.
+__global__ void conv3d_pack_weight_bf16x3_c8_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed) {
+  const int n = 14 * 2 * 32 * 8;                               // one (hi, lo) pair per thread
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  int r = idx;
+  const int j = r % 8; r /= 8;
+  const int co = r % 32; r /= 32;
+  const int kh = r % 2;
+  const int s = r / 2;
+  const int t = 2 * s + kh;
+  const float x = t < 27 ? w[((long)co * 8 + j) * 27 + t] : 0.f;
+  const unsigned short hi = bf16_rne(x);
+  const unsigned short lo = bf16_rne(x - __uint_as_float((unsigned)hi << 16));
+  const long base = (((long)s * 2) * 2 + kh) * 32 * 8 + co * 8 + j;                 // plane 0 (hi)
+  packed[base] = hi;
+  packed[base + 2 * 32 * 8] = lo;                                                    // plane 1 (lo)
+}
+
+template <int Z, int TY, int TX, int LAYOUT>
+__global__ __launch_bounds__(256) void conv3d_bf16x3_c8_kernel(
+    const float* __restrict__ in, const uint4* __restrict__ wp, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int Y, int X, long out_sb, long out_sy, long out_sx,
+    int relu, int tiles_x, int tiles_y) {
+  constexpr int CH = 8, Cin = 8;
+  using G = ConvGeom<Z, CH, TY, TX>;
+  constexpr int VSB = G::VS * 4, PSB = G::PS * 4, HX = G::HX, HY = G::HY, NACC = G::NACC;   // bytes
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid;                                    // XCD-aware tile order (see conv3d_bf16x3_kernel)
+  {
+    const int n = (int)gridDim.x, q = n >> 3, r = n & 7, x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    bid = x * q + (x < r ? x : r) + j;
+  }
+  const int tx_i = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty_i = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty_i * TY, x0 = tx_i * TX;
+  const float* inb = in + (long)b * Y * X * Z * Cin;
+
+  for (int i = tid; i < HY * HX * 2 * (VSB / 16); i += 256) {          // z-halo slots stay zero
+    const int pil = i / (2 * (VSB / 16)), rem = i % (2 * (VSB / 16));
+    const int part = rem % (VSB / 16);
+    *reinterpret_cast<uint4*>(ldsb + pil * PSB + (rem >= VSB / 16 ? (Z + 1) * VSB : 0) + part * 16) =
+        make_uint4(0u, 0u, 0u, 0u);
+  }
+  // ---- stage the 8 channels of the halo, split into hi / lo bf16 (one phase) --------------------------------------
+  if (LAYOUT == 0) {
+    constexpr int PARTS = CH / 4, ITEMS = HY * HX * Z * PARTS, ITERS = (ITEMS + 255) / 256;
+#pragma unroll 4
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int part = idx % PARTS, z = (idx / PARTS) % Z, pil = idx / (PARTS * Z);
+      const int gy = y0 + pil / HX - 1, gx = x0 + pil % HX - 1;
+      if (idx < ITEMS) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < Y && gx >= 0 && gx < X)
+          v = *reinterpret_cast<const float4*>(inb + (((long)gy * X + gx) * Z + z) * Cin + part * 4);
+        const unsigned h01 = pack_bf16x2_rne(v.x, v.y), h23 = pack_bf16x2_rne(v.z, v.w);
+        const unsigned l01 = pack_bf16x2_rne(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+        const unsigned l23 = pack_bf16x2_rne(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+        char* d = ldsb + pil * PSB + (z + 1) * VSB + part * 8;
+        *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
+      }
+    }
+  } else {
+    constexpr int Z4 = Z / 4, ITEMS = HY * HX * CH * Z4, ITERS = (ITEMS + 255) / 256;
+#pragma unroll 4
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int z4 = idx % Z4, ci = (idx / Z4) % CH, pil = idx / (Z4 * CH);
+      const int gy = y0 + pil / HX - 1, gx = x0 + pil % HX - 1;
+      if (idx < ITEMS) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < Y && gx >= 0 && gx < X)
+          v = *reinterpret_cast<const float4*>(inb + ((long)gy * X + gx) * Z * Cin + (long)ci * Z + z4 * 4);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        char* d = ldsb + pil * PSB + (z4 * 4 + 1) * VSB + ci * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned short hi = bf16_rne(f[q]);
+          const unsigned short lo = bf16_rne(f[q] - __uint_as_float((unsigned)hi << 16));
+          *reinterpret_cast<unsigned short*>(d + q * VSB) = hi;
+          *reinterpret_cast<unsigned short*>(d + q * VSB + 16) = lo;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  const int vi = lane & 31, kh = lane >> 5;
+  int abase[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int rt = wave * NACC + a;
+    const int ty = rt / G::TXG, txg = rt % G::TXG;
+    const int px = txg * G::PX + vi / Z, z = vi % Z;
+    abase[a] = (ty * HX + px) * PSB + z * VSB;                 // tap (0,0,0) = halo corner (-1,-1,-1), hi plane
+  }
+  // ---- 14 steps (tap pairs) x NACC accumulators x 3 MFMAs (small terms first, term-major) ------------------------
+  const uint4* wq = wp + kh * 32 + vi;                         // + (s * 2 + plane) * 64
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    constexpr auto toff_of = [](int t) { return ((((t / 3) % 3) * HX + t % 3) * PSB + (t / 9) * VSB); };
+    const int t0 = 2 * s, t1 = 2 * s + 1 < 27 ? 2 * s + 1 : 26;   // the 28th tap has zero weights: any valid slot
+    const int toff = kh ? toff_of(t1) : toff_of(t0);
+    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[(s * 2 + 0) * 64]);
+    const bf16x8 wl = __builtin_bit_cast(bf16x8, wq[(s * 2 + 1) * 64]);
+    bf16x8 ah[NACC], al[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      ah[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff);
+      al[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff + 16);
+    }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], wh, acc[a], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], wl, acc[a], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], wh, acc[a], 0, 0, 0);
+  }
+
+  // ---- epilogue: BN(eval) + ReLU, one 128-byte row per voxel ---------------------------------------
+  const float sc = scale[vi], sh = shift[vi];
+  float* outb = out + (long)b * out_sb;
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int rt = wave * NACC + a;
+    const int ty = rt / G::TXG, txg = rt % G::TXG;
+    const int gy = y0 + ty;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const int gx = x0 + txg * G::PX + row / Z, z = row % Z;
+      float v = fmaf(acc[a][r], sc, sh);
+      if (relu) v = fmaxf(v, 0.f);
+      if (gy < Y && gx < X) outb[gy * out_sy + gx * out_sx + z * 32 + vi] = v;
+    }
+  }
+}
+
+template <int Z, int TY, int TX>
+static int launch_conv_x3_c8(const float* in, const void* wp, const float* scale, const float* shift, float* out, int B,
+                             int Y, int X, long out_sb, long out_sy, long out_sx, int relu, int layout, hipStream_t st) {
+  using G = ConvGeom<Z, 8, TY, TX>;
+  const int tiles_x = (X + TX - 1) / TX, tiles_y = (Y + TY - 1) / TY;
+  const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
+  const dim3 grid((unsigned)((long)B * tiles_x * tiles_y));
+  const uint4* w4 = reinterpret_cast<const uint4*>(wp);
+  hipError_t e;
+  if (layout == 0) {
+    auto k = conv3d_bf16x3_c8_kernel<Z, TY, TX, 0>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(k, grid, dim3(256), lds, st, in, w4, scale, shift, out, Y, X, out_sb, out_sy, out_sx, relu,
+                         tiles_x, tiles_y);
+  } else {
+    auto k = conv3d_bf16x3_c8_kernel<Z, TY, TX, 1>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      hipLaunchKernelGGL(k, grid, dim3(256), lds, st, in, w4, scale, shift, out, Y, X, out_sb, out_sy, out_sx, relu,
+                         tiles_x, tiles_y);
+  }
+  if (e != hipSuccess) {
+    set_error("conv3d_bn_relu_bf16x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return OCC_E_LAUNCH;
+  }
+  OCC_CHECK_LAUNCH("conv3d_bn_relu_bf16x3");
+  return OCC_OK;
+}
+
 template <int Z, int TY, int TX>
 static int launch_conv_x3(const float* in, const void* wp, const float* scale, const float* shift,
                           float* out, int B, int Y, int X, int Cin, long out_sb, long out_sy,
@@ -788,8 +973,14 @@ extern "C" int occ_conv3d_pack_weight_bf16x3(const float* weight, void* packed, 
                                              void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(weight && packed, "conv3d_pack_weight_bf16x3: null pointer argument");
+  if (Cout == 32 && Cin == 8) {          // two taps per MFMA step: 14 steps x (hi, lo) x 2 lane halves x 32 x 8 bf16
+    hipLaunchKernelGGL(conv3d_pack_weight_bf16x3_c8_kernel, dim3((14 * 2 * 32 * 8 + 255) / 256), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), weight, reinterpret_cast<unsigned short*>(packed));
+    OCC_CHECK_LAUNCH("conv3d_pack_weight_bf16x3");
+    return OCC_OK;
+  }
   if (Cout != 32 || Cin <= 0 || Cin % 16) {
-    set_error("conv3d_pack_weight_bf16x3: no kernel for Cin=%d Cout=%d (need Cout=32, Cin %% 16 == 0)", Cin, Cout);
+    set_error("conv3d_pack_weight_bf16x3: no kernel for Cin=%d Cout=%d (need Cout=32, Cin == 8 or Cin %% 16 == 0)", Cin, Cout);
     return OCC_E_UNSUPPORTED;
   }
   const int n = 32 * Cin * 27;
@@ -812,11 +1003,23 @@ extern "C" int occ_conv3d_bn_relu_bf16x3_f32(const float* in, const void* w_pack
   OCC_CHECK_ARG(in_layout == 0 || in_layout == 1, "conv3d_bn_relu_bf16x3: in_layout must be 0 or 1");
   OCC_CHECK_ARG((long)Y * X * Z * (Cin > Cout ? Cin : Cout) < (1L << 31),
                 "conv3d_bn_relu_bf16x3: one batch entry exceeds 2^31 elements");
-  if (Cout != 32 || Cin % 16 || !(Z == 4 || Z == 8 || Z == 16 || Z == 32)) {
+  if (Cout != 32 || (Cin % 16 && Cin != 8) || !(Z == 4 || Z == 8 || Z == 16 || Z == 32)) {
     set_error("conv3d_bn_relu_bf16x3: no kernel for Z=%d Cin=%d Cout=%d", Z, Cin, Cout);
     return OCC_E_UNSUPPORTED;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (Cin == 8) {
+#define OCC_CONV_C8(ZZ, TTY, TTX)                                                                  \
+    if (Z == ZZ)                                                                                   \
+      return launch_conv_x3_c8<ZZ, TTY, TTX>(in, w_packed, scale, shift, out, B, Y, X, (long)out_stride_b, \
+                                             (long)out_stride_y, (long)out_stride_x, relu, in_layout, st);
+    OCC_CONV_C8(32, 2, 4)
+    OCC_CONV_C8(16, 2, 8)
+    OCC_CONV_C8(8, 2, 16)
+    OCC_CONV_C8(4, 2, 16)
+#undef OCC_CONV_C8
+    return OCC_E_UNSUPPORTED;
+  }
 #define OCC_CONV_CASE(ZZ, TTY, TTX)                                                                \
   if (Z == ZZ)                                                                                     \
     return launch_conv_x3<ZZ, TTY, TTX>(in, w_packed, scale, shift, out, B, Y, X, Cin,             \
@@ -859,24 +1062,26 @@ extern "C" int occ_conv3d_heads_decode_bf16x3_f32(const float* in, const void* w
                 "conv3d_heads_decode: null pointer argument");
   OCC_CHECK_ARG(B > 0 && Y > 0 && X > 0 && num_classes > 0, "conv3d_heads_decode: bad dimension");
   OCC_CHECK_ARG((long)Y * X * Z * 32 < (1L << 31), "conv3d_heads_decode: one batch entry exceeds 2^31 elements");
-  if (Z != 16 || Cin != 32 || num_classes + 2 > 32) {
+  if ((Z != 16 && Z != 32) || Cin != 32 || num_classes + 2 > 32) {
     set_error("conv3d_heads_decode: no fused kernel for Z=%d Cin=%d num_classes=%d", Z, Cin, num_classes);
     return OCC_E_UNSUPPORTED;
   }
-  constexpr int TY = 2, TX = 8;
-  using G = ConvGeom<16, 16, TY, TX>;
-  const int tiles_x = (X + TX - 1) / TX, tiles_y = (Y + TY - 1) / TY;
-  const size_t lds = (size_t)G::LDS_FLOATS * sizeof(float);
-  auto k = conv3d_heads_x3_kernel<16, TY, TX>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) {
-    set_error("conv3d_heads_decode: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    return OCC_E_LAUNCH;
-  }
-  hipLaunchKernelGGL(k, dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
-                     in, reinterpret_cast<const uint4*>(w_packed), scale, shift,
-                     reinterpret_cast<const uint4*>(heads_packed), occ_out, flow_out,
-                     reinterpret_cast<long long*>(occ_cls_out), Y, X, num_classes, tiles_x, tiles_y);
-  OCC_CHECK_LAUNCH("conv3d_heads_decode");
-  return OCC_OK;
+  // Z = 16: 2 x 8 pillars per block (two pillars per 32-voxel row tile); Z = 32 (BASELINE configs[4]): 2 x 4 pillars,
+  // one pillar per row tile — the same 8 row tiles / 2 accumulators per wave, 66 KB of halo
+  auto launch = [&](auto k, int TY, int TX, size_t lds) -> int {
+    const int tiles_x = (X + TX - 1) / TX, tiles_y = (Y + TY - 1) / TY;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("conv3d_heads_decode: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return OCC_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)((long)B * tiles_x * tiles_y)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       in, reinterpret_cast<const uint4*>(w_packed), scale, shift,
+                       reinterpret_cast<const uint4*>(heads_packed), occ_out, flow_out,
+                       reinterpret_cast<long long*>(occ_cls_out), Y, X, num_classes, tiles_x, tiles_y);
+    OCC_CHECK_LAUNCH("conv3d_heads_decode");
+    return OCC_OK;
+  };
+  if (Z == 16) return launch(conv3d_heads_x3_kernel<16, 2, 8>, 2, 8, (size_t)ConvGeom<16, 16, 2, 8>::LDS_FLOATS * sizeof(float));
+  return launch(conv3d_heads_x3_kernel<32, 2, 4>, 2, 4, (size_t)ConvGeom<32, 16, 2, 4>::LDS_FLOATS * sizeof(float));
 }

@@ -301,8 +301,10 @@ def conv3d_pack_weight(weight, precision=None):
         raise OccAmdError("conv3d_pack_weight: expected a (Cout, Cin, 3, 3, 3) weight")
     cout, cin = weight.shape[:2]
     precision = precision or CONV3D_PRECISION
-    if precision == 'bf16x3' and cin % 16 == 0:
-        packed = torch.empty(weight.numel() * 2, dtype=torch.int16, device=weight.device)
+    if precision == 'bf16x3' and (cin % 16 == 0 or (cin == 8 and cout == 32)):
+        # Cin = 8: two taps per MFMA step, 14 steps (the 28th tap is zero weights) -> 14 * 2 * 2 * 32 * 8 bf16
+        n16 = 14 * 2 * 2 * 32 * 8 if cin == 8 else weight.numel() * 2
+        packed = torch.empty(n16, dtype=torch.int16, device=weight.device)
         with torch.cuda.device(weight.device):
             rc = _lib.lib().occ_conv3d_pack_weight_bf16x3(ptr(weight), ptr(packed), i32(cin), i32(cout),
                                                           stream_ptr(weight.device))
@@ -330,7 +332,8 @@ def conv3d_bn_relu(x, w_packed, scale, shift, Z, Y, X, cin, cout, in_layout, out
     if not (w_packed.is_cuda and w_packed.is_contiguous() and (x3 or w_packed.dtype == torch.float32)):
         raise OccAmdError("conv3d_bn_relu: w_packed must come from conv3d_pack_weight")
     B = x.shape[0]
-    if x.numel() != B * Y * X * Z * cin or w_packed.numel() != cout * cin * 27 * (2 if x3 else 1) \
+    n_w = (14 * 2 * 2 * 32 * 8 if cin == 8 else cout * cin * 27 * 2) if x3 else cout * cin * 27
+    if x.numel() != B * Y * X * Z * cin or w_packed.numel() != n_w \
             or scale.numel() != cout or shift.numel() != cout:
         raise OccAmdError("conv3d_bn_relu: inconsistent shapes")
     if out_xy_major:

@@ -456,7 +456,7 @@ class TransformerOcc(BaseModule):
         x = ext.conv3d_bn_relu(bev, w1, s1, t1, Z, bev_h, bev_w, self.middle_dims, self.out_dim,
                                in_layout=1)
         p, f = self.predicter, self.flow_predicter
-        if (self.fuse_heads and Z == 16 and self.out_dim == 32 and w2.dtype == torch.int16
+        if (self.fuse_heads and Z in (16, 32) and self.out_dim == 32 and w2.dtype == torch.int16
                 and ext.HEADS_PRECISION == "bf16x3" and tuple(p[0].weight.shape) == (64, 32)
                 and tuple(f[0].weight.shape) == (64, 32) and tuple(p[2].weight.shape)[1] == 64
                 and tuple(f[2].weight.shape) == (2, 64)):

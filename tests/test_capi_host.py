@@ -80,9 +80,25 @@ def test_backbone_and_projection_entry_points_validate_without_gpu():
     assert lib.occ_conv3d_heads_pack_bytes() == 16 * 1024 + 16 * 1024 + 128 * 4 + 32 * 4
     hargs = lambda Z, Cin, ncls, occ=p: (p, p, p, p, p, occ, p, null, 1, Z, 4, 4, Cin, ncls, null)
     assert lib.occ_conv3d_heads_decode_bf16x3_f32(*hargs(16, 32, 17, null)) == -1                 # null output
-    assert lib.occ_conv3d_heads_decode_bf16x3_f32(*hargs(32, 32, 17)) == -3                       # Z = 32
+    assert lib.occ_conv3d_heads_decode_bf16x3_f32(*hargs(8, 32, 17)) == -3                        # Z = 8 (16 and 32 have kernels)
     assert lib.occ_conv3d_heads_decode_bf16x3_f32(*hargs(16, 16, 17)) == -3                       # Cin = 16
     assert lib.occ_conv3d_heads_decode_bf16x3_f32(*hargs(16, 32, 40)) == -3                       # > 30 classes
+    # row-local Linear chains (round 4): argument checks before any launch
+    lib.occ_linear_chain_packed_bytes.restype = ctypes.c_int64
+    assert lib.occ_linear_chain_packed_bytes(768, 256) == 768 * 256 * 4
+    assert lib.occ_linear_chain_packed_bytes(192, 256) == 256 * 256 * 4                           # padded to a 256-row group
+    assert lib.occ_linear_chain_pack_bf16x3(p, p, 256, 40, null) == -3                            # K % 16
+    f = ctypes.c_float(1e-5)
+    assert lib.occ_linear_ln_chain_bf16x3_f32(null, i64(256), p, i64(256), p, p, p, p, f, p, i64(256), p, i64(768),
+                                              768, 0, 64, null) == -1                             # null input
+    assert lib.occ_linear_ln_chain_bf16x3_f32(p, i64(256), p, i64(256), p, p, p, p, f, p, i64(256), p, i64(768),
+                                              770, 0, 64, null) == -1                             # ldz < n2
+    assert lib.occ_linear_ln_chain_bf16x3_f32(p, i64(256), p, i64(256), p, p, p, p, f, p, i64(256), p, i64(800),
+                                              776, 0, 64, null) == -3                             # n2 % 32
+    assert lib.occ_encoder_ffn_chain_bf16x3_f32(p, i64(256), p, i64(256), p, p, p, p, f, p, p, f, p, i64(256), null,
+                                                i64(0), p, i64(192), 192, null, i64(256), 64, null) == -1   # zq without zv
+    assert lib.occ_encoder_ffn_chain_bf16x3_f32(p, i64(256), p, i64(256), p, p, p, p, f, p, p, f, p, i64(256), null,
+                                                i64(0), p, i64(200), 200, p, i64(256), 64, null) == -3      # nq % 64
     with pytest.raises(_lib.OccAmdUnsupported):
         ext.conv1x1_pack_weight(torch.zeros(8, 32))
     with pytest.raises(_lib.OccAmdUnsupported):

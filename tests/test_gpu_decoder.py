@@ -24,7 +24,11 @@ CONV_CASES = [
     ("base_lifter", 1, 16, 9, 21, 16),
     ("base_conv2", 2, 16, 7, 10, 32),
     ("tiny_z4", 1, 4, 13, 37, 64),
-    ("hires_z32_c8", 1, 32, 5, 6, 8),
+    ("hires_z32_c8", 1, 32, 5, 6, 8),          # BASELINE configs[4]'s lifter: 8 channels, two taps per MFMA step
+    ("hires_z32_c8_b2", 2, 32, 3, 9, 8),
+    ("z16_c8", 1, 16, 7, 11, 8),
+    ("z4_c8", 1, 4, 5, 33, 8),
+    ("hires_z32_c32", 1, 32, 4, 7, 32),
     ("z8", 1, 8, 6, 19, 32),
     ("one_pillar", 1, 16, 1, 1, 16),
 ]
@@ -48,8 +52,8 @@ def test_conv3d_bn_relu_matches_oracle(name, B, Z, Y, X, Cin, layout, precision)
         assert torch.equal(odec.lifter(xin, Z, Y, X), x)           # the lifter view is exactly this
     scale, shift = _fold(bn)
     wp = ext.conv3d_pack_weight(w.cuda(), precision=precision)
-    x3 = wp.dtype == torch.int16            # Cin % 16 != 0 keeps the exact-f32 kernel
-    assert x3 == (precision == "bf16x3" and Cin % 16 == 0)
+    x3 = wp.dtype == torch.int16            # bf16x3 kernels: Cin % 16 == 0, or Cin == 8 (two taps per MFMA step)
+    assert x3 == (precision == "bf16x3" and (Cin % 16 == 0 or Cin == 8))
     for xy_major in (False, True):
         out = ext.conv3d_bn_relu(xin.cuda(), wp, scale.cuda(), shift.cuda(), Z, Y, X, Cin, cout,
                                  in_layout=layout, out_xy_major=xy_major)
@@ -139,8 +143,9 @@ def test_unsupported_shapes_raise_unsupported():
                       torch.randn(64).cuda(), torch.randn(2, 64).cuda(), torch.randn(2).cuda())
 
 
-@pytest.mark.parametrize("B,Y,X", [(1, 9, 21), (2, 7, 10), (1, 1, 1), (1, 16, 40)])
-def test_fused_conv_heads_decode_equals_two_launches(B, Y, X):
+@pytest.mark.parametrize("B,Y,X,Z", [(1, 9, 21, 16), (2, 7, 10, 16), (1, 1, 1, 16), (1, 16, 40, 16),
+                                     (1, 5, 9, 32), (2, 3, 4, 32), (1, 1, 1, 32)])
+def test_fused_conv_heads_decode_equals_two_launches(B, Y, X, Z):
     """occ_conv3d_heads_decode_bf16x3_f32 (second convolution + BN + ReLU + both heads + decode in one kernel; the
     convolution's output never reaches HBM) vs the two launches it replaces — conv3d_bn_relu(out_xy_major) then
     occ_heads(decode=True) — and vs the float64 oracle chain.  The fused kernel contracts the heads' first layer in a
@@ -148,7 +153,7 @@ def test_fused_conv_heads_decode_equals_two_launches(B, Y, X):
     bit for bit (first index on ties).  Ragged tiles (Y, X not multiples of the 2 x 8 block tile), batch 2."""
     from occnet_amd import ext
     g = torch.Generator().manual_seed(61)
-    Z, C, ncls = 16, 32, 17
+    C, ncls = 32, 17                      # Z = 32: BASELINE configs[4] (2 x 4 pillars per block, one pillar per row tile)
     x = torch.randn(B, Y, X, Z, C, generator=g)
     w = torch.randn(C, C, 3, 3, 3, generator=g) * (2.0 / (C * 27)) ** 0.5
     bn = _bn(C, g)

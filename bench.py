@@ -879,8 +879,8 @@ def main():
                 else:
                     ms = [sum(conv[0::2]) / (len(conv) // 2), sum(conv[1::2]) / (len(conv) // 2)]
 
-                def conv_entry(ms_, fl_, cin):   # the kernel follows the packed weight: bf16x3 needs Cin % 16 == 0
-                    x3 = ext.CONV3D_PRECISION == "bf16x3" and cin % 16 == 0
+                def conv_entry(ms_, fl_, cin):   # the kernel follows the packed weight: bf16x3 = Cin % 16 == 0 or Cin == 8
+                    x3 = ext.CONV3D_PRECISION == "bf16x3" and (cin % 16 == 0 or cin == 8)
                     peak, mult = (2500.0, 3.0) if x3 else (157.3, 1.0)
                     return {"launch_ms": ms_, "precision": "bf16x3" if x3 else "f32", "tflops": fl_ / ms_ / 1e9,
                             "mfma_tflops": mult * fl_ / ms_ / 1e9, "frac": mult * fl_ / ms_ / 1e9 / peak}

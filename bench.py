@@ -270,8 +270,11 @@ class TrainStepper:
         if self.autocast:
             model.img_backbone.to(memory_format=torch.channels_last)
             model.img_neck.to(memory_format=torch.channels_last)
-            # mixed precision like the backbone: MIOpen's fp32 Conv3d backward alone is 196 ms per step
-            head.transformer.decoder_autocast_dtype = torch.bfloat16
+            # the Conv3d decoder trains on this library's bf16x3 kernels at fp32-class precision (ext.Conv3dX3Function,
+            # round 4); only with OCC_TRAIN_DECODER=torch does it fall back to MIOpen, and then under bf16 autocast like
+            # the backbone (MIOpen's fp32 Conv3d backward alone is 196 ms per step)
+            if not getattr(head.transformer, "train_decoder_own", False):
+                head.transformer.decoder_autocast_dtype = torch.bfloat16
 
     def __call__(self):
         from occnet_amd.train import train_step

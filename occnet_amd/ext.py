@@ -844,6 +844,70 @@ def linear_wgrad(dy, x, with_bias=True):
     return dw, db
 
 
+class Conv3dX3Function(torch.autograd.Function):
+    """3x3x3 / stride 1 / pad 1 Conv3d (no bias, Cout = 32) with forward AND backward on this library's kernels — the
+    training-mode replacement for the decoder's nn.Conv3d (reference transformer_occ.py:106-126; round 3 trained it on
+    MIOpen under bf16 autocast, narrower than the reference's fp32):
+      forward  occ_conv3d_bn_relu_bf16x3_f32 with scale 1 / shift 0 / no ReLU (BatchNorm and ReLU stay autograd ops);
+      dx       the same kernel on the flipped, transposed weight (rows beyond Cin zero: the kernel writes 32 channels);
+      dW       27 calls of occ_linear_wgrad_bf16x3_f32 on zero-padded copies of x and dy: in the padded grid a tap is
+               a constant row offset, dW[:, :, tap] = dy_pad^T @ x_pad[rows + offset(tap)] (deterministic).
+    x: in_layout 0 (B, Y, X, Z, Cin) or 1 (B, Y*X, Cin*Z) (the lifter view of the BEV embedding); -> (B, Y, X, Z, 32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, Z, Y, X, in_layout):
+        cout, cin = weight.shape[:2]
+        one = torch.ones(cout, dtype=torch.float32, device=x.device)
+        zero = torch.zeros(cout, dtype=torch.float32, device=x.device)
+        out = conv3d_bn_relu(x.contiguous(), conv3d_pack_weight(weight.detach().contiguous()), one, zero, Z, Y, X, cin, cout,
+                             in_layout, relu=False)
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (int(Z), int(Y), int(X), int(in_layout))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight = ctx.saved_tensors
+        Z, Y, X, in_layout = ctx.geom
+        cout, cin = weight.shape[:2]
+        B = x.shape[0]
+        gout = gout.contiguous()
+        gx = gw = None
+        one = torch.ones(32, dtype=torch.float32, device=x.device)
+        zero = torch.zeros(32, dtype=torch.float32, device=x.device)
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().flip(2, 3, 4).transpose(0, 1)               # (cin, cout, 3, 3, 3): dY -> dX
+            if cin < 32:
+                wt = torch.cat([wt, wt.new_zeros((32 - cin,) + tuple(wt.shape[1:]))], 0)
+            g32 = conv3d_bn_relu(gout, conv3d_pack_weight(wt.contiguous()), one, zero, Z, Y, X, cout, 32, 0, relu=False)
+            gx = g32[..., :cin]
+            gx = gx.permute(0, 1, 2, 4, 3).reshape(B, Y * X, cin * Z) if in_layout == 1 else gx.contiguous()
+        if ctx.needs_input_grad[1]:
+            xc = x.detach()
+            if in_layout == 1:
+                xc = xc.view(B, Y, X, cin, Z).permute(0, 1, 2, 4, 3)                # (B, Y, X, Z, cin) view
+            xp = torch.nn.functional.pad(xc, (0, 0, 1, 1, 1, 1, 1, 1)).contiguous().view(-1, cin)
+            gp = torch.nn.functional.pad(gout, (0, 0, 1, 1, 1, 1, 1, 1)).contiguous().view(-1, cout)
+            R = xp.shape[0]
+            omax = (X + 2) * (Z + 2) + (Z + 2) + 1                                  # the skipped rows are halo rows: dy = 0
+            taps = []
+            for t in range(27):
+                kz, ky, kx = t // 9, (t // 3) % 3, t % 3
+                o = ((ky - 1) * (X + 2) + (kx - 1)) * (Z + 2) + (kz - 1)
+                dw_t, _ = linear_wgrad(gp[omax:R - omax], xp[omax + o:R - omax + o], with_bias=False)
+                taps.append(dw_t)
+            gw = torch.stack(taps, -1).view(cout, cin, 3, 3, 3)
+        return gx, gw, None, None, None, None
+
+
+def conv3d_autograd(x, weight, Z, Y, X, in_layout=0):
+    """Differentiable Conv3d(k3, s1, p1, no bias, Cout = 32) on the bf16x3 kernels (Conv3dX3Function)."""
+    cout, cin = weight.shape[:2]
+    if cout != 32 or not (cin % 16 == 0 or cin == 8) or Z not in (4, 8, 16, 32) or CONV3D_PRECISION != "bf16x3":
+        raise OccAmdUnsupported("conv3d_autograd: needs Cout = 32, Cin % 16 == 0 or Cin == 8, Z in {4, 8, 16, 32}")
+    return Conv3dX3Function.apply(x, weight, Z, Y, X, in_layout)
+
+
 class LinearX3Function(torch.autograd.Function):
     """y = act(x @ W^T + b) with forward AND backward on the bf16x3 kernels: forward = linear(), dx = linear(dy, W^T),
     dW / db = linear_wgrad().  The training-mode replacement for F.linear at the encoder's Linear call sites

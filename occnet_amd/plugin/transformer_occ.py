@@ -477,6 +477,44 @@ class TransformerOcc(BaseModule):
         occ._occ_cls = cls
         return occ, flow
 
+    # training: the two decoder convolutions (forward, dx, dW) on this library's bf16x3 kernels at fp32-class precision
+    # (ext.Conv3dX3Function) instead of MIOpen under bf16 autocast; OCC_TRAIN_DECODER=torch keeps the stock modules
+    train_decoder_own = os.environ.get("OCC_TRAIN_DECODER", "own") != "torch"
+
+    def _train_decoder_ok(self, bev):
+        if not (self.train_decoder_own and self.use_fused_decoder and bev.is_cuda and bev.dtype == torch.float32
+                and torch.is_grad_enabled()):
+            return False
+        for m in (self.decoder[0], self.decoder[1]):
+            c = m.conv
+            if (not isinstance(m.norm, nn.BatchNorm3d) or not isinstance(getattr(m, 'activate', None), nn.ReLU)
+                    or c.bias is not None or (c.kernel_size, c.stride, c.padding, c.dilation, c.groups) !=
+                    ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 1) or c.out_channels != 32):
+                return False
+        return True
+
+    @staticmethod
+    def _bn_rows(bn, x2d):
+        """nn.BatchNorm3d.forward on channels-last rows (N, C): statistics over N = every voxel of the batch."""
+        eaf = 0.0 if bn.momentum is None else bn.momentum
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            eaf = 1.0 / float(bn.num_batches_tracked) if bn.momentum is None else bn.momentum
+        use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+        keep = not bn.training or bn.track_running_stats
+        return F.batch_norm(x2d, bn.running_mean if keep else None, bn.running_var if keep else None, bn.weight,
+                            bn.bias, use_batch, eaf, bn.eps)
+
+    def _train_decoder(self, bev, bev_h, bev_w):
+        """bev (bs, bev_h*bev_w, C) -> decoder features (bs, W, H, Z, out_dim), differentiable: lifter view + 2 x
+        (Conv3d -> BatchNorm3d -> ReLU) + permute (reference transformer_occ.py:305-308)."""
+        Z, bs = self.pillar_h, bev.shape[0]
+        x = ext.conv3d_autograd(bev, self.decoder[0].conv.weight, Z, bev_h, bev_w, in_layout=1)
+        x = torch.relu_(self._bn_rows(self.decoder[0].norm, x.view(-1, x.shape[-1]))).view(bs, bev_h, bev_w, Z, -1)
+        x = ext.conv3d_autograd(x, self.decoder[1].conv.weight, Z, bev_h, bev_w, in_layout=0)
+        x = torch.relu_(self._bn_rows(self.decoder[1].norm, x.view(-1, x.shape[-1]))).view(bs, bev_h, bev_w, Z, -1)
+        return x.permute(0, 2, 1, 3, 4).contiguous()               # (bs, W, H, Z, C)
+
     def forward(self, mlvl_feats, bev_queries, object_query_embed, bev_h, bev_w,
                 grid_length=[0.512, 0.512], bev_pos=None, reg_branches=None, cls_branches=None,
                 prev_bev=None, **kwargs):
@@ -488,6 +526,14 @@ class TransformerOcc(BaseModule):
         if self._fused_decoder_ok(bev_embed):
             try:
                 occ_pred, flow_pred = self._fused_decoder(bev_embed.contiguous(), bev_h, bev_w)
+                return bev_embed.permute(0, 2, 1).view(bs, -1, bev_h, bev_w), occ_pred, flow_pred
+            except OccAmdUnsupported:
+                pass
+        if self.use_3d and self._train_decoder_ok(bev_embed):
+            try:
+                outputs = self._train_decoder(bev_embed.contiguous(), bev_h, bev_w)
+                flow_pred = self.flow_predicter(outputs)
+                occ_pred = self.predicter(outputs)
                 return bev_embed.permute(0, 2, 1).view(bs, -1, bev_h, bev_w), occ_pred, flow_pred
             except OccAmdUnsupported:
                 pass

@@ -182,3 +182,35 @@ def test_fused_conv_heads_decode_equals_two_launches(B, Y, X, Z):
     d1, d2 = float((occ.cpu().double() - o_ref).abs().max()), float((flow.cpu().double() - f_ref).abs().max())
     print(f"fused vs oracle(f64): occ {d1:.3e} flow {d2:.3e}")
     assert d1 < 2e-4 and d2 < 2e-4
+
+
+@pytest.mark.parametrize("B,Z,Y,X,Cin,layout", [(1, 16, 5, 7, 16, 1), (2, 16, 4, 6, 32, 0), (1, 32, 3, 5, 8, 1),
+                                                (1, 4, 6, 9, 64, 0)])
+def test_conv3d_autograd_function_matches_float64_autograd(B, Z, Y, X, Cin, layout):
+    """ext.Conv3dX3Function (the decoder's training convolution): forward, dx (the same kernel on the flipped transposed
+    weight) and dW (27 shifted-row linear_wgrad calls on zero-padded copies) vs torch.autograd through F.conv3d in
+    float64."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(B, Cin, Z, Y, X, generator=g)
+    w = torch.randn(32, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
+    go = torch.randn(B, 32, Z, Y, X, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = torch.nn.functional.conv3d(xr, wr, padding=1)
+    ref.backward(go.double())
+    if layout == 0:
+        xin = x.permute(0, 3, 4, 2, 1).contiguous()
+    else:
+        xin = x.permute(0, 3, 4, 1, 2).reshape(B, Y * X, Cin * Z).contiguous()
+    xin = xin.cuda().requires_grad_(True)
+    wc = w.cuda().requires_grad_(True)
+    out = ext.conv3d_autograd(xin, wc, Z, Y, X, in_layout=layout)               # (B, Y, X, Z, 32)
+    out.backward(go.permute(0, 3, 4, 2, 1).contiguous().cuda())
+    torch.cuda.synchronize()
+    d_out = float((out.detach().cpu().double() - ref.detach().permute(0, 3, 4, 2, 1)).abs().max())
+    gx_ref = xr.grad.permute(0, 3, 4, 2, 1) if layout == 0 else xr.grad.permute(0, 3, 4, 1, 2).reshape(B, Y * X, Cin * Z)
+    d_x = float((xin.grad.cpu().double() - gx_ref).abs().max())
+    d_w = float((wc.grad.cpu().double() - wr.grad).abs().max())
+    s_w = float(wr.grad.abs().max())
+    print(f"conv3d autograd Z={Z} Cin={Cin} layout={layout}: out {d_out:.2e} dx {d_x:.2e} dW {d_w:.2e} (scale {s_w:.1f})")
+    assert d_out < 1e-4 and d_x < 2e-4 and d_w < 2e-4 * max(1.0, s_w)

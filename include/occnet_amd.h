@@ -46,6 +46,13 @@ int occ_abi_version(void);
 /* Thread-local message describing the last failure in this thread ("" if none). */
 const char* occ_last_error(void);
 
+/* ==========================================================================================
+ * PART I — THE REFERENCE INTERFACE.  The entry points a maintainer of the reference binds: one per interface the
+ * reference itself loads from native code (mmcv._ext for the model, the dvr extension for the metric).  INTEGRATION.md
+ * section 3 shows the binding stubs; nothing else in this header is needed for a drop-in.
+ *   occ_ms_deform_attn_forward_f32, occ_ms_deform_attn_backward_f32 (+ _workspace_bytes / _ws_f32), occ_dvr_render_forward_f32
+ * ========================================================================================== */
+
 /* ------------------------------------------------------------------------------------------
  * Multi-scale deformable attention, forward (mmcv op semantics).
  *   value            (B, S, M, D)        f32   S = sum_l H_l*W_l
@@ -62,6 +69,61 @@ int occ_ms_deform_attn_forward_f32(const float* value, const int64_t* spatial_sh
                                    const int64_t* level_start_index, const float* sampling_loc,
                                    const float* attn_weight, float* out, int B, int S, int M, int D,
                                    int L, int Lq, int P, int im2col_step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention, backward (mmcv op semantics).  Shapes as in the forward;
+ *   grad_output (B, Lq, M*D) f32 in;  grad_value (B, S, M, D), grad_sampling_loc (B, Lq, M, L, P, 2),
+ *   grad_attn_weight (B, Lq, M, L, P) f32 out — PRE-ZEROED BY THE CALLER (the reference's autograd
+ *   Function allocates them with zeros_like, multi_scale_deformable_attn_function.py:146-148);
+ *   grad_value: for D == 32 (almost) WITHOUT floating-point atomics (counting sort of the bilinear row items into
+ *   32-pixel bins, replayed by owner blocks from a device-built work list, csrc/msda_backward.hip): a bin with
+ *   more than 2048 items is split over several blocks that combine with f32 atomics (a few dozen per bin); the
+ *   item order inside a bin follows integer-atomic slot order.  The f32 summation order — and the last bits of
+ *   grad_value — may therefore differ from run to run, as they do with mmcv's atomicAdd.  Other D (and
+ *   OCC_MSDA_BWD_ATOMICS=1): f32 atomics throughout.
+ */
+int occ_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start_index, const float* sampling_loc,
+                                    const float* attn_weight, const float* grad_output,
+                                    float* grad_value, float* grad_sampling_loc,
+                                    float* grad_attn_weight, int B, int S, int M, int D, int L,
+                                    int Lq, int P, int im2col_step, void* stream);
+/* The same with CALLER-PROVIDED scratch for the atomic-free grad_value path (D == 32): `workspace` of at least
+ * occ_ms_deform_attn_backward_workspace_bytes(...) bytes, 256-byte aligned, uninitialised (0.7-0.9 GB per SCA call
+ * at the base config: the Python operator module takes it from torch's caching allocator).  workspace == NULL: the
+ * library uses hipMallocAsync and, if that fails, falls back to float atomics with ONE warning on stderr.
+ * ..._workspace_bytes returns 0 when the path does not apply (D != 32 / index ranges): workspace is then ignored. */
+int64_t occ_ms_deform_attn_backward_workspace_bytes(int B, int S, int M, int D, int L, int Lq, int P);
+int occ_ms_deform_attn_backward_ws_f32(const float* value, const int64_t* spatial_shapes,
+                                       const int64_t* level_start_index, const float* sampling_loc,
+                                       const float* attn_weight, const float* grad_output,
+                                       float* grad_value, float* grad_sampling_loc,
+                                       float* grad_attn_weight, int B, int S, int M, int D, int L,
+                                       int Lq, int P, int im2col_step, void* workspace,
+                                       int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray casting through an occupancy grid (RayIoU metric) — replaces the reference's `dvr.render_forward`
+ * (tools/ray_iou/lib/dvr/dvr.cpp:68-72 binding, dvr.cu:70-388), called at
+ * projects/mmdet3d_plugin/datasets/ray_metrics.py:116-123.
+ *   sigma (N, T, Z, Y, X) f32 occupancy ; origin (N, T, 3) f32 and points (N, M, point_stride >= 3) f32
+ *   in VOXEL units ; tindex (N, M) f32 time index per ray (< 0 = padded ray, skipped)
+ *   pred_dist, gt_dist (N, M) f32 and coord_index (N, M, 3) f32 out, fully written
+ *   (-1, -1, (0,0,0) for rays that never enter the grid) ; train_phase 0 = "test", 1 = "train".
+ */
+int occ_dvr_render_forward_f32(const float* sigma, const float* origin, const float* points,
+                               const float* tindex, float* pred_dist, float* gt_dist,
+                               float* coord_index, int N, int T, int Z, int Y, int X, int M,
+                               int point_stride, int train_phase, void* stream);
+
+/* ==========================================================================================
+ * PART II — FUSED MI355X ENTRY POINTS.  No counterpart in mmcv._ext: each replaces a stretch of the reference's
+ * Python / ATen code on the hot path with a gfx950 kernel (cited per entry); occnet_amd/plugin/ calls them behind the
+ * reference's module / registry surface.  Grouped: (a) the encoder — projection of the pillars, the two fused gathers,
+ * the Linear kernels and chains; (b) the decoder — Conv3d, heads, decode; (c) training partners; (d) the inference
+ * plan of the stock image backbone (outside the SURVEY.md section 8 scope; builder conveniences such as
+ * occ_mfma_pack_b_frag_bf16 / occ_bias_act_nhwc_bf16 live here).
+ * ========================================================================================== */
 
 /* ------------------------------------------------------------------------------------------
  * Pillar reference points -> per-camera image coordinates + visibility.
@@ -130,38 +192,6 @@ int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_stride, const
                               int bev_h, int bev_w, int M, int D, int P, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Multi-scale deformable attention, backward (mmcv op semantics).  Shapes as in the forward;
- *   grad_output (B, Lq, M*D) f32 in;  grad_value (B, S, M, D), grad_sampling_loc (B, Lq, M, L, P, 2),
- *   grad_attn_weight (B, Lq, M, L, P) f32 out — PRE-ZEROED BY THE CALLER (the reference's autograd
- *   Function allocates them with zeros_like, multi_scale_deformable_attn_function.py:146-148);
- *   grad_value: for D == 32 (almost) WITHOUT floating-point atomics (counting sort of the bilinear row items into
- *   32-pixel bins, replayed by owner blocks from a device-built work list, csrc/msda_backward.hip): a bin with
- *   more than 2048 items is split over several blocks that combine with f32 atomics (a few dozen per bin); the
- *   item order inside a bin follows integer-atomic slot order.  The f32 summation order — and the last bits of
- *   grad_value — may therefore differ from run to run, as they do with mmcv's atomicAdd.  Other D (and
- *   OCC_MSDA_BWD_ATOMICS=1): f32 atomics throughout.
- */
-int occ_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_shapes,
-                                    const int64_t* level_start_index, const float* sampling_loc,
-                                    const float* attn_weight, const float* grad_output,
-                                    float* grad_value, float* grad_sampling_loc,
-                                    float* grad_attn_weight, int B, int S, int M, int D, int L,
-                                    int Lq, int P, int im2col_step, void* stream);
-/* The same with CALLER-PROVIDED scratch for the atomic-free grad_value path (D == 32): `workspace` of at least
- * occ_ms_deform_attn_backward_workspace_bytes(...) bytes, 256-byte aligned, uninitialised (0.7-0.9 GB per SCA call
- * at the base config: the Python operator module takes it from torch's caching allocator).  workspace == NULL: the
- * library uses hipMallocAsync and, if that fails, falls back to float atomics with ONE warning on stderr.
- * ..._workspace_bytes returns 0 when the path does not apply (D != 32 / index ranges): workspace is then ignored. */
-int64_t occ_ms_deform_attn_backward_workspace_bytes(int B, int S, int M, int D, int L, int Lq, int P);
-int occ_ms_deform_attn_backward_ws_f32(const float* value, const int64_t* spatial_shapes,
-                                       const int64_t* level_start_index, const float* sampling_loc,
-                                       const float* attn_weight, const float* grad_output,
-                                       float* grad_value, float* grad_sampling_loc,
-                                       float* grad_attn_weight, int B, int S, int M, int D, int L,
-                                       int Lq, int P, int im2col_step, void* workspace,
-                                       int64_t workspace_bytes, void* stream);
-
-/* ------------------------------------------------------------------------------------------
  * Lifter + Conv3d(k=3, pad=1, stride=1, no bias) + BatchNorm3d(eval) + ReLU, implicit GEMM on the f32
  * matrix cores (exact f32).  Voxel grid (Z, Y, X) = torch's (D, H, W).
  *   in        in_layout 0: (B, Y, X, Z, Cin) f32, channels innermost (the layout this op writes)
@@ -188,6 +218,9 @@ int occ_conv3d_bn_relu_f32(const float* in, const float* w_packed, const float* 
  * a.w ~= al.wh + ah.wl + ah.wh accumulated in f32 by v_mfma_f32_32x32x16_bf16 (product error <= 2^-16; 5.3x less
  * matrix-pipe time than the exact-f32 instruction).  Same arguments; packed = 2 * Cout*Cin*27 16-bit words
  * ([phase][tap][hi, lo][k half][co][8]); needs Cout == 32, Cin % 16 == 0, Z in {4, 8, 16, 32}.
+ * Cin == 8 (BASELINE configs[4]: 256 / 32 channels per voxel; round 4): two TAPS per 16-k MFMA step — lanes 0-31
+ * contract tap 2s, lanes 32-63 tap 2s + 1, 14 steps; packed = 14 * 2 * 2 * 32 * 8 16-bit words
+ * ([step][hi, lo][tap parity][co][8], the 28th tap zero).
  */
 int occ_conv3d_pack_weight_bf16x3(const float* weight, void* packed, int Cin, int Cout, void* stream);
 int occ_conv3d_bn_relu_bf16x3_f32(const float* in, const void* w_packed, const float* scale, const float* shift,
@@ -202,7 +235,8 @@ int occ_conv3d_bn_relu_bf16x3_f32(const float* in, const void* w_packed, const f
  * occ_conv3d_heads_pack(...) (occ_conv3d_heads_pack_bytes() bytes: the eight head tensors of occ_occ_heads_f32 as bf16
  * hi/lo MFMA fragments + biases, C = 32, hidden = 64).  Outputs in the reference's (B, X, Y, Z, .) order:
  * occ_out (.., num_classes), flow_out (.., 2), occ_cls_out (..) int64 or NULL — the same values occ_conv3d_bn_relu_bf16x3_f32
- * (out (X, Y)-major) followed by occ_occ_heads_decode_f32(exact_f32 = 0) produce.  Z == 16, Cin == 32 only. */
+ * (out (X, Y)-major) followed by occ_occ_heads_decode_f32(exact_f32 = 0) produce.  Cin == 32; Z == 16 (2 x 8 pillars per
+ * block) or Z == 32 (2 x 4 pillars, BASELINE configs[4]; round 4). */
 int64_t occ_conv3d_heads_pack_bytes(void);
 int occ_conv3d_heads_pack(const float* w1_occ, const float* b1_occ, const float* w2_occ, const float* b2_occ,
                           const float* w1_flow, const float* b1_flow, const float* w2_flow, const float* b2_flow,
@@ -341,20 +375,6 @@ int occ_rows_gather_sum_f32(const float* x, int64_t x_batch_stride, const int64_
 int64_t occ_linear_wgrad_workspace_bytes(int M, int N, int K);
 int occ_linear_wgrad_bf16x3_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
                                 void* workspace, int64_t workspace_bytes, int M, int N, int K, void* stream);
-
-/* ------------------------------------------------------------------------------------------
- * Ray casting through an occupancy grid (RayIoU metric) — replaces the reference's `dvr.render_forward`
- * (tools/ray_iou/lib/dvr/dvr.cpp:68-72 binding, dvr.cu:70-388), called at
- * projects/mmdet3d_plugin/datasets/ray_metrics.py:116-123.
- *   sigma (N, T, Z, Y, X) f32 occupancy ; origin (N, T, 3) f32 and points (N, M, point_stride >= 3) f32
- *   in VOXEL units ; tindex (N, M) f32 time index per ray (< 0 = padded ray, skipped)
- *   pred_dist, gt_dist (N, M) f32 and coord_index (N, M, 3) f32 out, fully written
- *   (-1, -1, (0,0,0) for rays that never enter the grid) ; train_phase 0 = "test", 1 = "train".
- */
-int occ_dvr_render_forward_f32(const float* sigma, const float* origin, const float* points,
-                               const float* tindex, float* pred_dist, float* gt_dist,
-                               float* coord_index, int N, int T, int Z, int Y, int X, int M,
-                               int point_stride, int train_phase, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backbone tail (outside the hand-written hot path): in place x = relu?(x + bias[c] (+ residual)) on an

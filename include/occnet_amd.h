@@ -376,6 +376,16 @@ int64_t occ_linear_wgrad_workspace_bytes(int M, int N, int K);
 int occ_linear_wgrad_bf16x3_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dw, float* db,
                                 void* workspace, int64_t workspace_bytes, int M, int N, int K, void* stream);
 
+/* Training partner of occ_conv3d_bn_relu_bf16x3_f32 (csrc/linear_wgrad.hip linear_wgrad_n32_kernel; round 4): weight
+ * gradient of a 3x3x3 / stride 1 / pad 1 Conv3d with 32 output channels — the decoder's two convolutions, reference
+ * transformer_occ.py:106-126 (autograd of nn.Conv3d).  dy_pad (B, Y+2, X+2, Z+2, 32) and x_pad (B, Y+2, X+2, Z+2, Cin) are
+ * ZERO-PADDED channels-last copies of the output gradient and the input: in the padded grid a tap is a constant row
+ * offset, dW = dy_pad^T . im2col(x_pad) in one launch.  dw (32, 27, Cin): dW[co][kz*9 + ky*3 + kx][ci].  The input
+ * gradient needs no entry point: dx = occ_conv3d_bn_relu_bf16x3_f32(dy, pack(flipped, transposed W), scale 1, shift 0). */
+int64_t occ_conv3d_wgrad_workspace_bytes(int B, int Z, int Y, int X, int Cin);
+int occ_conv3d_wgrad_bf16x3_f32(const float* dy_pad, const float* x_pad, float* dw, void* workspace,
+                                int64_t workspace_bytes, int B, int Z, int Y, int X, int Cin, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Backbone tail (outside the hand-written hot path): in place x = relu?(x + bias[c] (+ residual)) on an
  * NHWC bf16 activation of `rows` = N*H*W pixels x C channels (C % 8 == 0, 16-byte aligned).  Replaces the

@@ -158,6 +158,105 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_x3_kernel(
   }
 }
 
+// ---- N <= 32 outputs, optional Conv3d addressing ----------------------------------------------------------------------
+// Weight gradient of the decoder's 3 x 3 x 3 convolutions (reference transformer_occ.py:106-126, autograd of nn.Conv3d):
+//   dW[co][tap][ci] = sum over voxels v of dY[v][co] * X[v + shift(tap)][ci]
+// On ZERO-PADDED copies of x and dy (one halo voxel on every side, the same (Y+2, X+2, Z+2) grid for both) a tap is a
+// constant row offset, so this is dW = dY^T . Xcol with the virtual im2col matrix Xcol[r][tap * Cin + ci] =
+// Xpad[r + off(tap)][ci]: the lane that owns a column only adds its tap's offset to its base pointer.  N = 32 output
+// channels = ONE dY column tile: a block is 4 waves x (32 n x 64 k) = 256 columns (the 128 x 128 tiling above would idle
+// three quarters of its lanes), dY is read once per 256 columns instead of once per tap (27 separate launches of the
+// kernel above took 7 ms per training step).  conv_cin = 0: plain linear addressing for N <= 32.
+__global__ __launch_bounds__(256, 2) void linear_wgrad_n32_kernel(
+    const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, float* __restrict__ part_w, int M,
+    int N, int K, int MC, int conv_cin, int xp2, int zp2) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, g = lane >> 5;
+  const int c = blockIdx.y;
+  const int k0 = blockIdx.x * 256 + wave * 64;
+  const int m_begin = c * MC;
+  const int m_end = m_begin + MC < M ? m_begin + MC : M;
+  const float* pa = dy + (col < N ? col : N - 1);
+  const float* pb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int kk = k0 + 32 * t + col;
+    if (kk >= K) kk = K - 1;
+    if (conv_cin > 0) {
+      const int tap = kk / conv_cin, ci = kk - tap * conv_cin;
+      const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+      pb[t] = x + (long)(((ky - 1) * xp2 + (kx - 1)) * zp2 + (kz - 1)) * ldx + ci;
+    } else {
+      pb[t] = x + kk;
+    }
+  }
+  wg_f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  auto load = [&](int m, float (&a)[8], float (&b0)[8], float (&b1)[8]) {
+    const int left = m_end - m;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = m + 8 * g + j;
+      const long r = row < M ? row : M - 1;
+      a[j] = pa[r * lddy];
+      b0[j] = pb[0][r * ldx];
+      b1[j] = pb[1][r * ldx];
+    }
+    if (left < 16) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = 8 * g + j < left;
+        a[j] = ok ? a[j] : 0.f;           // a zero dY row contributes nothing whatever X holds there
+      }
+    }
+  };
+  auto step = [&](const float (&a)[8], const float (&b0)[8], const float (&b1)[8]) {
+    wg_bf16x8 ah, al, bh0, bl0, bh1, bl1;
+    wg_frag(a, ah, al);
+    wg_frag(b0, bh0, bl0);
+    wg_frag(b1, bh1, bl1);
+    // FOUR terms here (al.bl too: products exact to ~2^-24): a convolution weight's gradient is a sum over every voxel of
+    // the grid of terms that largely cancel (|sum| < |term|); with three terms the 2^-16 product rounding left a noise
+    // floor of 0.2 % of the largest gradient on decoder.0.conv.weight (round 4, tests/test_gpu_training.py).  The kernel
+    // is load-bound: the two extra MFMAs per step are free.
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl1, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);
+  };
+  float a0[8], b0[8], b1[8], a1[8], d0[8], d1[8];
+  int m = m_begin;
+  if (m < m_end) load(m, a0, b0, b1);
+  while (m < m_end) {
+    const int m1 = m + 16;
+    if (m1 < m_end) load(m1, a1, d0, d1);
+    step(a0, b0, b1);
+    if (m1 >= m_end) break;
+    const int m2 = m1 + 16;
+    if (m2 < m_end) load(m2, a0, b0, b1);
+    step(a1, d0, d1);
+    m = m2;
+  }
+  float* pw = part_w + (long)c * N * K;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int kk = k0 + 32 * t + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 8 * (r >> 2) + 4 * g + (r & 3);
+      if (n < N && kk < K) pw[(long)n * K + kk] = acc[t][r];
+    }
+  }
+}
+
 // dW = sum_c partial[c], db likewise, in a fixed order: a block owns 64 consecutive outputs, its 4 waves each add
 // every 4th chunk (4 independent loads in flight per lane), and the four wave sums are combined in wave order through
 // LDS.  (One thread per output walking all chunks serially ran at 0.7 TB/s: as long as the MFMA kernel itself.)
@@ -240,5 +339,53 @@ extern "C" int occ_linear_wgrad_bf16x3_f32(const float* dy, int64_t lddy, const 
   hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)red_blocks), dim3(256), 0, st, part_w,
                      part_b, dw, db, NK, N, chunks);
   OCC_CHECK_LAUNCH("linear_wgrad_reduce");
+  return OCC_OK;
+}
+
+
+// Weight gradient of a 3x3x3 / stride 1 / pad 1 Conv3d with 32 output channels (linear_wgrad_n32_kernel): dy_pad
+// (B, Y+2, X+2, Z+2, 32) and x_pad (B, Y+2, X+2, Z+2, Cin) are ZERO-PADDED channels-last copies of the output gradient and
+// of the input; dw (32, 27, Cin) f32 = dW[co][kz*9 + ky*3 + kx][ci] (the caller permutes to torch's (32, Cin, 3, 3, 3)).
+// workspace: occ_conv3d_wgrad_workspace_bytes(B, Z, Y, X, Cin) bytes, 16-byte aligned.  Deterministic (fixed-order
+// reduction of the row chunks).
+extern "C" int64_t occ_conv3d_wgrad_workspace_bytes(int B, int Z, int Y, int X, int Cin) {
+  using namespace occ;
+  if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || Cin <= 0) return 0;
+  const long R = (long)B * (Y + 2) * (X + 2) * (Z + 2), omax = (long)(X + 2) * (Z + 2) + (Z + 2) + 1;
+  const long M = R - 2 * omax;
+  if (M <= 0 || M >= (1L << 31)) return 0;
+  const int K = 27 * Cin, tiles = (K + 255) / 256;
+  int want = (512 + tiles - 1) / tiles;
+  const long max_chunks = (M + 63) / 64;
+  if (want > max_chunks) want = (int)max_chunks;
+  if (want < 1) want = 1;
+  return (int64_t)want * 32 * K * 4;
+}
+
+extern "C" int occ_conv3d_wgrad_bf16x3_f32(const float* dy_pad, const float* x_pad, float* dw, void* workspace,
+                                           int64_t workspace_bytes, int B, int Z, int Y, int X, int Cin, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(dy_pad && x_pad && dw && workspace, "conv3d_wgrad: null pointer argument");
+  OCC_CHECK_ARG(B > 0 && Z > 0 && Y > 0 && X > 0 && Cin > 0, "conv3d_wgrad: bad dimension");
+  const int64_t need = occ_conv3d_wgrad_workspace_bytes(B, Z, Y, X, Cin);
+  OCC_CHECK_ARG(need > 0, "conv3d_wgrad: grid beyond the 32-bit row range");
+  OCC_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0,
+                "conv3d_wgrad: workspace too small (%lld bytes, need %lld) or not 16-byte aligned",
+                (long long)workspace_bytes, (long long)need);
+  const long R = (long)B * (Y + 2) * (X + 2) * (Z + 2), omax = (long)(X + 2) * (Z + 2) + (Z + 2) + 1;
+  const int M = (int)(R - 2 * omax), K = 27 * Cin, tiles = (K + 255) / 256;
+  const int chunks = (int)(need / ((int64_t)32 * K * 4));
+  const int MC = ((M + chunks - 1) / chunks + 15) / 16 * 16;
+  const int used = (M + MC - 1) / MC;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  // rows [omax, R - omax): the skipped rows are halo rows of dy_pad (zero); every tap offset stays inside x_pad
+  hipLaunchKernelGGL(linear_wgrad_n32_kernel, dim3((unsigned)tiles, (unsigned)used), dim3(256), 0, st,
+                     dy_pad + omax * 32, 32L, x_pad + omax * Cin, (long)Cin, part, M, 32, K, MC, Cin, X + 2, Z + 2);
+  OCC_CHECK_LAUNCH("conv3d_wgrad");
+  const long NK = 32L * K;
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((NK + 63) / 64)), dim3(256), 0, st, part, nullptr, dw,
+                     nullptr, NK, 32, used);
+  OCC_CHECK_LAUNCH("conv3d_wgrad_reduce");
   return OCC_OK;
 }

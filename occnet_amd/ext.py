@@ -850,8 +850,8 @@ class Conv3dX3Function(torch.autograd.Function):
     MIOpen under bf16 autocast, narrower than the reference's fp32):
       forward  occ_conv3d_bn_relu_bf16x3_f32 with scale 1 / shift 0 / no ReLU (BatchNorm and ReLU stay autograd ops);
       dx       the same kernel on the flipped, transposed weight (rows beyond Cin zero: the kernel writes 32 channels);
-      dW       27 calls of occ_linear_wgrad_bf16x3_f32 on zero-padded copies of x and dy: in the padded grid a tap is
-               a constant row offset, dW[:, :, tap] = dy_pad^T @ x_pad[rows + offset(tap)] (deterministic).
+      dW       occ_conv3d_wgrad_bf16x3_f32 on zero-padded copies of x and dy: in the padded grid a tap is a constant
+               row offset, so dW = dy_pad^T @ im2col(x_pad) is ONE launch of the N = 32 wgrad kernel (deterministic).
     x: in_layout 0 (B, Y, X, Z, Cin) or 1 (B, Y*X, Cin*Z) (the lifter view of the BEV embedding); -> (B, Y, X, Z, 32)."""
 
     @staticmethod
@@ -877,26 +877,33 @@ class Conv3dX3Function(torch.autograd.Function):
         zero = torch.zeros(32, dtype=torch.float32, device=x.device)
         if ctx.needs_input_grad[0]:
             wt = weight.detach().flip(2, 3, 4).transpose(0, 1)               # (cin, cout, 3, 3, 3): dY -> dX
-            if cin < 32:
-                wt = torch.cat([wt, wt.new_zeros((32 - cin,) + tuple(wt.shape[1:]))], 0)
-            g32 = conv3d_bn_relu(gout, conv3d_pack_weight(wt.contiguous()), one, zero, Z, Y, X, cout, 32, 0, relu=False)
-            gx = g32[..., :cin]
+            parts = []
+            for c0 in range(0, cin, 32):                                     # the kernel writes 32 channels per launch
+                wg = wt[c0:c0 + 32]
+                if wg.shape[0] < 32:
+                    wg = torch.cat([wg, wg.new_zeros((32 - wg.shape[0],) + tuple(wg.shape[1:]))], 0)
+                g32 = conv3d_bn_relu(gout, conv3d_pack_weight(wg.contiguous()), one, zero, Z, Y, X, cout, 32, 0, relu=False)
+                parts.append(g32[..., :min(32, cin - c0)])
+            gx = parts[0] if len(parts) == 1 else torch.cat(parts, -1)
             gx = gx.permute(0, 1, 2, 4, 3).reshape(B, Y * X, cin * Z) if in_layout == 1 else gx.contiguous()
         if ctx.needs_input_grad[1]:
             xc = x.detach()
             if in_layout == 1:
                 xc = xc.view(B, Y, X, cin, Z).permute(0, 1, 2, 4, 3)                # (B, Y, X, Z, cin) view
-            xp = torch.nn.functional.pad(xc, (0, 0, 1, 1, 1, 1, 1, 1)).contiguous().view(-1, cin)
-            gp = torch.nn.functional.pad(gout, (0, 0, 1, 1, 1, 1, 1, 1)).contiguous().view(-1, cout)
-            R = xp.shape[0]
-            omax = (X + 2) * (Z + 2) + (Z + 2) + 1                                  # the skipped rows are halo rows: dy = 0
-            taps = []
-            for t in range(27):
-                kz, ky, kx = t // 9, (t // 3) % 3, t % 3
-                o = ((ky - 1) * (X + 2) + (kx - 1)) * (Z + 2) + (kz - 1)
-                dw_t, _ = linear_wgrad(gp[omax:R - omax], xp[omax + o:R - omax + o], with_bias=False)
-                taps.append(dw_t)
-            gw = torch.stack(taps, -1).view(cout, cin, 3, 3, 3)
+            xp = torch.nn.functional.pad(xc, (0, 0, 1, 1, 1, 1, 1, 1)).contiguous()      # (B, Y+2, X+2, Z+2, cin)
+            gp = torch.nn.functional.pad(gout, (0, 0, 1, 1, 1, 1, 1, 1)).contiguous()    # (B, Y+2, X+2, Z+2, 32)
+            lib = _lib.lib()
+            lib.occ_conv3d_wgrad_workspace_bytes.restype = ctypes.c_int64
+            nbytes = int(lib.occ_conv3d_wgrad_workspace_bytes(i32(B), i32(Z), i32(Y), i32(X), i32(cin)))
+            if nbytes <= 0:
+                raise OccAmdUnsupported("conv3d wgrad: grid beyond the kernel's 32-bit row range")
+            ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+            dw = torch.empty((cout, 27, cin), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device), _timed('conv3d_wgrad'):
+                rc = lib.occ_conv3d_wgrad_bf16x3_f32(ptr(gp), ptr(xp), ptr(dw), ptr(ws), i64(nbytes), i32(B), i32(Z),
+                                                     i32(Y), i32(X), i32(cin), stream_ptr(x.device))
+            _lib.check(rc, "conv3d_wgrad")
+            gw = dw.permute(0, 2, 1).reshape(cout, cin, 3, 3, 3)
         return gx, gw, None, None, None, None
 
 

@@ -161,7 +161,7 @@ int occ_sca_fused_forward_f32(const float* value, const int64_t* spatial_shapes,
                               float* slots, uint64_t* stats, int B, int NC, int S, int M, int D,
                               int L, int P, int Z, int Nq, void* stream);
 
-/* The same gather over fp16 VALUE maps (SURVEY.md §8d's e_v = 2 variant), as written by occ_value_proj_bf16_f16 /
+/* The same gather over fp16 VALUE maps (SURVEY.md §8d's e_v = 2 variant), as written by occ_value_proj_bf16_f16pairs /
  * occ_value_proj_bf16_planes.  One head row of a pixel is 64 bytes = 4 lanes x 16 bytes, so a wave load fetches 16 rows
  * instead of 8 (the texture path retires wave loads, not bytes: csrc/sca_fused.hip).  LAYOUT: pixel PAIRS —
  * value_f16[b * NC + c][pix >> 1][head (M)][pix & 1][D] fp16, pix = level_start + y * W + x, so the two x-neighbours
@@ -414,7 +414,7 @@ int occ_value_proj_bf16_f32(int n_segments, const void* const* a, const int64_t*
 /* same with the output written as fp16 for occ_sca_fused_forward_f16v, IN ITS PIXEL-PAIR ORDER: row r = out_row0[s] + i of
  * group g's block lands at out[(g*out_group_rows + (r & ~1)) * ldo + (n / 32) * 64 + (r & 1) * 32 + n % 32].  Needs
  * ldo == N, N % 32 == 0, out_group_rows even (pad an odd pixel count by one row). */
-int occ_value_proj_bf16_f16(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
+int occ_value_proj_bf16_f16pairs(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
                             const int64_t* rows_per_group, const int64_t* out_row0,
                             const float* const* group_bias, int bias_groups, const void* weight_packed,
                             void* out, int64_t ldo, int K, int N, int64_t out_group_rows, void* stream);

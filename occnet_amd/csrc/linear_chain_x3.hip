@@ -38,7 +38,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kChRows = 64;                       // rows per block
 constexpr int kChPlane = kChRows * 512;           // one bf16 plane of the operand tile: 64 rows x 256 k
 constexpr int kChRed = 2 * kChPlane;              // LayerNorm exchange: float[2][4][64]
-constexpr int kChLds = kChRed + 2 * 4 * kChRows * 4;
+constexpr int kChPrm = kChRed + 2 * 4 * kChRows * 4;       // per-column parameters: float[kChBiasMax] biases | g1 | b1 | g2 | b2
+constexpr int kChBiasMax = 1536;                  // program B with its tail: 256 + 512 + 256 + 2 x 256
+constexpr int kChLds = kChPrm + (kChBiasMax + 4 * 256) * 4;       // 77 824 B: two blocks per CU
 constexpr int kChStepBytes = 16384;               // weights of one k-step (16 k) of one 256-column pass: 8 tiles x (hi, lo) x 1 KB
 
 struct ChainArgs {
@@ -55,8 +57,13 @@ struct ChainArgs {
   float* z1; long ldz1; int n1;                   // tail columns [0, n1) -> z1
   float* z2; long ldz2; int off2; int n2;         // tail columns [off2, off2 + n2) -> z2 (column - off2)
   int M;
-  int dbg;                                        // development: 1 = skip the row stores, 2 = non-temporal row stores
 };
+
+// Block barrier that orders LDS traffic only.  __syncthreads() is a full fence: hipcc puts `s_waitcnt vmcnt(0)` in front of
+// the s_barrier, so every barrier after a row-store phase waited for the stores' L2 acknowledgements and for the weight
+// ring's look-ahead (round 4 ISA reading).  Global memory is never shared between the threads of a block here (the one
+// re-read of a block's own stores, x2, is by the lane that wrote it and sits behind an explicit vmcnt(0)).
+__device__ __forceinline__ void ch_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ void ch_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
   hi = pack_bf16x2_rne(x0, x1);
@@ -121,6 +128,10 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
                                          const int wv, const int step0, const int next0, const char* tl, const unsigned abase,
                                          const int rot) {
   bf16x8 af[2][2][2];                               // [buffer][row tile][plane hi, lo]
+  // the pinned group sequence must see the loop's own instructions only: the DS reads of an accumulator initialisation in
+  // front of it (or the LayerNorm exchange behind it) in the same scheduling region are matched into the DS groups and
+  // slide every fragment read two steps late; at the loop's end the last ring requests sank to their uses
+  if (ABL == 0) __builtin_amdgcn_sched_barrier(0);
   OCC_CH_AFRAG(0, rot & 15)
   // the group sequence below is matched to instructions in program order: without this leading group the four reads
   // above fill step 0's fragment groups and EVERY step's reads slide one step late — issued right before their use
@@ -173,28 +184,50 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     }
   }
+  if (ABL == 0) __builtin_amdgcn_sched_barrier(0);
 }
 
-// accumulators <- bias[column] (+ src[row][column]): register 4 q + i of tile (rt, t) = row rt * 32 + vi, column
-// c0 + 32 t + 8 q + 4 kb + i.  `rows` = this lane's two (clamped) global rows.
-__device__ __forceinline__ void ch_init(f32x16 (&acc)[2][2], const float* __restrict__ bias, const float* src, long ld,
-                                        const long (&rows)[2], int c0, int kb) {
+// Per-column parameters (biases, LayerNorm gamma / beta) are staged ONCE per block in LDS (`prm`): as global loads in
+// front of every pass they sat behind the previous pass's row stores in the in-order vmcnt queue — every pass opened
+// with a full store round trip.  Register 4 q + i of tile (rt, t) = row rt * 32 + vi, column c0 + 32 t + 8 q + 4 kb + i.
+__device__ __forceinline__ void ch_set_bias(f32x16 (&acc)[2][2], const float* prm_bias, int kb) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int c = c0 + 32 * t + 8 * q + 4 * kb;
-      const float4 b = *reinterpret_cast<const float4*>(bias + c);
+      const float4 b = *reinterpret_cast<const float4*>(prm_bias + 32 * t + 8 * q + 4 * kb);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (src) s = *reinterpret_cast<const float4*>(src + rows[rt] * ld + c);
-        acc[rt][t][4 * q + 0] = s.x + b.x;
-        acc[rt][t][4 * q + 1] = s.y + b.y;
-        acc[rt][t][4 * q + 2] = s.z + b.z;
-        acc[rt][t][4 * q + 3] = s.w + b.w;
+        acc[rt][t][4 * q + 0] = b.x; acc[rt][t][4 * q + 1] = b.y; acc[rt][t][4 * q + 2] = b.z; acc[rt][t][4 * q + 3] = b.w;
       }
     }
+}
+
+__device__ __forceinline__ void ch_add_bias(f32x16 (&acc)[2][2], const float* prm_bias, int kb) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = *reinterpret_cast<const float4*>(prm_bias + 32 * t + 8 * q + 4 * kb);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[rt][t][4 * q + 0] += b.x; acc[rt][t][4 * q + 1] += b.y; acc[rt][t][4 * q + 2] += b.z; acc[rt][t][4 * q + 3] += b.w;
+      }
+    }
+}
+
+// accumulators <- src[row][column] (this lane's two rows, clamped): 16 quad loads, all requested before the first use
+__device__ __forceinline__ void ch_load_rows(f32x16 (&acc)[2][2], const float* __restrict__ src, long ld, const long (&rows)[2],
+                                             int c0, int kb) {
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(src + rows[rt] * ld + c0 + 32 * t + 8 * q + 4 * kb);
+        acc[rt][t][4 * q + 0] = v.x; acc[rt][t][4 * q + 1] = v.y; acc[rt][t][4 * q + 2] = v.z; acc[rt][t][4 * q + 3] = v.w;
+      }
 }
 
 // register quads -> the operand tile (hi / lo planes): piece 8 wave + 4 t + q of row rt * 32 + vi, half kb
@@ -229,7 +262,7 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, co
     s[rt] = v;
     if (kb == 0) red[wave * kChRows + rt * 32 + vi] = v;
   }
-  __syncthreads();          // also: every wave is past its k loop, the operand tile may be rewritten after this point
+  ch_sync();          // also: every wave is past its k loop, the operand tile may be rewritten after this point
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     const int r = rt * 32 + vi;
@@ -246,7 +279,7 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, co
     v += __shfl_xor(v, 32);
     if (kb == 0) red[4 * kChRows + wave * kChRows + r] = v;
   }
-  __syncthreads();
+  ch_sync();
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
     const int r = rt * 32 + vi;
@@ -270,30 +303,25 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, co
     }
 }
 
-// register quads -> row-major global rows (column c0 + 32 t + 8 q + 4 kb of row rows[rt]); rows beyond M are skipped
+// register quads -> row-major global rows (column c0 + 32 t + 8 q + 4 kb of row rows[rt]); rows beyond M are skipped.
+// One exec-mask region per row tile and one uniform branch per column tile: per-store conditions made hipcc wrap every
+// store in three scalar branches (round 4 ISA reading).
 __device__ __forceinline__ void ch_store(const f32x16 (&acc)[2][2], float* dst, long ld, const long (&rows)[2],
-                                         const bool (&live)[2], int c0, int kb, bool t0_on, bool t1_on, bool relu, int dbg = 0) {
+                                         const bool (&live)[2], int c0, int kb, bool t0_on, bool t1_on) {
   // c0 = column of `dst` that receives the wave's first column
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < 2; ++rt) {
+    if (!live[rt]) continue;
+    float* o = dst + rows[rt] * ld + c0 + 4 * kb;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      if (!(t == 0 ? t0_on : t1_on)) continue;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v = make_float4(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1], acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]);
-        if (relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        if (live[rt] && (t == 0 ? t0_on : t1_on)) {
-          float4* o = reinterpret_cast<float4*>(dst + rows[rt] * ld + c0 + 32 * t + 8 * q + 4 * kb);
-          if (dbg == 0) *o = v;
-          else if (dbg == 2) {
-            typedef float occ_f32x4 __attribute__((ext_vector_type(4)));
-            const occ_f32x4 vv = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(vv, reinterpret_cast<occ_f32x4*>(o));
-          }
-        }
-      }
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(o + 32 * t + 8 * q) =
+            make_float4(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1], acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]);
+    }
+  }
 }
 
 __device__ __forceinline__ void ch_relu(f32x16 (&acc)[2][2]) {
@@ -310,10 +338,26 @@ template <int PROG, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs p) {
   extern __shared__ __attribute__((aligned(16))) char tl[];
   float* red = reinterpret_cast<float*>(tl + kChRed);
+  float* prm = reinterpret_cast<float*>(tl + kChPrm);
+  const float* prm_ln = prm + kChBiasMax;           // g1 | b1 | g2 | b2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kb = lane >> 5;
   const long m0 = (long)blockIdx.x * kChRows;
   const int M = p.M;
+
+  // (De-phasing the two blocks of a CU — the one in the upper half of the CU's LDS, HW_REG_LDS_ALLOC base != 0, starting
+  // 1.7 - 14 us late — was measured and changes nothing: profiles/r04_c16_stagger.txt.  The kernel is bound by the row
+  // traffic itself, which is write-dominated; stock copy kernels with this read : write mix reach 3.5 TB/s on this part.)
+  // ---- everything the first stage needs is requested before the first wait (round 4 ISA reading: hipcc had sunk the
+  // tile's 16 row loads to their uses, 3-4 in flight, and put every residual load behind its own branch: five to six
+  // serial HBM round trips per tile instead of one) -----------------------------------------------------------------------
+  // per-column parameters (L2 hits): thread t fetches bias quads t and t + 256 and one quad of a LayerNorm vector
+  const int nb4 = ((PROG == 0 ? 256 : 1024) + 256 * p.npass) / 4;
+  const float4 pb0 = reinterpret_cast<const float4*>(p.bias)[tid < nb4 ? tid : nb4 - 1];
+  const float4 pb1 = reinterpret_cast<const float4*>(p.bias)[tid + 256 < nb4 ? tid + 256 : nb4 - 1];
+  const float* lnv = wave == 0 ? p.ln1_g : wave == 1 ? p.ln1_b : wave == 2 ? p.ln2_g : p.ln2_b;
+  if (PROG == 0 && wave >= 2) lnv = p.ln1_g;        // program A has one LayerNorm: waves 2, 3 fetch (and drop) a duplicate
+  const float4 pl = reinterpret_cast<const float4*>(lnv)[lane];
 
   // weight ring: slot (step & 3) = {hi tile 0, lo tile 0, hi tile 1, lo tile 1} of the wave's 64 columns of flat step
   occ_u32x4 w[4][4];
@@ -335,63 +379,70 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
     rows[rt] = live[rt] ? r : (long)M - 1;
   }
 
-  // ---- stage input: 64 rows x 256 f32 -> hi / lo planes (a wave instruction = one whole row, 1 KB)
+  // stage input: 64 rows x 256 f32 (a wave instruction = one whole row, 1 KB), and the residual rows straight into the
+  // accumulators
   f32x16 acc[2][2];
-  {
-    float4 v[16];
+  float4 v[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = j * 4 + wave;
-      long m = m0 + row;
-      if (m >= M) m = (long)M - 1;
-      v[j] = *reinterpret_cast<const float4*>(p.a + m * p.lda + lane * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = j * 4 + wave;
-      unsigned h01, h23, l01, l23;
-      ch_split2(v[j].x, v[j].y, h01, l01);
-      ch_split2(v[j].z, v[j].w, h23, l23);
-      char* q = tl + row * 512 + (((lane >> 1) ^ row) & 31) * 16 + (lane & 1) * 8;
-      *reinterpret_cast<uint2*>(q) = make_uint2(h01, h23);
-      *reinterpret_cast<uint2*>(q + kChPlane) = make_uint2(l01, l23);
-    }
+  for (int j = 0; j < 16; ++j) {
+    const int row = j * 4 + wave;
+    long m = m0 + row;
+    if (m >= M) m = (long)M - 1;
+    v[j] = *reinterpret_cast<const float4*>(p.a + m * p.lda + lane * 4);
   }
-  // ---- stage 1: output_proj + bias + residual -> LayerNorm -------------------------------------------------------------
-  ch_init(acc, p.bias, p.res, p.ldres, rows, wave * 64, kb);
+  ch_load_rows(acc, p.res, p.ldres, rows, wave * 64, kb);
+  __builtin_amdgcn_sched_barrier(0);                // nothing below may be hoisted between the requests above
+
+  reinterpret_cast<float4*>(prm)[tid] = pb0;
+  if (tid + 256 < nb4) reinterpret_cast<float4*>(prm)[tid + 256] = pb1;
+  if (PROG == 1 || wave < 2) reinterpret_cast<float4*>(prm + kChBiasMax)[tid] = pl;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {                    // -> hi / lo planes
+    const int row = j * 4 + wave;
+    unsigned h01, h23, l01, l23;
+    ch_split2(v[j].x, v[j].y, h01, l01);
+    ch_split2(v[j].z, v[j].w, h23, l23);
+    char* q = tl + row * 512 + (((lane >> 1) ^ row) & 31) * 16 + (lane & 1) * 8;
+    *reinterpret_cast<uint2*>(q) = make_uint2(h01, h23);
+    *reinterpret_cast<uint2*>(q + kChPlane) = make_uint2(l01, l23);
+  }
   const unsigned abase = (unsigned)(vi * 512 + ((kb ^ vi) & 31) * 16);
-  __syncthreads();
+  ch_sync();
+  // ---- stage 1: output_proj + bias + residual -> LayerNorm -------------------------------------------------------------
+  ch_add_bias(acc, prm + wave * 64, kb);
   ch_kloop<ABL>(acc, w, wr, wv, 0, (0) + 16, tl, abase, rot);
-  ch_layernorm(acc, red, p.ln1_g, p.ln1_b, p.eps1, wave, vi, kb);
-  ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false, p.dbg);       // A: x1.  B: x2 parked in its own rows of y
+  ch_layernorm(acc, red, prm_ln, prm_ln + 256, p.eps1, wave, vi, kb);
+  ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true);       // A: x1.  B: x2 parked in its own rows of y
   ch_to_tile(acc, tl, wave, vi, kb);
-  __syncthreads();
+  ch_sync();
   int step = 16;
   int bias_off = 256;
 
   if constexpr (PROG == 1) {
     // ---- FFN: both hidden halves from the x2 tile (registers), then the second Linear over the two K halves ------------
     f32x16 ha[2][2], hb[2][2];
-    ch_init(ha, p.bias + 256, nullptr, 0, rows, wave * 64, kb);
+    ch_set_bias(ha, prm + 256 + wave * 64, kb);
     ch_kloop<ABL>(ha, w, wr, wv, 16, (16) + 16, tl, abase, rot);
     ch_relu(ha);
-    ch_init(hb, p.bias + 512, nullptr, 0, rows, wave * 64, kb);
+    ch_set_bias(hb, prm + 512 + wave * 64, kb);
     ch_kloop<ABL>(hb, w, wr, wv, 32, (32) + 16, tl, abase, rot);
     ch_relu(hb);
-    __syncthreads();                                // every wave has read the x2 tile for the last time
+    ch_sync();                                // every wave has read the x2 tile for the last time
     ch_to_tile(ha, tl, wave, vi, kb);
-    __syncthreads();                                // (also keeps the x2 reload below from being hoisted over ha's last use)
-    ch_init(acc, p.bias + 768, p.y, p.ldy, rows, wave * 64, kb);       // b2 + x2 (this lane's own stores)
+    ch_sync();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the x2 stores (two k loops ago) have landed
+    ch_load_rows(acc, p.y, p.ldy, rows, wave * 64, kb);                  // x2 (this lane's own stores)
+    ch_add_bias(acc, prm + 768 + wave * 64, kb);                         // + b2
     ch_kloop<ABL>(acc, w, wr, wv, 48, (48) + 16, tl, abase, rot);
-    __syncthreads();
+    ch_sync();
     ch_to_tile(hb, tl, wave, vi, kb);
-    __syncthreads();
+    ch_sync();
     ch_kloop<ABL>(acc, w, wr, wv, 64, (64) + 16, tl, abase, rot);
-    ch_layernorm(acc, red, p.ln2_g, p.ln2_b, p.eps2, wave, vi, kb);
-    ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true, false, p.dbg);     // x3
+    ch_layernorm(acc, red, prm_ln + 512, prm_ln + 768, p.eps2, wave, vi, kb);
+    ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true);     // x3
     if (p.npass > 0) {
       ch_to_tile(acc, tl, wave, vi, kb);
-      __syncthreads();
+      ch_sync();
     }
     step = 80;
     bias_off = 1024;
@@ -401,15 +452,21 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
 #pragma unroll 1
   for (int ps = 0; ps < p.npass; ++ps) {
     const int c0 = ps * 256 + wave * 64;            // the wave's first tail column of this pass
-    const bool tm = p.term != nullptr && c0 < p.term_cols;          // term_cols is a multiple of 64: whole waves
-    ch_init(acc, p.bias + bias_off, tm ? p.term : nullptr, p.ldterm, rows, c0, kb);
+    const float* pbias = prm + bias_off + c0;
+    if (p.term != nullptr && c0 < p.term_cols) {    // term_cols is a multiple of 64: whole waves
+      ch_load_rows(acc, p.term, p.ldterm, rows, c0, kb);
+      ch_add_bias(acc, pbias, kb);
+    } else {
+      ch_set_bias(acc, pbias, kb);
+    }
     ch_kloop<ABL>(acc, w, wr, wv, step + ps * 16, (step + ps * 16) + 16, tl, abase, rot);
+    if (p.act) ch_relu(acc);
     // the wave's two 32-column tiles go to z1 (columns < n1) or z2 (columns in [off2, off2 + n2)) or nowhere (padding)
     const int ca = c0, cb = c0 + 32;
     const bool a1 = ca < p.n1, b1 = cb < p.n1;
     const bool a2 = ca >= p.off2 && ca < p.off2 + p.n2, b2 = cb >= p.off2 && cb < p.off2 + p.n2;
-    if (a1 || b1) ch_store(acc, p.z1, p.ldz1, rows, live, c0, kb, a1, b1, p.act != 0, p.dbg);
-    if (a2 || b2) ch_store(acc, p.z2, p.ldz2, rows, live, c0 - p.off2, kb, a2, b2, p.act != 0, p.dbg);
+    if (a1 || b1) ch_store(acc, p.z1, p.ldz1, rows, live, c0, kb, a1, b1);
+    if (a2 || b2) ch_store(acc, p.z2, p.ldz2, rows, live, c0 - p.off2, kb, a2, b2);
   }
 }
 
@@ -444,11 +501,10 @@ template <int PROG>
 int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what) {
   using namespace occ;
   // OCC_CHAIN_ABLATE (program A, timing only — results wrong by construction): 1 no weight loads in the k loops,
-  // 2 no MFMAs, 4 no operand-fragment reads; OCC_CHAIN_DBG: 1 no row stores, 2 non-temporal row stores
+  // 2 no MFMAs, 4 no operand-fragment reads.  (A switch that skipped / streamed the row stores produced
+  // profiles/r04_c9_stores.txt and was removed: its run-time test put three branches around every store.)
   static const int abl = [] { const char* e = getenv("OCC_CHAIN_ABLATE"); return e ? atoi(e) : 0; }();
-  static const int dbg = [] { const char* e = getenv("OCC_CHAIN_DBG"); return e ? atoi(e) : 0; }();
-  ChainArgs args = args_in;
-  args.dbg = dbg;
+  const ChainArgs& args = args_in;
   const int ntiles = (args.M + kChRows - 1) / kChRows;
   void (*kern)(const ChainArgs) = linear_chain_x3_kernel<PROG, 0>;
   if (PROG == 0 && abl == 1) kern = linear_chain_x3_kernel<0, 1>;
@@ -483,6 +539,10 @@ extern "C" int occ_linear_ln_chain_bf16x3_f32(const float* a, int64_t lda, const
   ChainArgs g = {};
   g.a = a; g.lda = lda; g.res = residual; g.ldres = ldres;
   g.npass = (n2 + 255) / 256;
+  if (256 + 256 * g.npass > kChBiasMax) {
+    set_error("linear_ln_chain: n2=%d exceeds the %d tail columns the kernel stages parameters for", n2, kChBiasMax - 256);
+    return OCC_E_UNSUPPORTED;
+  }
   g.wp = reinterpret_cast<const uint4*>(w_chain);
   g.wbytes = (unsigned)(16 + 16 * g.npass) * (unsigned)kChStepBytes;
   g.bias = bias_chain;

@@ -531,8 +531,10 @@ extern "C" int occ_value_proj_bf16_f32(int n_segments, const void* const* a, con
                                 weight_packed, out, ldo, K, N, out_group_rows, false, stream);
 }
 
-// same, output written as fp16 (ldo in fp16 elements): the opt-in fp16-value mode of the SCA gather
-extern "C" int occ_value_proj_bf16_f16(int n_segments, const void* const* a, const int64_t* lda,
+// same, output written as fp16 IN THE PIXEL-PAIR ORDER of occ_sca_fused_forward_f16v (ldo in fp16 elements); the symbol was
+// occ_value_proj_bf16_f16 while the rows were in pixel order (round 2) — renamed with the layout so that a C caller
+// linked against the old contract fails at link time instead of reading permuted rows
+extern "C" int occ_value_proj_bf16_f16pairs(int n_segments, const void* const* a, const int64_t* lda,
                                        const int64_t* rows, const int64_t* rows_per_group,
                                        const int64_t* out_row0, const float* const* group_bias,
                                        int bias_groups, const void* weight_packed, void* out, int64_t ldo,
@@ -544,7 +546,7 @@ extern "C" int occ_value_proj_bf16_f16(int n_segments, const void* const* a, con
 // Several projections of the SAME rows in one launch (the four encoder layers' SCA value projections depend on the
 // camera features only): weight_packed = pack of the (n_planes * plane_cols, K) stacked weights, group_bias[s]
 // (bias_groups, n_planes * plane_cols); projection p writes plane p of `out` (plane_stride elements apart, rows of ldo
-// elements, plane_cols columns) exactly as occ_value_proj_bf16_f16 / _f32 would.  The column blocks of a row block run
+// elements, plane_cols columns) exactly as occ_value_proj_bf16_f16pairs / _f32 would.  The column blocks of a row block run
 // on one XCD back to back, so the feature maps are read from HBM once instead of once per layer.  plane_cols % 256 == 0.
 extern "C" int occ_value_proj_bf16_planes(int n_segments, const void* const* a, const int64_t* lda,
                                           const int64_t* rows, const int64_t* rows_per_group,

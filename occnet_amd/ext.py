@@ -525,7 +525,7 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
     packed = linear_pack_weight_bf16x3(weight)
     arr64 = lambda v: (ctypes.c_int64 * S)(*[int(x) for x in v])
     a_ptrs = (ctypes.c_void_p * S)(*[a.data_ptr() for a in a_list])
-    fn = _lib.lib().occ_value_proj_bf16_f16 if out_half else _lib.lib().occ_value_proj_bf16_f32
+    fn = _lib.lib().occ_value_proj_bf16_f16pairs if out_half else _lib.lib().occ_value_proj_bf16_f32
     with torch.cuda.device(out.device), _timed('value_proj'):
         rc = fn(
             i32(S), a_ptrs, arr64([a.stride(0) for a in a_list]), arr64([a.shape[0] for a in a_list]),

@@ -27,7 +27,10 @@
 // as the LDS tile (half of it at a time).  x2, the FFN's residual, is parked in the block's own rows of `y` (written
 // and re-read by the same lane, overwritten by x3 at the end).  Two blocks per CU (66 KB of LDS, <= 256 registers):
 // one block's epilogues run under the other's MFMAs.
+#include <stdio.h>
 #include <stdlib.h>
+#include <string>
+#include <vector>
 #include "common.h"
 
 namespace occ {
@@ -57,6 +60,8 @@ struct ChainArgs {
   float* z1; long ldz1; int n1;                   // tail columns [0, n1) -> z1
   float* z2; long ldz2; int off2; int n2;         // tail columns [off2, off2 + n2) -> z2 (column - off2)
   int M;
+  int nfull;                                      // blocks with 64-row tiles (the rest: 32-row tiles)
+  long long* trace;                               // TRACE builds: 16 wall-clock stamps per block (development)
 };
 
 // Block barrier that orders LDS traffic only.  __syncthreads() is a full fence: hipcc puts `s_waitcnt vmcnt(0)` in front of
@@ -105,16 +110,16 @@ __global__ void linear_chain_pack_kernel(const float* __restrict__ w, unsigned s
     w[SLOT][3] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 3072, so, 0);                      \
   }
 
-// operand fragments of (physical) k-step KK — wave-uniform, run time: piece 2 KK + kb of rows vi and 32 + vi, both planes
+// operand fragments of (physical) k-step KK — wave-uniform, run time: piece 2 KK + kb of rows vi and (RT == 2) 32 + vi, both planes
 // (slot of piece p in row r = p ^ (r & 31))
 #define OCC_CH_AFRAG(BUF, KK)                                                                      \
   {                                                                                                \
     const char* ap = tl + (abase ^ (unsigned)((KK) * 32));                                         \
     /* lo planes first: the step's first MFMAs (small term wh . al) read them */                   \
     af[BUF][0][1] = *reinterpret_cast<const bf16x8*>(ap + kChPlane);                               \
-    af[BUF][1][1] = *reinterpret_cast<const bf16x8*>(ap + kChPlane + 32 * 512);                    \
+    if constexpr (RT == 2) af[BUF][1][1] = *reinterpret_cast<const bf16x8*>(ap + kChPlane + 32 * 512);     \
     af[BUF][0][0] = *reinterpret_cast<const bf16x8*>(ap);                                          \
-    af[BUF][1][0] = *reinterpret_cast<const bf16x8*>(ap + 32 * 512);                               \
+    if constexpr (RT == 2) af[BUF][1][0] = *reinterpret_cast<const bf16x8*>(ap + 32 * 512);        \
   }
 
 // one 256-column pass over the K = 256 tile: 16 k-steps, flat ring steps step0 .. step0 + 15 (requests run 3 ahead).
@@ -123,11 +128,11 @@ __global__ void linear_chain_pack_kernel(const float* __restrict__ w, unsigned s
 // 4 096 line requests into the few L2 channels that hold that chunk while the others idle (round 4, call 2: one block
 // per CU alone took ~1 000 clocks per k-step, two took twice that: the L2 request rate of a hot channel, not MFMA, not
 // L1 bandwidth).  With the rotation the resident blocks are spread over all 16 chunks of a pass at any time.
-template <int ABL = 0>
-__device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][4], const __amdgpu_buffer_rsrc_t wr,
+template <int ABL = 0, int RT>
+__device__ __forceinline__ void ch_kloop(f32x16 (&acc)[RT][2], occ_u32x4 (&w)[4][4], const __amdgpu_buffer_rsrc_t wr,
                                          const int wv, const int step0, const int next0, const char* tl, const unsigned abase,
                                          const int rot) {
-  bf16x8 af[2][2][2];                               // [buffer][row tile][plane hi, lo]
+  bf16x8 af[2][RT][2];                              // [buffer][row tile][plane hi, lo]
   // the pinned group sequence must see the loop's own instructions only: the DS reads of an accumulator initialisation in
   // front of it (or the LayerNorm exchange behind it) in the same scheduling region are matched into the DS groups and
   // slide every fragment read two steps late; at the loop's end the last ring requests sank to their uses
@@ -136,7 +141,7 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
   // the group sequence below is matched to instructions in program order: without this leading group the four reads
   // above fill step 0's fragment groups and EVERY step's reads slide one step late — issued right before their use
   // (that is what the first cuts of this kernel did: rocprofv3 round 4 call 2, 56 % of the wave cycles issue-stalled)
-  if (ABL == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+  if (ABL == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * RT, 0);
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) {
     if (!(ABL & 4) || ks == 0) OCC_CH_AFRAG((ks + 1) & 1, (ks + 1 + rot) & 15)
@@ -146,19 +151,19 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
     // D[column][row] (weights as the row operand); small terms first, term-major over the four accumulators
     if (!(ABL & 2)) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
         acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t]), af[ks & 1][rt][1],
                                                              acc[rt][t], 0, 0, 0);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
         acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t + 1]), af[ks & 1][rt][0],
                                                              acc[rt][t], 0, 0, 0);
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
         acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[ks & 3][2 * t]), af[ks & 1][rt][0],
@@ -168,12 +173,13 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
 #pragma unroll
       for (int t = 0; t < 4; ++t) asm volatile("" :: "v"(w[ks & 3][t]));
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) { asm volatile("" :: "v"(af[ks & 1][rt][0])); asm volatile("" :: "v"(af[ks & 1][rt][1])); }
+      for (int rt = 0; rt < RT; ++rt) { asm volatile("" :: "v"(af[ks & 1][rt][0])); asm volatile("" :: "v"(af[ks & 1][rt][1])); }
     }
     if (ABL == 0) {
     // pin the software pipeline (hipcc otherwise sinks every ring request down to its use: load, vmcnt(0), MFMA).  The
     // operand fragments of step s + 1 are requested at the TOP of step s, lo planes first: the next step opens with the
     // MFMAs that read them
+    if constexpr (RT == 2) {
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // operand fragments of step s + 1 (lo planes)
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // (hi planes)
@@ -182,6 +188,14 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    } else {                                             // 32-row tiles: six MFMAs per step
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
     }
   }
   if (ABL == 0) __builtin_amdgcn_sched_barrier(0);
@@ -190,37 +204,40 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[2][2], occ_u32x4 (&w)[4][
 // Per-column parameters (biases, LayerNorm gamma / beta) are staged ONCE per block in LDS (`prm`): as global loads in
 // front of every pass they sat behind the previous pass's row stores in the in-order vmcnt queue — every pass opened
 // with a full store round trip.  Register 4 q + i of tile (rt, t) = row rt * 32 + vi, column c0 + 32 t + 8 q + 4 kb + i.
-__device__ __forceinline__ void ch_set_bias(f32x16 (&acc)[2][2], const float* prm_bias, int kb) {
+template <int RT>
+__device__ __forceinline__ void ch_set_bias(f32x16 (&acc)[RT][2], const float* prm_bias, int kb) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 b = *reinterpret_cast<const float4*>(prm_bias + 32 * t + 8 * q + 4 * kb);
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         acc[rt][t][4 * q + 0] = b.x; acc[rt][t][4 * q + 1] = b.y; acc[rt][t][4 * q + 2] = b.z; acc[rt][t][4 * q + 3] = b.w;
       }
     }
 }
 
-__device__ __forceinline__ void ch_add_bias(f32x16 (&acc)[2][2], const float* prm_bias, int kb) {
+template <int RT>
+__device__ __forceinline__ void ch_add_bias(f32x16 (&acc)[RT][2], const float* prm_bias, int kb) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 b = *reinterpret_cast<const float4*>(prm_bias + 32 * t + 8 * q + 4 * kb);
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         acc[rt][t][4 * q + 0] += b.x; acc[rt][t][4 * q + 1] += b.y; acc[rt][t][4 * q + 2] += b.z; acc[rt][t][4 * q + 3] += b.w;
       }
     }
 }
 
 // accumulators <- src[row][column] (this lane's two rows, clamped): 16 quad loads, all requested before the first use
-__device__ __forceinline__ void ch_load_rows(f32x16 (&acc)[2][2], const float* __restrict__ src, long ld, const long (&rows)[2],
+template <int RT>
+__device__ __forceinline__ void ch_load_rows(f32x16 (&acc)[RT][2], const float* __restrict__ src, long ld, const long (&rows)[RT],
                                              int c0, int kb) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -231,9 +248,10 @@ __device__ __forceinline__ void ch_load_rows(f32x16 (&acc)[2][2], const float* _
 }
 
 // register quads -> the operand tile (hi / lo planes): piece 8 wave + 4 t + q of row rt * 32 + vi, half kb
-__device__ __forceinline__ void ch_to_tile(const f32x16 (&acc)[2][2], char* tl, int wave, int vi, int kb) {
+template <int RT>
+__device__ __forceinline__ void ch_to_tile(const f32x16 (&acc)[RT][2], char* tl, int wave, int vi, int kb) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -248,11 +266,12 @@ __device__ __forceinline__ void ch_to_tile(const f32x16 (&acc)[2][2], char* tl, 
 }
 
 // LayerNorm over the 256 columns of every row, in place in the accumulators (two passes: mean, then squared deviations)
-__device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, const float* __restrict__ g,
+template <int RT>
+__device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[RT][2], float* red, const float* __restrict__ g,
                                              const float* __restrict__ b, float eps, int wave, int vi, int kb) {
-  float s[2];
+  float s[RT];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     float v = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -264,7 +283,7 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, co
   }
   ch_sync();          // also: every wave is past its k loop, the operand tile may be rewritten after this point
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int r = rt * 32 + vi;
     const float mean = ((red[r] + red[kChRows + r]) + (red[2 * kChRows + r] + red[3 * kChRows + r])) * (1.f / 256.f);
     float v = 0.f;
@@ -281,7 +300,7 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, co
   }
   ch_sync();
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int r = rt * 32 + vi;
     const float* rr = red + 4 * kChRows;
     s[rt] = rsqrtf(((rr[r] + rr[kChRows + r]) + (rr[2 * kChRows + r] + rr[3 * kChRows + r])) * (1.f / 256.f) + eps);
@@ -294,7 +313,7 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, co
       const float4 gv = *reinterpret_cast<const float4*>(g + c);
       const float4 bv = *reinterpret_cast<const float4*>(b + c);
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         acc[rt][t][4 * q + 0] = fmaf(acc[rt][t][4 * q + 0] * s[rt], gv.x, bv.x);
         acc[rt][t][4 * q + 1] = fmaf(acc[rt][t][4 * q + 1] * s[rt], gv.y, bv.y);
         acc[rt][t][4 * q + 2] = fmaf(acc[rt][t][4 * q + 2] * s[rt], gv.z, bv.z);
@@ -306,11 +325,12 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[2][2], float* red, co
 // register quads -> row-major global rows (column c0 + 32 t + 8 q + 4 kb of row rows[rt]); rows beyond M are skipped.
 // One exec-mask region per row tile and one uniform branch per column tile: per-store conditions made hipcc wrap every
 // store in three scalar branches (round 4 ISA reading).
-__device__ __forceinline__ void ch_store(const f32x16 (&acc)[2][2], float* dst, long ld, const long (&rows)[2],
-                                         const bool (&live)[2], int c0, int kb, bool t0_on, bool t1_on) {
+template <int RT>
+__device__ __forceinline__ void ch_store(const f32x16 (&acc)[RT][2], float* dst, long ld, const long (&rows)[RT],
+                                         const bool (&live)[RT], int c0, int kb, bool t0_on, bool t1_on) {
   // c0 = column of `dst` that receives the wave's first column
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     if (!live[rt]) continue;
     float* o = dst + rows[rt] * ld + c0 + 4 * kb;
 #pragma unroll
@@ -324,9 +344,10 @@ __device__ __forceinline__ void ch_store(const f32x16 (&acc)[2][2], float* dst, 
   }
 }
 
-__device__ __forceinline__ void ch_relu(f32x16 (&acc)[2][2]) {
+template <int RT>
+__device__ __forceinline__ void ch_relu(f32x16 (&acc)[RT][2]) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -334,16 +355,21 @@ __device__ __forceinline__ void ch_relu(f32x16 (&acc)[2][2]) {
 }
 
 // PROG 0: program A, PROG 1: program B (file header)
-template <int PROG, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char tl[];
+#define OCC_CH_STAMP(I)                                                                            \
+  if constexpr (TRACE) {                                                                           \
+    if (threadIdx.x == 0) p.trace[(long)blockIdx.x * 16 + (I)] = wall_clock64();                   \
+  }
+
+// One tile of RT x 32 rows starting at row m0 through the whole program.
+template <int PROG, int ABL, bool TRACE, int RT>
+__device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const long m0) {
   float* red = reinterpret_cast<float*>(tl + kChRed);
   float* prm = reinterpret_cast<float*>(tl + kChPrm);
   const float* prm_ln = prm + kChBiasMax;           // g1 | b1 | g2 | b2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kb = lane >> 5;
-  const long m0 = (long)blockIdx.x * kChRows;
   const int M = p.M;
+  OCC_CH_STAMP(0)
 
   // (De-phasing the two blocks of a CU — the one in the upper half of the CU's LDS, HW_REG_LDS_ALLOC base != 0, starting
   // 1.7 - 14 us late — was measured and changes nothing: profiles/r04_c16_stagger.txt.  The kernel is bound by the row
@@ -369,22 +395,22 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
   OCC_CH_LOAD(1, (rot + 1) & 15)
   OCC_CH_LOAD(2, (rot + 2) & 15)
 
-  // this lane's two rows (clamped for the loads)
-  long rows[2];
-  bool live[2];
+  // this lane's rows (clamped for the loads)
+  long rows[RT];
+  bool live[RT];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const long r = m0 + rt * 32 + vi;
     live[rt] = r < M;
     rows[rt] = live[rt] ? r : (long)M - 1;
   }
 
-  // stage input: 64 rows x 256 f32 (a wave instruction = one whole row, 1 KB), and the residual rows straight into the
+  // stage input: RT x 32 rows x 256 f32 (a wave instruction = one whole row, 1 KB), and the residual rows straight into the
   // accumulators
-  f32x16 acc[2][2];
-  float4 v[16];
+  f32x16 acc[RT][2];
+  float4 v[8 * RT];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < 8 * RT; ++j) {
     const int row = j * 4 + wave;
     long m = m0 + row;
     if (m >= M) m = (long)M - 1;
@@ -397,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
   if (tid + 256 < nb4) reinterpret_cast<float4*>(prm)[tid + 256] = pb1;
   if (PROG == 1 || wave < 2) reinterpret_cast<float4*>(prm + kChBiasMax)[tid] = pl;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {                    // -> hi / lo planes
+  for (int j = 0; j < 8 * RT; ++j) {                // -> hi / lo planes
     const int row = j * 4 + wave;
     unsigned h01, h23, l01, l23;
     ch_split2(v[j].x, v[j].y, h01, l01);
@@ -408,42 +434,52 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
   }
   const unsigned abase = (unsigned)(vi * 512 + ((kb ^ vi) & 31) * 16);
   ch_sync();
+  OCC_CH_STAMP(1)                                   // first-stage rows landed, tile built
   // ---- stage 1: output_proj + bias + residual -> LayerNorm -------------------------------------------------------------
   ch_add_bias(acc, prm + wave * 64, kb);
   ch_kloop<ABL>(acc, w, wr, wv, 0, (0) + 16, tl, abase, rot);
+  OCC_CH_STAMP(2)
   ch_layernorm(acc, red, prm_ln, prm_ln + 256, p.eps1, wave, vi, kb);
   ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true);       // A: x1.  B: x2 parked in its own rows of y
   ch_to_tile(acc, tl, wave, vi, kb);
   ch_sync();
+  OCC_CH_STAMP(3)                                   // LayerNorm, row stores issued, tile rebuilt
   int step = 16;
   int bias_off = 256;
 
   if constexpr (PROG == 1) {
     // ---- FFN: both hidden halves from the x2 tile (registers), then the second Linear over the two K halves ------------
-    f32x16 ha[2][2], hb[2][2];
+    f32x16 ha[RT][2], hb[RT][2];
     ch_set_bias(ha, prm + 256 + wave * 64, kb);
     ch_kloop<ABL>(ha, w, wr, wv, 16, (16) + 16, tl, abase, rot);
     ch_relu(ha);
+    OCC_CH_STAMP(4)
     ch_set_bias(hb, prm + 512 + wave * 64, kb);
     ch_kloop<ABL>(hb, w, wr, wv, 32, (32) + 16, tl, abase, rot);
     ch_relu(hb);
+    OCC_CH_STAMP(5)
     ch_sync();                                // every wave has read the x2 tile for the last time
     ch_to_tile(ha, tl, wave, vi, kb);
     ch_sync();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the x2 stores (two k loops ago) have landed
     ch_load_rows(acc, p.y, p.ldy, rows, wave * 64, kb);                  // x2 (this lane's own stores)
     ch_add_bias(acc, prm + 768 + wave * 64, kb);                         // + b2
+    OCC_CH_STAMP(6)                                 // ha in the tile, x2 reloaded
     ch_kloop<ABL>(acc, w, wr, wv, 48, (48) + 16, tl, abase, rot);
+    OCC_CH_STAMP(7)
     ch_sync();
     ch_to_tile(hb, tl, wave, vi, kb);
     ch_sync();
+    OCC_CH_STAMP(8)
     ch_kloop<ABL>(acc, w, wr, wv, 64, (64) + 16, tl, abase, rot);
+    OCC_CH_STAMP(9)
     ch_layernorm(acc, red, prm_ln + 512, prm_ln + 768, p.eps2, wave, vi, kb);
     ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true);     // x3
     if (p.npass > 0) {
       ch_to_tile(acc, tl, wave, vi, kb);
       ch_sync();
     }
+    OCC_CH_STAMP(10)                                // LayerNorm 2, x3 stores issued, tile rebuilt
     step = 80;
     bias_off = 1024;
   }
@@ -460,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
       ch_set_bias(acc, pbias, kb);
     }
     ch_kloop<ABL>(acc, w, wr, wv, step + ps * 16, (step + ps * 16) + 16, tl, abase, rot);
+    OCC_CH_STAMP(11 + ps)                           // (passes 0 .. 3)
     if (p.act) ch_relu(acc);
     // the wave's two 32-column tiles go to z1 (columns < n1) or z2 (columns in [off2, off2 + n2)) or nowhere (padding)
     const int ca = c0, cb = c0 + 32;
@@ -468,6 +505,23 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
     if (a1 || b1) ch_store(acc, p.z1, p.ldz1, rows, live, c0, kb, a1, b1);
     if (a2 || b2) ch_store(acc, p.z2, p.ldz2, rows, live, c0 - p.off2, kb, a2, b2);
   }
+  OCC_CH_STAMP(15)
+}
+#undef OCC_CH_STAMP
+
+// Blocks [0, nfull) own 64-row tiles; the rows behind them are cut into 32-row tiles (blocks nfull ..).  The launcher uses
+// the second kind for the tiles that would otherwise form a thin last round: 40 000 rows are 625 tiles on 512 resident
+// slots, and the 113 blocks of the second round ran one per CU — at the single-block rate, with 143 CUs idle — for as
+// long as the whole first round (stamped timeline: profiles/r04_c18_chain_trace.txt).  As 226 half tiles that round
+// occupies every CU and each block carries half the rows.
+template <int PROG, int ABL = 0, bool TRACE = false>
+__global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char tl[];
+  const int b = (int)blockIdx.x;
+  if (b < p.nfull)
+    chain_tile<PROG, ABL, TRACE, 2>(p, tl, (long)b * kChRows);
+  else
+    chain_tile<PROG, ABL, TRACE, 1>(p, tl, (long)p.nfull * kChRows + (long)(b - p.nfull) * 32);
 }
 
 
@@ -504,13 +558,36 @@ int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what
   // 2 no MFMAs, 4 no operand-fragment reads.  (A switch that skipped / streamed the row stores produced
   // profiles/r04_c9_stores.txt and was removed: its run-time test put three branches around every store.)
   static const int abl = [] { const char* e = getenv("OCC_CHAIN_ABLATE"); return e ? atoi(e) : 0; }();
-  const ChainArgs& args = args_in;
-  const int ntiles = (args.M + kChRows - 1) / kChRows;
+  ChainArgs args = args_in;
+  // tile split (kernel comment): the last, partial round of 64-row tiles becomes 32-row tiles when it would fill less
+  // than half of the resident slots.  OCC_CHAIN_HALF_TILES=0 keeps 64-row tiles throughout (development).
+  static const int slots = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return 2 * n;
+  }();
+  static const bool half_tiles = [] { const char* e = getenv("OCC_CHAIN_HALF_TILES"); return !(e && e[0] == '0'); }();
+  const int n64 = (args.M + kChRows - 1) / kChRows;
+  const int rem = n64 % slots;
+  args.nfull = (half_tiles && n64 > slots && rem > 0 && 2 * rem <= slots) ? n64 - rem : n64;
+  const long rows_left = (long)args.M - (long)args.nfull * kChRows;          // rows behind the 64-row tiles
+  const int ntiles = args.nfull + (rows_left > 0 ? (int)((rows_left + 31) / 32) : 0);
   void (*kern)(const ChainArgs) = linear_chain_x3_kernel<PROG, 0>;
   if (PROG == 0 && abl == 1) kern = linear_chain_x3_kernel<0, 1>;
   if (PROG == 0 && abl == 2) kern = linear_chain_x3_kernel<0, 2>;
   if (PROG == 0 && abl == 4) kern = linear_chain_x3_kernel<0, 4>;
   if (PROG == 0 && abl == 3) kern = linear_chain_x3_kernel<0, 3>;
+  // OCC_CHAIN_TRACE=<file prefix> (development, tools_dev/chain_probe.py): every launch runs the stamped build, waits for
+  // it and appends its 16 wall-clock stamps per block (100 MHz) to <prefix>.<A|B>.bin
+  const char* trace_to = getenv("OCC_CHAIN_TRACE");
+  if (trace_to && *trace_to) {
+    kern = linear_chain_x3_kernel<PROG, 0, true>;
+    if (hipMalloc(reinterpret_cast<void**>(&args.trace), (size_t)ntiles * 16 * sizeof(long long)) != hipSuccess) {
+      set_error("%s: trace buffer allocation failed", what);
+      return OCC_E_LAUNCH;
+    }
+    (void)hipMemsetAsync(args.trace, 0, (size_t)ntiles * 16 * sizeof(long long), st);
+  }
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kChLds);
   if (e != hipSuccess) {
@@ -519,6 +596,17 @@ int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), kChLds, st, args);
   OCC_CHECK_LAUNCH(what);
+  if (args.trace) {
+    std::vector<long long> host((size_t)ntiles * 16);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(host.data(), args.trace, host.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    (void)hipFree(args.trace);
+    const std::string path = std::string(trace_to) + (PROG == 0 ? ".A.bin" : ".B.bin");
+    if (FILE* f = fopen(path.c_str(), "ab")) {
+      fwrite(host.data(), sizeof(long long), host.size(), f);
+      fclose(f);
+    }
+  }
   return OCC_OK;
 }
 }  // namespace

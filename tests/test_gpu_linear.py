@@ -393,7 +393,8 @@ def _chain_inputs(g, M, n2):
 
 
 @pytest.mark.parametrize("M,n2,act2", [(64, 768, None), (1, 256, None), (77, 768, None), (4099, 768, None),
-                                       (333, 512, 'relu'), (130, 192, None), (40000, 768, None)])
+                                       (333, 512, 'relu'), (130, 192, None), (40000, 768, None),
+                                       (512 * 64 + 101, 768, None)])      # thin last round: 32-row tiles, ragged end
 def test_linear_ln_chain_matches_oracle(M, n2, act2):
     """Program A: LayerNorm(a W1^T + b1 + res) and act2(y W2^T + b2) — asymmetric random operands, ragged last
     block, one / two / three tail passes, a tail narrower than a pass."""
@@ -419,7 +420,7 @@ def test_linear_ln_chain_matches_oracle(M, n2, act2):
 
 
 @pytest.mark.parametrize("M,tail,term", [(64, False, False), (77, True, True), (1, True, False), (4099, True, True),
-                                         (40000, True, True), (40000, False, False)])
+                                         (40000, True, True), (40000, False, False), (512 * 64 + 101, True, True)])
 def test_encoder_ffn_chain_matches_oracle(M, tail, term):
     """Program B: output_proj + LN, FFN (512 hidden) + LN, and the optional tail (192 query columns with a per-row
     term + 256 value columns)."""

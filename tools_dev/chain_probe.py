@@ -93,3 +93,46 @@ for rnd in range(int(os.environ.get("CHAIN_ROUNDS", "2"))):
           f"   max|dy| {md(o_sb[0], o_cb[0]):.1e} max|dzq| {md(o_sb[1], o_cb[1]):.1e} max|dzv| {md(o_sb[2], o_cb[2]):.1e}", flush=True)
     print(f"round {rnd}: program B without tail  separate (3 launches) {t_sb0:7.1f} us   chain {t_cb0:7.1f} us   max|dy| {md(o_sb0[0], o_cb0[0]):.1e}",
           flush=True)
+
+# per-block phase timeline (CHAIN_TRACE=1): the stamped build of the kernels writes 16 wall-clock stamps per block
+# (100 MHz); reported relative to the launch's first stamp, as medians over the blocks of the first resident round
+# (two per CU) and over the tail round
+if os.environ.get("CHAIN_TRACE", "0") == "1":
+    import numpy as np
+    import tempfile
+    NAMES = {"A": [(0, 1, "rows in, tile built"), (1, 2, "S1 k-loop"), (2, 3, "LN + x1 stores + tile"), (3, 11, "pass 0 k-loop"),
+                   (11, 12, "stores 0 + pass 1 k-loop"), (12, 13, "stores 1 + pass 2 k-loop"), (13, 15, "stores 2")],
+             "B": [(0, 1, "rows in, tile built"), (1, 2, "S1 k-loop"), (2, 3, "LN + x2 stores + tile"), (3, 4, "S2a k-loop"),
+                   (4, 5, "S2b k-loop"), (5, 6, "ha -> tile, x2 reload"), (6, 7, "S3a k-loop"), (7, 8, "hb -> tile"),
+                   (8, 9, "S3b k-loop"), (9, 10, "LN2 + x3 stores + tile"), (10, 11, "term rows + pass 0 k-loop"),
+                   (11, 12, "stores 0 + pass 1 k-loop"), (12, 15, "stores 1")]}
+    prefix = os.path.join(tempfile.mkdtemp(), "chain")
+    for m in (int(x) for x in os.environ.get("CHAIN_TRACE_ROWS", "32768,40000").split(",")):
+        aa, rr, qq = a[:m], res[:m], qt[:m]
+        for prog, fn in (("A", lambda: ext.linear_ln_chain(aa, rr, wo, bo, ln1, wq, bq)),
+                         ("B", lambda: ext.encoder_ffn_chain(aa, rr, wo, bo, ln1, w1, b1, w2, b2, ln2, tail=(wt, qq, wv, bv)))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            path = f"{prefix}.{prog}.bin"
+            if os.path.exists(path):
+                os.remove(path)
+            os.environ["OCC_CHAIN_TRACE"] = prefix
+            fn()
+            torch.cuda.synchronize()
+            os.environ.pop("OCC_CHAIN_TRACE")
+            st = np.fromfile(path, dtype=np.int64).reshape(-1, 16).astype(np.float64)
+            st = (st - st[:, 0].min()) * 0.01            # us since the first block started
+            nblk = st.shape[0]
+            first = st[:min(nblk, 512)]
+            print(f"--- program {prog}, {m} rows, {nblk} blocks: launch span {st[:, 15].max():.1f} us; first-round blocks start "
+                  f"{np.median(first[:, 0]):.1f} us (max {first[:, 0].max():.1f}), end {np.median(first[:, 15]):.1f} us "
+                  f"(min {first[:, 15].min():.1f}, max {first[:, 15].max():.1f})")
+            groups = [("first round", first)] + ([("tail round", st[512:])] if nblk > 512 else [])
+            for gname, gs in groups:
+                if gname == "tail round":
+                    print(f"    tail round: {gs.shape[0]} blocks start {np.median(gs[:, 0]):.1f} us (min {gs[:, 0].min():.1f}, max {gs[:, 0].max():.1f}), "
+                          f"end {np.median(gs[:, 15]):.1f} us (max {gs[:, 15].max():.1f})")
+                for i0, i1, label in NAMES[prog]:
+                    d = gs[:, i1] - gs[:, i0]
+                    print(f"    {gname:11s} {label:28s} median {np.median(d):6.2f} us   p10 {np.percentile(d, 10):6.2f}   p90 {np.percentile(d, 90):6.2f}")

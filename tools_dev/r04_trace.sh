@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+T=${1:-r04_c18}
+CHAIN_SWEEP=0 CHAIN_FLOOR=0 CHAIN_ROUNDS=0 CHAIN_TRACE=1 CHAIN_TRACE_ROWS=${2:-16384,32768,40000} timeout 300 python tools_dev/chain_probe.py > gpurun_out/${T}_chain_trace.txt 2>&1; grep -v amdgpu.ids gpurun_out/${T}_chain_trace.txt | cut -c1-200

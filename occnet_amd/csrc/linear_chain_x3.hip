@@ -61,7 +61,7 @@ struct ChainArgs {
   float* z2; long ldz2; int off2; int n2;         // tail columns [off2, off2 + n2) -> z2 (column - off2)
   int M;
   int nfull;                                      // blocks with 64-row tiles (the rest: 32-row tiles)
-  long long* trace;                               // TRACE builds: 16 wall-clock stamps per block (development)
+  long long* trace;                               // TRACE builds: 16 wall-clock stamps per wave (development)
 };
 
 // Block barrier that orders LDS traffic only.  __syncthreads() is a full fence: hipcc puts `s_waitcnt vmcnt(0)` in front of
@@ -357,7 +357,7 @@ __device__ __forceinline__ void ch_relu(f32x16 (&acc)[RT][2]) {
 // PROG 0: program A, PROG 1: program B (file header)
 #define OCC_CH_STAMP(I)                                                                            \
   if constexpr (TRACE) {                                                                           \
-    if (threadIdx.x == 0) p.trace[(long)blockIdx.x * 16 + (I)] = wall_clock64();                   \
+    if ((threadIdx.x & 63) == 0) p.trace[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (I)] = wall_clock64();   \
   }
 
 // One tile of RT x 32 rows starting at row m0 through the whole program.
@@ -440,8 +440,11 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
   ch_kloop<ABL>(acc, w, wr, wv, 0, (0) + 16, tl, abase, rot);
   OCC_CH_STAMP(2)
   ch_layernorm(acc, red, prm_ln, prm_ln + 256, p.eps1, wave, vi, kb);
+  if constexpr (PROG == 0) { OCC_CH_STAMP(4) }
   ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true);       // A: x1.  B: x2 parked in its own rows of y
+  if constexpr (PROG == 0) { OCC_CH_STAMP(5) }
   ch_to_tile(acc, tl, wave, vi, kb);
+  if constexpr (PROG == 0) { OCC_CH_STAMP(6) }
   ch_sync();
   OCC_CH_STAMP(3)                                   // LayerNorm, row stores issued, tile rebuilt
   int step = 16;
@@ -578,15 +581,15 @@ int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what
   if (PROG == 0 && abl == 4) kern = linear_chain_x3_kernel<0, 4>;
   if (PROG == 0 && abl == 3) kern = linear_chain_x3_kernel<0, 3>;
   // OCC_CHAIN_TRACE=<file prefix> (development, tools_dev/chain_probe.py): every launch runs the stamped build, waits for
-  // it and appends its 16 wall-clock stamps per block (100 MHz) to <prefix>.<A|B>.bin
+  // it and appends its 16 wall-clock stamps per wave (100 MHz) to <prefix>.<A|B>.bin
   const char* trace_to = getenv("OCC_CHAIN_TRACE");
   if (trace_to && *trace_to) {
     kern = linear_chain_x3_kernel<PROG, 0, true>;
-    if (hipMalloc(reinterpret_cast<void**>(&args.trace), (size_t)ntiles * 16 * sizeof(long long)) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&args.trace), (size_t)ntiles * 64 * sizeof(long long)) != hipSuccess) {
       set_error("%s: trace buffer allocation failed", what);
       return OCC_E_LAUNCH;
     }
-    (void)hipMemsetAsync(args.trace, 0, (size_t)ntiles * 16 * sizeof(long long), st);
+    (void)hipMemsetAsync(args.trace, 0, (size_t)ntiles * 64 * sizeof(long long), st);
   }
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kChLds);
@@ -597,7 +600,7 @@ int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what
   hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), kChLds, st, args);
   OCC_CHECK_LAUNCH(what);
   if (args.trace) {
-    std::vector<long long> host((size_t)ntiles * 16);
+    std::vector<long long> host((size_t)ntiles * 64);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(host.data(), args.trace, host.size() * sizeof(long long), hipMemcpyDeviceToHost);
     (void)hipFree(args.trace);

@@ -100,7 +100,8 @@ for rnd in range(int(os.environ.get("CHAIN_ROUNDS", "2"))):
 if os.environ.get("CHAIN_TRACE", "0") == "1":
     import numpy as np
     import tempfile
-    NAMES = {"A": [(0, 1, "rows in, tile built"), (1, 2, "S1 k-loop"), (2, 3, "LN + x1 stores + tile"), (3, 11, "pass 0 k-loop"),
+    NAMES = {"A": [(0, 1, "rows in, tile built"), (1, 2, "S1 k-loop"), (2, 4, "LayerNorm (2 barriers)"), (4, 5, "x1 stores issued"),
+                   (5, 6, "tile rebuilt"), (6, 3, "block barrier"), (3, 11, "pass 0 k-loop"),
                    (11, 12, "stores 0 + pass 1 k-loop"), (12, 13, "stores 1 + pass 2 k-loop"), (13, 15, "stores 2")],
              "B": [(0, 1, "rows in, tile built"), (1, 2, "S1 k-loop"), (2, 3, "LN + x2 stores + tile"), (3, 4, "S2a k-loop"),
                    (4, 5, "S2b k-loop"), (5, 6, "ha -> tile, x2 reload"), (6, 7, "S3a k-loop"), (7, 8, "hb -> tile"),
@@ -121,8 +122,9 @@ if os.environ.get("CHAIN_TRACE", "0") == "1":
             fn()
             torch.cuda.synchronize()
             os.environ.pop("OCC_CHAIN_TRACE")
-            st = np.fromfile(path, dtype=np.int64).reshape(-1, 16).astype(np.float64)
-            st = (st - st[:, 0].min()) * 0.01            # us since the first block started
+            sw = np.fromfile(path, dtype=np.int64).reshape(-1, 4, 16).astype(np.float64)
+            sw = (sw - sw[:, :, 0].min()) * 0.01         # us since the first wave started; [block][wave][stamp]
+            st = sw[:, 0, :]                             # the timeline below follows wave 0
             nblk = st.shape[0]
             first = st[:min(nblk, 512)]
             print(f"--- program {prog}, {m} rows, {nblk} blocks: launch span {st[:, 15].max():.1f} us; first-round blocks start "
@@ -133,6 +135,9 @@ if os.environ.get("CHAIN_TRACE", "0") == "1":
                 if gname == "tail round":
                     print(f"    tail round: {gs.shape[0]} blocks start {np.median(gs[:, 0]):.1f} us (min {gs[:, 0].min():.1f}, max {gs[:, 0].max():.1f}), "
                           f"end {np.median(gs[:, 15]):.1f} us (max {gs[:, 15].max():.1f})")
+                gw = sw[:min(nblk, 512)] if gname == "first round" else sw[512:]
                 for i0, i1, label in NAMES[prog]:
                     d = gs[:, i1] - gs[:, i0]
-                    print(f"    {gname:11s} {label:28s} median {np.median(d):6.2f} us   p10 {np.percentile(d, 10):6.2f}   p90 {np.percentile(d, 90):6.2f}")
+                    skew = gw[:, :, i1].max(axis=1) - gw[:, :, i1].min(axis=1)       # arrival spread of the block's 4 waves
+                    print(f"    {gname:11s} {label:28s} median {np.median(d):6.2f} us   p10 {np.percentile(d, 10):6.2f}   p90 {np.percentile(d, 90):6.2f}"
+                          f"   wave skew at its end: median {np.median(skew):5.2f}  p90 {np.percentile(skew, 90):5.2f}")

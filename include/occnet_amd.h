@@ -342,6 +342,15 @@ int occ_encoder_ffn_chain_bf16x3_f32(const float* a, int64_t lda, const float* r
                                      const float* q_term, int64_t ldq_term, float* zq, int64_t ldzq, int nq,
                                      float* zv, int64_t ldzv, int M, void* stream);
 
+/* Program C: the tail stage alone — two Linears of the SAME 256-wide rows in one launch (the first encoder layer's TSA
+ * query Linears and value projection, temporal_self_attention.py:197-209,239-240, straight from the BEV queries):
+ *   zq (M, nq) = a . Wq^T + q_term (or + 0),   zv (M, 256) = a . Wv^T + bv.
+ * w_chain = chain packs of [Wq (nq <= 256 rows, zero-padded to 256), Wv]; bias_chain = [256 zeros | bv].
+ * nq % 64 == 0; rows 16-byte aligned. */
+int occ_linear_pair_chain_bf16x3_f32(const float* a, int64_t lda, const void* w_chain, const float* bias_chain,
+                                     const float* q_term, int64_t ldq_term, float* zq, int64_t ldzq, int nq,
+                                     float* zv, int64_t ldzv, int M, void* stream);
+
 /* Training path of SpatialCrossAttention, query side (csrc/sca_prep.hip; reference spatial_cross_attention.py:338-373
  * applied to the per-camera rebatched rows): from proj (B, Q, >= 3*M*L*P) = [sampling_offsets | attention_weights]
  * Linear outputs per BEV query, row_to_query (R) (-1 = padded row) and the rebatched reference points ref_rb

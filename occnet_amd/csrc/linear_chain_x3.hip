@@ -14,6 +14,9 @@
 //                                       z  = [y.Wsum^T + term | y.Wv^T + bv]                 (optional: the NEXT layer's TSA
 //                                            query Linears with the positional term folded in, and its value projection)
 //
+//   program C (layer 0, no producer):  z  = [a.Wsum^T + term | a.Wv^T + bv]                  (the tail stage alone: the first
+//                                            layer's TSA query Linears and value projection straight from the BEV queries)
+//
 // A block owns 64 rows for ALL columns of every stage.  The stage input is a 64 x 256 tile in LDS as hi and lo bf16
 // planes (64 KB, 16-byte pieces XOR-swizzled by row: conflict-free ds_read_b128 of the MFMA fragments); the four waves
 // each own 64 of the 256 output columns of a pass (2 x 2 accumulator tiles) and stream their hi/lo weight fragments
@@ -354,7 +357,7 @@ __device__ __forceinline__ void ch_relu(f32x16 (&acc)[RT][2]) {
       for (int r = 0; r < 16; ++r) acc[rt][t][r] = fmaxf(acc[rt][t][r], 0.f);
 }
 
-// PROG 0: program A, PROG 1: program B (file header)
+// PROG 0: program A, PROG 1: program B, PROG 2: program C (file header)
 #define OCC_CH_STAMP(I)                                                                            \
   if constexpr (TRACE) {                                                                           \
     if ((threadIdx.x & 63) == 0) p.trace[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (I)] = wall_clock64();   \
@@ -378,11 +381,12 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
   // tile's 16 row loads to their uses, 3-4 in flight, and put every residual load behind its own branch: five to six
   // serial HBM round trips per tile instead of one) -----------------------------------------------------------------------
   // per-column parameters (L2 hits): thread t fetches bias quads t and t + 256 and one quad of a LayerNorm vector
-  const int nb4 = ((PROG == 0 ? 256 : 1024) + 256 * p.npass) / 4;
+  const int nb4 = ((PROG == 0 ? 256 : PROG == 1 ? 1024 : 0) + 256 * p.npass) / 4;
   const float4 pb0 = reinterpret_cast<const float4*>(p.bias)[tid < nb4 ? tid : nb4 - 1];
   const float4 pb1 = reinterpret_cast<const float4*>(p.bias)[tid + 256 < nb4 ? tid + 256 : nb4 - 1];
   const float* lnv = wave == 0 ? p.ln1_g : wave == 1 ? p.ln1_b : wave == 2 ? p.ln2_g : p.ln2_b;
   if (PROG == 0 && wave >= 2) lnv = p.ln1_g;        // program A has one LayerNorm: waves 2, 3 fetch (and drop) a duplicate
+  if (PROG == 2) lnv = p.bias;                      // program C has none
   const float4 pl = reinterpret_cast<const float4*>(lnv)[lane];
 
   // weight ring: slot (step & 3) = {hi tile 0, lo tile 0, hi tile 1, lo tile 1} of the wave's 64 columns of flat step
@@ -416,12 +420,12 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
     if (m >= M) m = (long)M - 1;
     v[j] = *reinterpret_cast<const float4*>(p.a + m * p.lda + lane * 4);
   }
-  ch_load_rows(acc, p.res, p.ldres, rows, wave * 64, kb);
+  if constexpr (PROG != 2) ch_load_rows(acc, p.res, p.ldres, rows, wave * 64, kb);
   __builtin_amdgcn_sched_barrier(0);                // nothing below may be hoisted between the requests above
 
   reinterpret_cast<float4*>(prm)[tid] = pb0;
   if (tid + 256 < nb4) reinterpret_cast<float4*>(prm)[tid + 256] = pb1;
-  if (PROG == 1 || wave < 2) reinterpret_cast<float4*>(prm + kChBiasMax)[tid] = pl;
+  if (PROG == 1 || (PROG == 0 && wave < 2)) reinterpret_cast<float4*>(prm + kChBiasMax)[tid] = pl;
 #pragma unroll
   for (int j = 0; j < 8 * RT; ++j) {                // -> hi / lo planes
     const int row = j * 4 + wave;
@@ -435,20 +439,24 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
   const unsigned abase = (unsigned)(vi * 512 + ((kb ^ vi) & 31) * 16);
   ch_sync();
   OCC_CH_STAMP(1)                                   // first-stage rows landed, tile built
+  int step = 0;
+  int bias_off = 0;
+  if constexpr (PROG != 2) {
   // ---- stage 1: output_proj + bias + residual -> LayerNorm -------------------------------------------------------------
-  ch_add_bias(acc, prm + wave * 64, kb);
-  ch_kloop<ABL>(acc, w, wr, wv, 0, (0) + 16, tl, abase, rot);
-  OCC_CH_STAMP(2)
-  ch_layernorm(acc, red, prm_ln, prm_ln + 256, p.eps1, wave, vi, kb);
-  if constexpr (PROG == 0) { OCC_CH_STAMP(4) }
-  ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true);       // A: x1.  B: x2 parked in its own rows of y
-  if constexpr (PROG == 0) { OCC_CH_STAMP(5) }
-  ch_to_tile(acc, tl, wave, vi, kb);
-  if constexpr (PROG == 0) { OCC_CH_STAMP(6) }
-  ch_sync();
-  OCC_CH_STAMP(3)                                   // LayerNorm, row stores issued, tile rebuilt
-  int step = 16;
-  int bias_off = 256;
+    ch_add_bias(acc, prm + wave * 64, kb);
+    ch_kloop<ABL>(acc, w, wr, wv, 0, (0) + 16, tl, abase, rot);
+    OCC_CH_STAMP(2)
+    ch_layernorm(acc, red, prm_ln, prm_ln + 256, p.eps1, wave, vi, kb);
+    if constexpr (PROG == 0) { OCC_CH_STAMP(4) }
+    ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true);       // A: x1.  B: x2 parked in its own rows of y
+    if constexpr (PROG == 0) { OCC_CH_STAMP(5) }
+    ch_to_tile(acc, tl, wave, vi, kb);
+    if constexpr (PROG == 0) { OCC_CH_STAMP(6) }
+    ch_sync();
+    OCC_CH_STAMP(3)                                   // LayerNorm, row stores issued, tile rebuilt
+  step = 16;
+  bias_off = 256;
+  }
 
   if constexpr (PROG == 1) {
     // ---- FFN: both hidden halves from the x2 tile (registers), then the second Linear over the two K halves ------------
@@ -679,4 +687,30 @@ extern "C" int occ_encoder_ffn_chain_bf16x3_f32(const float* a, int64_t lda, con
   g.z2 = zv; g.ldz2 = ldzv; g.off2 = 256; g.n2 = tail ? 256 : 0;
   g.M = M;
   return chain_launch<1>(g, reinterpret_cast<hipStream_t>(stream), "encoder_ffn_chain");
+}
+
+extern "C" int occ_linear_pair_chain_bf16x3_f32(const float* a, int64_t lda, const void* w_chain, const float* bias_chain,
+                                                const float* q_term, int64_t ldq_term, float* zq, int64_t ldzq, int nq,
+                                                float* zv, int64_t ldzv, int M, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(a && w_chain && bias_chain && zq && zv, "linear_pair_chain: null pointer argument");
+  OCC_CHECK_ARG(M > 0 && nq > 0 && nq <= 256, "linear_pair_chain: bad dimension (M=%d nq=%d)", M, nq);
+  OCC_CHECK_ARG(lda >= 256 && ldzq >= nq && ldzv >= 256 && (!q_term || ldq_term >= nq),
+                "linear_pair_chain: leading dimension smaller than the row");
+  if (lda % 4 || nq % 64 || ldzq % 4 || ldzv % 4 || ldq_term % 4) {
+    set_error("linear_pair_chain: nq=%d must be a multiple of 64 and all rows 16-byte aligned", nq);
+    return OCC_E_UNSUPPORTED;
+  }
+  ChainArgs g = {};
+  g.a = a; g.lda = lda;
+  g.npass = 2;
+  g.wp = reinterpret_cast<const uint4*>(w_chain);
+  g.wbytes = (unsigned)(16 * g.npass) * (unsigned)kChStepBytes;
+  g.bias = bias_chain;
+  g.act = 0;
+  g.term = q_term; g.ldterm = ldq_term; g.term_cols = nq;
+  g.z1 = zq; g.ldz1 = ldzq; g.n1 = nq;
+  g.z2 = zv; g.ldz2 = ldzv; g.off2 = 256; g.n2 = 256;
+  g.M = M;
+  return chain_launch<2>(g, reinterpret_cast<hipStream_t>(stream), "linear_pair_chain");
 }

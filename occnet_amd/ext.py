@@ -816,6 +816,33 @@ def encoder_ffn_chain(a, residual, wo, bo, ln1, w1, b1, w2, b2, ln2, tail=None):
     return y, zq, zv
 
 
+def linear_pair_chain(a, wq, q_term, wv, bv):
+    """Program C of csrc/linear_chain_x3.hip: zq = a @ wq^T (+ q_term), zv = a @ wv^T + bv in ONE launch (the rows are
+    read once).  a (…, 256); wq (nq <= 256, nq % 64 == 0, 256); wv (256, 256).  -> (zq, zv)."""
+    if LINEAR_PRECISION != "bf16x3":
+        raise OccAmdUnsupported("linear chain: bf16x3 precision mode only")
+    a_, M, lda = _chain_rows("a", a)
+    nq = wq.shape[0]
+    if wq.dim() != 2 or wq.shape[1] != 256 or nq > 256 or nq % 64 or tuple(wv.shape) != (256, 256):
+        raise OccAmdUnsupported("linear_pair_chain: needs wq (nq <= 256, nq % 64 == 0, 256) and wv (256, 256)")
+    ldq = 0
+    if q_term is not None:
+        _, Mq, _, ldq = _rows2d("q_term", q_term, nq)
+        if Mq != M:
+            raise OccAmdError("linear_pair_chain: q_term differs in rows")
+    wp = linear_chain_pack([wq, wv])
+    bias = _chain_bias([(None, 256), (bv, 256)], a.device)
+    zq = torch.empty(a.shape[:-1] + (nq,), dtype=torch.float32, device=a.device)
+    zv = torch.empty(a.shape[:-1] + (256,), dtype=torch.float32, device=a.device)
+    _chain_time(2.0 * M * 256 * (nq + 256))
+    with torch.cuda.device(a.device), _timed('linear'):
+        rc = _lib.lib().occ_linear_pair_chain_bf16x3_f32(
+            ptr(a_), i64(lda), ptr(wp), ptr(bias), ptr(q_term), i64(ldq), ptr(zq), i64(nq), i32(nq), ptr(zv), i64(256),
+            i32(M), stream_ptr(a.device))
+    _lib.check(rc, "linear_pair_chain")
+    return zq, zv
+
+
 def linear_wgrad(dy, x, with_bias=True):
     """Weight / bias gradient of out = x @ W^T + b on the bf16x3 matrix-core kernel (csrc/linear_wgrad.hip):
     dW (N, K) = dy^T @ x, db (N) = dy.sum(rows).  dy (…, N), x (…, K) float32 device tensors with the same leading

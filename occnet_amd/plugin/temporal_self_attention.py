@@ -122,6 +122,18 @@ class TemporalSelfAttention(BaseModule):
                 # no history: cat([q, q + pos]) @ W^T + b = q @ (Wa + Wb)^T + (pos @ Wb^T + b); the
                 # position term is constant while weights and positional encoding are (inference)
                 w_sum, pos_term = self._folded_query_weights(w, b, query_pos)
+                if ext.LINEAR_CHAIN and ext.LINEAR_PRECISION == "bf16x3" and bs == 1:
+                    try:        # both Linears of the same rows in one launch (program C of csrc/linear_chain_x3.hip)
+                        lin, v = ext.linear_pair_chain(query.contiguous(), w_sum, pos_term, self.value_proj.weight,
+                                                       self.value_proj.bias)
+                    except OccAmdUnsupported:
+                        lin = None
+                    if lin is not None:
+                        v = v.view(v.shape[0], num_query, self.num_heads, -1)
+                        return ext.tsa_fused_forward(v, lin[..., :n_off], lin[..., n_off:],
+                                                     reference_points.float().contiguous(), bev_h, bev_w,
+                                                     self.num_heads, self.num_points, shared_queue=shared,
+                                                     order=bev_order)
                 lin = ext.linear(query.contiguous(), w_sum, None, residual=pos_term)
             else:
                 lin = ext.linear(value_first.contiguous(), w, b, a2=query.contiguous(),

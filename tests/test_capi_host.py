@@ -95,6 +95,14 @@ def test_backbone_and_projection_entry_points_validate_without_gpu():
                                               770, 0, 64, null) == -1                             # ldz < n2
     assert lib.occ_linear_ln_chain_bf16x3_f32(p, i64(256), p, i64(256), p, p, p, p, f, p, i64(256), p, i64(800),
                                               776, 0, 64, null) == -3                             # n2 % 32
+    assert lib.occ_linear_pair_chain_bf16x3_f32(p, i64(256), p, p, null, i64(0), null, i64(192), 192, p, i64(256), 64,
+                                                null) == -1                                       # null zq
+    assert lib.occ_linear_pair_chain_bf16x3_f32(p, i64(256), p, p, null, i64(0), p, i64(192), 200, p, i64(256), 64,
+                                                null) == -1                                       # ldzq < nq
+    assert lib.occ_linear_pair_chain_bf16x3_f32(p, i64(256), p, p, null, i64(0), p, i64(192), 160, p, i64(256), 64,
+                                                null) == -3                                       # nq % 64
+    assert lib.occ_linear_ln_chain_bf16x3_f32(p, i64(256), p, i64(256), p, p, p, p, f, p, i64(256), p, i64(1536),
+                                              1536, 0, 64, null) == -3                            # more tail columns than staged parameters
     assert lib.occ_encoder_ffn_chain_bf16x3_f32(p, i64(256), p, i64(256), p, p, p, p, f, p, p, f, p, i64(256), null,
                                                 i64(0), p, i64(192), 192, null, i64(256), 64, null) == -1   # zq without zv
     assert lib.occ_encoder_ffn_chain_bf16x3_f32(p, i64(256), p, i64(256), p, p, p, p, f, p, p, f, p, i64(256), null,

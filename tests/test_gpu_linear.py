@@ -456,6 +456,30 @@ def test_encoder_ffn_chain_matches_oracle(M, tail, term):
         assert zq is None and zv is None
 
 
+@pytest.mark.parametrize("M,term", [(1, False), (77, True), (4099, True), (40000, True), (512 * 64 + 101, False)])
+def test_linear_pair_chain_matches_oracle(M, term):
+    """Program C: the first layer's TSA query Linears (192 columns + a per-row term) and value projection (256 columns)
+    of the same rows in one launch."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(63)
+    s = (1.0 / 256) ** 0.5
+    t = dict(a=_mk(g, M, 256), wq=_mk(g, 192, 256, scale=s), qt=_mk(g, M, 192), wv=_mk(g, 256, 256, scale=s),
+             bv=_mk(g, 256, scale=0.1))
+    d = {k: v.double() for k, v in t.items()}
+    zq_ref = odense.linear_chain(d['a'], d['wq'], None, residual=d['qt'] if term else None)
+    zv_ref = odense.linear_chain(d['a'], d['wv'], d['bv'])
+    c = {k: v.cuda() for k, v in t.items()}
+    zq, zv = ext.linear_pair_chain(c['a'], c['wq'], c['qt'] if term else None, c['wv'], c['bv'])
+    torch.cuda.synchronize()
+    dq = float((zq.cpu().double() - zq_ref).abs().max())
+    dv = float((zv.cpu().double() - zv_ref).abs().max())
+    print(f"chain C M={M}: max|zq - oracle| = {dq:.3e}, max|zv - oracle| = {dv:.3e}")
+    assert zq.shape == (M, 192) and zv.shape == (M, 256) and dq < 2e-4 and dv < 2e-4
+    z1 = ext.linear(c['a'], c['wq'], None, residual=c['qt'] if term else None)
+    z2 = ext.linear(c['a'], c['wv'], c['bv'])
+    assert float((zq - z1).abs().max()) < 1e-4 and float((zv - z2).abs().max()) < 1e-4
+
+
 def test_linear_chain_rejects_other_shapes():
     from occnet_amd import ext
     from occnet_amd._lib import OccAmdUnsupported

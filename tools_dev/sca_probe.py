@@ -68,3 +68,31 @@ for mode in ("f32", "f16"):
     med, mn = timed(lambda: lf.project(vp))
     print(json.dumps(dict(kernel=f"value_proj_bf16 -> {mode}", median_ms=med, min_ms=mn)), flush=True)
 ext.SCA_VALUES = "f32"
+
+# Where do the gather's operands live when it runs?  In the step each layer's value plane was written ~1 GB of traffic
+# earlier (cold), the query Linear outputs right before (warm).  SCA_COLD=1: time single launches after (a) nothing (hot:
+# the loop above), (b) a 1 GB flush (everything cold), (c) the flush, then a streaming READ of the value plane (value
+# warm in the memory-side cache, the rest cold), (d) the flush, then reads of value AND the query Linear outputs.
+if os.environ.get("SCA_COLD", "0") == "1":
+    kk = dict(k, value_layout="pairs")
+    junk = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)          # 1 GB
+    offs_t, logit_t = a[3], a[4]            # sca_fused_forward(value, shapes, start, offsets, logits, ...)
+    def once(prep):
+        ts = []
+        for _ in range(12):
+            junk.fill_(1.0)
+            prep()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); orig(v16, *a[1:], **kk); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return ts[len(ts) // 2]
+    t_stream, _ = timed(lambda: v16.sum())
+    print(json.dumps(dict(experiment="sca gather, operand residency",
+                          hot_ms=timed(lambda: orig(v16, *a[1:], **kk))[0],
+                          all_cold_ms=once(lambda: None),
+                          value_streamed_ms=once(lambda: v16.sum()),
+                          value_and_linear_streamed_ms=once(lambda: (v16.sum(), offs_t.sum(), logit_t.sum())),
+                          linear_streamed_only_ms=once(lambda: (offs_t.sum(), logit_t.sum())),
+                          stream_read_of_value_ms=t_stream)), flush=True)

@@ -33,6 +33,7 @@ def invalidate_caches(model=None):
     from . import ext
     ext._PACKED_W.clear()
     ext._STACKED_VP.clear()
+    ext._STACKED_GB.clear()
     ext._CHAIN_PACKS.clear()
     if model is not None and getattr(model, '_inference_backbone', None) is not None:
         model.enable_fused_backbone(**model._inference_backbone_args)

@@ -536,6 +536,7 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
 
 
 _STACKED_VP = {}        # (weights' (ptr, version) ..., epoch) -> (stacked weight, its pack) of value_proj_bf16_planes
+_STACKED_GB = {}        # (bias tables' (ptr, version) ..., epoch) -> (their concatenation, the sources kept alive)
 
 
 def value_proj_planes_prepare(weights):
@@ -576,7 +577,15 @@ def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, o
     hit = value_proj_planes_prepare(weights)
     gb_ptrs, G, gb_keep = None, 0, None
     if group_biases is not None and group_biases[0] is not None:
-        gb_keep = torch.cat(list(group_biases), 2).contiguous()                  # (S, G, P*N)
+        # (S, G, P*N), cached on the per-projection bias tables' identities: it was a cat kernel per step in front of the
+        # side stream's projection launch
+        gkey = tuple((g.data_ptr(), g._version) for g in group_biases) + (str(out.device), cache_epoch())
+        ghit = _STACKED_GB.get(gkey)
+        if ghit is None:
+            if len(_STACKED_GB) >= 8:
+                _STACKED_GB.pop(next(iter(_STACKED_GB)))
+            ghit = _STACKED_GB[gkey] = (torch.cat(list(group_biases), 2).contiguous(), list(group_biases))
+        gb_keep = ghit[0]
         G = gb_keep.shape[1]
         gb_ptrs = (ctypes.c_void_p * S)(*[gb_keep[s].data_ptr() for s in range(S)])
     arr64 = lambda v: (ctypes.c_int64 * S)(*[int(x) for x in v])

@@ -235,19 +235,24 @@ __device__ __forceinline__ void ch_add_bias(f32x16 (&acc)[RT][2], const float* p
     }
 }
 
-// accumulators <- src[row][column] (this lane's two rows, clamped): 16 quad loads, all requested before the first use
+// Row I/O goes through buffer instructions: an SGPR resource per matrix (base, M x ld x 4 bytes), a 32-bit byte offset per
+// lane.  Rows beyond M fall outside the resource — loads return 0, stores are dropped by the bounds check — so there are no
+// clamped indices, no `live` predicates and no 64-bit address arithmetic in the vector registers (program B spilled for them).
+// accumulators <- src[row][column]: 16 quad loads, all requested before the first use
 template <int RT>
-__device__ __forceinline__ void ch_load_rows(f32x16 (&acc)[RT][2], const float* __restrict__ src, long ld, const long (&rows)[RT],
-                                             int c0, int kb) {
+__device__ __forceinline__ void ch_load_rows(f32x16 (&acc)[RT][2], const __amdgpu_buffer_rsrc_t src, const unsigned ldb,
+                                             const unsigned (&row)[RT], int c0, int kb) {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt) {
+    const unsigned ro = row[rt] * ldb + (unsigned)(c0 + 4 * kb) * 4u;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(src + rows[rt] * ld + c0 + 32 * t + 8 * q + 4 * kb);
+        const float4 v = buf_load16(src, ro + (unsigned)(32 * t + 8 * q) * 4u);
         acc[rt][t][4 * q + 0] = v.x; acc[rt][t][4 * q + 1] = v.y; acc[rt][t][4 * q + 2] = v.z; acc[rt][t][4 * q + 3] = v.w;
       }
+  }
 }
 
 // register quads -> the operand tile (hi / lo planes): piece 8 wave + 4 t + q of row rt * 32 + vi, half kb
@@ -325,24 +330,23 @@ __device__ __forceinline__ void ch_layernorm(f32x16 (&acc)[RT][2], float* red, c
     }
 }
 
-// register quads -> row-major global rows (column c0 + 32 t + 8 q + 4 kb of row rows[rt]); rows beyond M are skipped.
-// One exec-mask region per row tile and one uniform branch per column tile: per-store conditions made hipcc wrap every
-// store in three scalar branches (round 4 ISA reading).
+// register quads -> row-major rows of `dst` (column c0 + 32 t + 8 q + 4 kb of row row[rt]); rows beyond M are dropped by the
+// resource's bounds check.  One uniform branch per column tile.
 template <int RT>
-__device__ __forceinline__ void ch_store(const f32x16 (&acc)[RT][2], float* dst, long ld, const long (&rows)[RT],
-                                         const bool (&live)[RT], int c0, int kb, bool t0_on, bool t1_on) {
+__device__ __forceinline__ void ch_store(const f32x16 (&acc)[RT][2], const __amdgpu_buffer_rsrc_t dst, const unsigned ldb,
+                                         const unsigned (&row)[RT], int c0, int kb, bool t0_on, bool t1_on) {
   // c0 = column of `dst` that receives the wave's first column
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    if (!live[rt]) continue;
-    float* o = dst + rows[rt] * ld + c0 + 4 * kb;
+    const unsigned ro = row[rt] * ldb + (unsigned)(c0 + 4 * kb) * 4u;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (!(t == 0 ? t0_on : t1_on)) continue;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(o + 32 * t + 8 * q) =
-            make_float4(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1], acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]);
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = make_float4(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1], acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(occ_u32x4, v), dst, (int)(ro + (unsigned)(32 * t + 8 * q) * 4u), 0, 0);
+      }
     }
   }
 }
@@ -399,28 +403,27 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
   OCC_CH_LOAD(1, (rot + 1) & 15)
   OCC_CH_LOAD(2, (rot + 2) & 15)
 
-  // this lane's rows (clamped for the loads)
-  long rows[RT];
-  bool live[RT];
+  // this lane's rows, and the matrices as buffer resources of M rows (see ch_load_rows)
+  unsigned row[RT];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const long r = m0 + rt * 32 + vi;
-    live[rt] = r < M;
-    rows[rt] = live[rt] ? r : (long)M - 1;
-  }
+  for (int rt = 0; rt < RT; ++rt) row[rt] = (unsigned)m0 + (unsigned)(rt * 32 + vi);
+  const unsigned lda_b = (unsigned)p.lda * 4u, ldres_b = (unsigned)p.ldres * 4u, ldy_b = (unsigned)p.ldy * 4u;
+  const unsigned ldt_b = (unsigned)p.ldterm * 4u, ldz1_b = (unsigned)p.ldz1 * 4u, ldz2_b = (unsigned)p.ldz2 * 4u;
+  const __amdgpu_buffer_rsrc_t ra = uniform_rsrc(p.a, (unsigned)M * lda_b);
+  const __amdgpu_buffer_rsrc_t rres = uniform_rsrc(p.res, (unsigned)M * ldres_b);
+  const __amdgpu_buffer_rsrc_t ry = uniform_rsrc(p.y, (unsigned)M * ldy_b);
+  const __amdgpu_buffer_rsrc_t rterm = uniform_rsrc(p.term, (unsigned)M * ldt_b);
+  const __amdgpu_buffer_rsrc_t rz1 = uniform_rsrc(p.z1, (unsigned)M * ldz1_b);
+  const __amdgpu_buffer_rsrc_t rz2 = uniform_rsrc(p.z2, (unsigned)M * ldz2_b);
 
   // stage input: RT x 32 rows x 256 f32 (a wave instruction = one whole row, 1 KB), and the residual rows straight into the
   // accumulators
   f32x16 acc[RT][2];
   float4 v[8 * RT];
 #pragma unroll
-  for (int j = 0; j < 8 * RT; ++j) {
-    const int row = j * 4 + wave;
-    long m = m0 + row;
-    if (m >= M) m = (long)M - 1;
-    v[j] = *reinterpret_cast<const float4*>(p.a + m * p.lda + lane * 4);
-  }
-  if constexpr (PROG != 2) ch_load_rows(acc, p.res, p.ldres, rows, wave * 64, kb);
+  for (int j = 0; j < 8 * RT; ++j)                   // (the row offset stays in the VGPR offset: the bounds check covers it)
+    v[j] = buf_load16(ra, ((unsigned)m0 + (unsigned)(j * 4 + wave)) * lda_b + (unsigned)lane * 16u);
+  if constexpr (PROG != 2) ch_load_rows(acc, rres, ldres_b, row, wave * 64, kb);
   __builtin_amdgcn_sched_barrier(0);                // nothing below may be hoisted between the requests above
 
   reinterpret_cast<float4*>(prm)[tid] = pb0;
@@ -448,7 +451,7 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
     OCC_CH_STAMP(2)
     ch_layernorm(acc, red, prm_ln, prm_ln + 256, p.eps1, wave, vi, kb);
     if constexpr (PROG == 0) { OCC_CH_STAMP(4) }
-    ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true);       // A: x1.  B: x2 parked in its own rows of y
+    ch_store(acc, ry, ldy_b, row, wave * 64, kb, true, true);               // A: x1.  B: x2 parked in its own rows of y
     if constexpr (PROG == 0) { OCC_CH_STAMP(5) }
     ch_to_tile(acc, tl, wave, vi, kb);
     if constexpr (PROG == 0) { OCC_CH_STAMP(6) }
@@ -473,7 +476,7 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
     ch_to_tile(ha, tl, wave, vi, kb);
     ch_sync();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the x2 stores (two k loops ago) have landed
-    ch_load_rows(acc, p.y, p.ldy, rows, wave * 64, kb);                  // x2 (this lane's own stores)
+    ch_load_rows(acc, ry, ldy_b, row, wave * 64, kb);                    // x2 (this lane's own stores)
     ch_add_bias(acc, prm + 768 + wave * 64, kb);                         // + b2
     OCC_CH_STAMP(6)                                 // ha in the tile, x2 reloaded
     ch_kloop<ABL>(acc, w, wr, wv, 48, (48) + 16, tl, abase, rot);
@@ -485,7 +488,7 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
     ch_kloop<ABL>(acc, w, wr, wv, 64, (64) + 16, tl, abase, rot);
     OCC_CH_STAMP(9)
     ch_layernorm(acc, red, prm_ln + 512, prm_ln + 768, p.eps2, wave, vi, kb);
-    ch_store(acc, p.y, p.ldy, rows, live, wave * 64, kb, true, true);     // x3
+    ch_store(acc, ry, ldy_b, row, wave * 64, kb, true, true);             // x3
     if (p.npass > 0) {
       ch_to_tile(acc, tl, wave, vi, kb);
       ch_sync();
@@ -501,7 +504,7 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
     const int c0 = ps * 256 + wave * 64;            // the wave's first tail column of this pass
     const float* pbias = prm + bias_off + c0;
     if (p.term != nullptr && c0 < p.term_cols) {    // term_cols is a multiple of 64: whole waves
-      ch_load_rows(acc, p.term, p.ldterm, rows, c0, kb);
+      ch_load_rows(acc, rterm, ldt_b, row, c0, kb);
       ch_add_bias(acc, pbias, kb);
     } else {
       ch_set_bias(acc, pbias, kb);
@@ -513,8 +516,8 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
     const int ca = c0, cb = c0 + 32;
     const bool a1 = ca < p.n1, b1 = cb < p.n1;
     const bool a2 = ca >= p.off2 && ca < p.off2 + p.n2, b2 = cb >= p.off2 && cb < p.off2 + p.n2;
-    if (a1 || b1) ch_store(acc, p.z1, p.ldz1, rows, live, c0, kb, a1, b1);
-    if (a2 || b2) ch_store(acc, p.z2, p.ldz2, rows, live, c0 - p.off2, kb, a2, b2);
+    if (a1 || b1) ch_store(acc, rz1, ldz1_b, row, c0, kb, a1, b1);
+    if (a2 || b2) ch_store(acc, rz2, ldz2_b, row, c0 - p.off2, kb, a2, b2);
   }
   OCC_CH_STAMP(15)
 }
@@ -570,6 +573,15 @@ int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what
   // profiles/r04_c9_stores.txt and was removed: its run-time test put three branches around every store.)
   static const int abl = [] { const char* e = getenv("OCC_CHAIN_ABLATE"); return e ? atoi(e) : 0; }();
   ChainArgs args = args_in;
+  {
+    // 32-bit byte offsets inside the kernel (buffer instructions): every matrix, padded by one tile of rows, stays below 4 GB
+    const long lds[6] = {args.lda, args.ldres, args.ldy, args.ldterm, args.ldz1, args.ldz2};
+    for (long ld : lds)
+      if (((long)args.M + kChRows) * ld * 4 >= (1L << 32)) {
+        set_error("%s: M=%d rows of %ld floats exceed the 4 GB a buffer resource addresses", what, args.M, ld);
+        return OCC_E_UNSUPPORTED;
+      }
+  }
   // tile split (kernel comment): the last, partial round of 64-row tiles becomes 32-row tiles when it would fill less
   // than half of the resident slots.  OCC_CHAIN_HALF_TILES=0 keeps 64-row tiles throughout (development).
   static const int slots = [] {

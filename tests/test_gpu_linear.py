@@ -480,6 +480,44 @@ def test_linear_pair_chain_matches_oracle(M, term):
     assert float((zq - z1).abs().max()) < 1e-4 and float((zv - z2).abs().max()) < 1e-4
 
 
+def test_linear_chain_never_writes_past_the_last_row(monkeypatch):
+    """The chain kernels address their matrices through buffer resources of M rows: the rows of the last tile that lie beyond M
+    must be dropped by the bounds check, not written.  Every output is allocated with 64 sentinel rows behind it."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(64)
+    M = 512 * 64 + 101 - 64 * 3            # ragged 64-row tail AND (M > 512 tiles) a ragged 32-row tail
+    guards = []
+    real_empty = torch.empty
+
+    def guarded_empty(*shape, **kw):
+        shp = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+        if len(shp) == 2 and shp[0] == M and kw.get('dtype') == torch.float32:
+            full = real_empty((M + 64, shp[1]), **kw)
+            full.fill_(-777.0)
+            guards.append(full)
+            return full[:M]
+        return real_empty(*shape, **kw)
+    s = (1.0 / 256) ** 0.5
+    c = {k: v.cuda() for k, v in dict(
+        a=_mk(g, M, 256), res=_mk(g, M, 256), wo=_mk(g, 256, 256, scale=s), bo=_mk(g, 256, scale=0.1),
+        g1=torch.rand(256, generator=g) + 0.5, be1=_mk(g, 256, scale=0.1), w1=_mk(g, 512, 256, scale=s),
+        b1=_mk(g, 512, scale=0.1), w2=_mk(g, 256, 512, scale=(1.0 / 512) ** 0.5), b2=_mk(g, 256, scale=0.1),
+        g2=torch.rand(256, generator=g) + 0.5, be2=_mk(g, 256, scale=0.1), wq=_mk(g, 192, 256, scale=s),
+        qt=_mk(g, M, 192), wv=_mk(g, 256, 256, scale=s), bv=_mk(g, 256, scale=0.1), w3=_mk(g, 768, 256, scale=s),
+        b3=_mk(g, 768, scale=0.1)).items()}
+    monkeypatch.setattr(torch, "empty", guarded_empty)
+    ext.linear_ln_chain(c['a'], c['res'], c['wo'], c['bo'], (c['g1'], c['be1'], 1e-5), c['w3'], c['b3'])
+    ext.encoder_ffn_chain(c['a'], c['res'], c['wo'], c['bo'], (c['g1'], c['be1'], 1e-5), c['w1'], c['b1'], c['w2'], c['b2'],
+                          (c['g2'], c['be2'], 1e-5), tail=(c['wq'], c['qt'], c['wv'], c['bv']))
+    ext.linear_pair_chain(c['a'], c['wq'], c['qt'], c['wv'], c['bv'])
+    torch.cuda.synchronize()
+    monkeypatch.undo()
+    assert len(guards) == 2 + 3 + 2, len(guards)
+    for full in guards:
+        assert bool((full[M:] == -777.0).all()), "a chain kernel wrote behind row M"
+        assert bool((full[:M] != -777.0).any())
+
+
 def test_linear_chain_rejects_other_shapes():
     from occnet_amd import ext
     from occnet_amd._lib import OccAmdUnsupported

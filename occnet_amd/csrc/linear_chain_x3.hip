@@ -64,7 +64,7 @@ struct ChainArgs {
   float* z2; long ldz2; int off2; int n2;         // tail columns [off2, off2 + n2) -> z2 (column - off2)
   int M;
   int nfull;                                      // blocks with 64-row tiles (the rest: 32-row tiles)
-  long long* trace;                               // TRACE builds: 16 wall-clock stamps per wave (development)
+  long long* trace;                               // TRACE builds: 24 wall-clock stamps per wave (development)
 };
 
 // Block barrier that orders LDS traffic only.  __syncthreads() is a full fence: hipcc puts `s_waitcnt vmcnt(0)` in front of
@@ -108,16 +108,20 @@ __global__ void linear_chain_pack_kernel(const float* __restrict__ w, unsigned s
   {                                                                                                \
     const int so = (STEP) * kChStepBytes;                                                          \
     w[SLOT][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so, 0);                             \
-    w[SLOT][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 1024, so, 0);                      \
-    w[SLOT][2] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 2048, so, 0);                      \
-    w[SLOT][3] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv + 3072, so, 0);                      \
+    w[SLOT][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so + 1024, 0);   /* (the tile offsets ride in the   */ \
+    w[SLOT][2] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so + 2048, 0);   /*  scalar offset: one address     */ \
+    w[SLOT][3] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so + 3072, 0);   /*  VGPR instead of four)          */ \
   }
 
 // operand fragments of (physical) k-step KK — wave-uniform, run time: piece 2 KK + kb of rows vi and (RT == 2) 32 + vi, both planes
 // (slot of piece p in row r = p ^ (r & 31))
 #define OCC_CH_AFRAG(BUF, KK)                                                                      \
   {                                                                                                \
-    const char* ap = tl + (abase ^ (unsigned)((KK) * 32));                                         \
+    /* the address is recomputed at every use from an opaque copy of the base: hipcc otherwise hoists the 16 per-step       \
+       addresses out of all seven k-loops of program B and keeps them live for the whole kernel (16 VGPRs, spills) */       \
+    unsigned ab_ = abase;                                                                          \
+    asm volatile("" : "+v"(ab_));                                                                  \
+    const char* ap = tl + (ab_ ^ (unsigned)((KK) * 32));                                           \
     /* lo planes first: the step's first MFMAs (small term wh . al) read them */                   \
     af[BUF][0][1] = *reinterpret_cast<const bf16x8*>(ap + kChPlane);                               \
     if constexpr (RT == 2) af[BUF][1][1] = *reinterpret_cast<const bf16x8*>(ap + kChPlane + 32 * 512);     \
@@ -131,10 +135,14 @@ __global__ void linear_chain_pack_kernel(const float* __restrict__ w, unsigned s
 // 4 096 line requests into the few L2 channels that hold that chunk while the others idle (round 4, call 2: one block
 // per CU alone took ~1 000 clocks per k-step, two took twice that: the L2 request rate of a hot channel, not MFMA, not
 // L1 bandwidth).  With the rotation the resident blocks are spread over all 16 chunks of a pass at any time.
-template <int ABL = 0, int RT>
+// ST: one quad of `sacc` (an already finished 64 x 64 register tile: the LayerNorm'd rows) is stored to `sdst` per k-step, so
+// that its 16 row stores trickle out under the MFMAs of the NEXT stage instead of leaving as one burst that the wave has to
+// sit through (stamped timeline: issuing 16 stores took 5 us, p90 14 us, profiles/r04_c21_chain_trace_waves.txt).
+template <int ABL = 0, bool ST = false, int RT>
 __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[RT][2], occ_u32x4 (&w)[4][4], const __amdgpu_buffer_rsrc_t wr,
                                          const int wv, const int step0, const int next0, const char* tl, const unsigned abase,
-                                         const int rot) {
+                                         const int rot, const f32x16 (&sacc)[RT][2], const __amdgpu_buffer_rsrc_t sdst,
+                                         const unsigned (&soff)[RT]) {   // soff: byte offset of the lane's first quad per row tile
   bf16x8 af[2][RT][2];                              // [buffer][row tile][plane hi, lo]
   // the pinned group sequence must see the loop's own instructions only: the DS reads of an accumulator initialisation in
   // front of it (or the LayerNorm exchange behind it) in the same scheduling region are matched into the DS groups and
@@ -151,6 +159,14 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[RT][2], occ_u32x4 (&w)[4]
     // logical step ks + 3 of this pass, or step ks + 3 - 16 of the k loop that follows (first step next0: the ring runs
     // across stage — and, in the persistent kernel, tile — boundaries)
     if (!(ABL & 1)) OCC_CH_LOAD((ks + 3) & 3, (ks + 3 < 16 ? step0 : next0) + ((ks + 3 + rot) & 15))
+    if constexpr (ST) {
+      if (ks < 8 * RT) {                            // quad (rt, t, q) = (ks >> 3, (ks >> 2) & 1, ks & 3)
+        const int rt = ks >> 3, t = (ks >> 2) & 1, q = ks & 3;
+        const float4 v = make_float4(sacc[rt][t][4 * q + 0], sacc[rt][t][4 * q + 1], sacc[rt][t][4 * q + 2], sacc[rt][t][4 * q + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(occ_u32x4, v), sdst,
+                                               (int)(soff[rt] + (unsigned)(32 * t + 8 * q) * 4u), 0, 0);
+      }
+    }
     // D[column][row] (weights as the row operand); small terms first, term-major over the four accumulators
     if (!(ABL & 2)) {
 #pragma unroll
@@ -185,6 +201,7 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[RT][2], occ_u32x4 (&w)[4]
     if constexpr (RT == 2) {
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // operand fragments of step s + 1 (lo planes)
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    if constexpr (ST) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // the step's row store
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // (hi planes)
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // ring requests of step s + 3
@@ -194,6 +211,7 @@ __device__ __forceinline__ void ch_kloop(f32x16 (&acc)[RT][2], occ_u32x4 (&w)[4]
     } else {                                             // 32-row tiles: six MFMAs per step
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    if constexpr (ST) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
@@ -364,7 +382,7 @@ __device__ __forceinline__ void ch_relu(f32x16 (&acc)[RT][2]) {
 // PROG 0: program A, PROG 1: program B, PROG 2: program C (file header)
 #define OCC_CH_STAMP(I)                                                                            \
   if constexpr (TRACE) {                                                                           \
-    if ((threadIdx.x & 63) == 0) p.trace[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (I)] = wall_clock64();   \
+    if ((threadIdx.x & 63) == 0) p.trace[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 24 + (I)] = wall_clock64();   \
   }
 
 // One tile of RT x 32 rows starting at row m0 through the whole program.
@@ -444,14 +462,15 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
   OCC_CH_STAMP(1)                                   // first-stage rows landed, tile built
   int step = 0;
   int bias_off = 0;
+  int ps0 = 0;                                      // first tail pass of the generic loop below
   if constexpr (PROG != 2) {
   // ---- stage 1: output_proj + bias + residual -> LayerNorm -------------------------------------------------------------
     ch_add_bias(acc, prm + wave * 64, kb);
-    ch_kloop<ABL>(acc, w, wr, wv, 0, (0) + 16, tl, abase, rot);
+    ch_kloop<ABL>(acc, w, wr, wv, 0, (0) + 16, tl, abase, rot, acc, wr, row);
     OCC_CH_STAMP(2)
     ch_layernorm(acc, red, prm_ln, prm_ln + 256, p.eps1, wave, vi, kb);
     if constexpr (PROG == 0) { OCC_CH_STAMP(4) }
-    ch_store(acc, ry, ldy_b, row, wave * 64, kb, true, true);               // A: x1.  B: x2 parked in its own rows of y
+    if constexpr (PROG == 0) ch_store(acc, ry, ldy_b, row, wave * 64, kb, true, true);      // x1 (B: x2 leaves under S2a)
     if constexpr (PROG == 0) { OCC_CH_STAMP(5) }
     ch_to_tile(acc, tl, wave, vi, kb);
     if constexpr (PROG == 0) { OCC_CH_STAMP(6) }
@@ -464,12 +483,16 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
   if constexpr (PROG == 1) {
     // ---- FFN: both hidden halves from the x2 tile (registers), then the second Linear over the two K halves ------------
     f32x16 ha[RT][2], hb[RT][2];
+    unsigned yoff[RT];                              // this lane's first quad of its rows of y
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) yoff[rt] = row[rt] * ldy_b + (unsigned)(wave * 64 + 4 * kb) * 4u;
     ch_set_bias(ha, prm + 256 + wave * 64, kb);
-    ch_kloop<ABL>(ha, w, wr, wv, 16, (16) + 16, tl, abase, rot);
+    // x2 (still in `acc`) is parked in the block's rows of y one quad per k-step, under the first hidden half's MFMAs
+    ch_kloop<ABL, true>(ha, w, wr, wv, 16, (16) + 16, tl, abase, rot, acc, ry, yoff);
     ch_relu(ha);
     OCC_CH_STAMP(4)
     ch_set_bias(hb, prm + 512 + wave * 64, kb);
-    ch_kloop<ABL>(hb, w, wr, wv, 32, (32) + 16, tl, abase, rot);
+    ch_kloop<ABL>(hb, w, wr, wv, 32, (32) + 16, tl, abase, rot, hb, wr, row);
     ch_relu(hb);
     OCC_CH_STAMP(5)
     ch_sync();                                // every wave has read the x2 tile for the last time
@@ -479,28 +502,50 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
     ch_load_rows(acc, ry, ldy_b, row, wave * 64, kb);                    // x2 (this lane's own stores)
     ch_add_bias(acc, prm + 768 + wave * 64, kb);                         // + b2
     OCC_CH_STAMP(6)                                 // ha in the tile, x2 reloaded
-    ch_kloop<ABL>(acc, w, wr, wv, 48, (48) + 16, tl, abase, rot);
+    ch_kloop<ABL>(acc, w, wr, wv, 48, (48) + 16, tl, abase, rot, acc, wr, row);
     OCC_CH_STAMP(7)
     ch_sync();
     ch_to_tile(hb, tl, wave, vi, kb);
     ch_sync();
     OCC_CH_STAMP(8)
-    ch_kloop<ABL>(acc, w, wr, wv, 64, (64) + 16, tl, abase, rot);
+    ch_kloop<ABL>(acc, w, wr, wv, 64, (64) + 16, tl, abase, rot, acc, wr, row);
     OCC_CH_STAMP(9)
     ch_layernorm(acc, red, prm_ln + 512, prm_ln + 768, p.eps2, wave, vi, kb);
-    ch_store(acc, ry, ldy_b, row, wave * 64, kb, true, true);             // x3
-    if (p.npass > 0) {
-      ch_to_tile(acc, tl, wave, vi, kb);
-      ch_sync();
-    }
-    OCC_CH_STAMP(10)                                // LayerNorm 2, x3 stores issued, tile rebuilt
+    OCC_CH_STAMP(16)
     step = 80;
     bias_off = 1024;
+    if (p.npass > 0) {
+      ch_to_tile(acc, tl, wave, vi, kb);
+      OCC_CH_STAMP(17)
+      ch_sync();
+      OCC_CH_STAMP(10)                              // LayerNorm 2, tile rebuilt
+      // tail pass 0 accumulates in `ha` (free by now) while x3 — still in `acc` — leaves one quad per k-step
+      const int c0 = wave * 64;
+      const float* pbias = prm + bias_off + c0;
+      if (p.term != nullptr && c0 < p.term_cols) {
+        ch_load_rows(ha, rterm, ldt_b, row, c0, kb);
+        ch_add_bias(ha, pbias, kb);
+      } else {
+        ch_set_bias(ha, pbias, kb);
+      }
+      ch_kloop<ABL, true>(ha, w, wr, wv, step, step + 16, tl, abase, rot, acc, ry, yoff);
+      OCC_CH_STAMP(11)
+      if (p.act) ch_relu(ha);
+      const int ca = c0, cb = c0 + 32;
+      const bool a1 = ca < p.n1, b1 = cb < p.n1;
+      const bool a2 = ca >= p.off2 && ca < p.off2 + p.n2, b2 = cb >= p.off2 && cb < p.off2 + p.n2;
+      if (a1 || b1) ch_store(ha, rz1, ldz1_b, row, c0, kb, a1, b1);
+      if (a2 || b2) ch_store(ha, rz2, ldz2_b, row, c0 - p.off2, kb, a2, b2);
+      ps0 = 1;
+    } else {
+      ch_store(acc, ry, ldy_b, row, wave * 64, kb, true, true);           // x3
+      OCC_CH_STAMP(10)
+    }
   }
 
   // ---- tail stage: npass passes of 256 columns over the LayerNorm'd tile -----------------------------------------------
 #pragma unroll 1
-  for (int ps = 0; ps < p.npass; ++ps) {
+  for (int ps = ps0; ps < p.npass; ++ps) {
     const int c0 = ps * 256 + wave * 64;            // the wave's first tail column of this pass
     const float* pbias = prm + bias_off + c0;
     if (p.term != nullptr && c0 < p.term_cols) {    // term_cols is a multiple of 64: whole waves
@@ -509,7 +554,7 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
     } else {
       ch_set_bias(acc, pbias, kb);
     }
-    ch_kloop<ABL>(acc, w, wr, wv, step + ps * 16, (step + ps * 16) + 16, tl, abase, rot);
+    ch_kloop<ABL>(acc, w, wr, wv, step + ps * 16, (step + ps * 16) + 16, tl, abase, rot, acc, wr, row);
     OCC_CH_STAMP(11 + ps)                           // (passes 0 .. 3)
     if (p.act) ch_relu(acc);
     // the wave's two 32-column tiles go to z1 (columns < n1) or z2 (columns in [off2, off2 + n2)) or nowhere (padding)
@@ -601,15 +646,15 @@ int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what
   if (PROG == 0 && abl == 4) kern = linear_chain_x3_kernel<0, 4>;
   if (PROG == 0 && abl == 3) kern = linear_chain_x3_kernel<0, 3>;
   // OCC_CHAIN_TRACE=<file prefix> (development, tools_dev/chain_probe.py): every launch runs the stamped build, waits for
-  // it and appends its 16 wall-clock stamps per wave (100 MHz) to <prefix>.<A|B>.bin
+  // it and appends its 24 wall-clock stamps per wave (100 MHz) to <prefix>.<A|B>.bin
   const char* trace_to = getenv("OCC_CHAIN_TRACE");
   if (trace_to && *trace_to) {
     kern = linear_chain_x3_kernel<PROG, 0, true>;
-    if (hipMalloc(reinterpret_cast<void**>(&args.trace), (size_t)ntiles * 64 * sizeof(long long)) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void**>(&args.trace), (size_t)ntiles * 96 * sizeof(long long)) != hipSuccess) {
       set_error("%s: trace buffer allocation failed", what);
       return OCC_E_LAUNCH;
     }
-    (void)hipMemsetAsync(args.trace, 0, (size_t)ntiles * 64 * sizeof(long long), st);
+    (void)hipMemsetAsync(args.trace, 0, (size_t)ntiles * 96 * sizeof(long long), st);
   }
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kChLds);
@@ -620,7 +665,7 @@ int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what
   hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), kChLds, st, args);
   OCC_CHECK_LAUNCH(what);
   if (args.trace) {
-    std::vector<long long> host((size_t)ntiles * 64);
+    std::vector<long long> host((size_t)ntiles * 96);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(host.data(), args.trace, host.size() * sizeof(long long), hipMemcpyDeviceToHost);
     (void)hipFree(args.trace);

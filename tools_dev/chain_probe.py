@@ -103,9 +103,10 @@ if os.environ.get("CHAIN_TRACE", "0") == "1":
     NAMES = {"A": [(0, 1, "rows in, tile built"), (1, 2, "S1 k-loop"), (2, 4, "LayerNorm (2 barriers)"), (4, 5, "x1 stores issued"),
                    (5, 6, "tile rebuilt"), (6, 3, "block barrier"), (3, 11, "pass 0 k-loop"),
                    (11, 12, "stores 0 + pass 1 k-loop"), (12, 13, "stores 1 + pass 2 k-loop"), (13, 15, "stores 2")],
-             "B": [(0, 1, "rows in, tile built"), (1, 2, "S1 k-loop"), (2, 3, "LN + x2 stores + tile"), (3, 4, "S2a k-loop"),
+             "B": [(0, 1, "rows in, tile built"), (1, 2, "S1 k-loop"), (2, 3, "LN + tile"), (3, 4, "S2a k-loop (+ x2 stores)"),
                    (4, 5, "S2b k-loop"), (5, 6, "ha -> tile, x2 reload"), (6, 7, "S3a k-loop"), (7, 8, "hb -> tile"),
-                   (8, 9, "S3b k-loop"), (9, 10, "LN2 + x3 stores + tile"), (10, 11, "term rows + pass 0 k-loop"),
+                   (8, 9, "S3b k-loop"), (9, 16, "LayerNorm 2 (2 barriers)"), (16, 17, "tile rebuilt"), (17, 10, "block barrier"),
+                   (10, 11, "term rows + pass 0 k-loop (+ x3 stores)"),
                    (11, 12, "stores 0 + pass 1 k-loop"), (12, 15, "stores 1")]}
     prefix = os.path.join(tempfile.mkdtemp(), "chain")
     for m in (int(x) for x in os.environ.get("CHAIN_TRACE_ROWS", "32768,40000").split(",")):
@@ -122,7 +123,7 @@ if os.environ.get("CHAIN_TRACE", "0") == "1":
             fn()
             torch.cuda.synchronize()
             os.environ.pop("OCC_CHAIN_TRACE")
-            sw = np.fromfile(path, dtype=np.int64).reshape(-1, 4, 16).astype(np.float64)
+            sw = np.fromfile(path, dtype=np.int64).reshape(-1, 4, 24).astype(np.float64)
             sw = (sw - sw[:, :, 0].min()) * 0.01         # us since the first wave started; [block][wave][stamp]
             st = sw[:, 0, :]                             # the timeline below follows wave 0
             nblk = st.shape[0]

@@ -45,6 +45,7 @@ constexpr int kChRows = 64;                       // rows per block
 constexpr int kChPlane = kChRows * 512;           // one bf16 plane of the operand tile: 64 rows x 256 k
 constexpr int kChRed = 2 * kChPlane;              // LayerNorm exchange: float[2][4][64]
 constexpr int kChPrm = kChRed + 2 * 4 * kChRows * 4;       // per-column parameters: float[kChBiasMax] biases | g1 | b1 | g2 | b2
+constexpr bool kChSpread = true;                  // program B: x2 / x3 row stores spread under the next stage's k-loop (false: burst after the LayerNorm; 127 vs 122-125 us, profiles/r04_c32_chain_probe_no_spills.txt)
 constexpr int kChBiasMax = 1536;                  // program B with its tail: 256 + 512 + 256 + 2 x 256
 constexpr int kChLds = kChPrm + (kChBiasMax + 4 * 256) * 4;       // 77 824 B: two blocks per CU
 constexpr int kChStepBytes = 16384;               // weights of one k-step (16 k) of one 256-column pass: 8 tiles x (hi, lo) x 1 KB
@@ -488,7 +489,8 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
     for (int rt = 0; rt < RT; ++rt) yoff[rt] = row[rt] * ldy_b + (unsigned)(wave * 64 + 4 * kb) * 4u;
     ch_set_bias(ha, prm + 256 + wave * 64, kb);
     // x2 (still in `acc`) is parked in the block's rows of y one quad per k-step, under the first hidden half's MFMAs
-    ch_kloop<ABL, true>(ha, w, wr, wv, 16, (16) + 16, tl, abase, rot, acc, ry, yoff);
+    if constexpr (!kChSpread) ch_store(acc, ry, ldy_b, row, wave * 64, kb, true, true);
+    ch_kloop<ABL, kChSpread>(ha, w, wr, wv, 16, (16) + 16, tl, abase, rot, acc, ry, yoff);
     ch_relu(ha);
     OCC_CH_STAMP(4)
     ch_set_bias(hb, prm + 512 + wave * 64, kb);
@@ -528,7 +530,8 @@ __device__ __forceinline__ void chain_tile(const ChainArgs& p, char* tl, const l
       } else {
         ch_set_bias(ha, pbias, kb);
       }
-      ch_kloop<ABL, true>(ha, w, wr, wv, step, step + 16, tl, abase, rot, acc, ry, yoff);
+      if constexpr (!kChSpread) ch_store(acc, ry, ldy_b, row, wave * 64, kb, true, true);
+      ch_kloop<ABL, kChSpread>(ha, w, wr, wv, step, step + 16, tl, abase, rot, acc, ry, yoff);
       OCC_CH_STAMP(11)
       if (p.act) ch_relu(ha);
       const int ca = c0, cb = c0 + 32;

@@ -182,6 +182,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base,
   return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// Block barrier that orders LDS traffic only.  __syncthreads() is a full fence — hipcc puts `s_waitcnt vmcnt(0)` in front of
+// the s_barrier, which drains every register ring of global loads that is meant to run ACROSS the barrier (and waits for the
+// acknowledgement of every earlier store).  Use only where no global memory is shared between the threads of the block.
+__device__ __forceinline__ void block_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
   return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0));
 }

@@ -235,6 +235,71 @@ __global__ void conv3d_pack_weight_bf16x3_kernel(const float* __restrict__ w, un
   packed[base + 2 * 32 * 8] = lo;                                                    // plane 1 (lo)
 }
 
+// ---- the 27 taps of one 16-channel pass, software-pipelined and PINNED -------------------------------------------------
+// As plain loops hipcc sinks every weight load and every fragment read to its use: one or two requests in flight, an
+// `s_waitcnt vmcnt(0)` in front of each tap's MFMAs (round 4 ISA reading: the matrix pipe 28 % busy).  Here the hi / lo weight
+// fragments of a tap (2 x 1 KB per wave) come through a 4-slot register ring of buffer loads requested THREE taps ahead, the
+// operand fragments of tap t + 1 are read from LDS under the MFMAs of tap t, and the issue order is fixed per tap with
+// sched_group_barrier (DS NACC . MFMA NACC . DS NACC . MFMA NACC . VMEM 2 . MFMA NACC), the whole loop fenced with
+// sched_barrier so that neighbouring code cannot be matched into the groups.  The ring runs across passes: a pass is 27 taps
+// + 1 bubble = 28 ring steps, so slot (t & 3) lines up in every pass; the requests of the last three steps are the first three
+// taps of the NEXT pass (clamped to the last tap of the weight when there is none).  TR: the MFMA operands swapped
+// (D = W . A^T: conv3d_heads_x3_kernel).  LO = byte distance of the lo plane inside a halo voxel slot.
+template <int NACC, bool TR, int HX, int PSB, int VSB, int LO>
+__device__ __forceinline__ void conv_taps27(f32x16 (&acc)[NACC], const char* ldsb, const int (&abase)[NACC],
+                                            occ_u32x4 (&w)[4][2], const __amdgpu_buffer_rsrc_t wr, const int wv,
+                                            const int T0, const int Tlast) {
+#define OCC_CV_TOFF(t) (((((t) / 3) % 3) * HX + (t) % 3) * PSB + ((t) / 9) * VSB)
+#define OCC_CV_REQ(SLOT, TN)                                                                        \
+  {                                                                                                \
+    const int tn_ = (TN) < Tlast ? (TN) : Tlast;                                                   \
+    w[SLOT][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, tn_ * 2048, 0);                     \
+    w[SLOT][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, tn_ * 2048 + 1024, 0);              \
+  }
+  bf16x8 ah[2][NACC], al[2][NACC];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) al[0][a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + OCC_CV_TOFF(0) + LO);
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) ah[0][a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + OCC_CV_TOFF(0));
+  __builtin_amdgcn_sched_group_barrier(0x100, 2 * NACC, 0);
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    if (t + 1 < 27) {
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+        al[(t + 1) & 1][a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + OCC_CV_TOFF(t + 1) + LO);
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+        ah[(t + 1) & 1][a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + OCC_CV_TOFF(t + 1));
+    }
+    if (t + 3 != 27) OCC_CV_REQ((t + 3) & 3, t + 3 <= 26 ? T0 + t + 3 : T0 + 27 + (t + 3 - 28))
+    const bf16x8 wh = __builtin_bit_cast(bf16x8, w[t & 3][0]), wl = __builtin_bit_cast(bf16x8, w[t & 3][1]);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+      acc[a] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al[t & 1][a], acc[a], 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t & 1][a], wh, acc[a], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+      acc[a] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah[t & 1][a], acc[a], 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][a], wl, acc[a], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+      acc[a] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah[t & 1][a], acc[a], 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][a], wh, acc[a], 0, 0, 0);
+    if (t + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, NACC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NACC, 0);
+    if (t + 1 < 27) __builtin_amdgcn_sched_group_barrier(0x100, NACC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NACC, 0);
+    if (t + 3 != 27) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NACC, 0);
+  }
+  OCC_CV_REQ(2, T0 + 27 + 2)                          // the bubble step: tap 2 of the next pass
+  __builtin_amdgcn_sched_barrier(0);
+#undef OCC_CV_REQ
+#undef OCC_CV_TOFF
+}
+
 template <int Z, int TY, int TX, int LAYOUT>
 __global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(
     const float* __restrict__ in, const uint4* __restrict__ wp, const float* __restrict__ scale,
@@ -286,8 +351,18 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(
   }
 
   const int nph = Cin / CH;
+  // weight ring (conv_taps27): the first three taps are requested before anything else
+  occ_u32x4 w[4][2];
+  const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(wp, (unsigned)nph * 27u * 2048u);
+  const int wv = lane * 16, Tlast = nph * 27 - 1;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tn = t < Tlast ? t : Tlast;
+    w[t][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, tn * 2048, 0);
+    w[t][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, tn * 2048 + 1024, 0);
+  }
   for (int p = 0; p < nph; ++p) {
-    if (p) __syncthreads();  // every wave is done reading the previous phase's halo
+    if (p) block_lds_sync();  // every wave is done reading the previous phase's halo
     // ---- stage 16 channels of the halo, split into hi / lo bf16 -------------------------------------
     if (LAYOUT == 0) {
       constexpr int PARTS = CH / 4, ITEMS = HY * HX * Z * PARTS, ITERS = (ITEMS + 255) / 256;
@@ -347,31 +422,10 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(
         }
       }
     }
-    __syncthreads();
+    block_lds_sync();
 
-    // ---- 27 taps x NACC accumulators x 3 MFMAs (small terms first) ----------------------------------
-    const uint4* wq = wp + ((long)p * 27 * 2 * 2 + kh) * 32 + vi;      // + (t*2 + plane) * 64
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
-      const int toff = (ky * HX + kx) * PSB + kz * VSB;
-      const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[(t * 2 + 0) * 64]);
-      const bf16x8 wl = __builtin_bit_cast(bf16x8, wq[(t * 2 + 1) * 64]);
-      // term-major over the NACC accumulators: three MFMAs on ONE accumulator back to back wait out the 64-cycle
-      // result latency (issue: 32 cycles)
-      bf16x8 ah[NACC], al[NACC];
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) {
-        ah[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff);
-        al[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff + 32);
-      }
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], wh, acc[a], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], wl, acc[a], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], wh, acc[a], 0, 0, 0);
-    }
+    // ---- 27 taps x NACC accumulators x 3 MFMAs (small terms first, term-major), weights through the ring ---------------
+    conv_taps27<NACC, false, HX, PSB, VSB, 32>(acc, ldsb, abase, w, wr, wv, p * 27, Tlast);
   }
 
   // ---- epilogue: BN(eval) + ReLU, one 128-byte row per voxel ---------------------------------------
@@ -738,8 +792,17 @@ __global__ __launch_bounds__(256) void conv3d_heads_x3_kernel(
     const int px = txg * G::PX + vi / Z, z = vi % Z;
     abase[a] = (ty * HX + px) * PSB + z * VSB + kh * 16;
   }
+  occ_u32x4 w[4][2];                          // weight ring (conv_taps27)
+  const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(wp, (unsigned)(Cin / CH) * 27u * 2048u);
+  const int wv = lane * 16, Tlast = (Cin / CH) * 27 - 1;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    w[t][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, t * 2048, 0);
+    w[t][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, t * 2048 + 1024, 0);
+  }
+#pragma unroll
   for (int p = 0; p < Cin / CH; ++p) {
-    if (p) __syncthreads();
+    if (p) block_lds_sync();
     {
       constexpr int PARTS = CH / 4, ITEMS = HY * HX * Z * PARTS, ITERS = (ITEMS + 255) / 256;
       float4 v[ITERS];
@@ -766,28 +829,8 @@ __global__ __launch_bounds__(256) void conv3d_heads_x3_kernel(
         }
       }
     }
-    __syncthreads();
-    const uint4* wq = wp + ((long)p * 27 * 2 * 2 + kh) * 32 + vi;
-#pragma unroll
-    for (int t = 0; t < 27; ++t) {
-      const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
-      const int toff = (ky * HX + kx) * PSB + kz * VSB;
-      const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[(t * 2 + 0) * 64]);
-      const bf16x8 wl = __builtin_bit_cast(bf16x8, wq[(t * 2 + 1) * 64]);
-      bf16x8 ah[NACC], al[NACC];
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) {
-        ah[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff);
-        al[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff + 32);
-      }
-      // TRANSPOSED: weights are the row operand -> D[output channel][voxel]
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al[a], acc[a], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah[a], acc[a], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah[a], acc[a], 0, 0, 0);
-    }
+    block_lds_sync();
+    conv_taps27<NACC, true, HX, PSB, VSB, 32>(acc, ldsb, abase, w, wr, wv, p * 27, Tlast);
   }
 
   // ---- the heads' operands replace the halo -------------------------------------------------------------------------

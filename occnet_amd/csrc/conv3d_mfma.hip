@@ -494,6 +494,15 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_c8_kernel(
   const int b = bid / tiles_y;
   const int y0 = ty_i * TY, x0 = tx_i * TX;
   const float* inb = in + (long)b * Y * X * Z * Cin;
+  // weight ring: 14 steps x (hi, lo) x 1 KB, requested three steps ahead (see conv_taps27)
+  occ_u32x4 w[4][2];
+  const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(wp, 14u * 2048u);
+  const int wv = lane * 16;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    w[s][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, s * 2048, 0);
+    w[s][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, s * 2048 + 1024, 0);
+  }
 
   for (int i = tid; i < HY * HX * 2 * (VSB / 16); i += 256) {          // z-halo slots stay zero
     const int pil = i / (2 * (VSB / 16)), rem = i % (2 * (VSB / 16));
@@ -502,20 +511,28 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_c8_kernel(
         make_uint4(0u, 0u, 0u, 0u);
   }
   // ---- stage the 8 channels of the halo, split into hi / lo bf16 (one phase) --------------------------------------
+  // (all requests first, then the conversions: as one loop hipcc waits for every load before it issues the next)
   if (LAYOUT == 0) {
     constexpr int PARTS = CH / 4, ITEMS = HY * HX * Z * PARTS, ITERS = (ITEMS + 255) / 256;
-#pragma unroll 4
+    float4 v[ITERS];
+#pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int idx = tid + it * 256;
       const int part = idx % PARTS, z = (idx / PARTS) % Z, pil = idx / (PARTS * Z);
       const int gy = y0 + pil / HX - 1, gx = x0 + pil % HX - 1;
+      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < ITEMS && gy >= 0 && gy < Y && gx >= 0 && gx < X)
+        v[it] = *reinterpret_cast<const float4*>(inb + (((long)gy * X + gx) * Z + z) * Cin + part * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int part = idx % PARTS, z = (idx / PARTS) % Z, pil = idx / (PARTS * Z);
       if (idx < ITEMS) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < Y && gx >= 0 && gx < X)
-          v = *reinterpret_cast<const float4*>(inb + (((long)gy * X + gx) * Z + z) * Cin + part * 4);
-        const unsigned h01 = pack_bf16x2_rne(v.x, v.y), h23 = pack_bf16x2_rne(v.z, v.w);
-        const unsigned l01 = pack_bf16x2_rne(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
-        const unsigned l23 = pack_bf16x2_rne(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+        const float4 u = v[it];
+        const unsigned h01 = pack_bf16x2_rne(u.x, u.y), h23 = pack_bf16x2_rne(u.z, u.w);
+        const unsigned l01 = pack_bf16x2_rne(u.x - __uint_as_float(h01 << 16), u.y - __uint_as_float(h01 & 0xffff0000u));
+        const unsigned l23 = pack_bf16x2_rne(u.z - __uint_as_float(h23 << 16), u.w - __uint_as_float(h23 & 0xffff0000u));
         char* d = ldsb + pil * PSB + (z + 1) * VSB + part * 8;
         *reinterpret_cast<uint2*>(d) = make_uint2(h01, h23);
         *reinterpret_cast<uint2*>(d + 16) = make_uint2(l01, l23);
@@ -523,16 +540,22 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_c8_kernel(
     }
   } else {
     constexpr int Z4 = Z / 4, ITEMS = HY * HX * CH * Z4, ITERS = (ITEMS + 255) / 256;
-#pragma unroll 4
+    float4 v[ITERS];
+#pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int idx = tid + it * 256;
       const int z4 = idx % Z4, ci = (idx / Z4) % CH, pil = idx / (Z4 * CH);
       const int gy = y0 + pil / HX - 1, gx = x0 + pil % HX - 1;
+      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < ITEMS && gy >= 0 && gy < Y && gx >= 0 && gx < X)
+        v[it] = *reinterpret_cast<const float4*>(inb + ((long)gy * X + gx) * Z * Cin + (long)ci * Z + z4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = tid + it * 256;
+      const int z4 = idx % Z4, ci = (idx / Z4) % CH, pil = idx / (Z4 * CH);
       if (idx < ITEMS) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < Y && gx >= 0 && gx < X)
-          v = *reinterpret_cast<const float4*>(inb + ((long)gy * X + gx) * Z * Cin + (long)ci * Z + z4 * 4);
-        const float f[4] = {v.x, v.y, v.z, v.w};
+        const float f[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
         char* d = ldsb + pil * PSB + (z4 * 4 + 1) * VSB + ci * 2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -544,7 +567,7 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_c8_kernel(
       }
     }
   }
-  __syncthreads();
+  block_lds_sync();
 
   f32x16 acc[NACC];
 #pragma unroll
@@ -560,28 +583,44 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_c8_kernel(
     const int px = txg * G::PX + vi / Z, z = vi % Z;
     abase[a] = (ty * HX + px) * PSB + z * VSB;                 // tap (0,0,0) = halo corner (-1,-1,-1), hi plane
   }
-  // ---- 14 steps (tap pairs) x NACC accumulators x 3 MFMAs (small terms first, term-major) ------------------------
-  const uint4* wq = wp + kh * 32 + vi;                         // + (s * 2 + plane) * 64
+  // ---- 14 steps (tap pairs) x NACC accumulators x 3 MFMAs (small terms first, term-major), pinned like conv_taps27 -------
+  constexpr auto toff_of = [](int t) { return ((((t / 3) % 3) * HX + t % 3) * PSB + (t / 9) * VSB); };
+  int fo[NACC];                                  // this lane half's tap offset is a run-time select of two constants
+  bf16x8 ah[2][NACC], al[2][NACC];
+  __builtin_amdgcn_sched_barrier(0);
+#define OCC_C8_FRAG(BUF, S)                                                                          \
+  {                                                                                                \
+    const int t0_ = 2 * (S), t1_ = 2 * (S) + 1 < 27 ? 2 * (S) + 1 : 26;   /* the 28th tap has zero weights */ \
+    const int toff_ = kh ? toff_of(t1_) : toff_of(t0_);                                            \
+    _Pragma("unroll") for (int a = 0; a < NACC; ++a) fo[a] = abase[a] + toff_;                     \
+    _Pragma("unroll") for (int a = 0; a < NACC; ++a) al[BUF][a] = *reinterpret_cast<const bf16x8*>(ldsb + fo[a] + 16); \
+    _Pragma("unroll") for (int a = 0; a < NACC; ++a) ah[BUF][a] = *reinterpret_cast<const bf16x8*>(ldsb + fo[a]);      \
+  }
+  OCC_C8_FRAG(0, 0)
+  __builtin_amdgcn_sched_group_barrier(0x100, 2 * NACC, 0);
 #pragma unroll
   for (int s = 0; s < 14; ++s) {
-    constexpr auto toff_of = [](int t) { return ((((t / 3) % 3) * HX + t % 3) * PSB + (t / 9) * VSB); };
-    const int t0 = 2 * s, t1 = 2 * s + 1 < 27 ? 2 * s + 1 : 26;   // the 28th tap has zero weights: any valid slot
-    const int toff = kh ? toff_of(t1) : toff_of(t0);
-    const bf16x8 wh = __builtin_bit_cast(bf16x8, wq[(s * 2 + 0) * 64]);
-    const bf16x8 wl = __builtin_bit_cast(bf16x8, wq[(s * 2 + 1) * 64]);
-    bf16x8 ah[NACC], al[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-      ah[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff);
-      al[a] = *reinterpret_cast<const bf16x8*>(ldsb + abase[a] + toff + 16);
+    if (s + 1 < 14) OCC_C8_FRAG((s + 1) & 1, s + 1)
+    if (s + 3 < 14) {
+      w[(s + 3) & 3][0] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, (s + 3) * 2048, 0);
+      w[(s + 3) & 3][1] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, (s + 3) * 2048 + 1024, 0);
     }
+    const bf16x8 wh = __builtin_bit_cast(bf16x8, w[s & 3][0]), wl = __builtin_bit_cast(bf16x8, w[s & 3][1]);
 #pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], wh, acc[a], 0, 0, 0);
+    for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s & 1][a], wh, acc[a], 0, 0, 0);
 #pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], wl, acc[a], 0, 0, 0);
+    for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s & 1][a], wl, acc[a], 0, 0, 0);
 #pragma unroll
-    for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], wh, acc[a], 0, 0, 0);
+    for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s & 1][a], wh, acc[a], 0, 0, 0);
+    if (s + 1 < 14) __builtin_amdgcn_sched_group_barrier(0x100, NACC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NACC, 0);
+    if (s + 1 < 14) __builtin_amdgcn_sched_group_barrier(0x100, NACC, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NACC, 0);
+    if (s + 3 < 14) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NACC, 0);
   }
+  __builtin_amdgcn_sched_barrier(0);
+#undef OCC_C8_FRAG
 
   // ---- epilogue: BN(eval) + ReLU, one 128-byte row per voxel ---------------------------------------
   const float sc = scale[vi], sh = shift[vi];

@@ -788,7 +788,8 @@ __global__ void conv3d_heads_pack_kernel(const float* __restrict__ w1o, const fl
   if (e < 32) bp[128 + e] = e < ncls ? b2o[e] : (e < ncls + 2 ? b2f[e - ncls] : 0.f);
 }
 
-template <int Z, int TY, int TX>
+// NCLS: the class count as a compile-time constant (17: the reference's heads) or 0 = the run-time `ncls`
+template <int Z, int TY, int TX, int NCLS>
 __global__ __launch_bounds__(256) void conv3d_heads_x3_kernel(
     const float* __restrict__ in, const uint4* __restrict__ wp, const float* __restrict__ scale,
     const float* __restrict__ shift, const uint4* __restrict__ heads_pack, float* __restrict__ occ,
@@ -968,9 +969,20 @@ __global__ __launch_bounds__(256) void conv3d_heads_x3_kernel(
     const int rt = wave * NACC + a;
     const int gy = y0 + rt / G::TXG, gx0 = x0 + (rt % G::TXG) * G::PX;
     if (gy < Y) {
-      for (int e = lane; e < 32 * ncls; e += 64) {
-        const int v = e / ncls, ch = e - v * ncls, gx = gx0 + v / Z;
-        if (gx < X) occ[((((long)b * X + gx) * Y + gy) * Z + v % Z) * ncls + ch] = sm[v * 33 + ch];
+      // a pillar's Z x ncls logits are one contiguous, 16-byte aligned run of the output (Z % 4 == 0): quad stores,
+      // element -> (height, class) by a constant division when NCLS is known
+      const int nc = NCLS ? NCLS : ncls;
+      const int quads = Z * nc / 4;                     // per pillar
+      for (int f = lane; f < (32 / Z) * quads; f += 64) {
+        const int pl = f / quads, e0 = 4 * (f - pl * quads), gx = gx0 + pl;
+        float q4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = e0 + i, z = e / nc, ch = e - z * nc;
+          q4[i] = sm[(pl * Z + z) * 33 + ch];
+        }
+        if (gx < X)
+          *reinterpret_cast<float4*>(occ + (((long)b * X + gx) * Y + gy) * Z * nc + e0) = make_float4(q4[0], q4[1], q4[2], q4[3]);
       }
       {
         const int v = lane >> 1, gx = gx0 + v / Z;
@@ -1144,6 +1156,7 @@ extern "C" int occ_conv3d_heads_decode_bf16x3_f32(const float* in, const void* w
                 "conv3d_heads_decode: null pointer argument");
   OCC_CHECK_ARG(B > 0 && Y > 0 && X > 0 && num_classes > 0, "conv3d_heads_decode: bad dimension");
   OCC_CHECK_ARG((long)Y * X * Z * 32 < (1L << 31), "conv3d_heads_decode: one batch entry exceeds 2^31 elements");
+  OCC_CHECK_ARG(((uintptr_t)occ_out & 15) == 0, "conv3d_heads_decode: occ_out must be 16-byte aligned (quad stores)");
   if ((Z != 16 && Z != 32) || Cin != 32 || num_classes + 2 > 32) {
     set_error("conv3d_heads_decode: no fused kernel for Z=%d Cin=%d num_classes=%d", Z, Cin, num_classes);
     return OCC_E_UNSUPPORTED;
@@ -1164,6 +1177,12 @@ extern "C" int occ_conv3d_heads_decode_bf16x3_f32(const float* in, const void* w
     OCC_CHECK_LAUNCH("conv3d_heads_decode");
     return OCC_OK;
   };
-  if (Z == 16) return launch(conv3d_heads_x3_kernel<16, 2, 8>, 2, 8, (size_t)ConvGeom<16, 16, 2, 8>::LDS_FLOATS * sizeof(float));
-  return launch(conv3d_heads_x3_kernel<32, 2, 4>, 2, 4, (size_t)ConvGeom<32, 16, 2, 4>::LDS_FLOATS * sizeof(float));
+  if (Z == 16) {
+    if (num_classes == 17)
+      return launch(conv3d_heads_x3_kernel<16, 2, 8, 17>, 2, 8, (size_t)ConvGeom<16, 16, 2, 8>::LDS_FLOATS * sizeof(float));
+    return launch(conv3d_heads_x3_kernel<16, 2, 8, 0>, 2, 8, (size_t)ConvGeom<16, 16, 2, 8>::LDS_FLOATS * sizeof(float));
+  }
+  if (num_classes == 17)
+    return launch(conv3d_heads_x3_kernel<32, 2, 4, 17>, 2, 4, (size_t)ConvGeom<32, 16, 2, 4>::LDS_FLOATS * sizeof(float));
+  return launch(conv3d_heads_x3_kernel<32, 2, 4, 0>, 2, 4, (size_t)ConvGeom<32, 16, 2, 4>::LDS_FLOATS * sizeof(float));
 }

@@ -247,11 +247,19 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
   for (int c = 0; c < NC; ++c) {
     if (!((vis >> c) & 1u)) continue;  // wave-uniform
     const float* rp = ref_cam + (((long)c * B + b) * Nq + q) * Z * 2;
+    // the K anchor points of this lane are requested together: inside the loop below each one sat behind the branches of
+    // the previous sample's set-up — K serial round trips per (query, camera) (round 4 ISA reading)
+    float2 rxy_k[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const int m = hm, s = sK * K + k;
-      const int z = (s % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
-      const float2 rxy = *reinterpret_cast<const float2*>(rp + 2 * z);
+      const int z = ((sK * K + k) % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
+      rxy_k[k] = *reinterpret_cast<const float2*>(rp + 2 * z);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int m = hm;
+      const float2 rxy = rxy_k[k];
       SampleParamB p;
       const float aw_k = aw[k], ox_k = ox[k], oy_k = oy[k];
       n_in += bilinear_setup_b(rxy.x + ox_k, rxy.y + oy_k, aw_k, lvH, lvW, lvS,

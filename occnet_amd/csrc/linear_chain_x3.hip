@@ -45,7 +45,8 @@ constexpr int kChRows = 64;                       // rows per block
 constexpr int kChPlane = kChRows * 512;           // one bf16 plane of the operand tile: 64 rows x 256 k
 constexpr int kChRed = 2 * kChPlane;              // LayerNorm exchange: float[2][4][64]
 constexpr int kChPrm = kChRed + 2 * 4 * kChRows * 4;       // per-column parameters: float[kChBiasMax] biases | g1 | b1 | g2 | b2
-constexpr bool kChSpread = true;                  // program B: x2 / x3 row stores spread under the next stage's k-loop (false: burst after the LayerNorm; 127 vs 122-125 us, profiles/r04_c32_chain_probe_no_spills.txt)
+constexpr bool kChSpread = true;                  // program B: x2 / x3 row stores spread under the next stage's k-loop (false = one
+                                                  // burst after the LayerNorm: 127 vs 122-125 us, profiles/r04_c32_chain_probe_no_spills.txt) (false: burst after the LayerNorm; 127 vs 122-125 us, profiles/r04_c32_chain_probe_no_spills.txt)
 constexpr int kChBiasMax = 1536;                  // program B with its tail: 256 + 512 + 256 + 2 x 256
 constexpr int kChLds = kChPrm + (kChBiasMax + 4 * 256) * 4;       // 77 824 B: two blocks per CU
 constexpr int kChStepBytes = 16384;               // weights of one k-step (16 k) of one 256-column pass: 8 tiles x (hi, lo) x 1 KB

@@ -747,8 +747,14 @@ static int launch_conv(const float* in, const float* wp, const float* scale, con
 // halo in LDS once the taps are done; the rest is occ_heads_x3_kernel's body (csrc/occ_heads.hip) per 32-voxel tile.
 constexpr int kHeadsPackBytes = 16 * 1024 + 16 * 1024 + 128 * 4 + 32 * 4;
 
-__device__ __forceinline__ float cvh_softplus(float x) {        // torch.nn.Softplus(beta=1, threshold=20)
-  return x > 20.f ? x : fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x)));
+// torch.nn.Softplus(beta=1, threshold=20) = max(x, 0) + log(1 + exp(-|x|)), branch-free on the two transcendental
+// instructions (v_exp_f32 / v_log_f32 on an argument in (1, 2]: ~1e-7 absolute).  Above the threshold exp(-x) < 2.1e-9 is below
+// half an ulp of x, 1 + e rounds to 1 and the expression returns x itself — what torch's cut-off returns.  (As
+// `x > 20 ? x : ... __logf(...)` hipcc emitted an exec-mask branch and a 12-instruction refined logarithm per element: the heads
+// phase of the fused kernel is VALU-bound.)
+__device__ __forceinline__ float cvh_softplus(float x) {
+  const float e = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504088896341f);
+  return fmaxf(x, 0.f) + __builtin_amdgcn_logf(1.f + e) * 0.693147180559945309f;
 }
 __device__ __forceinline__ void cvh_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
   hi = pack_bf16x2_rne(x0, x1);

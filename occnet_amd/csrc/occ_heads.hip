@@ -27,8 +27,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float softplus_f32(float x) {
   // torch.nn.Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x)), evaluated in the overflow-free
-  // form max(x,0) + log(1 + exp(-|x|)) on the hardware exp/log units (absolute error ~1e-7)
-  return x > 20.f ? x : fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x)));
+  // form max(x,0) + log(1 + exp(-|x|)) on the hardware exp/log units (absolute error ~1e-7), branch-free: above the
+  // threshold 1 + exp(-x) rounds to 1 and the sum is x itself (see cvh_softplus in conv3d_mfma.hip)
+  const float e = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504088896341f);
+  return fmaxf(x, 0.f) + __builtin_amdgcn_logf(1.f + e) * 0.693147180559945309f;
 }
 
 constexpr int kHeadWaves = 4;

@@ -814,6 +814,14 @@ def main():
             row_b = D * ev
             b_alg = [n_in * row_b + rows * S * 12 + rows * M * D * 4 for rows, n_in in stats]
             mean_ms = sum(sca) / len(sca)
+            # OCC_ENCODER_ROW_PIPELINE=K (experiment, off by default): a layer's gather is K launches, one per row band,
+            # co-running with other kernels — the per-layer figures below then sum the bands' launch times
+            from occnet_amd.plugin import encoder as _enc
+            n_bands = (len(_enc.row_bands(model.pts_bbox_head.bev_h, model.pts_bbox_head.bev_w, _enc._ROW_PIPELINE))
+                       if _enc._ROW_PIPELINE >= 2 and not args.history else 1)
+            if n_bands > 1:
+                out["config"]["encoder_row_pipeline"] = n_bands
+                mean_ms *= n_bands
             mean_bytes = sum(b_alg) / n_layers
             sec = mean_ms * 1e-3
             # bytes the kernel pulls through the texture-addresser / L1 path per launch: one row per in-map corner

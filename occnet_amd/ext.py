@@ -244,19 +244,23 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
 
 
 def tsa_fused_forward(value, offs, logits, ref_2d, bev_h, bev_w, num_heads, num_points,
-                      shared_queue=False, order=None):
+                      shared_queue=False, order=None, value_rows=None):
     """Fused TSA gather.  value: (B*2, Nq, M, D), or (B, Nq, M, D) with shared_queue=True when both
     queue entries are the same projected BEV (no history).  offs (B,Nq,M*2*P*2), logits
-    (B,Nq,M*2*P), ref_2d (B*2,Nq,1,2).  -> (B, Nq, M*D)."""
+    (B,Nq,M*2*P), ref_2d (B*2,Nq,1,2).  -> (B, Nq, M*D).
+    value_rows (B == 1 only): the queries are a ROW BAND of the BEV — offs / logits / ref_2d / order / the result cover
+    Nq < bev_h*bev_w queries (order holds band-local indices) while `value` is the whole (bev_h*bev_w = value_rows)-pixel
+    map: the encoder's row pipeline (plugin/encoder.py)."""
     _need_cuda_f32("value", value)
     _need_cuda_f32("ref_2d", ref_2d)
     _need_cuda_f32("offs", offs, contiguous=False)
     _need_cuda_f32("logits", logits, contiguous=False)
     B, Nq = offs.shape[:2]
     M, D, P = int(num_heads), value.shape[-1], int(num_points)
-    if Nq != bev_h * bev_w:
-        raise OccAmdError("tsa_fused_forward: Nq must equal bev_h*bev_w")
-    per = Nq * M * D
+    Nv = Nq if value_rows is None else int(value_rows)
+    if Nv != bev_h * bev_w or (value_rows is not None and B != 1):
+        raise OccAmdError("tsa_fused_forward: the value map must have bev_h*bev_w rows (a query band needs B == 1)")
+    per = Nv * M * D
     if shared_queue:
         if value.numel() != B * per:
             raise OccAmdError("tsa_fused_forward: shared value must be (B,Nq,M,D)")
@@ -779,12 +783,21 @@ def linear_ln_chain(a, residual, w1, b1, ln, w2, b2, act2=None):
     return y, z
 
 
-def encoder_ffn_chain(a, residual, wo, bo, ln1, w1, b1, w2, b2, ln2, tail=None):
+def _chain_out(name, t, M, ncols):
+    """caller-provided output rows (a row band of a larger buffer): -> leading dimension"""
+    _, Mo, _, ld = _rows2d(name, t, ncols)
+    if Mo != M:
+        raise OccAmdError(f"linear chain: {name} differs in rows")
+    return ld
+
+
+def encoder_ffn_chain(a, residual, wo, bo, ln1, w1, b1, w2, b2, ln2, tail=None, out=None):
     """Program B of csrc/linear_chain_x3.hip in ONE launch:
         x2 = LayerNorm1(a @ wo^T + bo + residual);  y = LayerNorm2(relu(x2 @ w1^T + b1) @ w2^T + b2 + x2)
     and, with tail = (wq (nq, 256), q_term (…, nq) or None, wv (256, 256), bv):  zq = y @ wq^T + q_term,
     zv = y @ wv^T + bv.  a, residual (…, 256); wo (256, 256); w1 (512, 256); w2 (256, 512).
-    -> (y, zq, zv)  (zq = zv = None without a tail).  Raises OccAmdUnsupported for other shapes."""
+    -> (y, zq, zv)  (zq = zv = None without a tail).  Raises OccAmdUnsupported for other shapes.
+    out = (y, zq, zv) caller-provided result rows (zq / zv None without a tail), e.g. row bands of full-size buffers."""
     if LINEAR_PRECISION != "bf16x3":
         raise OccAmdUnsupported("linear chain: bf16x3 precision mode only")
     a_, M, lda = _chain_rows("a", a)
@@ -810,17 +823,26 @@ def encoder_ffn_chain(a, residual, wo, bo, ln1, w1, b1, w2, b2, ln2, tail=None):
                 raise OccAmdError("encoder_ffn_chain: q_term differs in rows")
         weights += [wq, wv]
         biases += [(None, 256), (bv, 256)]
-        zq = torch.empty(a.shape[:-1] + (nq,), dtype=torch.float32, device=a.device)
-        zv = torch.empty(a.shape[:-1] + (256,), dtype=torch.float32, device=a.device)
+        if out is None:
+            zq = torch.empty(a.shape[:-1] + (nq,), dtype=torch.float32, device=a.device)
+            zv = torch.empty(a.shape[:-1] + (256,), dtype=torch.float32, device=a.device)
     wp = linear_chain_pack(weights)
     bias = _chain_bias(biases, a.device)
-    y = torch.empty(a.shape[:-1] + (256,), dtype=torch.float32, device=a.device)
+    ldy, ldzq, ldzv = 256, nq, 256
+    if out is None:
+        y = torch.empty(a.shape[:-1] + (256,), dtype=torch.float32, device=a.device)
+    else:
+        y = out[0]
+        ldy = _chain_out("out y", y, M, 256)
+        if tail is not None:
+            zq, zv = out[1], out[2]
+            ldzq, ldzv = _chain_out("out zq", zq, M, nq), _chain_out("out zv", zv, M, 256)
     _chain_time(2.0 * M * 256 * (256 + 512 + 512 + (nq + 256 if tail is not None else 0)))
     with torch.cuda.device(a.device), _timed('linear'):
         rc = _lib.lib().occ_encoder_ffn_chain_bf16x3_f32(
             ptr(a_), i64(lda), ptr(r_), i64(ldres), ptr(wp), ptr(bias), ptr(g1), ptr(be1), f32(eps1), ptr(g2),
-            ptr(be2), f32(eps2), ptr(y), i64(256), ptr(q_term), i64(ldq), ptr(zq), i64(nq), i32(nq), ptr(zv),
-            i64(256), i32(M), stream_ptr(a.device))
+            ptr(be2), f32(eps2), ptr(y), i64(ldy), ptr(q_term), i64(ldq), ptr(zq), i64(ldzq), i32(nq), ptr(zv),
+            i64(ldzv), i32(M), stream_ptr(a.device))
     _lib.check(rc, "encoder_ffn_chain")
     return y, zq, zv
 

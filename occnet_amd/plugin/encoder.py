@@ -31,6 +31,27 @@ from .spatial_cross_attention import _require_device
 # (6.764 -> 6.734 ms per sample, ABAB on one box; OCC_VPROJ_OVERLAP=0 restores the serial order)
 _VPROJ_OVERLAP = os.environ.get("OCC_VPROJ_OVERLAP", "1") == "1"
 
+# EXPERIMENT, off by default (written at the end of round 4 without GPU time left to tune it):
+# OCC_ENCODER_ROW_PIPELINE=K (K >= 2) cuts the BEV queries into K row bands and walks every layer band by band on K HIP
+# streams.  Between two TSA gathers everything is ROW-LOCAL — chain program A, the SCA gather (its value operand is the
+# camera planes, not the BEV) and chain program B only ever touch their own rows — so band 2's TSA gather / program A can
+# run under band 1's SCA gather, and band 1's program B under band 2's SCA gather: kernels bound by different units
+# (texture path / HBM writes / matrix cores) share the chip instead of running back to back, each with its own ramp-up
+# and drain.  Only the TSA gather of the NEXT layer needs all bands (its value operand is the whole BEV).
+# OCC_ROW_PIPELINE_SERIAL=0 drops the events that keep two launches of the SAME kernel from overlapping.
+_ROW_PIPELINE = int(os.environ.get("OCC_ENCODER_ROW_PIPELINE", "0") or 0)
+_ROW_PIPELINE_SERIAL = os.environ.get("OCC_ROW_PIPELINE_SERIAL", "1") != "0"
+
+
+def row_bands(bev_h, bev_w, k, tile_h=8):
+    """k contiguous bands of BEV rows with boundaries on multiples of tile_h (the gather kernels walk the queries in
+    tile_h x 8 tiles), as equal as the tile rows allow -> [(first query, one past the last query, band height)];
+    fewer than k bands when there are fewer tile rows."""
+    nt = (bev_h + tile_h - 1) // tile_h
+    k = max(1, min(int(k), nt))
+    ys = [min(bev_h, ((i * nt + k // 2) // k) * tile_h) for i in range(k)] + [bev_h]
+    return [(ys[i] * bev_w, ys[i + 1] * bev_w, ys[i + 1] - ys[i]) for i in range(k) if ys[i + 1] > ys[i]]
+
 
 @TRANSFORMER_LAYER.register_module()
 class MyCustomBaseTransformerLayer(BaseModule):
@@ -420,6 +441,133 @@ class BEVFormerEncoder(TransformerLayerSequence):
             self._order_cache[key] = torch.from_numpy(bev_tile_order(bev_h, bev_w, n_xcd=8)).to(device)
         return self._order_cache[key]
 
+    def _row_pipeline_plan(self, bev_h, bev_w, k, hybrid_ref_2d, device):
+        """Constant per (geometry, K): the bands, their band-local query orders and TSA reference points, the streams."""
+        key = (bev_h, bev_w, k, str(device), hybrid_ref_2d.data_ptr())
+        plan = getattr(self, '_row_plan', None)
+        if plan is None or plan['key'] != key:
+            bands = []
+            for m0, m1, h in row_bands(bev_h, bev_w, k):
+                order = torch.from_numpy(bev_tile_order(h, bev_w, n_xcd=8)).to(device)
+                bands.append(dict(m0=m0, m1=m1, order=order, ref_2d=hybrid_ref_2d[:, m0:m1].float().contiguous()))
+            plan = dict(key=key, bands=bands, src=hybrid_ref_2d,
+                        streams=[torch.cuda.Stream(device=device) for _ in bands])
+            self._row_plan = plan
+        return plan
+
+    def _forward_row_pipeline(self, k, bev_query, value, bev_pos, hybrid_ref_2d, bev_h, bev_w, reference_points_cam,
+                              spatial_shapes, level_start_index, vis_bits, gather_stats):
+        """OCC_ENCODER_ROW_PIPELINE (see the switch above): all layers on the chain kernels, band by band on one stream
+        per band.  Same kernels, same per-row arithmetic as forward_chain.  bs = 1, no history BEV.  -> the list of layer
+        outputs (bs, nq, C), or None when this call has to take the standard path — the first call after any weight /
+        cache change does, so that every derived operand (packed chain weights, folded positional terms, ...) is built
+        on the main stream by the standard path before several streams use it."""
+        sig = (cache_epoch(), sum(p._version for p in self.parameters()), bev_pos.data_ptr(), bev_pos._version)
+        if getattr(self, '_row_sig', None) != sig:
+            self._row_sig = sig
+            return None
+        dev = bev_query.device
+        main = torch.cuda.current_stream(dev)
+        plan = self._row_pipeline_plan(bev_h, bev_w, k, hybrid_ref_2d, dev)
+        bands, streams = plan['bands'], plan['streams']
+        if len(bands) < 2:
+            return None
+        nq, nl = bev_h * bev_w, len(self.layers)
+        q_full = bev_query.contiguous()
+        band = lambda t, b: t[0, b['m0']:b['m1']].unsqueeze(0)          # rows of a (1, nq, n) buffer, as (1, rows, n)
+        # ---- main stream, before the fork: band copies of the per-step operands, the first layer's TSA query Linears
+        # and value projection (program C on all rows: the first TSA gather needs the whole projected BEV), the buffers
+        # the bands share
+        ref_cam = reference_points_cam.float()
+        per_band = [dict(ref_cam=ref_cam[:, :, b['m0']:b['m1']].contiguous(), vis=vis_bits[:, b['m0']:b['m1']])
+                    for b in bands]
+        tsa0 = self.layers[0].attentions[0]
+        w_sum, pos_term, wv, bv = tsa0.chain_tail(bev_pos)
+        zq, zv = ext.linear_pair_chain(q_full, w_sum, pos_term, wv, bv)
+        outs = [torch.empty((1, nq, 256), dtype=torch.float32, device=dev) for _ in range(nl)]
+        tails = []
+        for lid in range(nl - 1):
+            nxt = self.layers[lid + 1].attentions[0]
+            t = nxt.chain_tail(bev_pos)
+            tails.append((t, torch.empty((1, nq, t[0].shape[0]), dtype=torch.float32, device=dev),
+                          torch.empty((1, nq, 256), dtype=torch.float32, device=dev)))
+        shared = [q_full, zq, zv, ref_cam, vis_bits] + outs + [x for _, a, b_ in tails for x in (a, b_)]
+        shared += [d['ref_cam'] for d in per_band]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for s in streams:
+            s.wait_event(fork)
+            for t in shared:
+                t.record_stream(s)
+        keep = []                                   # band-private tensors stay referenced until the join
+        prev_b = None                               # the previous layer's program-B events, one per band
+        q_prev = q_full
+        try:
+            for lid, layer in enumerate(self.layers):
+                tsa, sca = layer.attentions
+                ffn = layer.ffns[0]
+                fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
+                n_off = tsa.sampling_offsets.out_features
+                v4 = zv.view(1, nq, tsa.num_heads, -1)
+                wq, bq = sca.query_linear_operands()
+                plane = value.project_on(sca.deformable_attention.value_proj, streams)
+                st = [dict() for _ in bands]
+                ev = {name: [None] * len(bands) for name in 'TASB'}
+
+                def stage(name, fn):
+                    for i, (b, s) in enumerate(zip(bands, streams)):
+                        with torch.cuda.stream(s):
+                            if _ROW_PIPELINE_SERIAL and i > 0:
+                                s.wait_event(ev[name][i - 1])
+                            fn(i, b, s)
+                            e = torch.cuda.Event()
+                            e.record(s)
+                            ev[name][i] = e
+
+                def t_stage(i, b, s):
+                    if prev_b is not None:          # the TSA gather reads the WHOLE projected BEV of the layer before
+                        for j, e in enumerate(prev_b):
+                            if j != i:
+                                s.wait_event(e)
+                    lin = band(zq, b)
+                    st[i]['attn'] = ext.tsa_fused_forward(
+                        v4, lin[..., :n_off], lin[..., n_off:], b['ref_2d'], bev_h, bev_w, tsa.num_heads,
+                        tsa.num_points, shared_queue=True, order=b['order'], value_rows=nq)
+
+                def a_stage(i, b, s):
+                    st[i]['x1'], st[i]['lin'] = ext.linear_ln_chain(
+                        st[i]['attn'], band(q_prev, b), tsa.output_proj.weight, tsa.output_proj.bias, layer.norms[0],
+                        wq, bq)
+
+                def s_stage(i, b, s):
+                    st[i]['slots'] = sca.gather_projected(
+                        st[i]['lin'], plane, per_band[i]['ref_cam'], per_band[i]['vis'], spatial_shapes,
+                        level_start_index, b['order'], gather_stats)
+
+                def b_stage(i, b, s):
+                    tail, out = None, (band(outs[lid], b), None, None)
+                    if lid + 1 < nl:
+                        (tw, tterm, twv, tbv), nzq, nzv = tails[lid]
+                        tail = (tw, band(tterm, b), twv, tbv)
+                        out = (out[0], band(nzq, b), band(nzv, b))
+                    ext.encoder_ffn_chain(st[i]['slots'], st[i]['x1'], sca.output_proj.weight, sca.output_proj.bias,
+                                          layer.norms[1], fc1.weight, fc1.bias, fc2.weight, fc2.bias, layer.norms[2],
+                                          tail=tail, out=out)
+
+                stage('T', t_stage)
+                stage('A', a_stage)
+                stage('S', s_stage)
+                stage('B', b_stage)
+                keep.append(st)
+                prev_b = ev['B']
+                q_prev = outs[lid]
+                if lid + 1 < nl:
+                    zq, zv = tails[lid][1], tails[lid][2]
+        finally:
+            for s in streams:                       # join (also when a launch raised): nothing may outlive this call
+                main.wait_stream(s)
+        return outs
+
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
                 **kwargs):
@@ -459,6 +607,16 @@ class BEVFormerEncoder(TransformerLayerSequence):
         chain_ok = [chain and _chain_layer_ok(layer) for layer in self.layers]
         tsa_pre = None
         try:
+            if (_ROW_PIPELINE >= 2 and all(chain_ok) and bs == 1 and prev_bev is None and hasattr(value, 'project_on')
+                    and bev_pos is not None and not torch.is_grad_enabled()):
+                try:
+                    piped = self._forward_row_pipeline(
+                        _ROW_PIPELINE, bev_query, value, bev_pos, hybird_ref_2d, bev_h, bev_w, reference_points_cam,
+                        spatial_shapes, level_start_index, vis_bits, kwargs.get('gather_stats'))
+                except ext.OccAmdUnsupported:
+                    piped = None            # (streams joined; projections it consumed are redone by the layers below)
+                if piped is not None:
+                    return torch.stack(piped) if self.return_intermediate else piped[-1]
             for lid, layer in enumerate(self.layers):
                 output = None
                 if chain_ok[lid]:

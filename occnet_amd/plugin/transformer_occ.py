@@ -250,6 +250,22 @@ class LazyFeatures:
             return hit[0]
         return self._launch(value_proj, self._group_bias(value_proj))
 
+    def project_on(self, value_proj, streams):
+        """project() for consumers on SEVERAL streams (the encoder's row pipeline): every stream in `streams` waits for
+        the projection's event instead of torch's current stream, and the tensor is recorded on each of them (it was
+        allocated on the side / current stream: the allocator must not recycle it under their kernels)."""
+        hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
+        if hit is None:
+            out = self._launch(value_proj, self._group_bias(value_proj))
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            out, ev = hit
+        for s in streams:
+            s.wait_event(ev)
+            out.record_stream(s)
+        return out
+
 
 @TRANSFORMER.register_module()
 class TransformerOcc(BaseModule):

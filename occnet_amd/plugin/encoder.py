@@ -31,16 +31,24 @@ from .spatial_cross_attention import _require_device
 # (6.764 -> 6.734 ms per sample, ABAB on one box; OCC_VPROJ_OVERLAP=0 restores the serial order)
 _VPROJ_OVERLAP = os.environ.get("OCC_VPROJ_OVERLAP", "1") == "1"
 
-# EXPERIMENT, off by default (written at the end of round 4 without GPU time left to tune it):
+# EXPERIMENT, off by default (built and measured in the last GPU minutes of round 4):
 # OCC_ENCODER_ROW_PIPELINE=K (K >= 2) cuts the BEV queries into K row bands and walks every layer band by band on K HIP
 # streams.  Between two TSA gathers everything is ROW-LOCAL — chain program A, the SCA gather (its value operand is the
 # camera planes, not the BEV) and chain program B only ever touch their own rows — so band 2's TSA gather / program A can
 # run under band 1's SCA gather, and band 1's program B under band 2's SCA gather: kernels bound by different units
 # (texture path / HBM writes / matrix cores) share the chip instead of running back to back, each with its own ramp-up
 # and drain.  Only the TSA gather of the NEXT layer needs all bands (its value operand is the whole BEV).
-# OCC_ROW_PIPELINE_SERIAL=0 drops the events that keep two launches of the SAME kernel from overlapping.
+# What round 4 measured (profiles/r04_rowpipe_*): the banded launches are correct (one stream: 2.3e-5 against the standard
+# path after 4 layers; K streams: the same) but the EAGER pipeline is host-bound — 2 bands double the encoder's launches and
+# add stream switches and events: 2.44 ms of unqueued host time per hot-path step against 1.0 ms, so the wall time
+# (2.39 ms against 2.28 ms) is the launch cost, not the overlap.  The whole standard hot-path step captures into a
+# hipGraph (replay 2.31 ms); capturing the pipelined step crashed inside the runtime, which is where round 5 picks up.
+# OCC_ROW_PIPELINE_SERIAL=1 adds events that keep two launches of the SAME kernel from overlapping (band i + 1's stage
+# waits for band i's): KNOWN BAD — with them 60-100 of band 2's 19 200 queries come out wrong from the second layer on
+# (a device synchronize per layer cures it, stream-to-stream barriers do not: not understood, profiles/r04_rowpipe_debug3.log).
+# OCC_ROW_PIPELINE_STREAMS=0 / OCC_ROW_PIPELINE_DEBUG_SYNC=1|2 are the debugging switches of tools_dev/row_pipeline_debug.py.
 _ROW_PIPELINE = int(os.environ.get("OCC_ENCODER_ROW_PIPELINE", "0") or 0)
-_ROW_PIPELINE_SERIAL = os.environ.get("OCC_ROW_PIPELINE_SERIAL", "1") != "0"
+_ROW_PIPELINE_SERIAL = os.environ.get("OCC_ROW_PIPELINE_SERIAL", "0") == "1"
 
 
 def row_bands(bev_h, bev_w, k, tile_h=8):
@@ -450,8 +458,11 @@ class BEVFormerEncoder(TransformerLayerSequence):
             for m0, m1, h in row_bands(bev_h, bev_w, k):
                 order = torch.from_numpy(bev_tile_order(h, bev_w, n_xcd=8)).to(device)
                 bands.append(dict(m0=m0, m1=m1, order=order, ref_2d=hybrid_ref_2d[:, m0:m1].float().contiguous()))
+            # OCC_ROW_PIPELINE_STREAMS=0 (debugging): every band on the caller's stream — the banded launches, in order
+            one = os.environ.get("OCC_ROW_PIPELINE_STREAMS", "1") == "0"
             plan = dict(key=key, bands=bands, src=hybrid_ref_2d,
-                        streams=[torch.cuda.Stream(device=device) for _ in bands])
+                        streams=[torch.cuda.current_stream(device) if one else torch.cuda.Stream(device=device)
+                                 for _ in bands])
             self._row_plan = plan
         return plan
 
@@ -497,8 +508,9 @@ class BEVFormerEncoder(TransformerLayerSequence):
         fork.record(main)
         for s in streams:
             s.wait_event(fork)
-            for t in shared:
-                t.record_stream(s)
+            if s != main:
+                for t in shared:
+                    t.record_stream(s)
         keep = []                                   # band-private tensors stay referenced until the join
         prev_b = None                               # the previous layer's program-B events, one per band
         q_prev = q_full
@@ -559,13 +571,22 @@ class BEVFormerEncoder(TransformerLayerSequence):
                 stage('S', s_stage)
                 stage('B', b_stage)
                 keep.append(st)
+                dbg = os.environ.get("OCC_ROW_PIPELINE_DEBUG_SYNC")          # (debugging)
+                if dbg == "1":                      # a device barrier per layer
+                    torch.cuda.synchronize()
+                elif dbg == "2":                    # every band stream waits for every other one per layer (device side)
+                    for s in streams:
+                        for s2 in streams:
+                            if s2 != s:
+                                s.wait_stream(s2)
                 prev_b = ev['B']
                 q_prev = outs[lid]
                 if lid + 1 < nl:
                     zq, zv = tails[lid][1], tails[lid][2]
         finally:
             for s in streams:                       # join (also when a launch raised): nothing may outlive this call
-                main.wait_stream(s)
+                if s != main:
+                    main.wait_stream(s)
         return outs
 
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,

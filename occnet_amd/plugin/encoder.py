@@ -49,6 +49,10 @@ _VPROJ_OVERLAP = os.environ.get("OCC_VPROJ_OVERLAP", "1") == "1"
 # OCC_ROW_PIPELINE_STREAMS=0 / OCC_ROW_PIPELINE_DEBUG_SYNC=1|2 are the debugging switches of tools_dev/row_pipeline_debug.py.
 _ROW_PIPELINE = int(os.environ.get("OCC_ENCODER_ROW_PIPELINE", "0") or 0)
 _ROW_PIPELINE_SERIAL = os.environ.get("OCC_ROW_PIPELINE_SERIAL", "0") == "1"
+# OCC_ROW_PIPELINE_NATIVE=1: the banded sequence issued by ONE C-ABI call (csrc/encoder_bands.hip, ext.encoder_bands_forward)
+# instead of ~35 Python-side launches — written after the GPU budget of round 4 was spent: compiled, host-tested, never run on
+# an MI355X.  With OCC_ENCODER_ROW_PIPELINE=1 it is the unbanded chain path from one call.
+_ROW_PIPELINE_NATIVE = os.environ.get("OCC_ROW_PIPELINE_NATIVE", "0") == "1"
 
 
 def row_bands(bev_h, bev_w, k, tile_h=8):
@@ -481,6 +485,9 @@ class BEVFormerEncoder(TransformerLayerSequence):
         main = torch.cuda.current_stream(dev)
         plan = self._row_pipeline_plan(bev_h, bev_w, k, hybrid_ref_2d, dev)
         bands, streams = plan['bands'], plan['streams']
+        if _ROW_PIPELINE_NATIVE:
+            return self._forward_row_pipeline_native(plan, bev_query, value, bev_pos, bev_h, bev_w, reference_points_cam,
+                                                     spatial_shapes, level_start_index, vis_bits, gather_stats)
         if len(bands) < 2:
             return None
         nq, nl = bev_h * bev_w, len(self.layers)
@@ -589,6 +596,61 @@ class BEVFormerEncoder(TransformerLayerSequence):
                     main.wait_stream(s)
         return outs
 
+    def _forward_row_pipeline_native(self, plan, bev_query, value, bev_pos, bev_h, bev_w, reference_points_cam,
+                                     spatial_shapes, level_start_index, vis_bits, gather_stats):
+        """The banded sequence of _forward_row_pipeline through ext.encoder_bands_forward: this method only gathers the
+        operands (band copies of the per-step reference points, the first layer's TSA Linears, the planes and their
+        event, the result buffers); csrc/encoder_bands.hip forks the band streams, issues every launch and joins."""
+        dev = bev_query.device
+        main = torch.cuda.current_stream(dev)
+        bands, streams = plan['bands'], plan['streams']
+        if len(bands) == 1:
+            streams = [main]
+        nq, nl = bev_h * bev_w, len(self.layers)
+        sca0 = self.layers[0].attentions[1].deformable_attention
+        n_lin = sca0.sampling_offsets.out_features + sca0.attention_weights.out_features
+        ref_cam = reference_points_cam.float()
+        for b in bands:                              # band scratch: allocated once (main stream), reused every step
+            n = b['m1'] - b['m0']
+            if 'attn' not in b:
+                for name, w in (('attn', 256), ('x1', 256), ('slots', 256), ('lin', n_lin)):
+                    b[name] = torch.empty((1, n, w), dtype=torch.float32, device=dev)
+                b['ref_cam'] = torch.empty((ref_cam.shape[0], 1, n) + tuple(ref_cam.shape[3:]), dtype=torch.float32,
+                                           device=dev)
+            b['ref_cam'].copy_(ref_cam[:, :, b['m0']:b['m1']])
+        q_full = bev_query.contiguous()
+        tsa0 = self.layers[0].attentions[0]
+        zq0, zv0 = ext.linear_pair_chain(q_full, *tsa0.chain_tail(bev_pos))
+        shared = [q_full, zq0, zv0, vis_bits]
+        layers = []
+        for lid, layer in enumerate(self.layers):
+            tsa, sca = layer.attentions
+            ffn = layer.ffns[0]
+            wq, bq = sca.query_linear_operands()
+            plane, ev = value.take_on(sca.deformable_attention.value_proj, [s for s in streams if s != main])
+            y = dict(a=(tsa.output_proj.weight, tsa.output_proj.bias, layer.norms[0], wq, bq),
+                     b=(sca.output_proj.weight, sca.output_proj.bias, layer.norms[1], ffn.layers[0][0].weight,
+                        ffn.layers[0][0].bias, ffn.layers[1].weight, ffn.layers[1].bias, layer.norms[2]),
+                     plane=plane.view(plane.shape[0], plane.shape[1], sca.deformable_attention.num_heads, -1),
+                     plane_ready=ev, stats=gather_stats if gather_stats is not None else sca.gather_stats,
+                     out=torch.empty((1, nq, 256), dtype=torch.float32, device=dev))
+            shared.append(y['out'])
+            if lid + 1 < nl:
+                t = self.layers[lid + 1].attentions[0].chain_tail(bev_pos)
+                y.update(tail=t, zq=torch.empty((1, nq, t[0].shape[0]), dtype=torch.float32, device=dev),
+                         zv=torch.empty((1, nq, 256), dtype=torch.float32, device=dev))
+                shared += [y['zq'], y['zv']]
+            layers.append(y)
+        for s in streams:
+            if s != main:
+                for t in shared:
+                    t.record_stream(s)
+        tsa = self.layers[0].attentions[0]
+        ext.encoder_bands_forward(q_full, zq0, zv0, layers,
+                                  [dict(b, stream=s) for b, s in zip(bands, streams)], spatial_shapes, level_start_index,
+                                  vis_bits, bev_h, bev_w, sca0.num_levels, sca0.num_points, tsa.num_points)
+        return [y['out'] for y in layers]
+
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
                 **kwargs):
@@ -628,7 +690,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
         chain_ok = [chain and _chain_layer_ok(layer) for layer in self.layers]
         tsa_pre = None
         try:
-            if (_ROW_PIPELINE >= 2 and all(chain_ok) and bs == 1 and prev_bev is None and hasattr(value, 'project_on')
+            if ((_ROW_PIPELINE >= 2 or (_ROW_PIPELINE == 1 and _ROW_PIPELINE_NATIVE)) and all(chain_ok) and bs == 1
+                    and prev_bev is None and hasattr(value, 'project_on')
                     and bev_pos is not None and not torch.is_grad_enabled()):
                 try:
                     piped = self._forward_row_pipeline(

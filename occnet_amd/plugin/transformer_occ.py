@@ -266,6 +266,16 @@ class LazyFeatures:
             out.record_stream(s)
         return out
 
+    def take_on(self, value_proj, streams):
+        """project_on() without the waits: -> (tensor, the event its consumers have to wait for, or None when it was
+        launched on the current stream just now) — for a native launcher that issues the waits itself
+        (ext.encoder_bands_forward)."""
+        hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
+        out, ev = hit if hit is not None else (self._launch(value_proj, self._group_bias(value_proj)), None)
+        for s in streams:
+            out.record_stream(s)
+        return out, ev
+
 
 @TRANSFORMER.register_module()
 class TransformerOcc(BaseModule):

@@ -18,8 +18,10 @@ pytestmark = [pytest.mark.gpu,
                                  reason="opt-in: OCC_TEST_ROW_PIPELINE=1 (experimental row pipeline)")]
 
 
-@pytest.mark.parametrize("k", [2, 3])
-def test_row_pipeline_matches_the_standard_chain_path(monkeypatch, k):
+@pytest.mark.parametrize("k,native", [(2, False), (3, False), (1, True), (2, True), (3, True)])
+def test_row_pipeline_matches_the_standard_chain_path(monkeypatch, k, native):
+    """native: the same sequence issued by csrc/encoder_bands.hip in one call (never run in round 4)."""
+    monkeypatch.setattr(enc_mod, "_ROW_PIPELINE_NATIVE", native)
     g = dict(synthetic.BASE, num_points=8, num_layers=4)
     prod, _ = build_pair(g, seed=12)
     feats = [f.to(torch.bfloat16) for f in synthetic.make_features(g, seed=12)]
@@ -44,5 +46,5 @@ def test_row_pipeline_matches_the_standard_chain_path(monkeypatch, k):
     assert calls == [False, True], calls    # the second call really went through the pipeline
     for key in ('bev_embed', 'occ', 'flow'):
         d = maxdiff(got[key], want[key])
-        print(f"row pipeline K={k} {key}: max|pipeline - standard| = {d:.3e}")
+        print(f"row pipeline K={k} native={native} {key}: max|pipeline - standard| = {d:.3e}")
         assert d < 1e-4, (key, d)

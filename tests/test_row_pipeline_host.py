@@ -123,7 +123,49 @@ def _fake_ops(monkeypatch, bev_h, bev_w, log):
             return out
         return y, zq, zv
 
+    def encoder_bands_forward(q0, zq0, zv0, layers, bands, spatial_shapes, level_start_index, vis_bits, bh, bw,
+                              num_levels, num_points, tsa_points):
+        """csrc/encoder_bands.hip's launch sequence, on the stand-ins above (same pointer arithmetic, as slices)."""
+        assert (bh, bw) == (bev_h, bev_w) and [b['m0'] for b in bands] == [0] + [b['m1'] for b in bands[:-1]]
+        assert bands[-1]['m1'] == nq and len({id(b['stream']) for b in bands}) == len(bands)
+        n_lin = 8 * num_levels * num_points * 3
+        tsa_noff = 8 * 2 * tsa_points * 2
+        q_prev, zq, zv = q0, zq0, zv0
+        for l, y in enumerate(layers):
+            assert (y.get('tail') is not None) == (l + 1 < len(layers))
+            w1, b1, ln, w2, b2 = y['a']
+            wo, bo, ln1, f1, fb1, f2, fb2, ln2 = y['b']
+            for b in bands:
+                m0, m1 = b['m0'], b['m1']
+                n = m1 - m0
+                assert tuple(b['ref_cam'].shape[:3]) == (6, 1, n) and b['lin'].shape == (1, n, n_lin)
+                lin = zq[:, m0:m1]
+                b['attn'].copy_(tsa_fused_forward(zv.view(1, nq, 8, -1), lin[0, :, :tsa_noff].unsqueeze(0),
+                                                  lin[0, :, tsa_noff:].unsqueeze(0), b['ref_2d'], bh, bw, 8, tsa_points,
+                                                  shared_queue=True, order=b['order'], value_rows=nq))
+            for b in bands:
+                x1, z = linear_ln_chain(b['attn'], q_prev[:, b['m0']:b['m1']], w1, b1, ln, w2, b2)
+                b['x1'].copy_(x1)
+                b['lin'].copy_(z)
+            for b in bands:
+                b['slots'].copy_(sca_fused_forward(y['plane'], spatial_shapes, level_start_index,
+                                                   b['lin'][..., :n_lin // 3 * 2], b['lin'][..., n_lin // 3 * 2:],
+                                                   b['ref_cam'], vis_bits[:, b['m0']:b['m1']], 8, num_levels, num_points,
+                                                   order=b['order'], stats=y['stats'], value_layout="pairs"))
+            for b in bands:
+                m0, m1 = b['m0'], b['m1']
+                tail = y.get('tail')
+                if tail is not None:
+                    tail = (tail[0], None if tail[1] is None else tail[1][:, m0:m1], tail[2], tail[3])
+                encoder_ffn_chain(b['slots'], b['x1'], wo, bo, ln1, f1, fb1, f2, fb2, ln2, tail=tail,
+                                  out=(y['out'][:, m0:m1], None if tail is None else y['zq'][:, m0:m1],
+                                       None if tail is None else y['zv'][:, m0:m1]))
+            q_prev = y['out']
+            if l + 1 < len(layers):
+                zq, zv = y['zq'], y['zv']
+
     for name, fn in dict(linear=linear, linear_pair_chain=linear_pair_chain, tsa_fused_forward=tsa_fused_forward,
+                         encoder_bands_forward=encoder_bands_forward,
                          linear_ln_chain=linear_ln_chain, sca_fused_forward=sca_fused_forward,
                          encoder_ffn_chain=encoder_ffn_chain).items():
         monkeypatch.setattr(ext, name, fn)
@@ -146,6 +188,9 @@ class _Planes:
     def project_on(self, vp, streams):
         self.asked.append(id(vp))
         return self.planes[id(vp)]
+
+    def take_on(self, vp, streams):
+        return self.project_on(vp, streams), None
 
 
 def _reference_walk(encoder, q, planes, bev_pos, ref_2d, bev_h, bev_w, ref_cam, vis_bits, order):
@@ -172,8 +217,9 @@ def _reference_walk(encoder, q, planes, bev_pos, ref_2d, bev_h, bev_w, ref_cam, 
     return outs
 
 
-@pytest.mark.parametrize("k", [2, 3])
-def test_row_pipeline_plumbing_equals_the_unbanded_walk(monkeypatch, k):
+@pytest.mark.parametrize("k,native", [(2, False), (3, False), (1, True), (2, True), (3, True)])
+def test_row_pipeline_plumbing_equals_the_unbanded_walk(monkeypatch, k, native):
+    monkeypatch.setattr(enc_mod, "_ROW_PIPELINE_NATIVE", native)
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'occ_base_200x200x16.py'))
     torch.manual_seed(0)
     model = build_model(cfg.model)
@@ -213,6 +259,7 @@ def test_row_pipeline_plumbing_equals_the_unbanded_walk(monkeypatch, k):
     assert len(sizes) == k
     per_layer = [(s, n) for s in 'TASB' for n in sizes]
     assert log == per_layer * len(encoder.layers)
+    assert log.count(('B', sizes[0])) == len(encoder.layers) * sizes.count(sizes[0])
     # a weight update sends the next call down the standard path again
     with torch.no_grad():
         next(encoder.parameters()).add_(0.0)

@@ -357,7 +357,8 @@ int occ_encoder_ffn_chain_bf16x3_f32(const float* a, int64_t lda, const float* r
  *   layers: chain operands as occ_linear_ln_chain_bf16x3_f32 / occ_encoder_ffn_chain_bf16x3_f32 take them; `plane` the SCA
  *        value maps of the layer (fp16 pixel pairs when planes_f16, else f32 rows), `plane_ready` a hipEvent_t every band
  *        waits for before its gather (or NULL); out (Nq, 256), and for every layer but the last zq (Nq, nq_tail) /
- *        zv (Nq, 256) = the next layer's TSA operands (q_term (Nq, ldq_term) or NULL). */
+ *        zv (Nq, 256) = the next layer's TSA operands (q_term (Nq, ldq_term) or NULL).
+ *   flags: 0, or OCC_EB_* below (scheduling experiments; results do not depend on them). */
 typedef struct OccBand {
   int32_t m0, n;
   const int32_t* order;
@@ -381,7 +382,9 @@ int occ_encoder_bands_forward_f32(const float* q0, const float* zq0, int64_t ldz
                                   const OccBandLayer* layers, int n_layers, const OccBand* bands, int n_bands,
                                   const int64_t* spatial_shapes, const int64_t* level_start_index,
                                   const uint32_t* vis_bits, int Nq, int bev_h, int bev_w, int NC, int S, int L, int P,
-                                  int Z, int tsa_P, int planes_f16, void* main_stream);
+                                  int Z, int tsa_P, int planes_f16, int flags, void* main_stream);
+#define OCC_EB_STAGGER 1    /* flags: band i's first launch waits for band i - 1's first launch (bands one stage apart)  */
+#define OCC_EB_BAND_MAJOR 2 /* flags: submit band by band (T, A, S, B of band 0, then band 1, ...) instead of stage by stage */
 
 /* Program C: the tail stage alone — two Linears of the SAME 256-wide rows in one launch (the first encoder layer's TSA
  * query Linears and value projection, temporal_self_attention.py:197-209,239-240, straight from the BEV queries):

@@ -15,6 +15,10 @@
 // NEVER RUN on an MI355X.  Opt-in (OCC_ENCODER_ROW_PIPELINE=K with OCC_ROW_PIPELINE_NATIVE=1); tests/test_gpu_row_pipeline.py
 // is its parity test.
 //
+// flags (experiments for the round that first runs this): OCC_EB_STAGGER — band i's very first launch waits for band
+// i - 1's first launch, so the bands run one stage apart and DIFFERENT kernels share the chip (no per-stage events: the
+// Python pipeline's per-stage serialisation produced wrong rows, plugin/encoder.py); OCC_EB_BAND_MAJOR — submission order.
+//
 // The kernels are the library's own entry points (sca_fused.hip, tsa_fused.hip, linear_chain_x3.hip), called with band
 // pointers: at B = 1 the gathers index offsets / logits / reference points / visibility / output by query only and take a
 // band-local processing order, the chain kernels take row pointers (see OccBand in include/occnet_amd.h).
@@ -48,7 +52,7 @@ extern "C" int occ_encoder_bands_forward_f32(const float* q0, const float* zq0, 
                                              int n_bands, const int64_t* spatial_shapes,
                                              const int64_t* level_start_index, const uint32_t* vis_bits, int Nq,
                                              int bev_h, int bev_w, int NC, int S, int L, int P, int Z, int tsa_P,
-                                             int planes_f16, void* main_stream) {
+                                             int planes_f16, int flags, void* main_stream) {
   using namespace occ;
   constexpr int M = 8, D = 32, C = 256;
   OCC_CHECK_ARG(q0 && zq0 && zv0 && layers && bands && spatial_shapes && level_start_index && vis_bits,
@@ -111,51 +115,63 @@ extern "C" int occ_encoder_bands_forward_f32(const float* q0, const float* zq0, 
   const float* zq = zq0;                    // the TSA query Linears' outputs of this layer (Nq, ldzq)
   long ldzq = ldzq0;
   const float* zv = zv0;                    // this layer's projected BEV (Nq, 256): the TSA gather's value map
+  hipEvent_t first_done = nullptr;          // OCC_EB_STAGGER: the previous band's first launch
   for (int l = 0; l < n_layers && rc == OCC_OK; ++l) {
     const OccBandLayer& y = layers[l];
     const bool tail = l + 1 < n_layers;
-    // stage-major submission (T of every band, then A, S, B): the order the bands' kernels should meet the dispatcher in
-    for (int i = 0; i < n_bands && rc == OCC_OK; ++i) {            // T: TSA gather of the band against the WHOLE BEV
+    // submission order: stage-major (T of every band, then A, S, B: the bands' kernels of one kind reach the dispatcher
+    // together) or, OCC_EB_BAND_MAJOR, band-major (all four stages of band 0, then band 1, ...)
+    for (int step = 0; step < 4 * n_bands && rc == OCC_OK; ++step) {
+      const int stage = (flags & OCC_EB_BAND_MAJOR) ? step % 4 : step / n_bands;
+      const int i = (flags & OCC_EB_BAND_MAJOR) ? step / 4 : step % n_bands;
       const OccBand& b = bands[i];
-      if (l > 0)
-        for (int j = 0; j < n_bands; ++j)
-          if (j != i && st[j] != st[i]) OCC_EB_HIP(hipStreamWaitEvent(st[i], prev_b[j], 0));
-      if (rc != OCC_OK) break;
-      const float* lin = zq + (long)b.m0 * ldzq;
-      rc = occ_tsa_fused_forward_f32(zv, 0, lin, ldzq, lin + tsa_noff, ldzq, b.ref_2d, b.order, b.attn, 1, b.n, bev_h, bev_w,
-                                     M, D, tsa_P, st[i]);
-    }
-    for (int i = 0; i < n_bands && rc == OCC_OK; ++i) {            // A: output_proj + LN -> the SCA's query Linears
-      const OccBand& b = bands[i];
-      rc = occ_linear_ln_chain_bf16x3_f32(b.attn, C, q_prev + (long)b.m0 * C, C, y.wA, y.biasA, y.ln0_g, y.ln0_b, y.ln0_eps,
-                                          b.x1, C, b.lin, n_lin, n_lin, 0, b.n, st[i]);
-    }
-    for (int i = 0; i < n_bands && rc == OCC_OK; ++i) {            // S: SCA gather of the band's queries
-      const OccBand& b = bands[i];
-      if (y.plane_ready) OCC_EB_HIP(hipStreamWaitEvent(st[i], reinterpret_cast<hipEvent_t>(y.plane_ready), 0));
-      if (rc != OCC_OK) break;
-      rc = planes_f16 ? occ_sca_fused_forward_f16v(y.plane, spatial_shapes, level_start_index, b.lin, n_lin, b.lin + sca_noff,
-                                                   n_lin, b.ref_cam, vis_bits + b.m0, b.order, b.slots, y.stats, 1, NC, S,
-                                                   M, D, L, P, Z, b.n, st[i])
-                      : occ_sca_fused_forward_f32(reinterpret_cast<const float*>(y.plane), spatial_shapes, level_start_index,
-                                                  b.lin, n_lin, b.lin + sca_noff, n_lin, b.ref_cam, vis_bits + b.m0, b.order,
-                                                  b.slots, y.stats, 1, NC, S, M, D, L, P, Z, b.n, st[i]);
-    }
-    for (int i = 0; i < n_bands && rc == OCC_OK; ++i) {            // B: output_proj + LN + FFN + LN (+ the next TSA's Linears)
-      const OccBand& b = bands[i];
-      rc = occ_encoder_ffn_chain_bf16x3_f32(
-          b.slots, C, b.x1, C, y.wB, y.biasB, y.ln1_g, y.ln1_b, y.ln1_eps, y.ln2_g, y.ln2_b, y.ln2_eps,
-          y.out + (long)b.m0 * C, C, (tail && y.q_term) ? y.q_term + (long)b.m0 * y.ldq_term : nullptr, y.ldq_term,
-          tail ? y.zq + (long)b.m0 * y.nq_tail : nullptr, y.nq_tail, tail ? y.nq_tail : 0,
-          tail ? y.zv + (long)b.m0 * C : nullptr, C, b.n, st[i]);
-      if (rc == OCC_OK && tail && n_bands > 1) {
-        cur_b[i] = pool.get();
-        if (!cur_b[i]) {
-          set_error("encoder_bands_forward: hipEventCreate failed");
-          rc = OCC_E_LAUNCH;
-          break;
+      if (stage == 0) {            // T: TSA gather of the band against the WHOLE BEV of the layer before
+        if (l > 0)
+          for (int j = 0; j < n_bands; ++j)
+            if (j != i && st[j] != st[i]) OCC_EB_HIP(hipStreamWaitEvent(st[i], prev_b[j], 0));
+        if (l == 0 && i > 0 && (flags & OCC_EB_STAGGER) && first_done && st[i] != st[i - 1])
+          OCC_EB_HIP(hipStreamWaitEvent(st[i], first_done, 0));      // one stage behind the band before, once
+        if (rc != OCC_OK) break;
+        const float* lin = zq + (long)b.m0 * ldzq;
+        rc = occ_tsa_fused_forward_f32(zv, 0, lin, ldzq, lin + tsa_noff, ldzq, b.ref_2d, b.order, b.attn, 1, b.n, bev_h,
+                                       bev_w, M, D, tsa_P, st[i]);
+        if (rc == OCC_OK && l == 0 && (flags & OCC_EB_STAGGER) && i + 1 < n_bands) {
+          first_done = pool.get();
+          if (!first_done) {
+            set_error("encoder_bands_forward: hipEventCreate failed");
+            rc = OCC_E_LAUNCH;
+            break;
+          }
+          OCC_EB_HIP(hipEventRecord(first_done, st[i]));
         }
-        OCC_EB_HIP(hipEventRecord(cur_b[i], st[i]));
+      } else if (stage == 1) {     // A: output_proj + LN -> the SCA's query Linears
+        rc = occ_linear_ln_chain_bf16x3_f32(b.attn, C, q_prev + (long)b.m0 * C, C, y.wA, y.biasA, y.ln0_g, y.ln0_b,
+                                            y.ln0_eps, b.x1, C, b.lin, n_lin, n_lin, 0, b.n, st[i]);
+      } else if (stage == 2) {     // S: SCA gather of the band's queries
+        if (y.plane_ready) OCC_EB_HIP(hipStreamWaitEvent(st[i], reinterpret_cast<hipEvent_t>(y.plane_ready), 0));
+        if (rc != OCC_OK) break;
+        rc = planes_f16
+                 ? occ_sca_fused_forward_f16v(y.plane, spatial_shapes, level_start_index, b.lin, n_lin, b.lin + sca_noff,
+                                              n_lin, b.ref_cam, vis_bits + b.m0, b.order, b.slots, y.stats, 1, NC, S, M, D, L,
+                                              P, Z, b.n, st[i])
+                 : occ_sca_fused_forward_f32(reinterpret_cast<const float*>(y.plane), spatial_shapes, level_start_index,
+                                             b.lin, n_lin, b.lin + sca_noff, n_lin, b.ref_cam, vis_bits + b.m0, b.order,
+                                             b.slots, y.stats, 1, NC, S, M, D, L, P, Z, b.n, st[i]);
+      } else {                     // B: output_proj + LN + FFN + LN (+ the next layer's TSA Linears)
+        rc = occ_encoder_ffn_chain_bf16x3_f32(
+            b.slots, C, b.x1, C, y.wB, y.biasB, y.ln1_g, y.ln1_b, y.ln1_eps, y.ln2_g, y.ln2_b, y.ln2_eps,
+            y.out + (long)b.m0 * C, C, (tail && y.q_term) ? y.q_term + (long)b.m0 * y.ldq_term : nullptr, y.ldq_term,
+            tail ? y.zq + (long)b.m0 * y.nq_tail : nullptr, y.nq_tail, tail ? y.nq_tail : 0,
+            tail ? y.zv + (long)b.m0 * C : nullptr, C, b.n, st[i]);
+        if (rc == OCC_OK && tail && n_bands > 1) {
+          cur_b[i] = pool.get();
+          if (!cur_b[i]) {
+            set_error("encoder_bands_forward: hipEventCreate failed");
+            rc = OCC_E_LAUNCH;
+            break;
+          }
+          OCC_EB_HIP(hipEventRecord(cur_b[i], st[i]));
+        }
       }
     }
     prev_b.swap(cur_b);

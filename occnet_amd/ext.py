@@ -895,7 +895,7 @@ def _dp(t):
 
 
 def encoder_bands_forward(q0, zq0, zv0, layers, bands, spatial_shapes, level_start_index, vis_bits, bev_h, bev_w,
-                          num_levels, num_points, tsa_points):
+                          num_levels, num_points, tsa_points, flags=0):
     """EXPERIMENTAL (csrc/encoder_bands.hip; never run on an MI355X in round 4): the encoder's chain path — per layer TSA
     gather -> program A -> SCA gather -> program B — for the row bands `bands` on their streams, in ONE call.
     q0 (1, Nq, 256); zq0 (1, Nq, n) / zv0 (1, Nq, 256) = linear_pair_chain(q0, ...) of layer 0.
@@ -904,7 +904,8 @@ def encoder_bands_forward(q0, zq0, zv0, layers, bands, spatial_shapes, level_sta
         plane (NC, S, 8, 32) f16 pairs / f32 rows, plane_ready torch.cuda.Event or None, stats or None,
         out (1, Nq, 256), zq (1, Nq, nq) / zv (1, Nq, 256) or None (last layer).
     bands: dicts m0, m1, order (n) int32, ref_2d (2, n, 1, 2), ref_cam (NC, 1, n, Z, 2), attn / x1 / slots (1, n, 256),
-        lin (1, n, 8*L*P*3), stream (torch.cuda.Stream).  Everything float32 device memory unless noted."""
+        lin (1, n, 8*L*P*3), stream (torch.cuda.Stream).  Everything float32 device memory unless noted.
+    flags: OCC_EB_STAGGER (1) | OCC_EB_BAND_MAJOR (2), include/occnet_amd.h — scheduling only."""
     if LINEAR_PRECISION != "bf16x3":
         raise OccAmdUnsupported("encoder_bands_forward: bf16x3 precision mode only")
     dev = q0.device
@@ -1002,7 +1003,8 @@ def encoder_bands_forward(q0, zq0, zv0, layers, bands, spatial_shapes, level_sta
     with torch.cuda.device(dev), _timed('encoder_bands'):
         rc = fn(ptr(q0), ptr(zq0), i64(zq0.shape[-1]), ptr(zv0), cl, i32(len(layers)), cb, i32(len(bands)),
                 ptr(spatial_shapes), ptr(level_start_index), ptr(vis_bits), i32(Nq), i32(bev_h), i32(bev_w), i32(NC),
-                i32(S), i32(L), i32(P), i32(Z), i32(int(tsa_points)), i32(1 if planes_f16 else 0), stream_ptr(dev))
+                i32(S), i32(L), i32(P), i32(Z), i32(int(tsa_points)), i32(1 if planes_f16 else 0), i32(int(flags)),
+                stream_ptr(dev))
     _lib.check(rc, "encoder_bands_forward")
     del keep
 

@@ -53,6 +53,9 @@ _ROW_PIPELINE_SERIAL = os.environ.get("OCC_ROW_PIPELINE_SERIAL", "0") == "1"
 # instead of ~35 Python-side launches — written after the GPU budget of round 4 was spent: compiled, host-tested, never run on
 # an MI355X.  With OCC_ENCODER_ROW_PIPELINE=1 it is the unbanded chain path from one call.
 _ROW_PIPELINE_NATIVE = os.environ.get("OCC_ROW_PIPELINE_NATIVE", "0") == "1"
+# OCC_ROW_PIPELINE_FLAGS: scheduling flags of the native launcher (include/occnet_amd.h: 1 = bands one stage apart, 2 =
+# band-major submission)
+_ROW_PIPELINE_FLAGS = int(os.environ.get("OCC_ROW_PIPELINE_FLAGS", "0") or 0)
 
 
 def row_bands(bev_h, bev_w, k, tile_h=8):
@@ -648,7 +651,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
         tsa = self.layers[0].attentions[0]
         ext.encoder_bands_forward(q_full, zq0, zv0, layers,
                                   [dict(b, stream=s) for b, s in zip(bands, streams)], spatial_shapes, level_start_index,
-                                  vis_bits, bev_h, bev_w, sca0.num_levels, sca0.num_points, tsa.num_points)
+                                  vis_bits, bev_h, bev_w, sca0.num_levels, sca0.num_points, tsa.num_points,
+                                  flags=_ROW_PIPELINE_FLAGS)
         return [y['out'] for y in layers]
 
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,

@@ -204,7 +204,7 @@ def test_encoder_bands_structs_match_the_header_and_arguments_are_checked(tmp_pa
     null = ctypes.c_void_p(0)
     fn = lib.occ_encoder_bands_forward_f32
     assert fn(null, null, ctypes.c_int64(192), null, null, 1, null, 1, null, null, null, 40000, 200, 200, 6, 30826, 4, 8, 4,
-              4, 1, null) == -1 and b'null' in lib.occ_last_error()
+              4, 1, 0, null) == -1 and b'null' in lib.occ_last_error()
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p).value
     layer = (ext._OccBandLayer * 1)()
@@ -218,7 +218,7 @@ def test_encoder_bands_structs_match_the_header_and_arguments_are_checked(tmp_pa
             setattr(b, f, p)
     args = lambda nq, nb: (ctypes.c_void_p(p), ctypes.c_void_p(p), ctypes.c_int64(192), ctypes.c_void_p(p), layer, 1, bands,
                            nb, ctypes.c_void_p(p), ctypes.c_void_p(p), ctypes.c_void_p(p), nq, 200, 200, 6, 30826, 4, 8, 4,
-                           4, 1, null)
+                           4, 1, 0, null)
     assert fn(*args(40000, 2)) == -1 and b'cover 39800 of 40000' in lib.occ_last_error()
     assert fn(*args(39999, 2)) == -1 and b'bad dimension' in lib.occ_last_error()          # bev_h * bev_w != Nq
     bands[1].m0 = 20900

@@ -66,13 +66,13 @@ def _setup(n_layers, cuts, f16=True, same_stream=False):
     return layers, bands
 
 
-def _call(lib, layers, bands, f16=True, fail_at=-1):
+def _call(lib, layers, bands, f16=True, fail_at=-1, flags=0):
     lib.harness_reset(fail_at)
     q0, zq0, zv0 = _addr(23), _addr(24), _addr(25)
     rc = lib.occ_encoder_bands_forward_f32(
         ctypes.c_void_p(q0), ctypes.c_void_p(zq0), ctypes.c_int64(NQ_TAIL), ctypes.c_void_p(zv0), layers, len(layers), bands,
         len(bands), ctypes.c_void_p(_addr(26)), ctypes.c_void_p(_addr(27)), ctypes.c_void_p(_addr(28)), NQ, BH, BW, NC, S, L, P, Z,
-        TSA_P, 1 if f16 else 0, ctypes.c_void_p(MAIN))
+        TSA_P, 1 if f16 else 0, flags, ctypes.c_void_p(MAIN))
     ops = []
     for line in lib.harness_trace().decode().splitlines():
         head, *rest = line.split()
@@ -106,11 +106,13 @@ def _happens_before(ops):
     return kernels, after, last_on
 
 
-@pytest.mark.parametrize("cuts,n_layers,f16", [((0, 20800, 40000), 4, True), ((0, 12800, 27200, 40000), 3, True),
-                                               ((0, 40000), 4, True), ((0, 20800, 40000), 2, False)])
-def test_launch_sequence_pointers_and_ordering(harness, cuts, n_layers, f16):
+@pytest.mark.parametrize("cuts,n_layers,f16,flags", [
+    ((0, 20800, 40000), 4, True, 0), ((0, 12800, 27200, 40000), 3, True, 0), ((0, 40000), 4, True, 0),
+    ((0, 20800, 40000), 2, False, 0), ((0, 20800, 40000), 3, True, 1), ((0, 12800, 27200, 40000), 3, True, 2),
+    ((0, 12800, 27200, 40000), 2, True, 3), ((0, 40000), 2, True, 3)])
+def test_launch_sequence_pointers_and_ordering(harness, cuts, n_layers, f16, flags):
     layers, bands = _setup(n_layers, cuts, f16)
-    rc, ops, (q0, zq0, zv0) = _call(harness, layers, bands, f16)
+    rc, ops, (q0, zq0, zv0) = _call(harness, layers, bands, f16, flags=flags)
     assert rc == 0, harness.harness_error()
     K = len(bands)
     kernels, after, last_on = _happens_before(ops)
@@ -118,14 +120,18 @@ def test_launch_sequence_pointers_and_ordering(harness, cuts, n_layers, f16):
     sca_tag = "S16" if f16 else "S32"
     by = {}
     pos = 0
-    for l in range(n_layers):                                   # stage-major, band-minor submission order
-        for tag in ("T", "A", sca_tag, "B"):
-            for i in range(K):
-                idx, t, stream, a = kernels[pos]
-                pos += 1
-                assert t == tag and stream == bands[i].stream, (l, tag, i, t, hex(stream))
-                assert int(a["n"]) == bands[i].n
-                by[(l, tag[0], i)] = (idx, a)
+    tags = ("T", "A", sca_tag, "B")
+    for l in range(n_layers):                                   # submission order: stage-major, or band-major (flag 2)
+        order = [(tag, i) for i in range(K) for tag in tags] if flags & 2 else [(tag, i) for tag in tags for i in range(K)]
+        for tag, i in order:
+            idx, t, stream, a = kernels[pos]
+            pos += 1
+            assert t == tag and stream == bands[i].stream, (l, tag, i, t, hex(stream))
+            assert int(a["n"]) == bands[i].n
+            by[(l, tag[0], i)] = (idx, a)
+    for i in range(1, K):                                       # flag 1: one stage apart — band i's first launch is
+        staggered = by[(0, "T", i - 1)][0] in after[by[(0, "T", i)][0]]      # ordered behind band i - 1's first launch
+        assert staggered == bool(flags & 1)
     f4 = 4
     for l in range(n_layers):
         y = layers[l]

@@ -124,7 +124,7 @@ def _fake_ops(monkeypatch, bev_h, bev_w, log):
         return y, zq, zv
 
     def encoder_bands_forward(q0, zq0, zv0, layers, bands, spatial_shapes, level_start_index, vis_bits, bh, bw,
-                              num_levels, num_points, tsa_points):
+                              num_levels, num_points, tsa_points, flags=0):
         """csrc/encoder_bands.hip's launch sequence, on the stand-ins above (same pointer arithmetic, as slices)."""
         assert (bh, bw) == (bev_h, bev_w) and [b['m0'] for b in bands] == [0] + [b['m1'] for b in bands[:-1]]
         assert bands[-1]['m1'] == nq and len({id(b['stream']) for b in bands}) == len(bands)

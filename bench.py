@@ -114,6 +114,12 @@ def parse():
                     help="skip the short hot-path / --history 3 / hi-res passes reported under `extra`")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--step-graph", action="store_true",
+                    help="infer, experiment: capture one step (everything the stepper enqueues, side streams included) into "
+                         "a hipGraph after the warm-up and time REPLAYS — the launch-side cost of ~150 Python-driven "
+                         "launches per step becomes one graph launch.  Measured on the hot-path scope in round 4: 2.31 ms "
+                         "per replay = the eager figure (the step is GPU-bound at one rank); meant for hosts shared by "
+                         "many ranks.  No per-kernel timing in this mode (events cannot be timed inside a graph)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="plumbing only (runs without a GPU, gloo): spawn/rank env/barrier/MAX-reduce and the "
                          "one-JSON-line contract of the N-rank launch, no model")
@@ -691,6 +697,17 @@ def main():
     if args.history:    # every SCA module ran once per frame of the queue: counters per launch
         stats = [(r // (1 + args.history), n // (1 + args.history)) for r, n in stats]
 
+    run_step = stepper
+    if args.step_graph and args.mode == "infer" and args.streams == 1 and args.input == "resident-f32":
+        args.no_kernel_timing = True
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+            graph_out = stepper()           # static result buffers: valid until the next replay
+        torch.cuda.synchronize()
+        run_step = graph.replay
+    else:
+        args.step_graph = False
+
     def timed_pass(steps):
         """barrier + synchronize, `steps` steps, synchronize + barrier; MAX over ranks -> seconds"""
         if world > 1:
@@ -705,7 +722,7 @@ def main():
                 with torch.cuda.stream(lanes[step_i % len(lanes)]):
                     stepper()
             else:
-                stepper()
+                run_step()
             if args.per_step:
                 e1 = torch.cuda.Event(enable_timing=True); e1.record()
                 step_events.append((e0, e1))
@@ -792,7 +809,8 @@ def main():
                              f"prev_bev; value counts SAMPLES (queues), frames/s = value x {1 + args.history}"),
                 "mode": args.mode, "scope": stepper.scope, "input": args.input if stepper.scope == "e2e" else None,
                 "samples_per_gpu": 1, "global_batch": world,
-                "parallelism": f"dp{world}", "streams": args.streams, "hot_path_dtype": "f32",
+                "parallelism": f"dp{world}", "streams": args.streams, "step_graph": bool(args.step_graph),
+                "hot_path_dtype": "f32",
                 "linear_precision": ext.LINEAR_PRECISION,
                 "backbone_dtype": args.backbone_dtype if stepper.scope == "e2e" else None,
                 "hot_feat_format": None if stepper.scope == "e2e" else (

@@ -465,11 +465,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
             for m0, m1, h in row_bands(bev_h, bev_w, k):
                 order = torch.from_numpy(bev_tile_order(h, bev_w, n_xcd=8)).to(device)
                 bands.append(dict(m0=m0, m1=m1, order=order, ref_2d=hybrid_ref_2d[:, m0:m1].float().contiguous()))
-            # OCC_ROW_PIPELINE_STREAMS=0 (debugging): every band on the caller's stream — the banded launches, in order
-            one = os.environ.get("OCC_ROW_PIPELINE_STREAMS", "1") == "0"
             plan = dict(key=key, bands=bands, src=hybrid_ref_2d,
-                        streams=[torch.cuda.current_stream(device) if one else torch.cuda.Stream(device=device)
-                                 for _ in bands])
+                        streams=[torch.cuda.Stream(device=device) for _ in bands])
             self._row_plan = plan
         return plan
 
@@ -488,6 +485,9 @@ class BEVFormerEncoder(TransformerLayerSequence):
         main = torch.cuda.current_stream(dev)
         plan = self._row_pipeline_plan(bev_h, bev_w, k, hybrid_ref_2d, dev)
         bands, streams = plan['bands'], plan['streams']
+        if os.environ.get("OCC_ROW_PIPELINE_STREAMS", "1") == "0":     # (debugging) every band on the CALLER's stream —
+            streams = [main] * len(bands)                               # resolved per call: it may be a capturing stream
+            plan = dict(plan, streams=streams)
         if _ROW_PIPELINE_NATIVE:
             return self._forward_row_pipeline_native(plan, bev_query, value, bev_pos, bev_h, bev_w, reference_points_cam,
                                                      spatial_shapes, level_start_index, vis_bits, gather_stats)

@@ -52,10 +52,12 @@ with torch.no_grad():
     prod(x, metas)
     torch.cuda.synchronize()
     want = list(std)
-    for one in ("plain", "noserial", "xbarrier", "xbarrier+noserial"):
-        os.environ["OCC_ROW_PIPELINE_STREAMS"] = "1"
-        os.environ["OCC_ROW_PIPELINE_DEBUG_SYNC"] = "2" if "xbarrier" in one else "0"
-        enc_mod._ROW_PIPELINE_SERIAL = "noserial" not in one
+    # (profiles/r04_rowpipe_debug3.log was written by an earlier cut of this list: its "plain" = "serial" here, its
+    # "noserial" = "default")
+    for one in ("default", "one stream", "serial", "serial+sync", "serial+xbarrier"):
+        os.environ["OCC_ROW_PIPELINE_STREAMS"] = "0" if one == "one stream" else "1"
+        os.environ["OCC_ROW_PIPELINE_DEBUG_SYNC"] = "1" if "sync" in one else "2" if "xbarrier" in one else "0"
+        enc_mod._ROW_PIPELINE_SERIAL = "serial" in one
         encoder._row_plan = None
         enc_mod._ROW_PIPELINE = k
         for rep in range(3):

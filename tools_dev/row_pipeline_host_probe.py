@@ -11,9 +11,10 @@ cfgp = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "configs",
 dev = torch.device("cuda:0")
 cfg, model, geo = bench.build(cfgp, dev)
 st = bench.Stepper(model, geo, "hotpath", "bf16", dev, seed=0, plan="folded")
-for mode, k, serial in (("standard", 0, True), ("bands=2 no-serial", 2, False), ("bands=2 serial", 2, True),
-                        ("bands=2 no-serial, one stream", 2, False)):
-    enc_mod._ROW_PIPELINE, enc_mod._ROW_PIPELINE_SERIAL = k, serial
+for mode, k, serial, native in (("standard", 0, False, False), ("bands=2", 2, False, False), ("bands=2 serial", 2, True, False),
+                                ("bands=2, one stream", 2, False, False), ("native launcher, unbanded", 1, False, True),
+                                ("native launcher, bands=2", 2, False, True), ("native launcher, bands=3", 3, False, True)):
+    enc_mod._ROW_PIPELINE, enc_mod._ROW_PIPELINE_SERIAL, enc_mod._ROW_PIPELINE_NATIVE = k, serial, native
     os.environ["OCC_ROW_PIPELINE_STREAMS"] = "0" if "one stream" in mode else "1"
     model.pts_bbox_head.transformer.encoder._row_plan = None
     for _ in range(5):

@@ -5,7 +5,9 @@
 reference takes at projects/mmdet3d_plugin/bevformer/modules/spatial_cross_attention.py:395-396 and
 temporal_self_attention.py:252-253 — from its published algorithm.
 `msda_scalar_f64` is an independent re-derivation of the CUDA kernel's per-sample arithmetic
-(Appendix B.2), used to cross-check the former.
+(Appendix B.2), used to cross-check the former.  tests/test_oracle_golden.py additionally holds the restatement bit for
+bit against the Hugging Face transformers port of the same function (Deformable-DETR's ms_deform_attn_core_pytorch, which
+mmcv vendored) — an outside implementation, though still not a reference-owned vector.
 """
 import numpy as np
 import torch

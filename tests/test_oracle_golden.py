@@ -139,3 +139,38 @@ def test_refshim_does_not_import_product_leaves():
         with open(os.path.join(here, 'oracle', name)) as f:
             lines = [l for l in f if __import__('re').match(r'\s*(from|import)\s+occnet_amd', l)]
         assert lines == [], (name, lines)
+
+
+@pytest.mark.parametrize("shapes,B,M,D,Q,P", [([(6, 9), (3, 5)], 2, 4, 8, 7, 3), ([(29, 50), (15, 25), (8, 13), (4, 7)], 1, 8, 32, 40, 8),
+                                             ([(10, 10)], 2, 8, 32, 25, 4)])
+def test_msda_restatement_equals_the_transformers_port(shapes, B, M, D, Q, P):
+    """The one function of the path whose source is NOT under /root/reference (mmcv-full's
+    multi_scale_deformable_attn_pytorch, DESIGN.md 'Oracle pinning') against an INDEPENDENT third-party port of the same
+    published function that ships in this image: Hugging Face transformers' MultiScaleDeformableAttention (a port of
+    Deformable-DETR's ms_deform_attn_core_pytorch — the function mmcv vendored).  Sampling locations reach outside [0, 1]
+    (zero padding) and sit on pixel centres / borders.  Bit-for-bit: both are the same sequence of torch ops."""
+    hf = pytest.importorskip("transformers.models.deformable_detr.modeling_deformable_detr")
+    if not hasattr(hf, "MultiScaleDeformableAttention"):
+        pytest.skip("this transformers build has no MultiScaleDeformableAttention module")
+    import oracle.msda as om
+    g = torch.Generator().manual_seed(len(shapes) * 100 + Q)
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    v = torch.randn(B, S, M, D, generator=g)
+    loc = torch.rand(B, Q, M, L, P, 2, generator=g) * 1.4 - 0.2
+    loc[0, 0, 0, :, 0] = 0.5                                    # map centre
+    loc[0, 0, 1, :, 0] = torch.tensor([0.0, 1.0])               # corners of the normalised square
+    aw = torch.softmax(torch.randn(B, Q, M, L * P, generator=g), -1).view(B, Q, M, L, P)
+    st = torch.tensor(shapes)
+    try:
+        want = hf.MultiScaleDeformableAttention()(v, st, shapes, None, loc, aw, 64)
+    except TypeError:
+        pytest.skip("MultiScaleDeformableAttention.forward signature differs in this transformers build")
+    got = om.multi_scale_deformable_attn_pytorch(v, st, loc, aw)
+    assert torch.equal(got, want)
+    # and the scalar float64 re-derivation of the CUDA kernel's arithmetic agrees with both
+    start = [0]
+    for h, w in shapes[:-1]:
+        start.append(start[-1] + h * w)
+    ref64, _ = om.msda_scalar_f64(v[:1, :, :2].numpy(), shapes, start, loc[:1, :4, :2].numpy(), aw[:1, :4, :2].numpy())
+    assert np.abs(ref64.reshape(1, 4, -1) - want[:1, :4].view(1, 4, M, D)[:, :, :2].reshape(1, 4, -1).numpy()).max() < 2e-6

@@ -174,3 +174,33 @@ def test_msda_restatement_equals_the_transformers_port(shapes, B, M, D, Q, P):
         start.append(start[-1] + h * w)
     ref64, _ = om.msda_scalar_f64(v[:1, :, :2].numpy(), shapes, start, loc[:1, :4, :2].numpy(), aw[:1, :4, :2].numpy())
     assert np.abs(ref64.reshape(1, 4, -1) - want[:1, :4].view(1, 4, M, D)[:, :, :2].reshape(1, 4, -1).numpy()).max() < 2e-6
+
+
+def test_thirdparty_leaves_against_outside_implementations():
+    """Two of the oracle-owned third-party leaves have counterparts from OUTSIDE this repository in the image: mmdet's
+    LearnedPositionalEncoding is DETR's learned position embedding (transformers' DeformableDetrLearnedPositionEmbedding:
+    column embedding | row embedding, channels first), and pyquaternion's rotation matrix is scipy's Rotation (scalar-last
+    quaternions there).  FFN / ConvModule / the loss wrappers have no outside twin here: they stay restatement against
+    restatement (test_thirdparty_restatements_agree)."""
+    from oracle import thirdparty as tp
+    hf = pytest.importorskip("transformers.models.deformable_detr.modeling_deformable_detr")
+    if hasattr(hf, "DeformableDetrLearnedPositionEmbedding"):
+        h, w, nf = 7, 9, 8
+        ours = tp.LearnedPositionalEncoding(nf, row_num_embed=50, col_num_embed=50)
+        theirs = hf.DeformableDetrLearnedPositionEmbedding(embedding_dim=nf)
+        with torch.no_grad():
+            theirs.row_embeddings.weight.copy_(ours.row_embed.weight)
+            theirs.column_embeddings.weight.copy_(ours.col_embed.weight)
+        try:
+            want = theirs(torch.Size((2, 3, h, w)), "cpu", torch.float32)
+        except TypeError:
+            want = None
+        if want is not None:
+            with torch.no_grad():
+                assert torch.equal(ours(torch.zeros(2, h, w)), want)
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(11)
+    for _ in range(8):
+        q = rng.normal(size=4)                                  # (w, x, y, z), not normalised: both sides normalise
+        want = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()
+        assert np.abs(tp.quaternion_rotation_matrix(q) - want).max() < 1e-14

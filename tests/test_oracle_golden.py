@@ -180,8 +180,9 @@ def test_thirdparty_leaves_against_outside_implementations():
     """Two of the oracle-owned third-party leaves have counterparts from OUTSIDE this repository in the image: mmdet's
     LearnedPositionalEncoding is DETR's learned position embedding (transformers' DeformableDetrLearnedPositionEmbedding:
     column embedding | row embedding, channels first), and pyquaternion's rotation matrix is scipy's Rotation (scalar-last
-    quaternions there).  FFN / ConvModule / the loss wrappers have no outside twin here: they stay restatement against
-    restatement (test_thirdparty_restatements_agree)."""
+    quaternions there); mmcv's FFN is the feed-forward block of torch.nn.TransformerEncoderLayer.  ConvModule is torch's own
+    Conv3d + BatchNorm3d + ReLU by construction; the loss wrappers stay restatement against restatement
+    (test_thirdparty_restatements_agree)."""
     from oracle import thirdparty as tp
     hf = pytest.importorskip("transformers.models.deformable_detr.modeling_deformable_detr")
     if hasattr(hf, "DeformableDetrLearnedPositionEmbedding"):
@@ -198,6 +199,15 @@ def test_thirdparty_leaves_against_outside_implementations():
         if want is not None:
             with torch.no_grad():
                 assert torch.equal(ours(torch.zeros(2, h, w)), want)
+    # mmcv FFN (two Linears, ReLU, identity added) == the feed-forward block of torch's own TransformerEncoderLayer
+    ffn = tp.FFN(embed_dims=32, feedforward_channels=64, num_fcs=2, ffn_drop=0.1, act_cfg=dict(type='ReLU', inplace=True)).eval()
+    enc = torch.nn.TransformerEncoderLayer(32, 4, dim_feedforward=64, dropout=0.1, activation="relu", batch_first=True).eval()
+    if hasattr(enc, "_ff_block"):
+        with torch.no_grad():
+            enc.linear1.weight.copy_(ffn.layers[0][0].weight); enc.linear1.bias.copy_(ffn.layers[0][0].bias)
+            enc.linear2.weight.copy_(ffn.layers[1].weight); enc.linear2.bias.copy_(ffn.layers[1].bias)
+            x = torch.randn(3, 7, 32, generator=torch.Generator().manual_seed(2))
+            assert torch.equal(ffn(x), x + enc._ff_block(x))
     from scipy.spatial.transform import Rotation
     rng = np.random.default_rng(11)
     for _ in range(8):

@@ -513,3 +513,30 @@ def test_x3linear_on_host_is_a_plain_linear():
     assert torch.equal(m(x, act='relu'), torch.relu(y))
     y.sum().backward()
     assert m.weight.grad is not None and x.grad is not None
+
+
+def test_fp16_value_range_probe_warns_once_per_weight_state():
+    """LazyFeatures._range_probe (ADVICE r3): the stacked SCA value projection's max|v| is measured once per weight state;
+    beyond the range the fp16-row parity was measured in, a warning names OCC_SCA_VALUES=f32.  Never changes what runs."""
+    import warnings
+    from occnet_amd.plugin.transformer_occ import LazyFeatures
+
+    class Owner:
+        pass
+    lf = LazyFeatures.__new__(LazyFeatures)
+    lf.owner = Owner()
+    small = torch.full((2, 4, 8), 3.0, dtype=torch.float16)
+    big = small.clone()
+    big[1, 2, 3] = -40.0
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lf._range_probe(small)
+        assert not w and lf.owner._vrange_absmax == 3.0
+        lf._range_probe(big)                                   # same weight state: not measured again
+        assert not w and lf.owner._vrange_absmax == 3.0
+        lf.owner._vrange_epoch = None
+        lf._range_probe(big)
+        assert len(w) == 1 and "OCC_SCA_VALUES=f32" in str(w[0].message) and lf.owner._vrange_absmax == 40.0
+        lf.owner._vrange_epoch = None
+        lf._range_probe(big.float())                           # fp32 rows: nothing to warn about
+        assert len(w) == 1

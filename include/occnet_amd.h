@@ -167,12 +167,15 @@ int occ_sca_fused_forward_f32(const float* value, const int64_t* spatial_shapes,
  * value_f16[b * NC + c][pix >> 1][head (M)][pix & 1][D] fp16, pix = level_start + y * W + x, so the two x-neighbours
  * (2k, 2k + 1) of one head share one 128-byte line; S = pixel rows per camera entry INCLUDING padding to an even count.
  * Sampling arithmetic, attention weights and accumulation stay fp32 (v_fma_mix_f32); the value elements carry 11
- * significant bits. */
+ * significant bits.  value_scale: NULL, or a DEVICE float s (a power of two): the maps hold s * value (what the value
+ * projections write under out_scale = occ_value_range_scale_bf16's result, so that no finite feature map can pass the
+ * fp16 limit); the kernel divides its fp32 sums by count * s — exact, the result does not depend on s.  (abi 2) */
 int occ_sca_fused_forward_f16v(const void* value_f16, const int64_t* spatial_shapes,
                                const int64_t* level_start_index, const float* offs, int64_t offs_stride,
                                const float* logits, int64_t logits_stride, const float* ref_cam,
                                const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats,
-                               int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq, void* stream);
+                               int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq,
+                               const float* value_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused temporal self-attention gather over the 2-deep BEV queue (single level):
@@ -372,7 +375,7 @@ typedef struct OccBand {
 } OccBand;
 typedef struct OccBandLayer {
   const void* wA; const float* biasA; const float* ln0_g; const float* ln0_b; float ln0_eps;
-  const void* plane; void* plane_ready; uint64_t* stats;
+  const void* plane; void* plane_ready; const float* plane_scale; uint64_t* stats;
   const void* wB; const float* biasB; const float* ln1_g; const float* ln1_b; float ln1_eps;
   const float* ln2_g; const float* ln2_b; float ln2_eps;
   const float* q_term; int64_t ldq_term; int32_t nq_tail;
@@ -466,23 +469,41 @@ int occ_value_proj_bf16_f32(int n_segments, const void* const* a, const int64_t*
                             float* out, int64_t ldo, int K, int N, int64_t out_group_rows, void* stream);
 /* same with the output written as fp16 for occ_sca_fused_forward_f16v, IN ITS PIXEL-PAIR ORDER: row r = out_row0[s] + i of
  * group g's block lands at out[(g*out_group_rows + (r & ~1)) * ldo + (n / 32) * 64 + (r & 1) * 32 + n % 32].  Needs
- * ldo == N, N % 32 == 0, out_group_rows even (pad an odd pixel count by one row). */
+ * ldo == N, N % 32 == 0, out_group_rows even (pad an odd pixel count by one row).  out_scale: NULL, or a DEVICE float:
+ * out = fp16(out_scale[0] * (a . W^T + group_bias)) — the range scale of occ_value_range_scale_bf16 (abi 2). */
 int occ_value_proj_bf16_f16pairs(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
                             const int64_t* rows_per_group, const int64_t* out_row0,
                             const float* const* group_bias, int bias_groups, const void* weight_packed,
-                            void* out, int64_t ldo, int K, int N, int64_t out_group_rows, void* stream);
+                            void* out, int64_t ldo, int K, int N, int64_t out_group_rows, const float* out_scale,
+                            void* stream);
+
+/* Range-safe fp16 value rows (csrc/value_range.hip).  The reference keeps the SCA value rows in fp32
+ * (spatial_cross_attention.py:75,387-390, @force_fp32); stored as fp16 a plane whose values pass 65 504 would be clamped.
+ * This call derives, on the device and per call, one POWER-OF-TWO scale per projection plane from an a-priori bound:
+ *     |a . W_p^T + gb_p|  <=  max|a| * row_l1[p] + bias_max[p],      row_l1[p] = max_n sum_k |W_p[n][k]|,
+ *     scale_out[p] = 2^(15 - e) with bound_p = m 2^e, m in [0.5, 1)   (bound_p * scale <= 2^15 = half of the fp16 limit)
+ * so no finite input can saturate; a zero / Inf / NaN bound gives 1.  max|a| is measured over every segment (bf16 rows,
+ * K % 8 == 0, lda % 8 == 0); row_l1 / bias_max: HOST arrays of n_planes (<= 8) floats, constants of the weight state.
+ * scale_out: DEVICE floats [0, n_planes) scales, [n_planes] max|a|, [n_planes + 1, 2 n_planes + 1) the bounds.
+ * work: two DEVICE words, zero before the first call; the kernel leaves them zero (calls sharing `work` must be
+ * stream-ordered).  Scaling by a power of two is exact both ways: results equal the unscaled fp16-row path's wherever
+ * that one does not saturate. */
+int occ_value_range_scale_bf16(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows, int K,
+                               int n_planes, const float* row_l1, const float* bias_max, float* scale_out,
+                               uint32_t* work, void* stream);
 
 /* Several projections of the SAME rows in one launch — the four encoder layers' SCA value projections depend on the
  * camera features only (spatial_cross_attention.py:366 in each of the 4 layers): weight_packed = pack of the
  * (n_planes * plane_cols, K) stacked weights, group_bias[s] (bias_groups, n_planes * plane_cols); projection p writes
  * plane p of `out` (planes plane_stride elements apart, rows of ldo elements, plane_cols columns; fp16 when out_f16) just
  * as the single-projection calls above would.  The column blocks of a row block are dealt to one XCD back to back: the
- * feature maps are read from HBM once instead of once per layer.  plane_cols % 256 == 0, otherwise OCC_E_UNSUPPORTED. */
+ * feature maps are read from HBM once instead of once per layer.  plane_cols % 256 == 0, otherwise OCC_E_UNSUPPORTED.
+ * out_scale: NULL, or n_planes DEVICE floats: plane p is multiplied by out_scale[p] before it is stored (abi 2). */
 int occ_value_proj_bf16_planes(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
                                const int64_t* rows_per_group, const int64_t* out_row0,
                                const float* const* group_bias, int bias_groups, const void* weight_packed, void* out,
                                int out_f16, int64_t ldo, int K, int n_planes, int plane_cols, int64_t plane_stride,
-                               int64_t out_group_rows, void* stream);
+                               int64_t out_group_rows, const float* out_scale, void* stream);
 
 /* ResNet stem in one launch (outside the hand-written hot path):
  *   out = max_pool2d(relu(conv2d(x, W 7x7, stride 2, pad 3) + bias), kernel 3, stride 2, pad 1)

@@ -32,6 +32,7 @@ def declared_symbols(header=HEADER_PATH):
 
 
 _lib = None
+ABI = 2     # include/occnet_amd.h: bumped whenever a signature changes (2: range scales of the fp16 value rows)
 
 
 def lib():
@@ -44,6 +45,10 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.occ_last_error.restype = ctypes.c_char_p
         _lib.occ_abi_version.restype = ctypes.c_int
+        if _lib.occ_abi_version() != ABI:
+            got, _lib = _lib.occ_abi_version(), None
+            raise OccAmdError(f"{LIB_PATH} has C ABI {got}, this package binds ABI {ABI}: rebuild it "
+                              "(`python -m occnet_amd.build`)")
     return _lib
 
 

@@ -12,5 +12,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace occ
 
-extern "C" int occ_abi_version(void) { return 1; }
+extern "C" int occ_abi_version(void) { return 2; }
 extern "C" const char* occ_last_error(void) { return occ::g_err; }

@@ -153,7 +153,7 @@ extern "C" int occ_encoder_bands_forward_f32(const float* q0, const float* zq0, 
         rc = planes_f16
                  ? occ_sca_fused_forward_f16v(y.plane, spatial_shapes, level_start_index, b.lin, n_lin, b.lin + sca_noff,
                                               n_lin, b.ref_cam, vis_bits + b.m0, b.order, b.slots, y.stats, 1, NC, S, M, D, L,
-                                              P, Z, b.n, st[i])
+                                              P, Z, b.n, y.plane_scale, st[i])
                  : occ_sca_fused_forward_f32(reinterpret_cast<const float*>(y.plane), spatial_shapes, level_start_index,
                                              b.lin, n_lin, b.lin + sca_noff, n_lin, b.ref_cam, vis_bits + b.m0, b.order,
                                              b.slots, y.stats, 1, NC, S, M, D, L, P, Z, b.n, st[i]);

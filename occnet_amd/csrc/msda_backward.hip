@@ -562,8 +562,13 @@ __global__ __launch_bounds__(256) void msda_bwd_replay_det_kernel(
     float* __restrict__ grad_value, int S, int M, int L, int Lq, int bins_per_bm) {
   constexpr int D = 32;
   extern __shared__ long long acc_d[];                 // [8 half-waves][(kBinPix + 1) * D]
+  // a non-finite contribution (Inf / NaN in grad_output) has no fixed-point image: the pixels it touches are written as
+  // NaN, like the float path would leave them, instead of the finite garbage of a saturated conversion
+  __shared__ int bad_px[kBinPix + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ch = lane & 31;
   if ((int)blockIdx.x >= work_count[0]) return;
+  if (tid <= kBinPix) bad_px[tid] = 0;
+  __syncthreads();
   const int4 wk = work[blockIdx.x];
   const long bin_g = wk.x;
   const int beg = wk.y, end = wk.z;
@@ -592,8 +597,11 @@ __global__ __launch_bounds__(256) void msda_bwd_replay_det_kernel(
     const BwdItem it = items[idx];
     const float g = go[(long)(it.qpl >> 5) * M * D];
     const int pl = it.qpl & 31;
-    acc[pl * D + ch] += __double2ll_rn((double)(g * it.w0) * scale);
-    acc[(pl + 1) * D + ch] += __double2ll_rn((double)(g * it.w1) * scale);
+    const float c0 = g * it.w0, c1 = g * it.w1;
+    if (!(fabsf(c0) < 3.0e38f)) bad_px[pl] = 1;
+    else acc[pl * D + ch] += __double2ll_rn((double)c0 * scale);
+    if (!(fabsf(c1) < 3.0e38f)) bad_px[pl + 1] = 1;
+    else acc[(pl + 1) * D + ch] += __double2ll_rn((double)c1 * scale);
   }
   __syncthreads();
   const int p0 = bl * kBinPix, np = min(kBinPix, HW - p0);
@@ -603,7 +611,9 @@ __global__ __launch_bounds__(256) void msda_bwd_replay_det_kernel(
     long long sum = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) sum += acc_d[k * (kBinPix + 1) * D + px * D + c];
-    grad_value[((b * S + st + p0 + px) * M + m) * D + c] += (float)((double)sum * inv);     // the bin's only writer
+    float* dst = grad_value + ((b * S + st + p0 + px) * M + m) * D + c;                      // the bin's only writer
+    if (bad_px[px]) *dst = __builtin_nanf("");
+    else *dst += (float)((double)sum * inv);
   }
 }
 
@@ -841,6 +851,13 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
                          grad_sampling_loc, grad_attn_weight, nullptr, S, M, L, Lq, P, n_items);
     }
   } else {
+    {
+      const char* det_env = getenv("OCC_MSDA_BWD_DETERMINISTIC");
+      if (det_env != nullptr && det_env[0] == '1') {     // the generic kernel sums with float atomics: say so, do not pretend
+        set_error("ms_deform_attn_backward: OCC_MSDA_BWD_DETERMINISTIC=1 exists for D = 32 only (D = %d)", D);
+        return OCC_E_UNSUPPORTED;
+      }
+    }
     const int per_block = 256 / D > 0 ? 256 / D : 1;
     const int threads = per_block * D;
     const long blocks = (n_items + per_block - 1) / per_block;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     const float* __restrict__ logits, long logits_stride, const float* __restrict__ ref_cam,
     const uint32_t* __restrict__ vis_bits, const int32_t* __restrict__ order,
     float* __restrict__ slots, unsigned long long* __restrict__ stats, int B, int NC, int S, int Z,
-    int Nq) {
+    int Nq, const float* __restrict__ value_scale) {
   constexpr int M = 8, D = 32, LP = L * P;
   constexpr int K = M * LP / 64;  // samples resolved per lane
   static_assert(LP >= 8 && LP <= 32 && (LP & (LP - 1)) == 0, "L*P must be a power of two in [8,32]");
@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     ++n_rows;
   }
 
-  const float inv = (float)(count > 0 ? count : 1);
+  // value_scale: the power-of-two range scale s the projection stored the fp16 rows with (value_range.hip); dividing by
+  // count * s undoes it exactly
+  const float inv = (float)(count > 0 ? count : 1) * (value_scale != nullptr ? *value_scale : 1.f);
   // the two sample halves of a head sit 32 lanes apart
   acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32);
   acc.w += __shfl_xor(acc.w, 32);
@@ -309,12 +311,12 @@ static int launch_sca_h(const void* value, const int64_t* shapes, const int64_t*
                         const float* offs, long offs_stride, const float* logits, long logits_stride,
                         const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
                         float* slots, uint64_t* stats, int B, int NC, int S, int Z, int Nq,
-                        hipStream_t st) {
+                        hipStream_t st, const float* value_scale) {
   const long waves = (long)B * Nq;
   const long blocks = (waves + kScaWaves - 1) / kScaWaves;
   hipLaunchKernelGGL((sca_fused_h_kernel<L, P, WPS, DEPTH>), dim3((unsigned)blocks), dim3(256), 0, st, value,
                      shapes, lstart, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits,
-                     order, slots, reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq);
+                     order, slots, reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq, value_scale);
   OCC_CHECK_LAUNCH("sca_fused_forward_f16v");
   return OCC_OK;
 }
@@ -326,7 +328,8 @@ static int sca_dispatch(const void* value, bool halfv, const int64_t* spatial_sh
                         const int64_t* level_start_index, const float* offs, int64_t offs_stride,
                         const float* logits, int64_t logits_stride, const float* ref_cam,
                         const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats, int B,
-                        int NC, int S, int M, int D, int L, int P, int Z, int Nq, void* stream) {
+                        int NC, int S, int M, int D, int L, int P, int Z, int Nq, void* stream,
+                        const float* value_scale = nullptr) {
   OCC_CHECK_ARG(value && spatial_shapes && level_start_index && offs && logits && ref_cam &&
                     vis_bits && slots,
                 "sca_fused_forward: null pointer argument");
@@ -349,7 +352,8 @@ static int sca_dispatch(const void* value, bool halfv, const int64_t* spatial_sh
   if (L == LL && P == PP) {                                                                        \
     if (halfv)                                                                                     \
       return launch_sca_h<LL, PP>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits,     \
-                                  (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st); \
+                                  (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
+                                  value_scale);                                                                  \
     return launch_sca<LL, PP>(reinterpret_cast<const float*>(value), spatial_shapes, level_start_index, offs,    \
                               (long)offs_stride, logits, (long)logits_stride, ref_cam, vis_bits, order, slots,   \
                               stats, B, NC, S, Z, Nq, st);                                                       \
@@ -381,7 +385,9 @@ extern "C" int occ_sca_fused_forward_f16v(const void* value_f16, const int64_t* 
                                           int64_t logits_stride, const float* ref_cam,
                                           const uint32_t* vis_bits, const int32_t* order,
                                           float* slots, uint64_t* stats, int B, int NC, int S, int M,
-                                          int D, int L, int P, int Z, int Nq, void* stream) {
+                                          int D, int L, int P, int Z, int Nq, const float* value_scale,
+                                          void* stream) {
   return occ::sca_dispatch(value_f16, true, spatial_shapes, level_start_index, offs, offs_stride, logits,
-                           logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, M, D, L, P, Z, Nq, stream);
+                           logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, M, D, L, P, Z, Nq, stream,
+                           value_scale);
 }

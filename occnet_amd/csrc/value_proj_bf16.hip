@@ -57,7 +57,7 @@ struct VpSegments {
 template <int NT, int RT, bool OUTH>
 __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
     VpSegments seg, const uint4* __restrict__ wp, int bias_groups, void* __restrict__ out_, long ldo, int N,
-    int K, long out_group_rows, int ncb, int plane_cols, long plane_stride) {
+    int K, long out_group_rows, int ncb, int plane_cols, long plane_stride, const float* __restrict__ out_scale) {
   float* __restrict__ out = reinterpret_cast<float*>(out_);
   // (row block rb, column block n0).  One projection: the grid's x / y.  Stacked projections (ncb > 1, several layers'
   // weights along N): the ncb column blocks of a row block must read its 32-64 KB of feature rows from the SAME L2, so
@@ -193,6 +193,10 @@ __global__ __launch_bounds__(256, 2) void value_proj_bf16_kernel(
         }
         // column n lives in output plane n / plane_cols (one plane per stacked projection), column n % plane_cols
         const int nn = n0 + c;
+        if (out_scale != nullptr) {      // the plane's power-of-two range scale (value_range.hip): exact
+          const float s = out_scale[nn / plane_cols];
+          v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        }
         const long eo = (long)(nn / plane_cols) * plane_stride + (g * out_group_rows + out_row0 + i) * ldo + nn % plane_cols;
         if (OUTH) {
           // fp16 maps are the SCA gather's operand: pixel-PAIR layout [group][pix >> 1][head][pix & 1][32] (sca_fused.hip),
@@ -239,7 +243,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <bool OUTH>
 __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
     VpSegments seg, const uint4* __restrict__ wp, int bias_groups, void* __restrict__ out_, long ldo, int N,
-    long out_group_rows, int plane_cols, long plane_stride) {
+    long out_group_rows, int plane_cols, long plane_stride, const float* __restrict__ out_scale) {
   extern __shared__ __attribute__((aligned(16))) char vlds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int vi = lane & 31, kb = lane >> 5;
@@ -372,6 +376,8 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
     int elane = lane;                               // opaque per pass: the store offsets are recomputed here instead of
     asm volatile("" : "+v"(elane));                 // living (spilled) across the k loop
     const int plane = nw / plane_cols, pcol = nw - plane * plane_cols;     // the wave's 64 columns lie in one plane
+    // the plane's power-of-two range scale (value_range.hip; exact): the fp16 rows of a plane cannot saturate
+    const float osc = out_scale != nullptr ? out_scale[plane] : 1.f;
     char* const obase = reinterpret_cast<char*>(out_) + ((long)plane * plane_stride + pcol) * EB;
     char* const pbase = reinterpret_cast<char*>(out_) + (long)plane * plane_stride * EB;     // plane base (pair layout)
 #pragma unroll
@@ -384,15 +390,16 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               *reinterpret_cast<uint2*>(scratch + vi * kVprPitch + 16 * q + 8 * kb) =
-                  make_uint2(vp_sat_half2(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1]),
-                             vp_sat_half2(acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]));
+                  make_uint2(vp_sat_half2(acc[rt][t][4 * q + 0] * osc, acc[rt][t][4 * q + 1] * osc),
+                             vp_sat_half2(acc[rt][t][4 * q + 2] * osc, acc[rt][t][4 * q + 3] * osc));
             }
           } else {
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
               const int q = 2 * rd + qq;
               *reinterpret_cast<float4*>(scratch + vi * kVprPitch + 32 * qq + 16 * kb) =
-                  make_float4(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1], acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3]);
+                  make_float4(acc[rt][t][4 * q + 0] * osc, acc[rt][t][4 * q + 1] * osc, acc[rt][t][4 * q + 2] * osc,
+                              acc[rt][t][4 * q + 3] * osc);
             }
           }
           wave_lds_sync();
@@ -431,7 +438,7 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
                                   const int64_t* out_row0, const float* const* group_bias,
                                   int bias_groups, const void* weight_packed, void* out, int64_t ldo,
                                   int K, int N, int64_t out_group_rows, bool out_f16, void* stream,
-                                  int plane_cols = 0, int64_t plane_stride = 0) {
+                                  int plane_cols = 0, int64_t plane_stride = 0, const float* out_scale = nullptr) {
   using namespace occ;
   OCC_CHECK_ARG(a && lda && rows && rows_per_group && out_row0 && weight_packed && out,
                 "value_proj_bf16: null pointer argument");
@@ -491,7 +498,7 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
       if (e == hipSuccess)
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), kVprLdsBytes, st, seg,
                            reinterpret_cast<const uint4*>(weight_packed), bias_groups, out, (long)ldo, N,
-                           (long)out_group_rows, plane_cols, (long)plane_stride);
+                           (long)out_group_rows, plane_cols, (long)plane_stride, out_scale);
       return e;
     };
     const hipError_t e = out_f16 ? launch(value_proj_resident_kernel<true>) : launch(value_proj_resident_kernel<false>);
@@ -511,7 +518,7 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
                           : dim3((unsigned)blocks, (unsigned)((N + BNN - 1) / BNN)),                \
                      dim3(256), 0, st, seg, reinterpret_cast<const uint4*>(weight_packed), bias_groups, out, \
                      (long)ldo, N, K, (long)out_group_rows, walk ? (N + BNN - 1) / BNN : 1, plane_cols, \
-                     (long)plane_stride)
+                     (long)plane_stride, out_scale)
 #define OCC_VP_LAUNCH_(NTT, BNN, RTT) do { if (out_f16) OCC_VP_LAUNCH__(NTT, BNN, RTT, true); else OCC_VP_LAUNCH__(NTT, BNN, RTT, false); } while (0)
 #define OCC_VP_LAUNCH(NTT, BNN) do { if (bm == 128) OCC_VP_LAUNCH_(NTT, BNN, 4); else OCC_VP_LAUNCH_(NTT, BNN, 2); } while (0)
   if (N <= 128) OCC_VP_LAUNCH(1, 128); else OCC_VP_LAUNCH(2, 256);
@@ -538,9 +545,9 @@ extern "C" int occ_value_proj_bf16_f16pairs(int n_segments, const void* const* a
                                        const int64_t* rows, const int64_t* rows_per_group,
                                        const int64_t* out_row0, const float* const* group_bias,
                                        int bias_groups, const void* weight_packed, void* out, int64_t ldo,
-                                       int K, int N, int64_t out_group_rows, void* stream) {
+                                       int K, int N, int64_t out_group_rows, const float* out_scale, void* stream) {
   return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
-                                weight_packed, out, ldo, K, N, out_group_rows, true, stream);
+                                weight_packed, out, ldo, K, N, out_group_rows, true, stream, 0, 0, out_scale);
 }
 
 // Several projections of the SAME rows in one launch (the four encoder layers' SCA value projections depend on the
@@ -553,7 +560,7 @@ extern "C" int occ_value_proj_bf16_planes(int n_segments, const void* const* a, 
                                           const int64_t* out_row0, const float* const* group_bias,
                                           int bias_groups, const void* weight_packed, void* out, int out_f16,
                                           int64_t ldo, int K, int n_planes, int plane_cols, int64_t plane_stride,
-                                          int64_t out_group_rows, void* stream) {
+                                          int64_t out_group_rows, const float* out_scale, void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(n_planes > 0 && plane_cols > 0 && plane_stride > 0, "value_proj_bf16_planes: bad plane geometry");
   if (plane_cols % 256) {
@@ -562,5 +569,5 @@ extern "C" int occ_value_proj_bf16_planes(int n_segments, const void* const* a, 
   }
   return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
                                 weight_packed, out, ldo, K, n_planes * plane_cols, out_group_rows, out_f16 != 0, stream,
-                                plane_cols, plane_stride);
+                                plane_cols, plane_stride, out_scale);
 }

@@ -1,0 +1,158 @@
+// Range-safe fp16 value rows for the SCA gather (the reference keeps these rows in fp32:
+// `spatial_cross_attention.py:75,387-390`, @force_fp32).
+//
+// The projected value maps are stored as fp16 (sca_fused.hip): 11 significant bits, largest finite value 65 504.
+// A plane whose values pass that limit would be clamped silently (round 4 warned about |v| = 1.8e4 on the benchmarked
+// maps: 3.6x below the limit).  Here every plane gets a POWER-OF-TWO scale s, chosen per call and on the device from
+// an a-priori bound of the plane's values, so that no finite input can saturate:
+//
+//     |v[n]| = |sum_k x[k] W[n][k] + gbias[n]|  <=  max|x| * max_n sum_k |W[n][k]|  +  max|gbias|  =: bound
+//     s = 2^(15 - e),  bound = m * 2^e with m in [0.5, 1)      =>      |v * s| <= 2^15 = half of the fp16 limit
+//
+// max|x| is measured here (one pass over the bf16 feature maps, 16-bit integer maxima of the sign-stripped patterns:
+// two elements per VALU op, HBM/MALL-bound); the two weight-side terms are constants of the weight state and arrive
+// from the host.  The projection multiplies its fp32 accumulators by s before the fp16 conversion, the gather divides
+// its fp32 result by count * s: both are exact (power of two), so the only effect of the scale is WHERE the fp16
+// exponent window sits — fp16's relative precision is the same anywhere in its normal range (2^-14 .. 2^16), and with
+// the bound at 2^15 values down to 2^-29 of the bound are still normal numbers.  Inf / NaN in the maps give s = 1 (such
+// rows are Inf / NaN in the fp32 path as well).
+//
+// One launch, self-cleaning: the blocks fold their maxima into work[0] (atomic max), take a ticket from work[1], and
+// the last block to finish derives the scales and resets both words for the next call on the stream.
+#include "common.h"
+
+namespace occ {
+
+constexpr int kVrMaxSeg = 8, kVrMaxPlanes = 8;
+struct VrSegments {
+  const uint4* a[kVrMaxSeg];
+  long rows[kVrMaxSeg], lda8[kVrMaxSeg];
+  int n;
+};
+struct VrPlanes {
+  float row_l1[kVrMaxPlanes], bias_max[kVrMaxPlanes];
+  int n;
+};
+
+typedef unsigned short vr_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned vr_absmax2(unsigned m, unsigned x) {   // v_and + v_pk_max_u16
+  const vr_u16x2 a = __builtin_bit_cast(vr_u16x2, m), b = __builtin_bit_cast(vr_u16x2, x & 0x7fff7fffu);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(a, b));
+}
+__device__ __forceinline__ unsigned vr_absmax8(unsigned m, const uint4 v) {
+  return vr_absmax2(vr_absmax2(vr_absmax2(vr_absmax2(m, v.x), v.y), v.z), v.w);
+}
+
+// s = 2^(15 - e) for bound = m 2^e; 1 when the bound is zero, Inf or NaN
+__device__ __forceinline__ float vr_scale_of(float bound) {
+  if (!(bound > 0.f) || !(bound < __builtin_huge_valf())) return 1.f;
+  int e;
+  (void)frexpf(bound, &e);
+  int k = 15 - e;
+  k = k < -100 ? -100 : k > 100 ? 100 : k;       // s and 1/s stay normal fp32 numbers
+  return ldexpf(1.f, k);
+}
+
+__global__ __launch_bounds__(256) void value_range_scale_kernel(VrSegments seg, int K8, VrPlanes planes,
+                                                                float* __restrict__ scale_out,
+                                                                unsigned* __restrict__ work) {
+  __shared__ unsigned smax[4];
+  const long stride = (long)gridDim.x * 256;
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+  unsigned m = 0;
+  for (int s = 0; s < seg.n; ++s) {
+    const uint4* __restrict__ a = seg.a[s];
+    const long lda8 = seg.lda8[s];
+    const long n = seg.rows[s] * K8;
+    if (lda8 == K8) {                 // contiguous rows (the NHWC maps): four independent 16-byte loads per round
+      long i = tid;
+      for (; i + 3 * stride < n; i += 4 * stride) {
+        const uint4 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+        m = vr_absmax8(vr_absmax8(vr_absmax8(vr_absmax8(m, v0), v1), v2), v3);
+      }
+      for (; i < n; i += stride) m = vr_absmax8(m, a[i]);
+    } else {
+      for (long i = tid; i < n; i += stride) {
+        const long r = i / K8;
+        m = vr_absmax8(m, a[r * lda8 + (i - r * K8)]);
+      }
+    }
+  }
+  unsigned m16 = (m & 0xffffu) > (m >> 16) ? (m & 0xffffu) : (m >> 16);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)m16, d);
+    m16 = o > m16 ? o : m16;
+  }
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m16;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned b = smax[0];
+    for (int w = 1; w < 4; ++w) b = smax[w] > b ? smax[w] : b;
+    if (b) atomicMax(&work[0], b);
+    __threadfence();
+    const unsigned ticket = atomicAdd(&work[1], 1u);
+    if (ticket == gridDim.x - 1) {
+      __threadfence();
+      const unsigned bits = atomicExch(&work[0], 0u);        // read + reset for the next call
+      atomicExch(&work[1], 0u);
+      const float amax = __uint_as_float(bits << 16);        // bf16 pattern -> f32 (Inf / NaN patterns stay what they are)
+      scale_out[planes.n] = amax;
+      for (int p = 0; p < planes.n; ++p) {
+        // 2^-8 of slack on the weight term: the kernel's hi/lo bf16 weight split and fp32 accumulation are exact to
+        // 2^-17 of |x|.|w|, far inside it (and the target leaves another factor of two below the fp16 limit)
+        const float bound = planes.row_l1[p] * amax * 1.00390625f + planes.bias_max[p];
+        scale_out[p] = vr_scale_of(bound);
+        scale_out[planes.n + 1 + p] = bound;
+      }
+    }
+  }
+}
+
+}  // namespace occ
+
+extern "C" int occ_value_range_scale_bf16(int n_segments, const void* const* a, const int64_t* lda,
+                                          const int64_t* rows, int K, int n_planes, const float* row_l1,
+                                          const float* bias_max, float* scale_out, uint32_t* work, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(a && lda && rows && row_l1 && bias_max && scale_out && work,
+                "value_range_scale: null pointer argument");
+  OCC_CHECK_ARG(n_segments > 0 && n_segments <= kVrMaxSeg, "value_range_scale: 1..%d segments", kVrMaxSeg);
+  OCC_CHECK_ARG(n_planes > 0 && n_planes <= kVrMaxPlanes, "value_range_scale: 1..%d planes", kVrMaxPlanes);
+  OCC_CHECK_ARG(K > 0, "value_range_scale: bad K");
+  if (K % 8) {
+    set_error("value_range_scale: K=%d is not a multiple of 8 (16-byte pieces)", K);
+    return OCC_E_UNSUPPORTED;
+  }
+  VrSegments seg;
+  long pieces = 0;
+  for (int i = 0; i < kVrMaxSeg; ++i) {
+    const int j = i < n_segments ? i : n_segments - 1;
+    OCC_CHECK_ARG(a[j] && rows[j] > 0 && lda[j] >= K, "value_range_scale: bad segment %d", j);
+    if (lda[j] % 8) {
+      set_error("value_range_scale: segment %d row stride %ld is not 16-byte aligned", j, (long)lda[j]);
+      return OCC_E_UNSUPPORTED;
+    }
+    seg.a[i] = reinterpret_cast<const uint4*>(a[j]);
+    seg.rows[i] = rows[j];
+    seg.lda8[i] = lda[j] / 8;
+    if (i < n_segments) pieces += rows[j] * (K / 8);
+  }
+  seg.n = n_segments;
+  VrPlanes pl;
+  for (int p = 0; p < kVrMaxPlanes; ++p) {
+    const int j = p < n_planes ? p : n_planes - 1;
+    OCC_CHECK_ARG(!(row_l1[j] < 0.f) && !(bias_max[j] < 0.f), "value_range_scale: negative bound term for plane %d", j);
+    pl.row_l1[p] = row_l1[j];
+    pl.bias_max[p] = bias_max[j];
+  }
+  pl.n = n_planes;
+  // four 16-byte loads per thread and round; no more blocks than that needs, at most 8 per CU
+  long blocks = (pieces + 4 * 256 - 1) / (4 * 256);
+  blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+  hipLaunchKernelGGL(value_range_scale_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), seg, K / 8, pl, scale_out, work);
+  OCC_CHECK_LAUNCH("value_range_scale");
+  return OCC_OK;
+}

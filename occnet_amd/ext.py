@@ -196,14 +196,22 @@ def sca_unpair_layout(value_pairs, S=None):
 
 
 def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, ref_cam, vis_bits,
-                      num_heads, num_levels, num_points, order=None, stats=None, value_layout="rows"):
+                      num_heads, num_levels, num_points, order=None, stats=None, value_layout="rows", value_scale=None):
     """Fused SCA gather.  value (B*NC, S, M, D) float32 or float16; offs (B, Nq, M*L*P*2) / logits (B, Nq, M*L*P) may
     be column slices of one wider Linear output (last dim contiguous); ref_cam (NC,B,Nq,Z,2);
     vis_bits (B,Nq) int32.  -> slots (B, Nq, M*D) float32.
     fp16 maps reach the kernel in pixel-pair order (sca_pair_layout): value_layout="pairs" says the tensor already is
     (what value_proj_bf16 / value_proj_bf16_planes write into an fp16 output); "rows" (default) converts a row-ordered
-    fp16 tensor first (a copy: tests and the fp32-projection path only)."""
+    fp16 tensor first (a copy: tests and the fp32-projection path only).
+    value_scale (fp16 maps only): 1-element float32 device tensor s, a power of two — the maps hold s * value
+    (value_range_scale / f16_range_scaled), the kernel divides its fp32 sums by count * s: the same result, whatever s."""
     half = value.dtype == torch.float16
+    if value_scale is not None:
+        if not half:
+            raise OccAmdError("sca_fused_forward: value_scale goes with fp16 value maps")
+        if not (value_scale.is_cuda and value_scale.dtype == torch.float32 and value_scale.numel() == 1
+                and value_scale.device == value.device):
+            raise OccAmdError("sca_fused_forward: value_scale must be a 1-element float32 tensor on the value's device")
     if half:
         if value_layout not in ("rows", "pairs"):
             raise OccAmdError(f"sca_fused_forward: unknown value_layout {value_layout!r}")
@@ -235,10 +243,11 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
         raise OccAmdError("sca_fused_forward: order must be int32 (Nq)")
     slots = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
     fn = _lib.lib().occ_sca_fused_forward_f16v if half else _lib.lib().occ_sca_fused_forward_f32
+    tail = (ptr(value_scale), stream_ptr(value.device)) if half else (stream_ptr(value.device),)
     with torch.cuda.device(value.device), _timed('sca_fused_forward'):
         rc = fn(ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs), i64(offs.stride(1)), ptr(logits),
                 i64(logits.stride(1)), ptr(ref_cam), ptr(vis_bits), ptr(order), ptr(slots), ptr(stats), i32(B),
-                i32(NC), i32(S), i32(M), i32(D), i32(L), i32(P), i32(Z), i32(Nq), stream_ptr(value.device))
+                i32(NC), i32(S), i32(M), i32(D), i32(L), i32(P), i32(Z), i32(Nq), *tail)
     _lib.check(rc, "sca_fused_forward")
     return slots
 
@@ -488,14 +497,71 @@ def linear_pack_weight_bf16x3(weight):
     return packed
 
 
-def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_rows, out_row0):
+def _check_out_scale(what, out_scale, planes, out):
+    if out_scale is None:
+        return
+    if not (out_scale.is_cuda and out_scale.dtype == torch.float32 and out_scale.dim() == 1 and out_scale.is_contiguous()
+            and out_scale.numel() >= planes and out_scale.device == out.device):
+        raise OccAmdError(f"{what}: out_scale must be a contiguous float32 device vector of >= {planes} entries")
+
+
+_RANGE_WORK = {}        # (device, stream) -> the two self-resetting work words of occ_value_range_scale_bf16
+
+
+def value_range_scale(a_list, row_l1, bias_max):
+    """Per-plane power-of-two scales for fp16 storage of the projections of the bf16 feature rows `a_list` (csrc/value_range.hip):
+    -> float32 device vector t of 2 P + 1 entries, t[:P] = s_p with  (max|x| * row_l1[p] * (1 + 2^-8) + bias_max[p]) * s_p <= 2^15,
+    t[P] = max|x| over every map, t[P + 1 + p] = the bound of plane p (diagnostics).  row_l1[p] = max_n sum_k |W_p[n][k]|,
+    bias_max[p] = max |group bias of p| — host floats, constants of the weight state.  No host synchronisation; one launch on
+    the current stream.  Pass t[:P] as value_proj_bf16*(out_scale=) and t[p:p+1] as sca_fused_forward(value_scale=)."""
+    if isinstance(a_list, torch.Tensor):
+        a_list = [a_list]
+    S, P = len(a_list), len(row_l1)
+    if len(bias_max) != P:
+        raise OccAmdError("value_range_scale: row_l1 and bias_max must have one entry per plane")
+    K = a_list[0].shape[1]
+    for a in a_list:
+        if not (a.is_cuda and a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1 and a.shape[1] == K):
+            raise OccAmdUnsupported("value_range_scale: every a must be a (M, K) bfloat16 device matrix with unit column stride")
+    dev = a_list[0].device
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    work = _RANGE_WORK.get(key)
+    if work is None:
+        if len(_RANGE_WORK) >= 16:
+            _RANGE_WORK.pop(next(iter(_RANGE_WORK)))
+        work = _RANGE_WORK[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+    out = torch.empty(2 * P + 1, dtype=torch.float32, device=dev)
+    arr64 = lambda v: (ctypes.c_int64 * S)(*[int(x) for x in v])
+    arrf = lambda v: (ctypes.c_float * P)(*[float(x) for x in v])
+    a_ptrs = (ctypes.c_void_p * S)(*[a.data_ptr() for a in a_list])
+    with torch.cuda.device(dev), _timed('value_range'):
+        rc = _lib.lib().occ_value_range_scale_bf16(
+            i32(S), a_ptrs, arr64([a.stride(0) for a in a_list]), arr64([a.shape[0] for a in a_list]), i32(K), i32(P),
+            arrf(row_l1), arrf(bias_max), ptr(out), ptr(work), stream_ptr(dev))
+    _lib.check(rc, "value_range_scale")
+    return out
+
+
+def f16_range_scaled(v):
+    """fp32 value rows -> (fp16 rows holding s * v, s as a 1-element float32 device tensor), s the power of two that puts
+    max|v| into [2^14, 2^15]: the ATen counterpart of value_range_scale for value tensors that were projected in fp32 (the
+    non-LazyFeatures inputs of the fused SCA gather).  No host synchronisation; Inf / NaN / all-zero rows: s = 1."""
+    amax = v.detach().abs().amax().float()
+    _, e = torch.frexp(amax)
+    ok = torch.isfinite(amax) & (amax > 0)
+    s = torch.where(ok, torch.ldexp(torch.ones_like(amax), (15 - e).clamp(-100, 100)), torch.ones_like(amax))
+    return (v * s).clamp(-65504.0, 65504.0).half(), s.reshape(1)
+
+
+def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_rows, out_row0, out_scale=None):
     """For every segment s (FPN level) and row m = g*rows_per_group[s] + i of a_list[s]:
         out[g*out_group_rows + out_row0[s] + i] = a_list[s][m] @ weight.T + group_bias[s][g % G]   (fp32 out),
     all segments in one launch.  An fp16 `out` is the fused SCA gather's operand and is written in its pixel-PAIR
     order (sca_pair_layout: row r of a group's block lands at [r >> 1][head][r & 1][32]; out_group_rows must be even,
     N a multiple of 32, rows contiguous) — read it back in row order with sca_unpair_layout.  a_list[s] (M_s, K) bf16 with unit column stride (an NHWC feature map seen as
     pixels x channels); weight (N, K) fp32 Linear weight (packed hi/lo once, cached); group_bias (S, G, N) fp32
-    contiguous or None; out fp32 2-D (rows, N); rows_per_group / out_row0: one int per segment."""
+    contiguous or None; out fp32 2-D (rows, N); rows_per_group / out_row0: one int per segment.
+    out_scale (fp16 out only): float32 device vector, out = fp16(out_scale[0] * (...)) — value_range_scale()."""
     if isinstance(a_list, torch.Tensor):
         a_list, rows_per_group, out_row0 = [a_list], [rows_per_group], [out_row0]
         if group_bias is not None:
@@ -526,15 +592,19 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
             raise OccAmdError("value_proj_bf16: group_bias must be a contiguous (S, G, N) tensor")
         G = group_bias.shape[1]
         gb_ptrs = (ctypes.c_void_p * S)(*[group_bias[s].data_ptr() for s in range(S)])
+    if out_scale is not None and not out_half:
+        raise OccAmdError("value_proj_bf16: out_scale goes with an fp16 out")
+    _check_out_scale("value_proj_bf16", out_scale, 1, out)
     packed = linear_pack_weight_bf16x3(weight)
     arr64 = lambda v: (ctypes.c_int64 * S)(*[int(x) for x in v])
     a_ptrs = (ctypes.c_void_p * S)(*[a.data_ptr() for a in a_list])
     fn = _lib.lib().occ_value_proj_bf16_f16pairs if out_half else _lib.lib().occ_value_proj_bf16_f32
+    tail = (ptr(out_scale), stream_ptr(out.device)) if out_half else (stream_ptr(out.device),)
     with torch.cuda.device(out.device), _timed('value_proj'):
         rc = fn(
             i32(S), a_ptrs, arr64([a.stride(0) for a in a_list]), arr64([a.shape[0] for a in a_list]),
             arr64(rows_per_group), arr64(out_row0), gb_ptrs, i32(G), ptr(packed), ptr(out), i64(out.stride(0)),
-            i32(K), i32(N), i64(out_group_rows), stream_ptr(out.device))
+            i32(K), i32(N), i64(out_group_rows), *tail)
     _lib.check(rc, "value_proj_bf16")
     return out
 
@@ -558,11 +628,12 @@ def value_proj_planes_prepare(weights):
     return hit
 
 
-def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, out_group_rows, out_row0):
+def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, out_group_rows, out_row0, out_scale=None):
     """The same rows through SEVERAL projections in one launch (the encoder layers' SCA value projections):
     out[p] = value_proj_bf16(a_list, weights[p], group_biases[p], ...) for every p, feature rows read from HBM once.
     weights: list of P (N, K) fp32 Linear weights (N % 256 == 0); group_biases: list of P (S, G, N) fp32 or None;
-    out (P, rows, N) fp32 or fp16, contiguous."""
+    out (P, rows, N) fp32 or fp16, contiguous.  out_scale: float32 device vector of P per-plane factors
+    (value_range_scale()), plane p = out_scale[p] * (...)."""
     P, S = len(weights), len(a_list)
     N, K = weights[0].shape
     if any(tuple(w.shape) != (N, K) for w in weights) or N % 256:
@@ -578,6 +649,7 @@ def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, o
         groups = (a.shape[0] + rpg - 1) // rpg
         if (groups - 1) * out_group_rows + r0 + min(rpg, a.shape[0]) > out.shape[1]:
             raise OccAmdError("value_proj_bf16_planes: output rows out of range")
+    _check_out_scale("value_proj_bf16_planes", out_scale, P, out)
     hit = value_proj_planes_prepare(weights)
     gb_ptrs, G, gb_keep = None, 0, None
     if group_biases is not None and group_biases[0] is not None:
@@ -598,7 +670,8 @@ def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, o
         rc = _lib.lib().occ_value_proj_bf16_planes(
             i32(S), a_ptrs, arr64([a.stride(0) for a in a_list]), arr64([a.shape[0] for a in a_list]),
             arr64(rows_per_group), arr64(out_row0), gb_ptrs, i32(G), ptr(hit[1]), ptr(out), i32(1 if out_half else 0),
-            i64(N), i32(K), i32(P), i32(N), i64(out.stride(0)), i64(out_group_rows), stream_ptr(out.device))
+            i64(N), i32(K), i32(P), i32(N), i64(out.stride(0)), i64(out_group_rows), ptr(out_scale),
+            stream_ptr(out.device))
     _lib.check(rc, "value_proj_bf16_planes")
     return out
 
@@ -882,7 +955,8 @@ class _OccBand(ctypes.Structure):          # include/occnet_amd.h: OccBand
 class _OccBandLayer(ctypes.Structure):     # include/occnet_amd.h: OccBandLayer
     _fields_ = [("wA", ctypes.c_void_p), ("biasA", ctypes.c_void_p), ("ln0_g", ctypes.c_void_p),
                 ("ln0_b", ctypes.c_void_p), ("ln0_eps", ctypes.c_float),
-                ("plane", ctypes.c_void_p), ("plane_ready", ctypes.c_void_p), ("stats", ctypes.c_void_p),
+                ("plane", ctypes.c_void_p), ("plane_ready", ctypes.c_void_p), ("plane_scale", ctypes.c_void_p),
+                ("stats", ctypes.c_void_p),
                 ("wB", ctypes.c_void_p), ("biasB", ctypes.c_void_p), ("ln1_g", ctypes.c_void_p),
                 ("ln1_b", ctypes.c_void_p), ("ln1_eps", ctypes.c_float), ("ln2_g", ctypes.c_void_p),
                 ("ln2_b", ctypes.c_void_p), ("ln2_eps", ctypes.c_float),
@@ -969,9 +1043,10 @@ def encoder_bands_forward(q0, zq0, zv0, layers, bands, spatial_shapes, level_sta
         if tuple(y['out'].shape) != (1, Nq, 256):
             raise OccAmdError("encoder_bands_forward: out must be (1, Nq, 256)")
         ev = y.get('plane_ready')
-        keep += [wA, bA, wB, bB, g0, be0, g1, be1, g2, be2, plane, ev, q_term]
+        keep += [wA, bA, wB, bB, g0, be0, g1, be1, g2, be2, plane, ev, q_term, y.get('plane_scale')]
         c.wA, c.biasA, c.ln0_g, c.ln0_b, c.ln0_eps = _dp(wA), _dp(bA), _dp(g0), _dp(be0), eps0
         c.plane, c.plane_ready, c.stats = _dp(plane), (None if ev is None else ev.cuda_event), _dp(y.get('stats'))
+        c.plane_scale = _dp(y.get('plane_scale'))
         c.wB, c.biasB, c.ln1_g, c.ln1_b, c.ln1_eps = _dp(wB), _dp(bB), _dp(g1), _dp(be1), eps1
         c.ln2_g, c.ln2_b, c.ln2_eps = _dp(g2), _dp(be2), eps2
         c.q_term, c.ldq_term, c.nq_tail = _dp(q_term), ldq, nq

@@ -56,9 +56,11 @@ class BEVFormerOcc(BaseModule):
         """Mode switch + cache safety net.  Every derived-weight cache (packed Linear / chain weights, folded backbone
         plan, decoder / heads packs) is keyed on (address, _version) of its sources; writes through `.data`
         (param.data.copy_: mmcv's EMAHook swap before validation, manual loads) do not bump _version.  On a REAL
-        train -> eval transition the contents are therefore fingerprinted (one fused norm over all parameters and
-        buffers, one host sync) and the cache epoch is bumped when they changed since the last check; the eval <-> train
-        flips inside obtain_history_bev (twice per training step) skip it."""
+        train -> eval transition the contents are therefore fingerprinted (per tensor: 2-norm and a position-weighted sum,
+        compared element by element; one host sync) and the cache epoch is bumped when they changed since the last check
+        (the first check counts as a change); the eval <-> train flips inside obtain_history_bev (twice per training step)
+        skip it.  NOT covered: a `.data` write while the model already is in eval mode (no transition
+        to hang the check on) — call occnet_amd.invalidate_caches() after such a write."""
         was_training = self.training
         # parameters / BatchNorm statistics may change while training, and an eval() entry is where stale plans would be
         # served from: re-check the folded plan's sources at the next forward in either case
@@ -66,21 +68,30 @@ class BEVFormerOcc(BaseModule):
         out = super().train(mode)
         if was_training and not mode and not getattr(self, '_in_history', False):
             fp = self._content_fingerprint()
-            if fp is not None and fp != getattr(self, '_content_fp', None):
-                if getattr(self, '_content_fp', None) is not None:
-                    from .bricks import _bump_cache_epoch
-                    _bump_cache_epoch()
+            old = getattr(self, '_content_fp', None)
+            if fp is not None and (old is None or old.shape != fp.shape or not torch.equal(old, fp)):
+                from .bricks import _bump_cache_epoch
+                _bump_cache_epoch()
                 object.__setattr__(self, '_content_fp', fp)
         return out
 
     def _content_fingerprint(self):
-        """float64 sum of the per-tensor 2-norms of every device parameter / buffer (None on the host or without
-        floating-point tensors): changes whenever a weight is rewritten, however it was written."""
+        """(n_tensors, 2) float64 host tensor — per device parameter / buffer its 2-norm and its sum weighted by a fixed
+        pseudo-random ramp over the element index (None on the host or without floating-point tensors): changes whenever a
+        weight is rewritten, however it was written.  The weighted sum is ORDER-sensitive: a sign flip, a permutation or two
+        equal-norm tensors trading places, which a sum of norms cannot see, all move it."""
         ts = [t.detach() for t in list(self.parameters()) + list(self.buffers()) if t.is_cuda and t.is_floating_point()]
         if not ts:
             return None
+        n_max = max(t.numel() for t in ts)
+        ramp = getattr(self, '_fp_ramp', None)
+        if ramp is None or ramp.numel() < n_max or ramp.device != ts[0].device:
+            idx = torch.arange(n_max, device=ts[0].device, dtype=torch.float32)
+            ramp = torch.frac(torch.sin(idx * 12.9898 + 0.5) * 43758.5453) + 0.5           # in (-0.5, 1.5), fixed
+            object.__setattr__(self, '_fp_ramp', ramp)
         norms = torch._foreach_norm(ts)
-        return float(torch.stack([n.double() for n in norms]).sum().item())
+        dots = [torch.dot(t.reshape(-1).float(), ramp[:t.numel()]) for t in ts]
+        return torch.stack([torch.stack([n.double() for n in norms]), torch.stack([d.double() for d in dots])], 1).cpu()
 
     def _backbone_signature(self):
         mods = [m for m in (getattr(self, 'img_backbone', None), getattr(self, 'img_neck', None)) if m is not None]

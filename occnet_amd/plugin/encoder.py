@@ -533,6 +533,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
                 v4 = zv.view(1, nq, tsa.num_heads, -1)
                 wq, bq = sca.query_linear_operands()
                 plane = value.project_on(sca.deformable_attention.value_proj, streams)
+                plane_scale = value.value_scale(sca.deformable_attention.value_proj)
                 st = [dict() for _ in bands]
                 ev = {name: [None] * len(bands) for name in 'TASB'}
 
@@ -564,7 +565,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
                 def s_stage(i, b, s):
                     st[i]['slots'] = sca.gather_projected(
                         st[i]['lin'], plane, per_band[i]['ref_cam'], per_band[i]['vis'], spatial_shapes,
-                        level_start_index, b['order'], gather_stats)
+                        level_start_index, b['order'], gather_stats, value_scale=plane_scale)
 
                 def b_stage(i, b, s):
                     tail, out = None, (band(outs[lid], b), None, None)
@@ -597,6 +598,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
             for s in streams:                       # join (also when a launch raised): nothing may outlive this call
                 if s != main:
                     main.wait_stream(s)
+        if os.environ.get("OCC_ROW_PIPELINE_DEBUG_KEEP") == "1":     # (debugging: tools_dev/row_pipeline_bisect.py)
+            self._row_debug = dict(keep=keep, tails=tails, outs=outs, bands=bands)
         return outs
 
     def _forward_row_pipeline_native(self, plan, bev_query, value, bev_pos, bev_h, bev_w, reference_points_cam,
@@ -635,7 +638,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
                      b=(sca.output_proj.weight, sca.output_proj.bias, layer.norms[1], ffn.layers[0][0].weight,
                         ffn.layers[0][0].bias, ffn.layers[1].weight, ffn.layers[1].bias, layer.norms[2]),
                      plane=plane.view(plane.shape[0], plane.shape[1], sca.deformable_attention.num_heads, -1),
-                     plane_ready=ev, stats=gather_stats if gather_stats is not None else sca.gather_stats,
+                     plane_ready=ev, plane_scale=value.value_scale(sca.deformable_attention.value_proj),
+                     stats=gather_stats if gather_stats is not None else sca.gather_stats,
                      out=torch.empty((1, nq, 256), dtype=torch.float32, device=dev))
             shared.append(y['out'])
             if lid + 1 < nl:
@@ -687,7 +691,11 @@ class BEVFormerEncoder(TransformerLayerSequence):
                    for layer in self.layers for a in layer.attentions]
             value.prefetch([vp for vp in vps if vp is not None])
         # inference: the row-local Linear chains of a layer as two launches (BEVFormerLayer.forward_chain)
+        # (the chain path takes none of the mask / query_pos arguments of BEVFormerLayer.forward: a caller that passes one
+        # gets the unfused layer, never an unmasked result — ADVICE r4)
         chain = (ext.LINEAR_CHAIN and ext.LINEAR_PRECISION == "bf16x3" and not self.training and not args
+                 and all(kwargs.get(k) is None for k in ('attn_masks', 'query_key_padding_mask', 'key_padding_mask',
+                                                         'query_pos', 'mask'))
                  and bev_query.dtype == torch.float32 and value is not None
                  and not (torch.is_grad_enabled() and (bev_query.requires_grad or any(
                      p.requires_grad for p in self.parameters()))))
@@ -716,6 +724,15 @@ class BEVFormerEncoder(TransformerLayerSequence):
                             level_start_index=level_start_index, prev_bev=prev_bev, tsa_pre=tsa_pre, next_tsa=nxt,
                             bev_mask=bev_mask, gather_stats=kwargs.get('gather_stats'), **extra)
                     except ext.OccAmdUnsupported:
+                        output, tsa_pre = None, None
+                    except ext.OccAmdError as e:
+                        # a launch-side refusal (e.g. the 77.8 KB dynamic-LDS attribute of the chain kernels): the
+                        # separate launches of layer() compute the same thing
+                        if not getattr(self, '_chain_warned', False):
+                            import warnings
+                            warnings.warn(f"encoder chain kernels unavailable ({e}): this and later calls fall back to the "
+                                          f"per-op launches of BEVFormerLayer.forward")
+                            self._chain_warned = True
                         output, tsa_pre = None, None
                 if output is None:
                     tsa_pre = None

@@ -253,17 +253,18 @@ class SpatialCrossAttention(BaseModule):
         da = self.deformable_attention
         if gather_stats is None:
             gather_stats = self.gather_stats
-        layout = "rows"
+        layout, vscale = "rows", None
         if hasattr(value, 'project'):      # LazyFeatures: bf16 NHWC maps, projected level by level
             bs = value.bs
             v = value.project(da.value_proj)
+            vscale = value.value_scale(da.value_proj)                   # fp16 rows: the plane's range scale (exact)
             layout = "pairs" if v.dtype == torch.float16 else "rows"    # the projection's fp16 epilogue writes pairs
         else:
             num_cams, l, bs, _ = value.shape
             v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
             v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
             if ext.SCA_VALUES == "f16":
-                v = v.clamp(-65504.0, 65504.0).half()                   # saturating, like the projection's fp16 epilogue
+                v, vscale = ext.f16_range_scaled(v)                     # power-of-two scale: no fp16 saturation
         v = v.view(bs * self.num_cams, v.shape[1], da.num_heads, -1)
         n_off = da.sampling_offsets.out_features
         if vis_bits is None:
@@ -271,10 +272,10 @@ class SpatialCrossAttention(BaseModule):
         return ext.sca_fused_forward(v, spatial_shapes, level_start_index, lin[..., :n_off],
                                      lin[..., n_off:], reference_points_cam.float().contiguous(),
                                      vis_bits, da.num_heads, da.num_levels, da.num_points,
-                                     order=bev_order, stats=gather_stats, value_layout=layout)
+                                     order=bev_order, stats=gather_stats, value_layout=layout, value_scale=vscale)
 
     def gather_projected(self, lin, v, reference_points_cam, vis_bits, spatial_shapes, level_start_index,
-                         bev_order=None, gather_stats=None):
+                         bev_order=None, gather_stats=None, value_scale=None):
         """The gather half of fused_gather on an already projected value tensor `v` (bs*num_cams, rows, C) (fp16 =
         pixel-pair order, what LazyFeatures.project hands out).  `lin`, `reference_points_cam` (contiguous), `vis_bits`
         and `bev_order` may describe a ROW BAND of the BEV queries with band-local indices in `bev_order` (bs = 1): the
@@ -287,7 +288,7 @@ class SpatialCrossAttention(BaseModule):
         n_off = da.sampling_offsets.out_features
         return ext.sca_fused_forward(v, spatial_shapes, level_start_index, lin[..., :n_off], lin[..., n_off:],
                                      reference_points_cam, vis_bits, da.num_heads, da.num_levels, da.num_points,
-                                     order=bev_order, stats=gather_stats, value_layout=layout)
+                                     order=bev_order, stats=gather_stats, value_layout=layout, value_scale=value_scale)
 
     def forward_fused(self, query, value, reference_points_cam=None, bev_mask=None,
                       spatial_shapes=None, level_start_index=None, vis_bits=None, bev_order=None,

@@ -157,6 +157,9 @@ class LazyFeatures:
             side = self._side_streams[str(dev)] = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
         gbs = [self._group_bias(vp) for vp in value_projs]
+        if ext.SCA_VALUES == "f16":
+            for vp, gb in zip(value_projs, gbs):
+                self._range_terms(vp, gb)                    # host-side constants (first call of a weight state: one sync)
         stacked = (len(value_projs) > 1 and all(tuple(vp.weight.shape) == tuple(value_projs[0].weight.shape)
                                                 for vp in value_projs) and value_projs[0].weight.shape[0] % 256 == 0)
         if stacked:
@@ -170,8 +173,13 @@ class LazyFeatures:
         side.wait_stream(main)                               # the feature maps, packs and biases are ready
         for r in self.rows:
             r.record_stream(side)                            # read by side-stream kernels: keep them out of reuse
-        self._pending, self._side = {}, side
+        self._pending, self._side, self._scale_of = {}, side, {}
         with torch.cuda.stream(side):
+            scales = self._scales(value_projs, gbs)          # per-plane fp16 range scales of this call's maps
+            if scales is not None:
+                scales.record_stream(main)
+                for l, vp in enumerate(value_projs):
+                    self._scale_of[id(vp)] = scales[l:l + 1]
             if stacked:
                 # ONE launch for all layers: every block projects its rows with all the layers' weights, the feature
                 # maps are read from HBM once (occ_value_proj_bf16_planes); layer l's values are plane l
@@ -180,45 +188,52 @@ class LazyFeatures:
                     out = self._alloc(n, planes=len(value_projs))
                     ext.value_proj_bf16_planes(self.rows, [vp.weight for vp in value_projs], gbs, out,
                                                rows_per_group=[h * wd for h, wd in self.hw],
-                                               out_group_rows=self.group_rows, out_row0=self.starts)
+                                               out_group_rows=self.group_rows, out_row0=self.starts, out_scale=scales)
                     out.record_stream(main)
                     ev = torch.cuda.Event()
                     ev.record(side)
                     for l, vp in enumerate(value_projs):
                         self._pending[id(vp)] = (out[l].view(self.bs * self.num_cam, self.group_rows, n), ev)
-                    self._range_probe(out)
                 except ext.OccAmdError:          # e.g. the 74 KB LDS attribute refused: one launch per layer instead
                     stacked = False
                     self._pending = {}
             if not stacked:
-                for vp, gb in zip(value_projs, gbs):
-                    out = self._launch(vp, gb)
+                for l, (vp, gb) in enumerate(zip(value_projs, gbs)):
+                    out = self._launch(vp, gb, None if scales is None else scales[l:l + 1])
                     out.record_stream(main)                  # consumed (and released) on the main stream
                     ev = torch.cuda.Event()
                     ev.record(side)
                     self._pending[id(vp)] = (out, ev)
 
-    # fp16 value rows carry 11 significant bits: their absolute error grows with |v|.  Measured on this path: 2.2e-4 end to end
-    # (bound 1e-3) at max|v| ~ 6, the random-init / synthetic scale; a checkpoint whose projected values are several times
-    # larger leaves the budget.  Once per weight state the stacked projection's max|v| is measured and a warning
-    # names the fp32-row switch when it passes this threshold.  Warning only: it never changes what runs.
-    F16_RANGE_WARN = 16.0
+    # fp16 value rows carry 11 significant bits and end at 65 504.  Every plane is therefore stored times a power of two
+    # chosen per call ON THE DEVICE from an a-priori bound of its values (ext.value_range_scale: max|x| of this call's maps
+    # x the projection's largest absolute row sum + its largest bias), so that no finite feature map can saturate; the gather
+    # divides the scale out again (exact).  Round 4 only warned (|v| = 1.8e4 on the benchmarked maps, 3.6x under the limit).
+    def _range_terms(self, value_proj, gb):
+        """(max_n sum_k |W[n][k]|, max|group bias|) of a projection: host floats, measured once per weight state (the one
+        host synchronisation of this path, on the first call after a weight change)."""
+        w = value_proj.weight
+        key = (w.data_ptr(), w._version, gb.data_ptr(), gb._version, cache_epoch())
+        hit = getattr(value_proj, '_occ_range_terms', None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                t = torch.stack([w.detach().float().abs().sum(1).amax(), gb.detach().abs().amax()]).tolist()
+            hit = (key, float(t[0]), float(t[1]), w, gb)         # the sources stay referenced: the key stays unambiguous
+            value_proj._occ_range_terms = hit
+        return hit[1], hit[2]
 
-    def _range_probe(self, planes):
-        o = self.owner
-        if planes.dtype != torch.float16 or getattr(o, '_vrange_epoch', None) == cache_epoch():
-            return
-        try:
-            object.__setattr__(o, '_vrange_epoch', cache_epoch())
-            amax = float(planes.abs().amax().float().item())        # one 0.4 GB reduction + sync, once per weight state
-            object.__setattr__(o, '_vrange_absmax', amax)
-            if amax > self.F16_RANGE_WARN:
-                import warnings
-                warnings.warn(f"SCA value rows reach |v| = {amax:.3g}: stored as fp16 (default) they carry an absolute error "
-                              f"of up to {amax * 2.0 ** -11:.2g} per element — outside the range this path's 1e-3 parity was "
-                              f"measured in (|v| ~ 6).  OCC_SCA_VALUES=f32 keeps the rows in fp32.")
-        except Exception:           # a probe must never take the forward pass down
-            pass
+    def _scales(self, value_projs, gbs):
+        """The planes' range scales for THIS call's maps (one launch on the current stream), or None (fp32 rows)."""
+        if ext.SCA_VALUES != "f16":
+            return None
+        terms = [self._range_terms(vp, gb) for vp, gb in zip(value_projs, gbs)]
+        t = ext.value_range_scale(self.rows, [a for a, _ in terms], [b for _, b in terms])
+        self.range_report_ = t                                   # 2 P + 1 device floats: scales, max|x|, bounds
+        return t[:len(value_projs)]
+
+    def value_scale(self, value_proj):
+        """The 1-element device tensor the fused gather undoes plane `value_proj`'s range scale with (None: fp32 rows)."""
+        return getattr(self, '_scale_of', {}).get(id(value_proj))
 
     def finish(self):
         """Join the side stream: projections that no layer consumed (a layer fell back to the unfused path, an
@@ -256,12 +271,19 @@ class LazyFeatures:
         return torch.empty((rows, n) if planes is None else (planes, rows, n), device=self.rows[0].device,
                            dtype=torch.float16 if ext.SCA_VALUES == "f16" else torch.float32)
 
-    def _launch(self, value_proj, gb):
+    def _launch(self, value_proj, gb, scale="measure"):
+        """One projection on the current stream.  scale: its range scale (1-element device tensor), None (fp32 rows), or
+        "measure": derive it here (a projection that was not prefetched)."""
         w = value_proj.weight
         n = w.shape[0]
+        if isinstance(scale, str):
+            scale = self._scales([value_proj], [gb])
+            if not hasattr(self, '_scale_of'):
+                self._scale_of = {}
+            self._scale_of[id(value_proj)] = scale
         out = self._alloc(n)
         ext.value_proj_bf16(self.rows, w, gb, out, rows_per_group=[h * wd for h, wd in self.hw],
-                            out_group_rows=self.group_rows, out_row0=self.starts)
+                            out_group_rows=self.group_rows, out_row0=self.starts, out_scale=scale)
         return out.view(self.bs * self.num_cam, self.group_rows, n)
 
     def project(self, value_proj):
@@ -284,9 +306,12 @@ class LazyFeatures:
             ev.record()
         else:
             out, ev = hit
+        sc = self.value_scale(value_proj)
         for s in streams:
             s.wait_event(ev)
             out.record_stream(s)
+            if sc is not None:
+                sc.record_stream(s)
         return out
 
     def take_on(self, value_proj, streams):
@@ -295,8 +320,11 @@ class LazyFeatures:
         (ext.encoder_bands_forward)."""
         hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
         out, ev = hit if hit is not None else (self._launch(value_proj, self._group_bias(value_proj)), None)
+        sc = self.value_scale(value_proj)
         for s in streams:
             out.record_stream(s)
+            if sc is not None:
+                sc.record_stream(s)
         return out, ev
 
 
@@ -438,9 +466,13 @@ class TransformerOcc(BaseModule):
             flat, spatial_shapes, level_start_index = self.flatten_features(mlvl_feats)
             # reference axis order (num_cam, sum hw, bs, C) as a view of the (bs*num_cam, sum hw, C) buffer
             feat_flatten = flat.view(bs, num_cam, flat.shape[1], flat.shape[2]).permute(1, 2, 0, 3)
-        return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w,
-                            bev_pos=bev_pos, spatial_shapes=spatial_shapes,
-                            level_start_index=level_start_index, prev_bev=prev_bev, **kwargs)
+        out = self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w,
+                           bev_pos=bev_pos, spatial_shapes=spatial_shapes,
+                           level_start_index=level_start_index, prev_bev=prev_bev, **kwargs)
+        # diagnostics (a device tensor, no synchronisation): the fp16 value planes' range scales of this call, max|x| of
+        # its maps and the a-priori bounds (ext.value_range_scale) — bench.py's headline_feature_parity reports them
+        object.__setattr__(self, 'value_range_report', getattr(feat_flatten, 'range_report_', None))
+        return out
 
     # ------------------------------------------------------------------ fused decoder (inference)
     def _decoder_pack(self):
@@ -540,6 +572,13 @@ class TransformerOcc(BaseModule):
                     or c.bias is not None or (c.kernel_size, c.stride, c.padding, c.dilation, c.groups) !=
                     ((3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), 1) or c.out_channels != 32):
                 return False
+            # ext.conv3d_autograd's own shape conditions, checked for BOTH convolutions before the first one runs: nothing
+            # may raise OccAmdUnsupported after the first BatchNorm has updated its running statistics (the stock-decoder
+            # fallback would update them a second time)
+            if not (c.in_channels % 16 == 0 or c.in_channels == 8):
+                return False
+        if self.pillar_h not in (4, 8, 16, 32) or ext.CONV3D_PRECISION != "bf16x3":
+            return False
         return True
 
     @staticmethod

@@ -73,7 +73,7 @@ static int sca(const char* tag, const void* value, const float* offs, int64_t of
 int occ_sca_fused_forward_f16v(const void* value, const int64_t*, const int64_t*, const float* offs, int64_t offs_stride,
                                const float* logits, int64_t logits_stride, const float* ref_cam, const uint32_t* vis_bits,
                                const int32_t* order, float* slots, uint64_t* stats, int B, int NC, int S, int M, int D, int L,
-                               int P, int Z, int Nq, void* stream) {
+                               int P, int Z, int Nq, const float* /*value_scale*/, void* stream) {
   return sca("S16", value, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, M, D, L,
              P, Z, Nq, stream);
 }

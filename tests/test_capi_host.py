@@ -14,7 +14,7 @@ def test_library_exports_declared_symbols():
     assert 'occ_ms_deform_attn_forward_f32' in declared and 'occ_sca_fused_forward_f32' in declared
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.occ_abi_version() >= 1
+    assert lib.occ_abi_version() == _lib.ABI == 2
 
 
 def test_argument_validation_without_gpu():
@@ -70,11 +70,21 @@ def test_backbone_and_projection_entry_points_validate_without_gpu():
     assert lib.occ_value_proj_bf16_f32(*args(1, (ctypes.c_int64 * 1)(32), 64, 256)) == -1         # lda < K
     # stacked projections (round 3): plane geometry
     pargs = lambda n_planes, plane_cols, stride: (1, ptrs, one, one, one, zero, null, 0, p, p, 1, i64(256), 64, n_planes,
-                                                  plane_cols, i64(stride), i64(64), null)
+                                                  plane_cols, i64(stride), i64(64), null, null)
     assert lib.occ_value_proj_bf16_planes(*pargs(0, 256, 1 << 20)) == -1                          # no planes
     assert lib.occ_value_proj_bf16_planes(*pargs(4, 256, 0)) == -1                                # plane stride
     assert lib.occ_value_proj_bf16_planes(*pargs(4, 192, 1 << 20)) == -3                          # plane_cols % 256
     assert b'plane_cols' in lib.occ_last_error()
+    # range scales of the fp16 value rows (round 5): argument checks
+    f4 = (ctypes.c_float * 4)(1.0, 1.0, 1.0, 1.0)
+    neg = (ctypes.c_float * 4)(1.0, -1.0, 1.0, 1.0)
+    rargs = lambda n, lda, K, planes, l1=f4: (n, ptrs, lda, one, K, planes, l1, f4, p, p, null)
+    assert lib.occ_value_range_scale_bf16(*rargs(0, one, 64, 4)) == -1                            # no segments
+    assert lib.occ_value_range_scale_bf16(*rargs(1, one, 64, 9)) == -1                            # > 8 planes
+    assert lib.occ_value_range_scale_bf16(*rargs(1, one, 60, 4)) == -3                            # K % 8
+    assert lib.occ_value_range_scale_bf16(*rargs(1, (ctypes.c_int64 * 1)(32), 64, 4)) == -1       # lda < K
+    assert lib.occ_value_range_scale_bf16(*rargs(1, one, 64, 4, neg)) == -1 and b'negative' in lib.occ_last_error()
+    assert lib.occ_value_range_scale_bf16(1, ptrs, one, one, 64, 4, f4, f4, null, p, null) == -1  # no output
     # fused second convolution + heads + decode (round 3)
     lib.occ_conv3d_heads_pack_bytes.restype = ctypes.c_int64
     assert lib.occ_conv3d_heads_pack_bytes() == 16 * 1024 + 16 * 1024 + 128 * 4 + 32 * 4

@@ -168,3 +168,37 @@ def test_deterministic_mode_is_bit_reproducible(name, B, shapes, M, Lq, P, monke
     dn = float((d_gv.cpu().double() - gv_ref).abs().max()) / scale
     print(f"{name}: deterministic grad_value rel diff vs float64 {dd:.3e} (default path {dn:.3e}), scale {scale:.3e}")
     assert dd < 1e-5 and dd <= dn * 1.5 + 1e-7
+
+
+def test_deterministic_mode_propagates_non_finite_gradients_and_refuses_other_head_dims(monkeypatch):
+    """(i) an Inf / NaN in grad_output has no fixed-point image — the pixels its samples touch come back NaN
+    (as the float path leaves them), everything else is the clean run's bits, never finite garbage; (ii) the mode exists for
+    D = 32 only: any other head dim is refused instead of silently running the float-atomic kernel."""
+    from occnet_amd import ext
+    B, shapes, M, Lq, P = 1, [[12, 20], [6, 10]], 8, 600, 4
+    value, shapes_t, start, loc, attn = _inputs(B, shapes, M, 32, Lq, P, seed=25, adversarial=False)
+    loc = _interior(loc, shapes)
+    grad_out = torch.randn(B, Lq, M * 32, generator=torch.Generator().manual_seed(26)) * 1e-2
+    monkeypatch.setenv("OCC_MSDA_BWD_DETERMINISTIC", "1")
+
+    def run(go):
+        gv, gl, ga = (torch.zeros_like(t).cuda() for t in (value, loc, attn))
+        ext.ms_deform_attn_backward(*[t.cuda() for t in (value, shapes_t, start, loc, attn, go)], gv, gl, ga, im2col_step=64)
+        torch.cuda.synchronize()
+        return gv.cpu()
+    clean = run(grad_out)
+    assert torch.isfinite(clean).all()
+    for poison in (float('inf'), float('nan')):
+        go = grad_out.clone()
+        go[0, 17, 3 * 32 + 5] = poison                     # query 17, head 3, channel 5
+        got = run(go)
+        bad = ~torch.isfinite(got)
+        assert bad.any() and torch.isnan(got[bad]).all()                         # NaN, never a finite stand-in or +-Inf
+        assert bad.view(B, -1, M, 32)[:, :, [0, 1, 2, 4, 5, 6, 7]].sum() == 0    # only head 3's pixels are touched
+        assert int(bad.view(B, -1, M, 32)[0, :, 3].any(-1).sum()) <= len(shapes) * P * 4
+        assert torch.equal(got[~bad], clean[~bad])
+    v16, s16, st16, l16, a16 = _inputs(B, shapes, M, 16, 64, P, seed=27, adversarial=False)
+    go16 = torch.randn(B, 64, M * 16)
+    with pytest.raises(ext.OccAmdUnsupported):
+        gv, gl, ga = (torch.zeros_like(t).cuda() for t in (v16, l16, a16))
+        ext.ms_deform_attn_backward(*[t.cuda() for t in (v16, s16, st16, l16, a16, go16)], gv, gl, ga, im2col_step=64)

@@ -1,0 +1,60 @@
+"""-m gpu, always on: the DEFAULT hot path under co-scheduled load.
+
+Round 4's row-pipeline experiment produced wrong rows when kernels of different kinds overlapped on several streams, and
+the cause was not understood — which left open whether the default path (main stream + the value projection's side
+stream) is race-free or merely serialised.  This test runs the standard 4-layer step at the bench's hot-path
+configuration (full base geometry, bf16 NHWC maps) while a second stream keeps the chip busy with HBM-bound copies,
+LDS-heavy matrix-core GEMMs and a scratch-using kernel, and demands BIT-identical outputs to the solo run, 50 times.
+Every kernel of the path is deterministic (no float atomics; the gathers' statistics counters are off), so any
+difference is a hazard, not rounding."""
+import pytest
+import torch
+
+from occnet_amd import synthetic
+from tests.util import build_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(f):
+    B, N, C, h, w = f.shape
+    return f.reshape(B * N, C, h, w).cuda().contiguous(memory_format=torch.channels_last).view(B, N, C, h, w)
+
+
+def test_default_hot_path_is_bit_identical_under_co_scheduled_load():
+    g = dict(synthetic.BASE, num_points=8, num_layers=4)
+    prod, _ = build_pair(g, seed=12)
+    x = [_nhwc(f.to(torch.bfloat16)) for f in synthetic.make_features(g, seed=12)]
+    metas = synthetic.make_img_metas(g)
+    keys = ('bev_embed', 'occ', 'flow')
+    with torch.no_grad():
+        prod(x, metas)                                   # first call: builds the derived-weight caches
+        solo = {k: v.clone() for k, v in prod(x, metas).items() if k in keys}
+        torch.cuda.synchronize()
+        again = prod(x, metas)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(again[k], solo[k]), f"solo run not reproducible: {k}"
+
+        load = torch.cuda.Stream()
+        a = torch.randn(4096, 4096, device='cuda', dtype=torch.bfloat16)
+        b = torch.randn(4096, 4096, device='cuda', dtype=torch.bfloat16)
+        big = torch.empty(256 << 20, device='cuda', dtype=torch.float32)          # 1 GiB: past L2 and the memory-side cache
+        dst = torch.empty_like(big)
+        idx = torch.randint(0, 1 << 20, (1 << 22,), device='cuda')
+        tab = torch.randn(1 << 20, 64, device='cuda')
+        bad = []
+        for rep in range(50):
+            with torch.cuda.stream(load):
+                for _ in range(6):                       # ~ 5 ms of background work per repetition, of three kinds
+                    dst.copy_(big)                       # HBM streaming
+                    c = a @ b                            # matrix cores + LDS
+                    s = tab[idx[(rep % 4) << 20:((rep % 4) + 1) << 20]].sum(0)   # random gather (texture path)
+                    st = torch.sort(c[:256].float().view(-1))[0]                 # rocPRIM radix sort: LDS + scratch
+            out = prod(x, metas)
+            torch.cuda.synchronize()
+            for k in keys:
+                if not torch.equal(out[k], solo[k]):
+                    d = (out[k] - solo[k]).abs()
+                    bad.append((rep, k, int((d > 0).sum()), float(d.max())))
+        assert not bad, f"outputs changed under load (rep, tensor, elements, max diff): {bad[:8]}"

@@ -369,3 +369,21 @@ def test_data_copy_before_eval_is_caught_by_the_content_fingerprint():
     with torch.no_grad():
         out3 = head(feats, metas)['occ']
     assert float((out3 - out2).abs().max()) < 1e-6          # and an explicit invalidation changes nothing further
+    # a NORM-PRESERVING rewrite (sign flip; two equal-norm tensors trading places) is invisible to a sum of
+    # per-tensor norms — the fingerprint is order-sensitive per tensor
+    e1 = occnet_amd.cache_epoch()
+    model.train()
+    fc.weight.data.neg_()
+    model.eval()
+    assert occnet_amd.cache_epoch() > e1
+    e2 = occnet_amd.cache_epoch()
+    model.train()
+    n0, n1 = (head.transformer.encoder.layers[i].norms[0].weight for i in (0, 1))
+    n0.data.fill_(1.25), n1.data.fill_(0.75)
+    model.eval()
+    e3 = occnet_amd.cache_epoch()
+    assert e3 > e2
+    model.train()
+    n0.data.fill_(0.75), n1.data.fill_(1.25)                # the two tensors swap contents: same multiset of norms
+    model.eval()
+    assert occnet_amd.cache_epoch() > e3

@@ -1,0 +1,190 @@
+"""-m gpu: range-safe fp16 value rows of the SCA gather (csrc/value_range.hip).
+
+The reference keeps these rows in fp32 (`spatial_cross_attention.py:75,387-390`, @force_fp32).  The fused path stores them
+as fp16 times a per-plane power of two derived, per call and on the device, from an a-priori bound of the plane's values —
+so no finite feature map can reach the fp16 limit — and the gather divides the scale out again.  Both steps are exact:
+ * occ_value_range_scale_bf16 against torch (max|x|, bound, scale; strided rows; Inf / NaN / zero maps; the two work
+   words clean themselves);
+ * the projections under out_scale == the unscaled fp32 result times the scale, rounded once (bit for bit), where the
+   unscaled fp16 output of the same maps is clamped at 65 504;
+ * the gather under value_scale == the gather of the unscaled rows (bit for bit);
+ * the whole head against the CPU oracle (bound 1e-3) on feature maps scaled by 1 ... 1e7 — |v| up to ~1e8, three
+   orders of magnitude past the fp16 limit — with no plane element above 2^15, on the LazyFeatures path (bf16 NHWC maps)
+   and on the flatten path (fp32-projected rows, ext.f16_range_scaled)."""
+import pytest
+import torch
+
+from occnet_amd import ext, synthetic
+from tests.util import TOL, build_pair, maxdiff, small_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected_scale(bound):
+    if not (bound > 0 and bound < float('inf')):
+        return 1.0
+    _, e = torch.frexp(torch.tensor(bound, dtype=torch.float32))
+    return 2.0 ** max(-100, min(100, 15 - int(e)))
+
+
+@pytest.mark.parametrize("rows,K,strided", [((1, 7, 300), 64, False), ((184950 // 6, 2250, 640, 168), 256, False),
+                                            ((513, 64), 256, True)])
+def test_value_range_scale_matches_torch(rows, K, strided):
+    g = torch.Generator().manual_seed(5)
+    maps = []
+    for i, r in enumerate(rows):
+        t = (torch.randn(r, 2 * K if strided else K, generator=g) * (3.0 + i)).to(torch.bfloat16).cuda()
+        if strided:
+            t[:, K:] = 1e30                       # the columns behind a strided row are not part of the map
+        maps.append(t[:, :K] if strided else t)
+    maps[-1][rows[-1] // 2, K - 3] = -777.0       # the maximum: one element, negative, in the last segment
+    row_l1, bias_max = [13.5, 0.25, 40.0, 7.0], [0.5, 3.0, 0.0, 100.0]
+    for rep in range(3):                           # the same work words again: they must have been left clean
+        t = ext.value_range_scale(maps, row_l1, bias_max).cpu()
+        assert t.shape == (9,)
+        amax = max(float(m.float().abs().max()) for m in maps)
+        assert float(t[4]) == amax == 776.0       # bf16(777) = 776
+        for p in range(4):
+            bound = float(torch.tensor(row_l1[p]) * torch.tensor(amax) * torch.tensor(1.00390625) + bias_max[p])
+            assert float(t[5 + p]) == pytest.approx(bound, rel=1e-6)
+            assert float(t[p]) == _expected_scale(float(t[5 + p]))
+            assert float(t[5 + p]) * float(t[p]) <= 2.0 ** 15 and float(t[5 + p]) * float(t[p]) > 2.0 ** 14
+
+
+@pytest.mark.parametrize("poison", [float('inf'), float('nan'), 0.0])
+def test_value_range_scale_of_degenerate_maps_is_one(poison):
+    m = torch.zeros(100, 64, dtype=torch.bfloat16, device='cuda')
+    if poison != 0.0:
+        m[57, 9] = poison
+    t = ext.value_range_scale([m], [10.0], [0.0]).cpu()
+    assert float(t[0]) == 1.0
+    # a zero map with a bias still gets the bias' scale; the next call on clean maps is not affected by the poisoned one
+    m.zero_()
+    t = ext.value_range_scale([m], [10.0], [3.0]).cpu()
+    assert float(t[0]) == 2.0 ** 13 and float(t[1]) == 0.0 and float(t[2]) == 3.0
+
+
+def _maps(hws, G, K, amp, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(G * h * w, K, generator=g) * amp).to(torch.bfloat16).cuda() for h, w in hws]
+
+
+@pytest.mark.parametrize("hws", [[(12, 20), (16, 10)], [(12, 20), (6, 10)]], ids=["resident", "tiled"])
+@pytest.mark.parametrize("amp", [1.0, 3e4, 1e7])
+def test_value_projection_under_the_range_scale_is_exact_and_never_saturates(amp, hws):
+    """planes / single projection with out_scale: fp16(s * fp32 result) bit for bit; at amp >= 3e4 the unscaled fp16 output
+    of the same maps is clamped at the limit, the scaled one stays below 2^15.  Both kernels of value_proj_bf16.hip (the
+    activation-resident one needs >= 128 rows per group)."""
+    G, K, N, P = 3, 256, 256, 4
+    rpg = [h * w for h, w in hws]
+    starts, total = [0, rpg[0]], sum(rpg)
+    a_list = _maps(hws, G, K, amp, seed=11)
+    g = torch.Generator().manual_seed(12)
+    ws = [((torch.rand(N, K, generator=g) * 2 - 1) * 0.108).cuda() for _ in range(P)]
+    gbs = [torch.randn(len(hws), G, N, generator=g).cuda() for _ in range(P)]
+    l1 = [float(w.abs().sum(1).max()) for w in ws]
+    bm = [float(b.abs().max()) for b in gbs]
+    t = ext.value_range_scale(a_list, l1, bm)
+    scales = t[:P]
+    ref32 = torch.empty(P, G * total, N, device='cuda')
+    ext.value_proj_bf16_planes(a_list, ws, gbs, ref32, rows_per_group=rpg, out_group_rows=total, out_row0=starts)
+    out = torch.zeros(P, G * total, N, dtype=torch.float16, device='cuda')
+    ext.value_proj_bf16_planes(a_list, ws, gbs, out, rows_per_group=rpg, out_group_rows=total, out_row0=starts,
+                               out_scale=scales)
+    plain = torch.zeros_like(out)
+    ext.value_proj_bf16_planes(a_list, ws, gbs, plain, rows_per_group=rpg, out_group_rows=total, out_row0=starts)
+    one = torch.zeros(G * total, N, dtype=torch.float16, device='cuda')
+    ext.value_proj_bf16(a_list, ws[2], gbs[2], one, rows_per_group=rpg, out_group_rows=total, out_row0=starts,
+                        out_scale=scales[2:3])
+    for p in range(P):
+        want = (ref32[p] * scales[p]).half().view(G, total, N // 32, 32)
+        got = ext.sca_unpair_layout(out[p].view(G, total, N // 32, 32))
+        assert torch.equal(got, want), p
+        assert float(got.float().abs().max()) <= 2.0 ** 15
+        assert float(ref32[p].abs().max()) <= float(t[P + 1 + p])              # the a-priori bound holds
+    assert torch.equal(one, out[2])
+    sat = int((plain.float().abs() == 65504).sum())
+    print(f"amp {amp:g}: max|v| = {float(ref32.abs().max()):.3g}, scales {scales.tolist()}, unscaled fp16 output clamps "
+          f"{sat} elements")
+    assert (sat > 0) == (amp >= 3e4)
+
+
+@pytest.mark.parametrize("k", [-7, 9])
+def test_gather_under_the_range_scale_is_exact(k):
+    """sca_fused_forward(value * 2^k, value_scale = 2^k) == sca_fused_forward(value): bit for bit."""
+    g = torch.Generator().manual_seed(21)
+    hw = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    S = sum(h * w for h, w in hw)
+    S += S & 1
+    NC, B, Nq, Z, M, D, L, P = 3, 1, 500, 4, 8, 32, 4, 8
+    sign = (torch.rand(B * NC, S, M, D, generator=g) < 0.5).float() * 2 - 1
+    value = (sign * (0.5 + 3.5 * torch.rand(B * NC, S, M, D, generator=g))).half().cuda()   # exponents -1 .. 1: exact both ways
+    shapes = torch.tensor(hw, dtype=torch.long).cuda()
+    starts = torch.tensor([0] + [sum(h * w for h, w in hw[:i]) for i in range(1, L)], dtype=torch.long).cuda()
+    offs = (torch.randn(B, Nq, M * L * P * 2, generator=g) * 2).cuda()
+    logits = torch.randn(B, Nq, M * L * P, generator=g).cuda()
+    ref_cam = torch.rand(NC, B, Nq, Z, 2, generator=g).cuda()
+    vis = torch.randint(0, 1 << NC, (B, Nq), generator=g, dtype=torch.int32).cuda()
+    args = (shapes, starts, offs, logits, ref_cam, vis, M, L, P)
+    want = ext.sca_fused_forward(value, *args)
+    s = torch.tensor([2.0 ** k], device='cuda')
+    scaled = (value.float() * s).half()
+    assert torch.equal(scaled.float() / s, value.float())
+    got = ext.sca_fused_forward(scaled, *args, value_scale=s)
+    assert torch.equal(got, want)
+    assert float(want.abs().max()) > 0.1
+    with pytest.raises(ext.OccAmdError):
+        ext.sca_fused_forward(value.float(), *args, value_scale=s)                # fp32 rows take no scale
+
+
+@pytest.mark.parametrize("amp", [1.0, 1e3, 1e5, 1e7])
+def test_head_parity_holds_and_nothing_saturates_over_feature_scales(amp, monkeypatch):
+    """bf16 NHWC maps scaled by amp (projected |v| ~ 6 amp: past the fp16 limit from 1e5 on) through
+    the default path (stacked projection -> fp16 planes -> fused gather) against the CPU oracle on the same values."""
+    g = small_cfg()
+    prod, ora = build_pair(g, seed=3)
+    feats = [(f * amp).to(torch.bfloat16).float() for f in synthetic.make_features(g, batch=1, seed=3)]
+    metas = synthetic.make_img_metas(g, batch=1)
+    seen = []
+    real_planes, real_one = ext.value_proj_bf16_planes, ext.value_proj_bf16
+
+    def planes(*a, **k):
+        out = real_planes(*a, **k)
+        seen.append((out, k.get('out_scale')))
+        return out
+
+    def single(*a, **k):
+        out = real_one(*a, **k)
+        seen.append((out[None], k.get('out_scale')))
+        return out
+    monkeypatch.setattr(ext, 'value_proj_bf16_planes', planes)
+    monkeypatch.setattr(ext, 'value_proj_bf16', single)
+
+    def nhwc(f):
+        B, N, C, h, w = f.shape
+        return f.cuda().reshape(B * N, C, h, w).to(torch.bfloat16).contiguous(
+            memory_format=torch.channels_last).view(B, N, C, h, w)
+    with torch.no_grad():
+        out_o = ora(feats, metas, prev_bev=None)
+        out_p = prod([nhwc(f) for f in feats], metas, prev_bev=None)
+        torch.cuda.synchronize()
+        assert seen and all(o.dtype == torch.float16 and s is not None for o, s in seen)
+        vmax = 0.0
+        G, total = g['num_cams'], sum(h * w for h, w in g['feat_shapes'])
+        for o, s in seen:
+            for p in range(o.shape[0]):
+                # (the padding pixel of an odd map is never written: look at the real ones)
+                rows = ext.sca_unpair_layout(o[p].view(G, o.shape[1] // G, 8, 32), S=total)
+                top = float(rows.float().abs().max())
+                assert top <= 2.0 ** 15, (amp, p, top)
+                vmax = max(vmax, top / float(s[p]))
+        del seen[:]
+        prod.transformer.use_lazy_features = False
+        out_f = prod([nhwc(f) for f in feats], metas, prev_bev=None)          # flatten path: ext.f16_range_scaled
+    assert not seen
+    if amp >= 1e5:
+        assert vmax > 65504                        # these planes would not have fitted fp16 unscaled
+    for k in ('bev_embed', 'occ', 'flow'):
+        d, d2 = maxdiff(out_p[k], out_o[k]), maxdiff(out_f[k], out_o[k])
+        print(f"amp {amp:g} (max|v| {vmax:.3g}) {k}: lazy path vs oracle {d:.3e}, flatten path vs oracle {d2:.3e}")
+        assert d < TOL and d2 < TOL

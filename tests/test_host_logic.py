@@ -515,28 +515,32 @@ def test_x3linear_on_host_is_a_plain_linear():
     assert m.weight.grad is not None and x.grad is not None
 
 
-def test_fp16_value_range_probe_warns_once_per_weight_state():
-    """LazyFeatures._range_probe (ADVICE r3): the stacked SCA value projection's max|v| is measured once per weight state;
-    beyond the range the fp16-row parity was measured in, a warning names OCC_SCA_VALUES=f32.  Never changes what runs."""
-    import warnings
+def test_fp16_value_range_terms_and_aten_scale():
+    """Range-safe fp16 SCA value rows.  LazyFeatures._range_terms: the weight-side constants of the
+    a-priori bound (largest absolute row sum of W, largest |group bias|) are measured once per weight state and follow
+    in-place updates; ext.f16_range_scaled (the ATen counterpart for fp32-projected rows): a power-of-two scale that puts
+    max|v| into [2^14, 2^15], exact to undo, 1 for all-zero / non-finite rows."""
+    from occnet_amd import ext
     from occnet_amd.plugin.transformer_occ import LazyFeatures
-
-    class Owner:
-        pass
     lf = LazyFeatures.__new__(LazyFeatures)
-    lf.owner = Owner()
-    small = torch.full((2, 4, 8), 3.0, dtype=torch.float16)
-    big = small.clone()
-    big[1, 2, 3] = -40.0
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        lf._range_probe(small)
-        assert not w and lf.owner._vrange_absmax == 3.0
-        lf._range_probe(big)                                   # same weight state: not measured again
-        assert not w and lf.owner._vrange_absmax == 3.0
-        lf.owner._vrange_epoch = None
-        lf._range_probe(big)
-        assert len(w) == 1 and "OCC_SCA_VALUES=f32" in str(w[0].message) and lf.owner._vrange_absmax == 40.0
-        lf.owner._vrange_epoch = None
-        lf._range_probe(big.float())                           # fp32 rows: nothing to warn about
-        assert len(w) == 1
+    vp = torch.nn.Linear(8, 4)
+    with torch.no_grad():
+        vp.weight.copy_(torch.arange(32.).view(4, 8) - 10.0)
+    gb = torch.tensor([[[0.5, -7.25, 1.0, 2.0]]])
+    l1, bm = lf._range_terms(vp, gb)
+    assert l1 == float(vp.weight.abs().sum(1).max()) and bm == 7.25
+    assert lf._range_terms(vp, gb) == (l1, bm) and vp._occ_range_terms[0][1] == vp.weight._version
+    with torch.no_grad():
+        vp.weight.mul_(3.0)                                    # in-place update: new weight state, measured again
+    assert lf._range_terms(vp, gb)[0] == 3.0 * l1
+    for amp in (1e-6, 0.37, 6.0, 1.8e4, 1e5, 1e7, 3e30):
+        v = torch.randn(5, 7, 16) * amp
+        h, s = ext.f16_range_scaled(v)
+        m, e = torch.frexp(s)
+        assert h.dtype == torch.float16 and s.shape == (1,) and float(m) == 0.5                  # a power of two
+        top = float((v.abs().max() * s))
+        assert 2.0 ** 14 <= top <= 2.0 ** 15 and torch.isfinite(h).all() and float(h.abs().max()) < 65504
+        back = h.float() / s
+        assert float((back - v).abs().max()) <= float(v.abs().max()) * 2.0 ** -11
+    for bad in (torch.zeros(3, 4), torch.tensor([1.0, float('inf')]), torch.tensor([float('nan'), 2.0])):
+        assert float(ext.f16_range_scaled(bad)[1]) == 1.0

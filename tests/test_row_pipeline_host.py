@@ -90,7 +90,7 @@ def _fake_ops(monkeypatch, bev_h, bev_w, log):
         return y, F.linear(y, w2, b2)
 
     def sca_fused_forward(value, shapes, lsi, offs, logits, ref_cam, vis_bits, heads, levels, points, order=None,
-                          stats=None, value_layout="rows"):
+                          stats=None, value_layout="rows", value_scale=None):
         NC, B, n, Z, _ = ref_cam.shape
         assert ref_cam.is_contiguous() and tuple(vis_bits.shape) == (1, n) and vis_bits.is_contiguous()
         assert tuple(offs.shape[:2]) == (1, n) and offs.stride(0) == n * offs.stride(1)
@@ -100,6 +100,8 @@ def _fake_ops(monkeypatch, bev_h, bev_w, log):
         cam = ref_cam[:, 0].reshape(NC, n, -1).sum((0, 2))                                   # (n,)
         c = value.shape[-1] * value.shape[-2]
         o = offs[0, :, :c] * cam[:, None] + logits[0, :, :c] + vis_bits[0].float()[:, None] + value.float().mean()
+        assert value_scale is not None and value_scale.numel() == 1          # fp16 planes travel with their range scale
+        o = o + value_scale.float()                                          # the LAYER's own scale reaches its gather
         log.append(('S', n))
         return o.view(1, n, c)
 
@@ -151,7 +153,8 @@ def _fake_ops(monkeypatch, bev_h, bev_w, log):
                 b['slots'].copy_(sca_fused_forward(y['plane'], spatial_shapes, level_start_index,
                                                    b['lin'][..., :n_lin // 3 * 2], b['lin'][..., n_lin // 3 * 2:],
                                                    b['ref_cam'], vis_bits[:, b['m0']:b['m1']], 8, num_levels, num_points,
-                                                   order=b['order'], stats=y['stats'], value_layout="pairs"))
+                                                   order=b['order'], stats=y['stats'], value_layout="pairs",
+                                                   value_scale=y['plane_scale']))
             for b in bands:
                 m0, m1 = b['m0'], b['m1']
                 tail = y.get('tail')
@@ -183,7 +186,11 @@ class _Planes:
         g = torch.Generator().manual_seed(5)
         self.planes = {id(l.attentions[1].deformable_attention.value_proj):
                        torch.randn(6, 64, 256, generator=g).half() for l in encoder.layers}
+        self.scales = {k: torch.tensor([2.0 ** (i - 3)]) for i, k in enumerate(self.planes)}     # one per layer, all different
         self.asked = []
+
+    def value_scale(self, vp):
+        return self.scales[id(vp)]
 
     def project_on(self, vp, streams):
         self.asked.append(id(vp))
@@ -207,7 +214,8 @@ def _reference_walk(encoder, q, planes, bev_pos, ref_2d, bev_h, bev_w, ref_cam, 
         wq, bq = sca.query_linear_operands()
         x1, lin = ext.linear_ln_chain(attn, q, tsa.output_proj.weight, tsa.output_proj.bias, layer.norms[0], wq, bq)
         slots = sca.gather_projected(lin, planes.planes[id(sca.deformable_attention.value_proj)], ref_cam, vis_bits,
-                                     None, None, order, None)
+                                     None, None, order, None,
+                                     value_scale=planes.value_scale(sca.deformable_attention.value_proj))
         ffn = layer.ffns[0]
         tail = layers[lid + 1].attentions[0].chain_tail(bev_pos) if lid + 1 < len(layers) else None
         q, zq, zv = ext.encoder_ffn_chain(slots, x1, sca.output_proj.weight, sca.output_proj.bias, layer.norms[1],

@@ -129,7 +129,10 @@ def fullsize_golden():
     ref = refshim.install()
     from tests.util import head_cfg, randomize
     torch.set_num_threads(os.cpu_count() or 1)
+    only = [a for a in sys.argv[1:] if a in FULL_CASES]          # `--full-only name ...`: just these cases
     for name, case in FULL_CASES.items():
+        if only and name not in only:
+            continue
         t0 = time.time()
         cfg = head_cfg(case['geometry'])
         head = ref.build_head(copy.deepcopy(cfg))

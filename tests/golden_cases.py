@@ -47,8 +47,17 @@ FULL_CASES = {
     # the BENCHMARKED depth (round 4): all four encoder layers of the base config
     'base_full_4layer': dict(seed=23, batch=1, prev=False, angle=0.0,
                              geometry=dict(synthetic.BASE, num_points=8, num_layers=4)),
+    # round 5: the benchmarked DEPTH for BASELINE configs[2] and configs[4] as well —
+    # four layers with a rotated history BEV (every layer's TSA attends to it), and the 400 x 400 x 32 grid
+    # (160 000 BEV queries, max_len ~ 39 600 padded rows per camera in the reference's rebatch)
+    'base_full_hist_4layer': dict(seed=24, batch=1, prev=True, angle=7.5,
+                                  geometry=dict(synthetic.BASE, num_points=8, num_layers=4)),
+    'hires_full_4layer': dict(seed=25, batch=1, prev=False, angle=0.0,
+                              geometry=dict(synthetic.HIRES, num_points=8, num_layers=4)),
 }
 FULL_STRIDE = 997            # prime, coprime to every tensor dimension: the subsample walks all axes
+FULL_FINE = 512              # round 5: sums of every 512 contiguous elements (a localised error in a
+                             # region the strided subsample skips moves one of these; 64 slab sums average it away)
 FULL_KEYS = ('bev_embed', 'occ', 'flow', 'layer0_tsa_out', 'layer0_sca_out')
 
 
@@ -66,8 +75,10 @@ def digest(t):
     import numpy as np
     a = np.ascontiguousarray(t.detach().cpu().numpy() if hasattr(t, 'detach') else t).reshape(-1)
     slabs = np.array([s.astype(np.float64).sum() for s in np.array_split(a, 64)])
+    pad = (-a.size) % FULL_FINE
+    fine = np.concatenate([a, np.zeros(pad, a.dtype)]).reshape(-1, FULL_FINE).astype(np.float64).sum(1).astype(np.float32)
     return dict(sub=a[::FULL_STRIDE].astype(np.float32).copy(), sum=np.float64(a.astype(np.float64).sum()),
-                abs_sum=np.float64(np.abs(a.astype(np.float64)).sum()), slabs=slabs, n=np.int64(a.size))
+                abs_sum=np.float64(np.abs(a.astype(np.float64)).sum()), slabs=slabs, n=np.int64(a.size), fine=fine)
 
 
 def compare_digest(name, t, gold, tol):
@@ -81,6 +92,13 @@ def compare_digest(name, t, gold, tol):
     per = int(d['n']) / 64.0
     slab_err = float(np.abs(d['slabs'] - gold[f'{name}_slabs']).max()) / per
     assert slab_err < tol / 10, f'{name}: mean error over a slab {slab_err}'
+    if f'{name}_fine' in gold:
+        # every element is covered: one element off by tol * sqrt(FULL_FINE) (0.023 at 1e-3) in an otherwise matching chunk
+        # fails; independent per-element errors of the size the fp16 value rows leave (<= 2.4e-4) sum to ~ 3e-3 at worst
+        fine = np.abs(d['fine'].astype(np.float64) - gold[f'{name}_fine'].astype(np.float64))
+        worst = int(fine.argmax())
+        assert float(fine.max()) < tol * FULL_FINE ** 0.5, \
+            f'{name}: elements [{worst * FULL_FINE}, {(worst + 1) * FULL_FINE}) sum to {float(fine.max())} off the reference'
     return sub_err, slab_err
 
 

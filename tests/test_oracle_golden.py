@@ -53,7 +53,8 @@ from tests.golden_cases import FULL_CASES, FULL_KEYS, compare_digest, full_case_
 @pytest.mark.parametrize('name', sorted(FULL_CASES))
 def test_oracle_matches_reference_golden_at_base_geometry(name):
     """oracle/model.py == the reference's own files at 40 000 queries / 6 x 30 825 keys / max_len ~ 9 900, one
-    layer, without and with a rotated history BEV (fixtures: oracle/gen_golden.py::fullsize_golden)."""
+    layer, without and with a rotated history BEV, and at the benchmarked depth of four layers for BASELINE configs[1],
+    configs[2] (history) and configs[4] (400 x 400 x 32: 160 000 queries) — fixtures: oracle/gen_golden.py::fullsize_golden."""
     case = FULL_CASES[name]
     gold = np.load(os.path.join(GOLD, f'{name}.npz'))
     head = _oracle_head(case)

@@ -940,7 +940,6 @@ def main():
                 "samples_per_gpu": 1, "global_batch": world,
                 "parallelism": f"dp{world}", "streams": args.streams, "step_graph": bool(args.step_graph),
                 "step_graph_note": step_graph_note,
-                "vproj_schedule": os.environ.get("OCC_VPROJ_SCHEDULE", "stacked"),
                 "hot_path_dtype": "f32",
                 "linear_precision": ext.LINEAR_PRECISION,
                 "backbone_dtype": args.backbone_dtype if stepper.scope == "e2e" else None,

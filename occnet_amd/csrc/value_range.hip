@@ -23,10 +23,11 @@
 
 namespace occ {
 
-constexpr int kVrMaxSeg = 8, kVrMaxPlanes = 8;
+constexpr int kVrMaxSeg = 8, kVrMaxPlanes = 8, kVrUnroll = 8;
 struct VrSegments {
   const uint4* a[kVrMaxSeg];
-  long rows[kVrMaxSeg], lda8[kVrMaxSeg];
+  int first[kVrMaxSeg + 1];           // cumulative 16-byte pieces: segment s holds pieces [first[s], first[s + 1])
+  int lda8[kVrMaxSeg];
   int n;
 };
 struct VrPlanes {
@@ -54,30 +55,46 @@ __device__ __forceinline__ float vr_scale_of(float bound) {
   return ldexpf(1.f, k);
 }
 
+template <bool CONTIG>
 __global__ __launch_bounds__(256) void value_range_scale_kernel(VrSegments seg, int K8, VrPlanes planes,
                                                                 float* __restrict__ scale_out,
                                                                 unsigned* __restrict__ work) {
   __shared__ unsigned smax[4];
-  const long stride = (long)gridDim.x * 256;
-  const long tid = (long)blockIdx.x * 256 + threadIdx.x;
+  const int stride = (int)gridDim.x * 256;
+  const int total = seg.first[seg.n];            // < 2^31 - kVrUnroll * stride (the launcher checks): 32-bit index arithmetic
   unsigned m = 0;
-  for (int s = 0; s < seg.n; ++s) {
-    const uint4* __restrict__ a = seg.a[s];
-    const long lda8 = seg.lda8[s];
-    const long n = seg.rows[s] * K8;
-    if (lda8 == K8) {                 // contiguous rows (the NHWC maps): four independent 16-byte loads per round
-      long i = tid;
-      for (; i + 3 * stride < n; i += 4 * stride) {
-        const uint4 v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
-        m = vr_absmax8(vr_absmax8(vr_absmax8(vr_absmax8(m, v0), v1), v2), v3);
+  // ONE index space over all segments, kVrUnroll independent 16-byte loads per thread and round: the first cut walked the
+  // segments one after the other with a one-load-at-a-time tail per segment — six serial memory round trips per thread,
+  // 85-141 us for the 95 MB of the base maps (profiles/r05_c2_hot_kernel_trace_stats.txt)
+  for (int base = (int)blockIdx.x * 256 + (int)threadIdx.x; base < total; base += stride * kVrUnroll) {
+    uint4 v[kVrUnroll];
+#pragma unroll
+    for (int k = 0; k < kVrUnroll; ++k) {
+      // branch-free: a piece beyond the index space re-reads the last piece (same maximum) instead of being skipped —
+      // with a branch per load hipcc waits for every load before it issues the next one
+      int g = base + k * stride;
+      g = g < total ? g : total - 1;
+      // the segment of g by a select chain over CONSTANT table indices (a per-lane index into the by-value table would be
+      // fetched with vector loads from the kernel-argument segment: two more dependent round trips per piece)
+      const uint4* ap = seg.a[0];
+      int first = 0, lda8 = seg.lda8[0];
+#pragma unroll
+      for (int i = 1; i < kVrMaxSeg; ++i) {
+        const bool hit = i < seg.n && g >= seg.first[i];
+        ap = hit ? seg.a[i] : ap;
+        first = hit ? seg.first[i] : first;
+        if (!CONTIG) lda8 = hit ? seg.lda8[i] : lda8;
       }
-      for (; i < n; i += stride) m = vr_absmax8(m, a[i]);
-    } else {
-      for (long i = tid; i < n; i += stride) {
-        const long r = i / K8;
-        m = vr_absmax8(m, a[r * lda8 + (i - r * K8)]);
+      const int local = g - first;
+      long off = local;
+      if (!CONTIG) {                  // strided rows: (row, piece) from the flat index
+        const int r = local / K8;
+        off = (long)r * lda8 + (local - r * K8);
       }
+      v[k] = ap[off];
     }
+#pragma unroll
+    for (int k = 0; k < kVrUnroll; ++k) m = vr_absmax8(m, v[k]);
   }
   unsigned m16 = (m & 0xffffu) > (m >> 16) ? (m & 0xffffu) : (m >> 16);
 #pragma unroll
@@ -135,10 +152,13 @@ extern "C" int occ_value_range_scale_bf16(int n_segments, const void* const* a, 
       return OCC_E_UNSUPPORTED;
     }
     seg.a[i] = reinterpret_cast<const uint4*>(a[j]);
-    seg.rows[i] = rows[j];
-    seg.lda8[i] = lda[j] / 8;
+    OCC_CHECK_ARG(lda[j] / 8 < (1L << 31) && pieces + rows[j] * (K / 8) < (1L << 31) - (long)kVrUnroll * 2048 * 256,
+                  "value_range_scale: more than 2^31 16-byte pieces");
+    seg.lda8[i] = (int)(lda[j] / 8);
+    seg.first[i] = (int)pieces;
     if (i < n_segments) pieces += rows[j] * (K / 8);
   }
+  for (int i = n_segments; i <= kVrMaxSeg; ++i) seg.first[i] = (int)pieces;
   seg.n = n_segments;
   VrPlanes pl;
   for (int p = 0; p < kVrMaxPlanes; ++p) {
@@ -148,11 +168,17 @@ extern "C" int occ_value_range_scale_bf16(int n_segments, const void* const* a, 
     pl.bias_max[p] = bias_max[j];
   }
   pl.n = n_planes;
-  // four 16-byte loads per thread and round; no more blocks than that needs, at most 8 per CU
-  long blocks = (pieces + 4 * 256 - 1) / (4 * 256);
+  // kVrUnroll 16-byte loads per thread and round; no more blocks than one round needs, at most 8 per CU
+  long blocks = (pieces + kVrUnroll * 256 - 1) / (kVrUnroll * 256);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
-  hipLaunchKernelGGL(value_range_scale_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), seg, K / 8, pl, scale_out, work);
+  bool contig = true;
+  for (int i = 0; i < n_segments; ++i) contig = contig && lda[i] == K;
+  if (contig)
+    hipLaunchKernelGGL(value_range_scale_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), seg, K / 8, pl, scale_out, work);
+  else
+    hipLaunchKernelGGL(value_range_scale_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), seg, K / 8, pl, scale_out, work);
   OCC_CHECK_LAUNCH("value_range_scale");
   return OCC_OK;
 }

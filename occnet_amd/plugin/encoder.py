@@ -296,12 +296,9 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
         attn = tsa.fused_gather(q, prev_bev, bev_pos, ref_2d, bev_h, bev_w, kwargs.get('bev_order'), pre=tsa_pre)
         wq, bq = sca.query_linear_operands()
         x1, lin = ext.linear_ln_chain(attn, q, tsa.output_proj.weight, tsa.output_proj.bias, self.norms[0], wq, bq)
-        kick = getattr(value, 'kick', None)          # LazyFeatures' layered projection schedules (experiment): no-ops by default
         slots = sca.fused_gather(lin, value, reference_points_cam, kwargs.get('bev_mask'), spatial_shapes,
                                  level_start_index, kwargs.get('vis_bits'), kwargs.get('bev_order'),
-                                 kwargs.get('gather_stats'), before_gather=None if kick is None else (lambda: kick("before_gather")))
-        if kick is not None:
-            kick("before_ffn")
+                                 kwargs.get('gather_stats'))
         tail = None
         if next_tsa is not None and prev_bev is None and bs == 1 and bev_pos is not None:
             tail = next_tsa.chain_tail(bev_pos)
@@ -545,6 +542,8 @@ class BEVFormerEncoder(TransformerLayerSequence):
                         with torch.cuda.stream(s):
                             if _ROW_PIPELINE_SERIAL and i > 0:
                                 s.wait_event(ev[name][i - 1])
+                                if os.environ.get("OCC_ROW_PIPELINE_DUMMY") == "1":     # (debugging) a tiny kernel between
+                                    torch.zeros(1, device=dev)                          # the waits and the stage's launch
                             fn(i, b, s)
                             e = torch.cuda.Event()
                             e.record(s)
@@ -718,8 +717,6 @@ class BEVFormerEncoder(TransformerLayerSequence):
                     return torch.stack(piped) if self.return_intermediate else piped[-1]
             for lid, layer in enumerate(self.layers):
                 output = None
-                if lid > 0 and hasattr(value, 'kick'):
-                    value.kick("layer_start")
                 if chain_ok[lid]:
                     nxt = self.layers[lid + 1].attentions[0] if lid + 1 < len(self.layers) and chain_ok[lid + 1] else None
                     try:

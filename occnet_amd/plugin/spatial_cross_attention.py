@@ -247,7 +247,7 @@ class SpatialCrossAttention(BaseModule):
         return da._qcat.get((da.sampling_offsets, da.attention_weights))
 
     def fused_gather(self, lin, value, reference_points_cam=None, bev_mask=None, spatial_shapes=None,
-                     level_start_index=None, vis_bits=None, bev_order=None, gather_stats=None, before_gather=None):
+                     level_start_index=None, vis_bits=None, bev_order=None, gather_stats=None):
         """Value projection + fused SCA gather for the query-side Linear outputs `lin` (bs, nq, n_off + n_att)
         -> slots (bs, nq, C) BEFORE output_proj.  Raises OccAmdUnsupported."""
         da = self.deformable_attention
@@ -269,8 +269,6 @@ class SpatialCrossAttention(BaseModule):
         n_off = da.sampling_offsets.out_features
         if vis_bits is None:
             vis_bits = pack_vis_bits(bev_mask)
-        if before_gather is not None:
-            before_gather()                  # (scheduling hook: the NEXT layer's value projection may start here)
         return ext.sca_fused_forward(v, spatial_shapes, level_start_index, lin[..., :n_off],
                                      lin[..., n_off:], reference_points_cam.float().contiguous(),
                                      vis_bits, da.num_heads, da.num_levels, da.num_points,

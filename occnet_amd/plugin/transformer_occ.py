@@ -142,32 +142,11 @@ class LazyFeatures:
         return self._flat
 
     _side_streams = {}
-    # OCC_VPROJ_SCHEDULE (round 5 experiment, VERDICT r4 item 3: the gather runs 0.219 ms on cold operands and 0.159 ms on
-    # warm ones, and the one stacked launch writes all four planes ~1 GB of traffic before the first of them is read):
-    #   stacked (default)  all layers' projections in ONE launch at the start of the encoder (maps read once);
-    #   layered            plane 0 at the start, plane l + 1 on the side stream from the START of layer l + 1 (under its TSA
-    #                      gather and chain program A), so that it is the most recent large write when its gather starts;
-    #   layered_early      plane l + 1 from layer l's chain program B on (MFMA-bound: HBM idle);
-    #   layered_gather     plane l + 1 from layer l's SCA gather on.
-    SCHEDULE = os.environ.get("OCC_VPROJ_SCHEDULE", "stacked")
-    _KICK_AT = {"layered": "layer_start", "layered_early": "before_ffn", "layered_gather": "before_gather"}
-
-    def kick(self, point):
-        """Scheduling hook of the layered schedules: the encoder / BEVFormerLayer.forward_chain call it at the named points of
-        every layer; the next queued projection starts on the side stream behind everything the main stream has enqueued so
-        far.  A no-op under the stacked schedule."""
-        q = getattr(self, '_queue', None)
-        if not q or self._KICK_AT.get(self.SCHEDULE) != point:
-            return
-        vp, gb, scale = q.pop(0)
-        main = torch.cuda.current_stream(self.mlvl_feats[0].device)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            out = self._launch(vp, gb, scale)
-            out.record_stream(main)
-            ev = torch.cuda.Event()
-            ev.record(self._side)
-        self._pending[id(vp)] = (out, ev)
+    # (Round 5 measured three LAYERED schedules — plane l + 1 projected on the side stream from the start of layer l + 1, from
+    # layer l's chain program B, or from layer l's gather on, so that it is the most recent large write when its gather
+    # starts — against this one stacked launch, same box: 2.576 / 2.588 / 2.545 ms per hot-path step against 2.49; the gather
+    # gained 3 % (0.197 against 0.202 ms), the chain kernels lost 5-12 % to the co-running projections.  Rejected;
+    # profiles/r05_c2_vproj_schedule_ab.txt.)
 
     def prefetch(self, value_projs):
         """Start project() for several layers' value_proj modules on a side stream (the projections depend on the
@@ -186,10 +165,8 @@ class LazyFeatures:
         if ext.SCA_VALUES == "f16":
             for vp, gb in zip(value_projs, gbs):
                 self._range_terms(vp, gb)                    # host-side constants (first call of a weight state: one sync)
-        layered = self.SCHEDULE in self._KICK_AT and len(value_projs) > 1
-        stacked = (not layered and len(value_projs) > 1
-                   and all(tuple(vp.weight.shape) == tuple(value_projs[0].weight.shape) for vp in value_projs)
-                   and value_projs[0].weight.shape[0] % 256 == 0)
+        stacked = (len(value_projs) > 1 and all(tuple(vp.weight.shape) == tuple(value_projs[0].weight.shape)
+                                                for vp in value_projs) and value_projs[0].weight.shape[0] % 256 == 0)
         if stacked:
             try:
                 ext.value_proj_planes_prepare([vp.weight for vp in value_projs])     # stack + pack on the MAIN stream
@@ -201,7 +178,7 @@ class LazyFeatures:
         side.wait_stream(main)                               # the feature maps, packs and biases are ready
         for r in self.rows:
             r.record_stream(side)                            # read by side-stream kernels: keep them out of reuse
-        self._pending, self._side, self._scale_of, self._queue = {}, side, {}, []
+        self._pending, self._side, self._scale_of = {}, side, {}
         with torch.cuda.stream(side):
             scales = self._scales(value_projs, gbs)          # per-plane fp16 range scales of this call's maps
             if scales is not None:
@@ -227,9 +204,6 @@ class LazyFeatures:
                     self._pending = {}
             if not stacked:
                 for l, (vp, gb) in enumerate(zip(value_projs, gbs)):
-                    if layered and l > 0:       # launched by kick() when the main stream reaches its layer
-                        self._queue.append((vp, gb, None if scales is None else scales[l:l + 1]))
-                        continue
                     out = self._launch(vp, gb, None if scales is None else scales[l:l + 1])
                     out.record_stream(main)                  # consumed (and released) on the main stream
                     ev = torch.cuda.Event()
@@ -272,7 +246,7 @@ class LazyFeatures:
         pending = getattr(self, '_pending', None)
         if pending:
             torch.cuda.current_stream(self.mlvl_feats[0].device).wait_stream(self._side)
-        self._pending, self._queue = {}, []
+        self._pending = {}
 
     def _group_bias(self, value_proj):
         """per-(level, camera) bias = (cams_embeds + level_embeds) . W^T + b: constant while the parameters are,
@@ -324,10 +298,6 @@ class LazyFeatures:
         if hit is not None:
             torch.cuda.current_stream(hit[0].device).wait_event(hit[1])
             return hit[0]
-        for i, (vp, gb, scale) in enumerate(getattr(self, '_queue', None) or []):
-            if vp is value_proj:             # queued by a layered schedule and never kicked: project it here and now
-                del self._queue[i]
-                return self._launch(vp, gb, scale)
         return self._launch(value_proj, self._group_bias(value_proj))
 
     def project_on(self, value_proj, streams):

@@ -48,7 +48,10 @@ def tensors(o):
 def wrap(name):
     def f(*a, **k):
         out = real[name](*a, **k)
-        trace.append((name, [t.detach().clone() for t in tensors(out)], (a, k)))
+        # OCC_PROBE_CLONE=1: clone the outputs (extra kernels on the stream: perturbs the timing); default: keep references —
+        # the path's outputs are fresh tensors that nothing overwrites, and a reference costs no launch
+        keepref = os.environ.get("OCC_PROBE_CLONE") != "1"
+        trace.append((name, [t.detach() if keepref else t.detach().clone() for t in tensors(out)], (a, k)))
         return out
     return f
 
@@ -89,7 +92,27 @@ for rep in range(reps):
                 s = tab[idx[(rep % 4) << 20:((rep % 4) + 1) << 20]].sum(0)
             if "sort" in kinds:
                 st = torch.sort(a[:256].float().view(-1))[0]
+        if "fresh" in kinds:
+            # operations this process has NOT run before (new code objects, library initialisation, first-use workspaces):
+            # a different set in every repetition — call 1's one failure was in the first loaded repetition only
+            xf = a[:1024, :1024].float()
+            fresh = [lambda: torch.fft.rfft(xf), lambda: torch.cumsum(xf, 1), lambda: torch.topk(xf, 7, 1),
+                     lambda: torch.erf(xf) + torch.lgamma(xf.abs() + 1), lambda: torch.linalg.norm(xf, dim=1),
+                     lambda: torch.nn.functional.conv2d(xf[None, None], xf[None, None, :5, :5]),
+                     lambda: torch.bmm(xf.view(16, 64, 1024), xf.view(16, 1024, 64)),
+                     lambda: torch.unique(idx[:100000]), lambda: torch.nn.functional.softmax(xf, 1).multinomial(3),
+                     lambda: torch.median(xf, 1), lambda: torch.argsort(xf, 1), lambda: xf.double() @ xf.double().t(),
+                     lambda: torch.nn.functional.max_pool2d(xf[None, None], 3), lambda: torch.kthvalue(xf, 5, 1),
+                     lambda: torch.nn.functional.layer_norm(xf, (1024,)), lambda: torch.cdist(xf[:256], xf[:256])]
+            for fn in fresh[(2 * rep) % len(fresh):][:2]:
+                try:
+                    fn()
+                except Exception as e:
+                    print("   fresh op failed:", repr(e)[:100])
     got_out, got = run()
+    rep_t = getattr(prod.transformer, "value_range_report", None)
+    if rep_t is not None:
+        print(f"rep {rep}: range report {[round(v, 6) for v in rep_t.tolist()[:5]]}", flush=True)
     first = None
     for i, ((n1, o1, io1), (n2, o2, io2)) in enumerate(zip(solo, got)):
         assert n1 == n2

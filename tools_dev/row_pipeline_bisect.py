@@ -59,6 +59,7 @@ def run(mode):
     os.environ["OCC_ROW_PIPELINE_STREAMS"] = "0" if mode == "one stream" else "1"
     os.environ["OCC_ROW_PIPELINE_DEBUG_SYNC"] = "0"
     enc_mod._ROW_PIPELINE_SERIAL = "serial" in mode
+    os.environ["OCC_ROW_PIPELINE_DUMMY"] = "1" if "dummy" in mode else "0"
     encoder._row_plan = None
     enc_mod._ROW_PIPELINE = k
     encoder._row_debug = None
@@ -79,7 +80,7 @@ with torch.no_grad():
     again = run("one stream")
     same = all(torch.equal(ref[key], again[key]) for key in ref)
     print(f"one stream twice: bit-identical = {same}", flush=True)
-    for mode in ("default", "serial"):
+    for mode in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("default", "serial")):
         for rep in range(reps):
             got = run(mode)
             first = None

@@ -954,10 +954,6 @@ def main():
         # loop time says nothing.  Far below ms_per_step = the GPU is the bottleneck; close to it = the rank is host-bound
         # (the first thing to look at when N ranks share a host: VERDICT r4 item 8)
         out["host_enqueue_ms_per_step"] = _median(enqueue_s) * 1e3 if enqueue_s else None
-        from occnet_amd.plugin import encoder as _enc
-        if _enc._ROW_PIPELINE and not args.history and args.mode == "infer":     # experiment, off by default
-            out["config"]["encoder_row_pipeline"] = {"bands": _enc._ROW_PIPELINE, "native_launcher": _enc._ROW_PIPELINE_NATIVE,
-                                                     "same_kernel_serialisation": _enc._ROW_PIPELINE_SERIAL}
         if args.mode == "train" and world > 1:
             from occnet_amd.dist import ddp_comm_stats
             # the path's ONLY collective: DDP's bucketed gradient all-reduce (RCCL over xGMI), as DDP's logger timed it
@@ -971,12 +967,6 @@ def main():
             row_b = D * ev
             b_alg = [n_in * row_b + rows * S * 12 + rows * M * D * 4 for rows, n_in in stats]
             mean_ms = sum(sca) / len(sca)
-            # OCC_ENCODER_ROW_PIPELINE=K (experiment, off by default): a layer's gather is K launches, one per row band,
-            # co-running with other kernels — the per-layer figures below then sum the bands' launch times
-            n_bands = (len(_enc.row_bands(model.pts_bbox_head.bev_h, model.pts_bbox_head.bev_w, _enc._ROW_PIPELINE))
-                       if _enc._ROW_PIPELINE >= 2 and not args.history else 1)
-            if n_bands > 1:
-                mean_ms *= n_bands
             mean_bytes = sum(b_alg) / n_layers
             sec = mean_ms * 1e-3
             # bytes the kernel pulls through the texture-addresser / L1 path per launch: one row per in-map corner

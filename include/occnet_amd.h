@@ -345,50 +345,6 @@ int occ_encoder_ffn_chain_bf16x3_f32(const float* a, int64_t lda, const float* r
                                      const float* q_term, int64_t ldq_term, float* zq, int64_t ldzq, int nq,
                                      float* zv, int64_t ldzv, int M, void* stream);
 
-/* ------------------------------------------------------------------------------------------
- * The encoder's chain path as ONE call (csrc/encoder_bands.hip): for every layer  TSA gather -> program A -> SCA gather ->
- * program B, for K row bands of the BEV queries on K streams.  Between two TSA gathers a BEVFormerLayer is row-local
- * (encoder.py:377-404: the TSA output projection, a query's SCA and the FFN touch that query's row only; only
- * temporal_self_attention.py:240-262 reads the whole BEV), so two bands can be in different kernels at the same time.
- * bs = 1, no history BEV, embed_dims 256, 8 heads.  K = 1 = the unbanded sequence on the caller's stream.
- * EXPERIMENTAL (round 4: compiled and argument-checked, not yet run on an MI355X; opt-in from plugin/encoder.py).
- *   q0   (Nq, 256)  layer-0 input rows;  zq0 (Nq, ldzq0) / zv0 (Nq, 256): layer 0's TSA query Linears (offsets | weights)
- *        and projected BEV (occ_linear_pair_chain_bf16x3_f32 on q0)
- *   bands tile [0, Nq) in order; a band's gathers run with Nq := n, so `order` holds band-LOCAL query indices and
- *        ref_2d (2, n, 1, 2) / ref_cam (NC, 1, n, Z, 2) are band copies; attn / x1 / slots (n, 256), lin (n, 8*L*P*3) are the
- *        band's scratch rows; `stream` its hipStream_t (forked from / joined into `main_stream` by this call)
- *   layers: chain operands as occ_linear_ln_chain_bf16x3_f32 / occ_encoder_ffn_chain_bf16x3_f32 take them; `plane` the SCA
- *        value maps of the layer (fp16 pixel pairs when planes_f16, else f32 rows), `plane_ready` a hipEvent_t every band
- *        waits for before its gather (or NULL); out (Nq, 256), and for every layer but the last zq (Nq, nq_tail) /
- *        zv (Nq, 256) = the next layer's TSA operands (q_term (Nq, ldq_term) or NULL).
- *   flags: 0, or OCC_EB_* below (scheduling experiments; results do not depend on them). */
-typedef struct OccBand {
-  int32_t m0, n;
-  const int32_t* order;
-  const float* ref_2d;
-  const float* ref_cam;
-  float* attn;
-  float* x1;
-  float* lin;
-  float* slots;
-  void* stream;
-} OccBand;
-typedef struct OccBandLayer {
-  const void* wA; const float* biasA; const float* ln0_g; const float* ln0_b; float ln0_eps;
-  const void* plane; void* plane_ready; const float* plane_scale; uint64_t* stats;
-  const void* wB; const float* biasB; const float* ln1_g; const float* ln1_b; float ln1_eps;
-  const float* ln2_g; const float* ln2_b; float ln2_eps;
-  const float* q_term; int64_t ldq_term; int32_t nq_tail;
-  float* out; float* zq; float* zv;
-} OccBandLayer;
-int occ_encoder_bands_forward_f32(const float* q0, const float* zq0, int64_t ldzq0, const float* zv0,
-                                  const OccBandLayer* layers, int n_layers, const OccBand* bands, int n_bands,
-                                  const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                  const uint32_t* vis_bits, int Nq, int bev_h, int bev_w, int NC, int S, int L, int P,
-                                  int Z, int tsa_P, int planes_f16, int flags, void* main_stream);
-#define OCC_EB_STAGGER 1    /* flags: band i's first launch waits for band i - 1's first launch (bands one stage apart)  */
-#define OCC_EB_BAND_MAJOR 2 /* flags: submit band by band (T, A, S, B of band 0, then band 1, ...) instead of stage by stage */
-
 /* Program C: the tail stage alone — two Linears of the SAME 256-wide rows in one launch (the first encoder layer's TSA
  * query Linears and value projection, temporal_self_attention.py:197-209,239-240, straight from the BEV queries):
  *   zq (M, nq) = a . Wq^T + q_term (or + 0),   zv (M, 256) = a . Wv^T + bv.

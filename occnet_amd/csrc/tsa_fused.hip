@@ -21,8 +21,9 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
     const float* __restrict__ value, long value_bt_stride, const float* __restrict__ offs,
     long offs_stride, const float* __restrict__ logits, long logits_stride,
     const float* __restrict__ ref_2d, const int32_t* __restrict__ order, float* __restrict__ out,
-    int B, int Nq, int bev_h, int bev_w) {
+    int B, int Nq, int bev_h, int bev_w, int dbg) {
   constexpr int M = 8, D = 32, P = 4, NS = 2 * P;  // samples per head
+  if (dbg & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // (hazard experiment) software acquire
   constexpr int NSp = NS + 1;
   __shared__ __attribute__((aligned(16))) SampleParamB smem[kTsaWaves * M * NSp];
   const int lane = threadIdx.x & 63;
@@ -37,14 +38,20 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
 
   // lane = m*8 + t*4 + p : exactly the memory order of both Linear outputs
   const int m = lane >> 3, t = (lane >> 2) & 1;
-  const float x = logits[((long)b * Nq + q) * logits_stride + lane];
+  float x = logits[((long)b * Nq + q) * logits_stride + lane];
+  if (dbg & 1) x = __hip_atomic_load(logits + ((long)b * Nq + q) * logits_stride + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float mx = fmaxf(x, __shfl_xor(x, 1));
   mx = fmaxf(mx, __shfl_xor(mx, 2));
   const float e = expf(x - mx);
   float sum = e + __shfl_xor(e, 1);
   sum += __shfl_xor(sum, 2);
   const float aw = e / sum;
-  const float2 o = *reinterpret_cast<const float2*>(offs + ((long)b * Nq + q) * offs_stride + 2 * lane);
+  float2 o = *reinterpret_cast<const float2*>(offs + ((long)b * Nq + q) * offs_stride + 2 * lane);
+  if (dbg & 1) {       // (hazard experiment) agent-coherent loads of the query's offsets
+    const float* op = offs + ((long)b * Nq + q) * offs_stride + 2 * lane;
+    o.x = __hip_atomic_load(op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    o.y = __hip_atomic_load(op + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const float2 rf = *reinterpret_cast<const float2*>(ref_2d + (((long)b * 2 + t) * Nq + q) * 2);
   // corners outside the BEV map carry an out-of-range byte offset: the buffer load returns 0 without a request (no
   // dummy load of row 0, no 0 * Inf)
@@ -105,78 +112,121 @@ __global__ __launch_bounds__(256, 3) void tsa_tile_kernel(
   const int wy0 = ty * kTsaTile - kTsaHalo, wx0 = tx * kTsaTile - kTsaHalo;
   if (tid < kTsaRowB / 4) reinterpret_cast<float*>(win + kTsaWinBytes)[tid] = 0.f;
   const bool shared = value_bt_stride == 0;
+  const int T = shared ? 1 : 2;                     // window stages per head: one per DIFFERENT queue entry
   const unsigned map_bytes = (unsigned)bev_h * (unsigned)bev_w * (unsigned)row_stride * 4u;
 
-  // the wave's queries: tile rows 2 * wave + pass, one query per 8-lane group
-  const int j = lane >> 3, c = lane & 7;
+  // the wave's queries: tile rows 2 * wave + pass, one query per 8-lane group; as set-up lane = (query j, sample s = t' * 4 + p)
+  const int j = lane >> 3, c = lane & 7, s_mine = lane & 7;
   const int qx = tx * kTsaTile + j;
   SampleParamB* sp = slab + wave * kTsaSlab;
+  bool live[2];
+  long qrow[2];
+  float2 rf[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int qy = ty * kTsaTile + 2 * wave + pass;
+    live[pass] = qy < bev_h && qx < bev_w;
+    qrow[pass] = (long)b * Nq + (live[pass] ? qy * bev_w + qx : 0);
+    rf[pass] = live[pass] ? *reinterpret_cast<const float2*>(ref_2d + (((long)b * 2 + (s_mine >> 2)) * Nq + (qrow[pass] - (long)b * Nq)) * 2)
+                          : make_float2(0.f, 0.f);
+  }
 
-  for (int h = 0; h < M; ++h) {
-    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    for (int t = 0; t < (shared ? 1 : 2); ++t) {
-      const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(value + ((long)b * 2 + t) * value_bt_stride, map_bytes);
-      // ---- stage the head's rows of the window: 18 * 18 * 8 sixteen-byte pieces, zero outside the map ----------------
-      constexpr int kPieces = kTsaWin * kTsaWin * 8, kIter = (kPieces + 255) / 256;
-      float4 v[kIter];
+  // Software pipeline: the window rows of stage st + 1 and the query-side operands of head h + 1 are REQUESTED before the
+  // gather of stage st and consumed after it — the first cut issued them where it needed them and spent nine tenths of a
+  // block's time waiting for memory (stage, barrier, set-up loads, gather: 99 us per launch against the wave-per-query
+  // kernel's 68, profiles/r05_c3_hot_kernel_trace_stats.txt).
+  constexpr int kPieces = kTsaWin * kTsaWin * 8, kIter = (kPieces + 255) / 256;
+  float4 wv[kIter];
+  float lg[2];
+  float2 of[2];
+#define OCC_TSA_WINDOW(ST)                                                                                          \
+  {                                                                                                                  \
+    const int h_ = (ST) / T, t_ = (ST) - h_ * T;                                                                     \
+    const __amdgpu_buffer_rsrc_t rs_ = uniform_rsrc(value + ((long)b * 2 + t_) * value_bt_stride, map_bytes);        \
+    _Pragma("unroll") for (int it = 0; it < kIter; ++it) {                                                           \
+      const int i = tid + it * 256;                                                                                  \
+      const int pix = i >> 3, wy = pix / kTsaWin, wx = pix - wy * kTsaWin;                                           \
+      const int y = wy0 + wy, x = wx0 + wx;                                                                          \
+      const bool in = i < kPieces && (unsigned)y < (unsigned)bev_h && (unsigned)x < (unsigned)bev_w;                 \
+      const unsigned goff = in ? (unsigned)(y * bev_w + x) * (unsigned)(row_stride * 4) +                            \
+                                     (unsigned)(h_ * kTsaRowB + (i & 7) * 16)                                        \
+                               : kOobOffset;                                                                         \
+      wv[it] = buf_load16(rs_, goff);                                                                                \
+    }                                                                                                                \
+  }
+#define OCC_TSA_PARAMS(H)                                                                                           \
+  _Pragma("unroll") for (int pass = 0; pass < 2; ++pass) {                                                           \
+    lg[pass] = live[pass] ? logits[qrow[pass] * logits_stride + (H) * 8 + s_mine] : 0.f;                             \
+    of[pass] = live[pass] ? *reinterpret_cast<const float2*>(offs + qrow[pass] * offs_stride + 2 * ((H) * 8 + s_mine)) \
+                          : make_float2(0.f, 0.f);                                                                   \
+  }
+  OCC_TSA_WINDOW(0)
+  OCC_TSA_PARAMS(0)
+  float4 acc[2];
+  float lgc[2];
+  float2 ofc[2];
+  for (int st = 0; st < M * T; ++st) {
+    const int h = st / T, t = st - h * T;
 #pragma unroll
-      for (int it = 0; it < kIter; ++it) {
-        const int i = tid + it * 256;
-        const int pix = i >> 3, wy = pix / kTsaWin, wx = pix - wy * kTsaWin;
-        const int y = wy0 + wy, x = wx0 + wx;
-        const bool in = i < kPieces && (unsigned)y < (unsigned)bev_h && (unsigned)x < (unsigned)bev_w;
-        const unsigned goff = in ? (unsigned)(y * bev_w + x) * (unsigned)(row_stride * 4) + (unsigned)(h * kTsaRowB + (i & 7) * 16)
-                                 : kOobOffset;
-        v[it] = buf_load16(rs, goff);
-      }
+    for (int it = 0; it < kIter; ++it) {
+      const int i = tid + it * 256;
+      if (i < kPieces) *reinterpret_cast<float4*>(win + i * 16) = wv[it];
+    }
+    block_lds_sync();
+    if (t == 0) {
+      acc[0] = acc[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      lgc[0] = lg[0]; lgc[1] = lg[1]; ofc[0] = of[0]; ofc[1] = of[1];
+      if (h + 1 < M) OCC_TSA_PARAMS(h + 1)
+    }
+    if (st + 1 < M * T) OCC_TSA_WINDOW(st + 1)
+    const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(value + ((long)b * 2 + t) * value_bt_stride, map_bytes);
 #pragma unroll
-      for (int it = 0; it < kIter; ++it) {
-        const int i = tid + it * 256;
-        if (i < kPieces) *reinterpret_cast<float4*>(win + i * 16) = v[it];
-      }
-      __syncthreads();
-      // ---- gather: two passes of 8 queries per wave ----------------------------------------------------------------------
+    for (int pass = 0; pass < 2; ++pass) {
+      bool far;
+      {
+        const float xl = lgc[pass];
+        float mx = fmaxf(xl, __shfl_xor(xl, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        const float e = expf(xl - mx);
+        float sum = e + __shfl_xor(e, 1);
+        sum += __shfl_xor(sum, 2);
+        const float aw = e / sum;
+        SampleParamB p;
+        // offsets in PIXELS first (pix_bytes = 1), then window-relative LDS bytes or a flagged global byte offset
+        bilinear_setup_b(rf[pass].x + ofc[pass].x / (float)bev_w, rf[pass].y + ofc[pass].y / (float)bev_h, aw, bev_h, bev_w,
+                         0, 1u, 0xffffffffu, live[pass], p);
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int qy = ty * kTsaTile + 2 * wave + pass;
-        const bool live = qy < bev_h && qx < bev_w;
-        const int q = live ? qy * bev_w + qx : 0;
-        // set-up: lane = (query j, sample s = t' * 4 + p) of head h — the memory order of both Linear outputs
-        {
-          const int s = lane & 7, ts = s >> 2;
-          const float xl = live ? logits[((long)b * Nq + q) * logits_stride + h * 8 + s] : 0.f;
-          float mx = fmaxf(xl, __shfl_xor(xl, 1));
-          mx = fmaxf(mx, __shfl_xor(mx, 2));
-          const float e = expf(xl - mx);
-          float sum = e + __shfl_xor(e, 1);
-          sum += __shfl_xor(sum, 2);
-          const float aw = e / sum;
-          float2 o = make_float2(0.f, 0.f), rf = make_float2(0.f, 0.f);
-          if (live) {
-            o = *reinterpret_cast<const float2*>(offs + ((long)b * Nq + q) * offs_stride + 2 * (h * 8 + s));
-            rf = *reinterpret_cast<const float2*>(ref_2d + (((long)b * 2 + ts) * Nq + q) * 2);
+        for (int k = 0; k < 4; ++k) {
+          if (p.o[k] == 0xffffffffu) {
+            p.o[k] = (unsigned)kTsaWinBytes;                         // the zero row
+          } else {
+            const int py = (int)p.o[k] / bev_w, px = (int)p.o[k] - py * bev_w;
+            const int wy = py - wy0, wx = px - wx0;
+            p.o[k] = ((unsigned)wy < (unsigned)kTsaWin && (unsigned)wx < (unsigned)kTsaWin)
+                         ? (unsigned)(wy * kTsaWin + wx) * (unsigned)kTsaRowB
+                         : (kTsaGlobalBit | (p.o[k] * (unsigned)(row_stride * 4) + (unsigned)(h * kTsaRowB)));
           }
-          SampleParamB p;
-          // offsets in PIXELS first (pix_bytes = 1), then window-relative LDS bytes or a flagged global byte offset
-          bilinear_setup_b(rf.x + o.x / (float)bev_w, rf.y + o.y / (float)bev_h, aw, bev_h, bev_w, 0, 1u, 0xffffffffu, live, p);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (p.o[k] == 0xffffffffu) {
-              p.o[k] = (unsigned)kTsaWinBytes;                         // the zero row
-            } else {
-              const int py = (int)p.o[k] / bev_w, px = (int)p.o[k] - py * bev_w;
-              const int wy = py - wy0, wx = px - wx0;
-              p.o[k] = ((unsigned)wy < (unsigned)kTsaWin && (unsigned)wx < (unsigned)kTsaWin)
-                           ? (unsigned)(wy * kTsaWin + wx) * (unsigned)kTsaRowB
-                           : (kTsaGlobalBit | (p.o[k] * (unsigned)(row_stride * 4) + (unsigned)(h * kTsaRowB)));
-            }
-          }
-          sp[j * 9 + s] = p;
         }
-        wave_lds_sync();
-        const int s_lo = shared ? 0 : t * P, s_hi = shared ? 2 * P : (t + 1) * P;
-        const SampleParamB* mine = sp + j * 9;
-        float4 a = acc[pass];
+        sp[j * 9 + s_mine] = p;
+        far = ((p.o[0] | p.o[1] | p.o[2] | p.o[3]) & kTsaGlobalBit) != 0;
+      }
+      wave_lds_sync();
+      const int s_lo = shared ? 0 : t * P, s_hi = shared ? 2 * P : (t + 1) * P;
+      const SampleParamB* mine = sp + j * 9;
+      float4 a = acc[pass];
+      // wave-uniform choice: the pure-LDS loop carries no vector-memory instruction, so nothing in it waits for the window
+      // rows that are in flight for the next stage (with the fallback load in the same loop hipcc put `s_waitcnt vmcnt(0)`
+      // behind every corner and the prefetch was drained before the first sample)
+      if (__builtin_amdgcn_ballot_w64(far) == 0) {
+        for (int s = s_lo; s < s_hi; ++s) {
+          const occ_u32x4 o = *reinterpret_cast<const occ_u32x4*>(mine[s].o);
+          const float4 w = *reinterpret_cast<const float4*>(mine[s].w);
+          float4 r[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) r[k] = *reinterpret_cast<const float4*>(win + o[k] + c * 16);
+          fma4(a, w.x, r[0]); fma4(a, w.y, r[1]); fma4(a, w.z, r[2]); fma4(a, w.w, r[3]);
+        }
+      } else {
         for (int s = s_lo; s < s_hi; ++s) {
           const occ_u32x4 o = *reinterpret_cast<const occ_u32x4*>(mine[s].o);
           const float4 w = *reinterpret_cast<const float4*>(mine[s].w);
@@ -188,21 +238,23 @@ __global__ __launch_bounds__(256, 3) void tsa_tile_kernel(
           }
           fma4(a, w.x, r[0]); fma4(a, w.y, r[1]); fma4(a, w.z, r[2]); fma4(a, w.w, r[3]);
         }
-        acc[pass] = a;
-        wave_lds_sync();                                               // WAR: the next pass rewrites the slab
       }
-      __syncthreads();                                                 // WAR: the next stage rewrites the window
+      acc[pass] = a;
+      wave_lds_sync();                                               // WAR: the next pass rewrites the slab
     }
+    block_lds_sync();                                                // WAR: the next stage rewrites the window
+    if (t == T - 1) {
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int qy = ty * kTsaTile + 2 * wave + pass;
-      if (qy < bev_h && qx < bev_w) {
-        const float4 a = acc[pass];
-        *reinterpret_cast<float4*>(out + ((long)b * Nq + (qy * bev_w + qx)) * row_stride + h * D + c * 4) =
-            make_float4(a.x * 0.5f, a.y * 0.5f, a.z * 0.5f, a.w * 0.5f);
-      }
+      for (int pass = 0; pass < 2; ++pass)
+        if (live[pass]) {
+          const float4 a = acc[pass];
+          *reinterpret_cast<float4*>(out + qrow[pass] * row_stride + h * D + c * 4) =
+              make_float4(a.x * 0.5f, a.y * 0.5f, a.z * 0.5f, a.w * 0.5f);
+        }
     }
   }
+#undef OCC_TSA_WINDOW
+#undef OCC_TSA_PARAMS
 }
 
 }  // namespace occ
@@ -229,6 +281,8 @@ extern "C" int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_st
   // the tile kernel (value rows staged through LDS) whenever the queries are the whole BEV map, query q at pixel
   // (q / bev_w, q % bev_w) — `order` is a locality hint of the wave-per-query kernel and plays no role there.
   // OCC_TSA_TILE=0 (development switch) keeps the wave-per-query kernel.
+  const char* dbg_env = getenv("OCC_DBG_TSA");             // (hazard experiment) 1: coherent loads of zq, 2: acquire fence
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
   const char* tile_env = getenv("OCC_TSA_TILE");           // read per call: the tests switch it inside one process
   const bool tile_on = !(tile_env && tile_env[0] == '0');
   if (tile_on && (long)Nq == (long)bev_h * bev_w) {
@@ -244,7 +298,7 @@ extern "C" int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_st
   const long blocks = (waves + kTsaWaves - 1) / kTsaWaves;
   hipLaunchKernelGGL(tsa_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, st, value,
                      (long)value_bt_stride, offs, (long)offs_stride, logits, (long)logits_stride,
-                     ref_2d, order, out, B, Nq, bev_h, bev_w);
+                     ref_2d, order, out, B, Nq, bev_h, bev_w, dbg);
   OCC_CHECK_LAUNCH("tsa_fused_forward");
   return OCC_OK;
 }

@@ -947,143 +947,6 @@ def linear_pair_chain(a, wq, q_term, wv, bv):
     return zq, zv
 
 
-class _OccBand(ctypes.Structure):          # include/occnet_amd.h: OccBand
-    _fields_ = [("m0", ctypes.c_int32), ("n", ctypes.c_int32)] + [
-        (k, ctypes.c_void_p) for k in ("order", "ref_2d", "ref_cam", "attn", "x1", "lin", "slots", "stream")]
-
-
-class _OccBandLayer(ctypes.Structure):     # include/occnet_amd.h: OccBandLayer
-    _fields_ = [("wA", ctypes.c_void_p), ("biasA", ctypes.c_void_p), ("ln0_g", ctypes.c_void_p),
-                ("ln0_b", ctypes.c_void_p), ("ln0_eps", ctypes.c_float),
-                ("plane", ctypes.c_void_p), ("plane_ready", ctypes.c_void_p), ("plane_scale", ctypes.c_void_p),
-                ("stats", ctypes.c_void_p),
-                ("wB", ctypes.c_void_p), ("biasB", ctypes.c_void_p), ("ln1_g", ctypes.c_void_p),
-                ("ln1_b", ctypes.c_void_p), ("ln1_eps", ctypes.c_float), ("ln2_g", ctypes.c_void_p),
-                ("ln2_b", ctypes.c_void_p), ("ln2_eps", ctypes.c_float),
-                ("q_term", ctypes.c_void_p), ("ldq_term", ctypes.c_int64), ("nq_tail", ctypes.c_int32),
-                ("out", ctypes.c_void_p), ("zq", ctypes.c_void_p), ("zv", ctypes.c_void_p)]
-
-
-def _dp(t):
-    return None if t is None else t.data_ptr()
-
-
-def encoder_bands_forward(q0, zq0, zv0, layers, bands, spatial_shapes, level_start_index, vis_bits, bev_h, bev_w,
-                          num_levels, num_points, tsa_points, flags=0):
-    """EXPERIMENTAL (csrc/encoder_bands.hip; never run on an MI355X in round 4): the encoder's chain path — per layer TSA
-    gather -> program A -> SCA gather -> program B — for the row bands `bands` on their streams, in ONE call.
-    q0 (1, Nq, 256); zq0 (1, Nq, n) / zv0 (1, Nq, 256) = linear_pair_chain(q0, ...) of layer 0.
-    layers: dicts with  a = (w1, b1, ln, w2, b2)  [program A: TSA output_proj, norm, SCA query Linears],
-        b = (wo, bo, ln1, w1, b1, w2, b2, ln2)  [program B], tail = (wq, q_term, wv, bv) or None,
-        plane (NC, S, 8, 32) f16 pairs / f32 rows, plane_ready torch.cuda.Event or None, stats or None,
-        out (1, Nq, 256), zq (1, Nq, nq) / zv (1, Nq, 256) or None (last layer).
-    bands: dicts m0, m1, order (n) int32, ref_2d (2, n, 1, 2), ref_cam (NC, 1, n, Z, 2), attn / x1 / slots (1, n, 256),
-        lin (1, n, 8*L*P*3), stream (torch.cuda.Stream).  Everything float32 device memory unless noted.
-    flags: OCC_EB_STAGGER (1) | OCC_EB_BAND_MAJOR (2), include/occnet_amd.h — scheduling only."""
-    if LINEAR_PRECISION != "bf16x3":
-        raise OccAmdUnsupported("encoder_bands_forward: bf16x3 precision mode only")
-    dev = q0.device
-    for n_, t in (("q0", q0), ("zq0", zq0), ("zv0", zv0)):
-        _need_cuda_f32(n_, t)
-    _need_cuda_i64("spatial_shapes", spatial_shapes)
-    _need_cuda_i64("level_start_index", level_start_index)
-    Nq = bev_h * bev_w
-    if tuple(q0.shape) != (1, Nq, 256) or tuple(zv0.shape) != (1, Nq, 256) or tuple(zq0.shape[:2]) != (1, Nq):
-        raise OccAmdError("encoder_bands_forward: q0 / zv0 must be (1, Nq, 256) and zq0 (1, Nq, n)")
-    if vis_bits.dtype != torch.int32 or tuple(vis_bits.shape) != (1, Nq) or not vis_bits.is_contiguous():
-        raise OccAmdError("encoder_bands_forward: vis_bits must be contiguous int32 (1, Nq)")
-    L, P = int(num_levels), int(num_points)
-    n_lin = 8 * L * P * 3
-    keep = []
-    cl = (_OccBandLayer * len(layers))()
-    planes_f16 = None
-    NC = S = None
-    for l, (y, c) in enumerate(zip(layers, cl)):
-        w1, b1, ln, w2, b2 = y['a']
-        if tuple(w1.shape) != (256, 256) or tuple(w2.shape) != (n_lin, 256):
-            raise OccAmdUnsupported("encoder_bands_forward: program A needs (256, 256) and (8*L*P*3, 256) weights")
-        g0, be0, eps0 = _ln_params(ln)
-        wA = linear_chain_pack([w1, w2])
-        bA = _chain_bias([(b1, 256), (b2, (n_lin + 255) // 256 * 256)], dev)
-        wo, bo, ln1, f1, fb1, f2, fb2, ln2 = y['b']
-        if tuple(wo.shape) != (256, 256) or tuple(f1.shape) != (512, 256) or tuple(f2.shape) != (256, 512):
-            raise OccAmdUnsupported("encoder_bands_forward: program B needs output_proj (256, 256) and a 256 -> 512 -> 256 FFN")
-        g1, be1, eps1 = _ln_params(ln1)
-        g2, be2, eps2 = _ln_params(ln2)
-        weights, biases = [wo, f1, f2], [(bo, 256), (fb1, 512), (fb2, 256)]
-        tail = y.get('tail')
-        q_term, ldq, nq = None, 0, 0
-        if tail is not None:
-            wq, q_term, wv, bv = tail
-            nq = wq.shape[0]
-            if wq.dim() != 2 or wq.shape[1] != 256 or nq > 256 or nq % 64 or tuple(wv.shape) != (256, 256):
-                raise OccAmdUnsupported("encoder_bands_forward: tail needs wq (nq <= 256, nq % 64 == 0, 256) and wv (256, 256)")
-            if q_term is not None:
-                _, Mq, _, ldq = _rows2d("q_term", q_term, nq)
-                if Mq != Nq:
-                    raise OccAmdError("encoder_bands_forward: q_term differs in rows")
-            weights += [wq, wv]
-            biases += [(None, 256), (bv, 256)]
-            for n_, t, w in (("zq", y['zq'], nq), ("zv", y['zv'], 256)):
-                _need_cuda_f32(n_, t)
-                if tuple(t.shape) != (1, Nq, w):
-                    raise OccAmdError(f"encoder_bands_forward: layer {l}: {n_} must be (1, Nq, {w})")
-        elif l + 1 < len(layers):
-            raise OccAmdError("encoder_bands_forward: every layer but the last needs a tail")
-        wB = linear_chain_pack(weights)
-        bB = _chain_bias(biases, dev)
-        plane = y['plane']
-        f16 = plane.dtype == torch.float16
-        if planes_f16 is None:
-            planes_f16, NC, S = f16, plane.shape[0], plane.shape[1]
-        if (f16 != planes_f16 or plane.dim() != 4 or tuple(plane.shape) != (NC, S, 8, 32) or not plane.is_cuda
-                or not plane.is_contiguous() or plane.dtype not in (torch.float16, torch.float32) or (f16 and S % 2)):
-            raise OccAmdError("encoder_bands_forward: planes must be contiguous (NC, S, 8, 32), all fp16 pairs or all f32")
-        _need_cuda_f32("out", y['out'])
-        if tuple(y['out'].shape) != (1, Nq, 256):
-            raise OccAmdError("encoder_bands_forward: out must be (1, Nq, 256)")
-        ev = y.get('plane_ready')
-        keep += [wA, bA, wB, bB, g0, be0, g1, be1, g2, be2, plane, ev, q_term, y.get('plane_scale')]
-        c.wA, c.biasA, c.ln0_g, c.ln0_b, c.ln0_eps = _dp(wA), _dp(bA), _dp(g0), _dp(be0), eps0
-        c.plane, c.plane_ready, c.stats = _dp(plane), (None if ev is None else ev.cuda_event), _dp(y.get('stats'))
-        c.plane_scale = _dp(y.get('plane_scale'))
-        c.wB, c.biasB, c.ln1_g, c.ln1_b, c.ln1_eps = _dp(wB), _dp(bB), _dp(g1), _dp(be1), eps1
-        c.ln2_g, c.ln2_b, c.ln2_eps = _dp(g2), _dp(be2), eps2
-        c.q_term, c.ldq_term, c.nq_tail = _dp(q_term), ldq, nq
-        c.out, c.zq, c.zv = _dp(y['out']), _dp(y.get('zq')), _dp(y.get('zv'))
-    cb = (_OccBand * len(bands))()
-    Z = None
-    for b, c in zip(bands, cb):
-        n = b['m1'] - b['m0']
-        rc_ = b['ref_cam']
-        if Z is None:
-            Z = rc_.shape[3]
-        _need_cuda_f32("ref_cam", rc_)
-        _need_cuda_f32("ref_2d", b['ref_2d'])
-        if tuple(rc_.shape) != (NC, 1, n, Z, 2) or tuple(b['ref_2d'].shape) != (2, n, 1, 2):
-            raise OccAmdError("encoder_bands_forward: band ref_cam must be (NC, 1, n, Z, 2) and ref_2d (2, n, 1, 2)")
-        if b['order'].dtype != torch.int32 or b['order'].numel() != n or not b['order'].is_cuda:
-            raise OccAmdError("encoder_bands_forward: band order must be int32 (n) device memory")
-        for n_, w in (("attn", 256), ("x1", 256), ("slots", 256), ("lin", n_lin)):
-            _need_cuda_f32(n_, b[n_])
-            if b[n_].numel() != n * w:
-                raise OccAmdError(f"encoder_bands_forward: band scratch {n_} must hold (n, {w}) floats")
-        c.m0, c.n = b['m0'], n
-        c.order, c.ref_2d, c.ref_cam = _dp(b['order']), _dp(b['ref_2d']), _dp(rc_)
-        c.attn, c.x1, c.lin, c.slots = _dp(b['attn']), _dp(b['x1']), _dp(b['lin']), _dp(b['slots'])
-        c.stream = b['stream'].cuda_stream
-    if Z is None or P % Z:
-        raise OccAmdError("encoder_bands_forward: num_points must be a multiple of the anchors per pillar")
-    fn = _lib.lib().occ_encoder_bands_forward_f32
-    with torch.cuda.device(dev), _timed('encoder_bands'):
-        rc = fn(ptr(q0), ptr(zq0), i64(zq0.shape[-1]), ptr(zv0), cl, i32(len(layers)), cb, i32(len(bands)),
-                ptr(spatial_shapes), ptr(level_start_index), ptr(vis_bits), i32(Nq), i32(bev_h), i32(bev_w), i32(NC),
-                i32(S), i32(L), i32(P), i32(Z), i32(int(tsa_points)), i32(1 if planes_f16 else 0), i32(int(flags)),
-                stream_ptr(dev))
-    _lib.check(rc, "encoder_bands_forward")
-    del keep
-
-
 def linear_wgrad(dy, x, with_bias=True):
     """Weight / bias gradient of out = x @ W^T + b on the bf16x3 matrix-core kernel (csrc/linear_wgrad.hip):
     dW (N, K) = dy^T @ x, db (N) = dy.sum(rows).  dy (…, N), x (…, K) float32 device tensors with the same leading

@@ -31,41 +31,12 @@ from .spatial_cross_attention import _require_device
 # (6.764 -> 6.734 ms per sample, ABAB on one box; OCC_VPROJ_OVERLAP=0 restores the serial order)
 _VPROJ_OVERLAP = os.environ.get("OCC_VPROJ_OVERLAP", "1") == "1"
 
-# EXPERIMENT, off by default (built and measured in the last GPU minutes of round 4):
-# OCC_ENCODER_ROW_PIPELINE=K (K >= 2) cuts the BEV queries into K row bands and walks every layer band by band on K HIP
-# streams.  Between two TSA gathers everything is ROW-LOCAL — chain program A, the SCA gather (its value operand is the
-# camera planes, not the BEV) and chain program B only ever touch their own rows — so band 2's TSA gather / program A can
-# run under band 1's SCA gather, and band 1's program B under band 2's SCA gather: kernels bound by different units
-# (texture path / HBM writes / matrix cores) share the chip instead of running back to back, each with its own ramp-up
-# and drain.  Only the TSA gather of the NEXT layer needs all bands (its value operand is the whole BEV).
-# What round 4 measured (profiles/r04_rowpipe_*): the banded launches are correct (one stream: 2.3e-5 against the standard
-# path after 4 layers; K streams: the same) but the EAGER pipeline is host-bound — 2 bands double the encoder's launches and
-# add stream switches and events: 2.44 ms of unqueued host time per hot-path step against 1.0 ms, so the wall time
-# (2.39 ms against 2.28 ms) is the launch cost, not the overlap.  The whole standard hot-path step captures into a
-# hipGraph (replay 2.31 ms); capturing the pipelined step crashed inside the runtime, which is where round 5 picks up.
-# OCC_ROW_PIPELINE_SERIAL=1 adds events that keep two launches of the SAME kernel from overlapping (band i + 1's stage
-# waits for band i's): KNOWN BAD — with them 60-100 of band 2's 19 200 queries come out wrong from the second layer on
-# (a device synchronize per layer cures it, stream-to-stream barriers do not: not understood, profiles/r04_rowpipe_debug3.log).
-# OCC_ROW_PIPELINE_STREAMS=0 / OCC_ROW_PIPELINE_DEBUG_SYNC=1|2 are the debugging switches of tools_dev/row_pipeline_debug.py.
-_ROW_PIPELINE = int(os.environ.get("OCC_ENCODER_ROW_PIPELINE", "0") or 0)
-_ROW_PIPELINE_SERIAL = os.environ.get("OCC_ROW_PIPELINE_SERIAL", "0") == "1"
-# OCC_ROW_PIPELINE_NATIVE=1: the banded sequence issued by ONE C-ABI call (csrc/encoder_bands.hip, ext.encoder_bands_forward)
-# instead of ~35 Python-side launches — written after the GPU budget of round 4 was spent: compiled, host-tested, never run on
-# an MI355X.  With OCC_ENCODER_ROW_PIPELINE=1 it is the unbanded chain path from one call.
-_ROW_PIPELINE_NATIVE = os.environ.get("OCC_ROW_PIPELINE_NATIVE", "0") == "1"
-# OCC_ROW_PIPELINE_FLAGS: scheduling flags of the native launcher (include/occnet_amd.h: 1 = bands one stage apart, 2 =
-# band-major submission)
-_ROW_PIPELINE_FLAGS = int(os.environ.get("OCC_ROW_PIPELINE_FLAGS", "0") or 0)
-
-
-def row_bands(bev_h, bev_w, k, tile_h=8):
-    """k contiguous bands of BEV rows with boundaries on multiples of tile_h (the gather kernels walk the queries in
-    tile_h x 8 tiles), as equal as the tile rows allow -> [(first query, one past the last query, band height)];
-    fewer than k bands when there are fewer tile rows."""
-    nt = (bev_h + tile_h - 1) // tile_h
-    k = max(1, min(int(k), nt))
-    ys = [min(bev_h, ((i * nt + k // 2) // k) * tile_h) for i in range(k)] + [bev_h]
-    return [(ys[i] * bev_w, ys[i + 1] * bev_w, ys[i + 1] - ys[i]) for i in range(k) if ys[i + 1] > ys[i]]
+# (Rounds 4-5 built and measured a ROW PIPELINE on top of the chain kernels — the BEV queries cut into K row bands, every
+# layer walked band by band on K streams so that the TSA gather / program A / SCA gather / program B of different bands
+# co-run — including a native launcher issuing the whole banded encoder from one C-ABI call.  Same box, round 5: 2.555 /
+# 2.548 ms per hot-path step with 2 bands against 2.541 / 2.522 for this path (profiles/r05_c1_rowpipe_ab.txt): the
+# kernels slow each other down by what the overlap gains.  Rejected; sources, tests and the hazard it exposed under
+# tools_dev/lab/row_pipeline/ (README there))
 
 
 @TRANSFORMER_LAYER.register_module()
@@ -456,211 +427,6 @@ class BEVFormerEncoder(TransformerLayerSequence):
             self._order_cache[key] = torch.from_numpy(bev_tile_order(bev_h, bev_w, n_xcd=8)).to(device)
         return self._order_cache[key]
 
-    def _row_pipeline_plan(self, bev_h, bev_w, k, hybrid_ref_2d, device):
-        """Constant per (geometry, K): the bands, their band-local query orders and TSA reference points, the streams."""
-        key = (bev_h, bev_w, k, str(device), hybrid_ref_2d.data_ptr())
-        plan = getattr(self, '_row_plan', None)
-        if plan is None or plan['key'] != key:
-            bands = []
-            for m0, m1, h in row_bands(bev_h, bev_w, k):
-                order = torch.from_numpy(bev_tile_order(h, bev_w, n_xcd=8)).to(device)
-                bands.append(dict(m0=m0, m1=m1, order=order, ref_2d=hybrid_ref_2d[:, m0:m1].float().contiguous()))
-            plan = dict(key=key, bands=bands, src=hybrid_ref_2d,
-                        streams=[torch.cuda.Stream(device=device) for _ in bands])
-            self._row_plan = plan
-        return plan
-
-    def _forward_row_pipeline(self, k, bev_query, value, bev_pos, hybrid_ref_2d, bev_h, bev_w, reference_points_cam,
-                              spatial_shapes, level_start_index, vis_bits, gather_stats):
-        """OCC_ENCODER_ROW_PIPELINE (see the switch above): all layers on the chain kernels, band by band on one stream
-        per band.  Same kernels, same per-row arithmetic as forward_chain.  bs = 1, no history BEV.  -> the list of layer
-        outputs (bs, nq, C), or None when this call has to take the standard path — the first call after any weight /
-        cache change does, so that every derived operand (packed chain weights, folded positional terms, ...) is built
-        on the main stream by the standard path before several streams use it."""
-        sig = (cache_epoch(), sum(p._version for p in self.parameters()), bev_pos.data_ptr(), bev_pos._version)
-        if getattr(self, '_row_sig', None) != sig:
-            self._row_sig = sig
-            return None
-        dev = bev_query.device
-        main = torch.cuda.current_stream(dev)
-        plan = self._row_pipeline_plan(bev_h, bev_w, k, hybrid_ref_2d, dev)
-        bands, streams = plan['bands'], plan['streams']
-        if os.environ.get("OCC_ROW_PIPELINE_STREAMS", "1") == "0":     # (debugging) every band on the CALLER's stream —
-            streams = [main] * len(bands)                               # resolved per call: it may be a capturing stream
-            plan = dict(plan, streams=streams)
-        if _ROW_PIPELINE_NATIVE:
-            return self._forward_row_pipeline_native(plan, bev_query, value, bev_pos, bev_h, bev_w, reference_points_cam,
-                                                     spatial_shapes, level_start_index, vis_bits, gather_stats)
-        if len(bands) < 2:
-            return None
-        nq, nl = bev_h * bev_w, len(self.layers)
-        q_full = bev_query.contiguous()
-        band = lambda t, b: t[0, b['m0']:b['m1']].unsqueeze(0)          # rows of a (1, nq, n) buffer, as (1, rows, n)
-        # ---- main stream, before the fork: band copies of the per-step operands, the first layer's TSA query Linears
-        # and value projection (program C on all rows: the first TSA gather needs the whole projected BEV), the buffers
-        # the bands share
-        ref_cam = reference_points_cam.float()
-        per_band = [dict(ref_cam=ref_cam[:, :, b['m0']:b['m1']].contiguous(), vis=vis_bits[:, b['m0']:b['m1']])
-                    for b in bands]
-        tsa0 = self.layers[0].attentions[0]
-        w_sum, pos_term, wv, bv = tsa0.chain_tail(bev_pos)
-        zq, zv = ext.linear_pair_chain(q_full, w_sum, pos_term, wv, bv)
-        outs = [torch.empty((1, nq, 256), dtype=torch.float32, device=dev) for _ in range(nl)]
-        tails = []
-        for lid in range(nl - 1):
-            nxt = self.layers[lid + 1].attentions[0]
-            t = nxt.chain_tail(bev_pos)
-            tails.append((t, torch.empty((1, nq, t[0].shape[0]), dtype=torch.float32, device=dev),
-                          torch.empty((1, nq, 256), dtype=torch.float32, device=dev)))
-        shared = [q_full, zq, zv, ref_cam, vis_bits] + outs + [x for _, a, b_ in tails for x in (a, b_)]
-        shared += [d['ref_cam'] for d in per_band]
-        fork = torch.cuda.Event()
-        fork.record(main)
-        for s in streams:
-            s.wait_event(fork)
-            if s != main:
-                for t in shared:
-                    t.record_stream(s)
-        keep = []                                   # band-private tensors stay referenced until the join
-        prev_b = None                               # the previous layer's program-B events, one per band
-        q_prev = q_full
-        try:
-            for lid, layer in enumerate(self.layers):
-                tsa, sca = layer.attentions
-                ffn = layer.ffns[0]
-                fc1, fc2 = ffn.layers[0][0], ffn.layers[1]
-                n_off = tsa.sampling_offsets.out_features
-                v4 = zv.view(1, nq, tsa.num_heads, -1)
-                wq, bq = sca.query_linear_operands()
-                plane = value.project_on(sca.deformable_attention.value_proj, streams)
-                plane_scale = value.value_scale(sca.deformable_attention.value_proj)
-                st = [dict() for _ in bands]
-                ev = {name: [None] * len(bands) for name in 'TASB'}
-
-                def stage(name, fn):
-                    for i, (b, s) in enumerate(zip(bands, streams)):
-                        with torch.cuda.stream(s):
-                            if _ROW_PIPELINE_SERIAL and i > 0:
-                                s.wait_event(ev[name][i - 1])
-                                if os.environ.get("OCC_ROW_PIPELINE_DUMMY") == "1":     # (debugging) a tiny kernel between
-                                    torch.zeros(1, device=dev)                          # the waits and the stage's launch
-                            fn(i, b, s)
-                            e = torch.cuda.Event()
-                            e.record(s)
-                            ev[name][i] = e
-
-                def t_stage(i, b, s):
-                    if prev_b is not None:          # the TSA gather reads the WHOLE projected BEV of the layer before
-                        for j, e in enumerate(prev_b):
-                            if j != i:
-                                s.wait_event(e)
-                    lin = band(zq, b)
-                    st[i]['attn'] = ext.tsa_fused_forward(
-                        v4, lin[..., :n_off], lin[..., n_off:], b['ref_2d'], bev_h, bev_w, tsa.num_heads,
-                        tsa.num_points, shared_queue=True, order=b['order'], value_rows=nq)
-
-                def a_stage(i, b, s):
-                    st[i]['x1'], st[i]['lin'] = ext.linear_ln_chain(
-                        st[i]['attn'], band(q_prev, b), tsa.output_proj.weight, tsa.output_proj.bias, layer.norms[0],
-                        wq, bq)
-
-                def s_stage(i, b, s):
-                    st[i]['slots'] = sca.gather_projected(
-                        st[i]['lin'], plane, per_band[i]['ref_cam'], per_band[i]['vis'], spatial_shapes,
-                        level_start_index, b['order'], gather_stats, value_scale=plane_scale)
-
-                def b_stage(i, b, s):
-                    tail, out = None, (band(outs[lid], b), None, None)
-                    if lid + 1 < nl:
-                        (tw, tterm, twv, tbv), nzq, nzv = tails[lid]
-                        tail = (tw, band(tterm, b), twv, tbv)
-                        out = (out[0], band(nzq, b), band(nzv, b))
-                    ext.encoder_ffn_chain(st[i]['slots'], st[i]['x1'], sca.output_proj.weight, sca.output_proj.bias,
-                                          layer.norms[1], fc1.weight, fc1.bias, fc2.weight, fc2.bias, layer.norms[2],
-                                          tail=tail, out=out)
-
-                stage('T', t_stage)
-                stage('A', a_stage)
-                stage('S', s_stage)
-                stage('B', b_stage)
-                keep.append(st)
-                dbg = os.environ.get("OCC_ROW_PIPELINE_DEBUG_SYNC")          # (debugging)
-                if dbg == "1":                      # a device barrier per layer
-                    torch.cuda.synchronize()
-                elif dbg == "2":                    # every band stream waits for every other one per layer (device side)
-                    for s in streams:
-                        for s2 in streams:
-                            if s2 != s:
-                                s.wait_stream(s2)
-                prev_b = ev['B']
-                q_prev = outs[lid]
-                if lid + 1 < nl:
-                    zq, zv = tails[lid][1], tails[lid][2]
-        finally:
-            for s in streams:                       # join (also when a launch raised): nothing may outlive this call
-                if s != main:
-                    main.wait_stream(s)
-        if os.environ.get("OCC_ROW_PIPELINE_DEBUG_KEEP") == "1":     # (debugging: tools_dev/row_pipeline_bisect.py)
-            self._row_debug = dict(keep=keep, tails=tails, outs=outs, bands=bands)
-        return outs
-
-    def _forward_row_pipeline_native(self, plan, bev_query, value, bev_pos, bev_h, bev_w, reference_points_cam,
-                                     spatial_shapes, level_start_index, vis_bits, gather_stats):
-        """The banded sequence of _forward_row_pipeline through ext.encoder_bands_forward: this method only gathers the
-        operands (band copies of the per-step reference points, the first layer's TSA Linears, the planes and their
-        event, the result buffers); csrc/encoder_bands.hip forks the band streams, issues every launch and joins."""
-        dev = bev_query.device
-        main = torch.cuda.current_stream(dev)
-        bands, streams = plan['bands'], plan['streams']
-        if len(bands) == 1:
-            streams = [main]
-        nq, nl = bev_h * bev_w, len(self.layers)
-        sca0 = self.layers[0].attentions[1].deformable_attention
-        n_lin = sca0.sampling_offsets.out_features + sca0.attention_weights.out_features
-        ref_cam = reference_points_cam.float()
-        for b in bands:                              # band scratch: allocated once (main stream), reused every step
-            n = b['m1'] - b['m0']
-            if 'attn' not in b:
-                for name, w in (('attn', 256), ('x1', 256), ('slots', 256), ('lin', n_lin)):
-                    b[name] = torch.empty((1, n, w), dtype=torch.float32, device=dev)
-                b['ref_cam'] = torch.empty((ref_cam.shape[0], 1, n) + tuple(ref_cam.shape[3:]), dtype=torch.float32,
-                                           device=dev)
-            b['ref_cam'].copy_(ref_cam[:, :, b['m0']:b['m1']])
-        q_full = bev_query.contiguous()
-        tsa0 = self.layers[0].attentions[0]
-        zq0, zv0 = ext.linear_pair_chain(q_full, *tsa0.chain_tail(bev_pos))
-        shared = [q_full, zq0, zv0, vis_bits]
-        layers = []
-        for lid, layer in enumerate(self.layers):
-            tsa, sca = layer.attentions
-            ffn = layer.ffns[0]
-            wq, bq = sca.query_linear_operands()
-            plane, ev = value.take_on(sca.deformable_attention.value_proj, [s for s in streams if s != main])
-            y = dict(a=(tsa.output_proj.weight, tsa.output_proj.bias, layer.norms[0], wq, bq),
-                     b=(sca.output_proj.weight, sca.output_proj.bias, layer.norms[1], ffn.layers[0][0].weight,
-                        ffn.layers[0][0].bias, ffn.layers[1].weight, ffn.layers[1].bias, layer.norms[2]),
-                     plane=plane.view(plane.shape[0], plane.shape[1], sca.deformable_attention.num_heads, -1),
-                     plane_ready=ev, plane_scale=value.value_scale(sca.deformable_attention.value_proj),
-                     stats=gather_stats if gather_stats is not None else sca.gather_stats,
-                     out=torch.empty((1, nq, 256), dtype=torch.float32, device=dev))
-            shared.append(y['out'])
-            if lid + 1 < nl:
-                t = self.layers[lid + 1].attentions[0].chain_tail(bev_pos)
-                y.update(tail=t, zq=torch.empty((1, nq, t[0].shape[0]), dtype=torch.float32, device=dev),
-                         zv=torch.empty((1, nq, 256), dtype=torch.float32, device=dev))
-                shared += [y['zq'], y['zv']]
-            layers.append(y)
-        for s in streams:
-            if s != main:
-                for t in shared:
-                    t.record_stream(s)
-        tsa = self.layers[0].attentions[0]
-        ext.encoder_bands_forward(q_full, zq0, zv0, layers,
-                                  [dict(b, stream=s) for b, s in zip(bands, streams)], spatial_shapes, level_start_index,
-                                  vis_bits, bev_h, bev_w, sca0.num_levels, sca0.num_points, tsa.num_points,
-                                  flags=_ROW_PIPELINE_FLAGS)
-        return [y['out'] for y in layers]
-
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
                 **kwargs):
@@ -704,17 +470,6 @@ class BEVFormerEncoder(TransformerLayerSequence):
         chain_ok = [chain and _chain_layer_ok(layer) for layer in self.layers]
         tsa_pre = None
         try:
-            if ((_ROW_PIPELINE >= 2 or (_ROW_PIPELINE == 1 and _ROW_PIPELINE_NATIVE)) and all(chain_ok) and bs == 1
-                    and prev_bev is None and hasattr(value, 'project_on')
-                    and bev_pos is not None and not torch.is_grad_enabled()):
-                try:
-                    piped = self._forward_row_pipeline(
-                        _ROW_PIPELINE, bev_query, value, bev_pos, hybird_ref_2d, bev_h, bev_w, reference_points_cam,
-                        spatial_shapes, level_start_index, vis_bits, kwargs.get('gather_stats'))
-                except ext.OccAmdUnsupported:
-                    piped = None            # (streams joined; projections it consumed are redone by the layers below)
-                if piped is not None:
-                    return torch.stack(piped) if self.return_intermediate else piped[-1]
             for lid, layer in enumerate(self.layers):
                 output = None
                 if chain_ok[lid]:

@@ -274,22 +274,6 @@ class SpatialCrossAttention(BaseModule):
                                      vis_bits, da.num_heads, da.num_levels, da.num_points,
                                      order=bev_order, stats=gather_stats, value_layout=layout, value_scale=vscale)
 
-    def gather_projected(self, lin, v, reference_points_cam, vis_bits, spatial_shapes, level_start_index,
-                         bev_order=None, gather_stats=None, value_scale=None):
-        """The gather half of fused_gather on an already projected value tensor `v` (bs*num_cams, rows, C) (fp16 =
-        pixel-pair order, what LazyFeatures.project hands out).  `lin`, `reference_points_cam` (contiguous), `vis_bits`
-        and `bev_order` may describe a ROW BAND of the BEV queries with band-local indices in `bev_order` (bs = 1): the
-        kernel only ever indexes them by query (the encoder's row pipeline).  -> slots (bs, n, C) before output_proj."""
-        da = self.deformable_attention
-        if gather_stats is None:
-            gather_stats = self.gather_stats
-        layout = "pairs" if v.dtype == torch.float16 else "rows"
-        v = v.view(v.shape[0], v.shape[1], da.num_heads, -1)
-        n_off = da.sampling_offsets.out_features
-        return ext.sca_fused_forward(v, spatial_shapes, level_start_index, lin[..., :n_off], lin[..., n_off:],
-                                     reference_points_cam, vis_bits, da.num_heads, da.num_levels, da.num_points,
-                                     order=bev_order, stats=gather_stats, value_layout=layout, value_scale=value_scale)
-
     def forward_fused(self, query, value, reference_points_cam=None, bev_mask=None,
                       spatial_shapes=None, level_start_index=None, vis_bits=None, bev_order=None,
                       gather_stats=None, post_norm=None):

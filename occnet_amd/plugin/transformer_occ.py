@@ -300,37 +300,6 @@ class LazyFeatures:
             return hit[0]
         return self._launch(value_proj, self._group_bias(value_proj))
 
-    def project_on(self, value_proj, streams):
-        """project() for consumers on SEVERAL streams (the encoder's row pipeline): every stream in `streams` waits for
-        the projection's event instead of torch's current stream, and the tensor is recorded on each of them (it was
-        allocated on the side / current stream: the allocator must not recycle it under their kernels)."""
-        hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
-        if hit is None:
-            out = self._launch(value_proj, self._group_bias(value_proj))
-            ev = torch.cuda.Event()
-            ev.record()
-        else:
-            out, ev = hit
-        sc = self.value_scale(value_proj)
-        for s in streams:
-            s.wait_event(ev)
-            out.record_stream(s)
-            if sc is not None:
-                sc.record_stream(s)
-        return out
-
-    def take_on(self, value_proj, streams):
-        """project_on() without the waits: -> (tensor, the event its consumers have to wait for, or None when it was
-        launched on the current stream just now) — for a native launcher that issues the waits itself
-        (ext.encoder_bands_forward)."""
-        hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
-        out, ev = hit if hit is not None else (self._launch(value_proj, self._group_bias(value_proj)), None)
-        sc = self.value_scale(value_proj)
-        for s in streams:
-            out.record_stream(s)
-            if sc is not None:
-                sc.record_stream(s)
-        return out, ev
 
 
 @TRANSFORMER.register_module()

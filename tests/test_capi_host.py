@@ -188,51 +188,3 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.occ_ms_deform_attn_backward_workspace_bytes(B, S, M, 64, L, Lq, P) == 0
     rc = lib.occ_ms_deform_attn_backward_ws_f32(p, p, p, p, p, p, p, p, p, 1, 4, 8, 32, 1, 4, 4, 64, p, i64(16), null)
     assert rc == -1 and b'workspace too small' in lib.occ_last_error()
-
-
-def test_encoder_bands_structs_match_the_header_and_arguments_are_checked(tmp_path):
-    """occ_encoder_bands_forward_f32 (csrc/encoder_bands.hip, experimental): the ctypes mirrors of OccBand / OccBandLayer have
-    the C compiler's layout of the structs in include/occnet_amd.h, and the argument checks answer before any HIP call."""
-    import os
-    import subprocess
-    src = tmp_path / "layout.c"
-    fields_b = [f for f, _ in ext._OccBand._fields_]
-    fields_l = [f for f, _ in ext._OccBandLayer._fields_]
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "occnet_amd.h"\nint main(void) {\n'
-                   '  printf("%zu %zu", sizeof(OccBand), sizeof(OccBandLayer));\n'
-                   + "".join(f'  printf(" %zu", offsetof(OccBand, {f}));\n' for f in fields_b)
-                   + "".join(f'  printf(" %zu", offsetof(OccBandLayer, {f}));\n' for f in fields_l)
-                   + '  return 0;\n}\n')
-    exe = tmp_path / "layout"
-    subprocess.run(["gcc", "-I", os.path.dirname(_lib.HEADER_PATH), "-o", str(exe), str(src)], check=True)
-    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    want = [ctypes.sizeof(ext._OccBand), ctypes.sizeof(ext._OccBandLayer)]
-    want += [getattr(ext._OccBand, f).offset for f in fields_b] + [getattr(ext._OccBandLayer, f).offset for f in fields_l]
-    assert got == want
-
-    lib = _lib.lib()
-    null = ctypes.c_void_p(0)
-    fn = lib.occ_encoder_bands_forward_f32
-    assert fn(null, null, ctypes.c_int64(192), null, null, 1, null, 1, null, null, null, 40000, 200, 200, 6, 30826, 4, 8, 4,
-              4, 1, 0, null) == -1 and b'null' in lib.occ_last_error()
-    buf = (ctypes.c_float * 64)()
-    p = ctypes.cast(buf, ctypes.c_void_p).value
-    layer = (ext._OccBandLayer * 1)()
-    for f, t in ext._OccBandLayer._fields_:
-        if t is ctypes.c_void_p and f not in ("zq", "zv", "q_term", "plane_ready", "stats"):
-            setattr(layer[0], f, p)
-    bands = (ext._OccBand * 2)()
-    for b, (m0, n) in zip(bands, ((0, 20800), (20800, 19000))):       # 200 queries short
-        b.m0, b.n = m0, n
-        for f in ("order", "ref_2d", "ref_cam", "attn", "x1", "lin", "slots"):
-            setattr(b, f, p)
-    args = lambda nq, nb: (ctypes.c_void_p(p), ctypes.c_void_p(p), ctypes.c_int64(192), ctypes.c_void_p(p), layer, 1, bands,
-                           nb, ctypes.c_void_p(p), ctypes.c_void_p(p), ctypes.c_void_p(p), nq, 200, 200, 6, 30826, 4, 8, 4,
-                           4, 1, 0, null)
-    assert fn(*args(40000, 2)) == -1 and b'cover 39800 of 40000' in lib.occ_last_error()
-    assert fn(*args(39999, 2)) == -1 and b'bad dimension' in lib.occ_last_error()          # bev_h * bev_w != Nq
-    bands[1].m0 = 20900
-    assert fn(*args(40000, 2)) == -1 and b'band 1 does not continue' in lib.occ_last_error()
-    bands[1].m0, bands[1].n = 20800, 19200
-    layer[0].zq = p                                                                         # a tail on the LAST layer
-    assert fn(*args(40000, 2)) == -1 and b'every layer but the last' in lib.occ_last_error()

@@ -67,7 +67,6 @@ struct ChainArgs {
   int M;
   int nfull;                                      // blocks with 64-row tiles (the rest: 32-row tiles)
   long long* trace;                               // TRACE builds: 24 wall-clock stamps per wave (development)
-  int end_fence;                                  // (hazard experiment, OCC_DBG_CHAIN_FENCE=1) agent-scope release at the end
 };
 
 // Block barrier that orders LDS traffic only.  __syncthreads() is a full fence: hipcc puts `s_waitcnt vmcnt(0)` in front of
@@ -586,7 +585,6 @@ __global__ __launch_bounds__(256, 2) void linear_chain_x3_kernel(const ChainArgs
     chain_tile<PROG, ABL, TRACE, 2>(p, tl, (long)b * kChRows);
   else
     chain_tile<PROG, ABL, TRACE, 1>(p, tl, (long)p.nfull * kChRows + (long)(b - p.nfull) * 32);
-  if (p.end_fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 
@@ -624,10 +622,6 @@ int chain_launch(const occ::ChainArgs& args_in, hipStream_t st, const char* what
   // profiles/r04_c9_stores.txt and was removed: its run-time test put three branches around every store.)
   static const int abl = [] { const char* e = getenv("OCC_CHAIN_ABLATE"); return e ? atoi(e) : 0; }();
   ChainArgs args = args_in;
-  {
-    const char* fe = getenv("OCC_DBG_CHAIN_FENCE");
-    args.end_fence = fe && fe[0] == '1';
-  }
   {
     // 32-bit byte offsets inside the kernel (buffer instructions): every matrix, padded by one tile of rows, stays below 4 GB
     const long lds[6] = {args.lda, args.ldres, args.ldy, args.ldterm, args.ldz1, args.ldz2};

@@ -21,9 +21,8 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
     const float* __restrict__ value, long value_bt_stride, const float* __restrict__ offs,
     long offs_stride, const float* __restrict__ logits, long logits_stride,
     const float* __restrict__ ref_2d, const int32_t* __restrict__ order, float* __restrict__ out,
-    int B, int Nq, int bev_h, int bev_w, int dbg) {
+    int B, int Nq, int bev_h, int bev_w) {
   constexpr int M = 8, D = 32, P = 4, NS = 2 * P;  // samples per head
-  if (dbg & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // (hazard experiment) software acquire
   constexpr int NSp = NS + 1;
   __shared__ __attribute__((aligned(16))) SampleParamB smem[kTsaWaves * M * NSp];
   const int lane = threadIdx.x & 63;
@@ -38,20 +37,14 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
 
   // lane = m*8 + t*4 + p : exactly the memory order of both Linear outputs
   const int m = lane >> 3, t = (lane >> 2) & 1;
-  float x = logits[((long)b * Nq + q) * logits_stride + lane];
-  if (dbg & 1) x = __hip_atomic_load(logits + ((long)b * Nq + q) * logits_stride + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float x = logits[((long)b * Nq + q) * logits_stride + lane];
   float mx = fmaxf(x, __shfl_xor(x, 1));
   mx = fmaxf(mx, __shfl_xor(mx, 2));
   const float e = expf(x - mx);
   float sum = e + __shfl_xor(e, 1);
   sum += __shfl_xor(sum, 2);
   const float aw = e / sum;
-  float2 o = *reinterpret_cast<const float2*>(offs + ((long)b * Nq + q) * offs_stride + 2 * lane);
-  if (dbg & 1) {       // (hazard experiment) agent-coherent loads of the query's offsets
-    const float* op = offs + ((long)b * Nq + q) * offs_stride + 2 * lane;
-    o.x = __hip_atomic_load(op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    o.y = __hip_atomic_load(op + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  const float2 o = *reinterpret_cast<const float2*>(offs + ((long)b * Nq + q) * offs_stride + 2 * lane);
   const float2 rf = *reinterpret_cast<const float2*>(ref_2d + (((long)b * 2 + t) * Nq + q) * 2);
   // corners outside the BEV map carry an out-of-range byte offset: the buffer load returns 0 without a request (no
   // dummy load of row 0, no 0 * Inf)
@@ -281,8 +274,6 @@ extern "C" int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_st
   // the tile kernel (value rows staged through LDS) whenever the queries are the whole BEV map, query q at pixel
   // (q / bev_w, q % bev_w) — `order` is a locality hint of the wave-per-query kernel and plays no role there.
   // OCC_TSA_TILE=0 (development switch) keeps the wave-per-query kernel.
-  const char* dbg_env = getenv("OCC_DBG_TSA");             // (hazard experiment) 1: coherent loads of zq, 2: acquire fence
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
   const char* tile_env = getenv("OCC_TSA_TILE");           // read per call: the tests switch it inside one process
   const bool tile_on = !(tile_env && tile_env[0] == '0');
   if (tile_on && (long)Nq == (long)bev_h * bev_w) {
@@ -298,7 +289,7 @@ extern "C" int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_st
   const long blocks = (waves + kTsaWaves - 1) / kTsaWaves;
   hipLaunchKernelGGL(tsa_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, st, value,
                      (long)value_bt_stride, offs, (long)offs_stride, logits, (long)logits_stride,
-                     ref_2d, order, out, B, Nq, bev_h, bev_w, dbg);
+                     ref_2d, order, out, B, Nq, bev_h, bev_w);
   OCC_CHECK_LAUNCH("tsa_fused_forward");
   return OCC_OK;
 }

@@ -26,10 +26,12 @@ from .registry import (TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_atte
 from .spatial_cross_attention import _require_device
 
 
-# the SCA value projections of ALL layers depend on the camera features only: they start on a side stream before the
-# first layer (LazyFeatures.prefetch) and run under the TSA / Linear kernels instead of serially before each gather
-# (6.764 -> 6.734 ms per sample, ABAB on one box; OCC_VPROJ_OVERLAP=0 restores the serial order)
-_VPROJ_OVERLAP = os.environ.get("OCC_VPROJ_OVERLAP", "1") == "1"
+# the SCA value projections of ALL layers depend on the camera features only: they are launched before the first layer
+# (LazyFeatures.prefetch: ONE stacked launch).  OCC_VPROJ_OVERLAP=1 puts that launch on a side stream under the first
+# layer's TSA / Linear kernels (rounds 2-4's default: 6.764 -> 6.734 ms per sample in round 2) — off since round 5: the
+# gathers return wrong rows now and then when one of this library's MFMA kernels runs next to them on another hardware
+# queue, so the library runs its kernels on ONE stream
+_VPROJ_OVERLAP = os.environ.get("OCC_VPROJ_OVERLAP", "0") == "1"
 
 # (Rounds 4-5 built and measured a ROW PIPELINE on top of the chain kernels — the BEV queries cut into K row bands, every
 # layer walked band by band on K streams so that the TSA gather / program A / SCA gather / program B of different bands
@@ -454,10 +456,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
         extra = dict(vis_bits=vis_bits, bev_order=self._bev_order(bev_h, bev_w, bev_query.device),
                      tsa_spatial_shapes=tsa_shapes, tsa_level_start_index=tsa_start)
         output = bev_query
-        if _VPROJ_OVERLAP and hasattr(value, 'prefetch') and not torch.is_grad_enabled():
+        if hasattr(value, 'prefetch') and not torch.is_grad_enabled():
             vps = [getattr(getattr(a, 'deformable_attention', None), 'value_proj', None)
                    for layer in self.layers for a in layer.attentions]
-            value.prefetch([vp for vp in vps if vp is not None])
+            value.prefetch([vp for vp in vps if vp is not None], overlap=_VPROJ_OVERLAP)
         # inference: the row-local Linear chains of a layer as two launches (BEVFormerLayer.forward_chain)
         # (the chain path takes none of the mask / query_pos arguments of BEVFormerLayer.forward: a caller that passes one
         # gets the unfused layer, never an unmasked result — ADVICE r4)

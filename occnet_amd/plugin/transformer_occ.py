@@ -148,19 +148,25 @@ class LazyFeatures:
     # gained 3 % (0.197 against 0.202 ms), the chain kernels lost 5-12 % to the co-running projections.  Rejected;
     # profiles/r05_c2_vproj_schedule_ab.txt.)
 
-    def prefetch(self, value_projs):
-        """Start project() for several layers' value_proj modules on a side stream (the projections depend on the
-        camera features only, not on the BEV queries, so they can run under the first layers' TSA / Linear kernels
-        instead of serially before each gather).  project() later hands the tensor out after making the consuming
-        stream wait for the side stream's event; finish() (the encoder calls it when the layer stack is done, also on
-        an exception) joins the side stream and drops whatever was never consumed.  OCC_VPROJ_OVERLAP=0 turns it off.
+    def prefetch(self, value_projs, overlap=False):
+        """project() for several layers' value_proj modules AHEAD of the layer stack: the projections depend on the camera
+        features only, not on the BEV queries, so all of them go in ONE stacked launch (the maps are read once).
+        Default (round 5): on the CALLER's stream, in front of the first layer.  overlap=True (OCC_VPROJ_OVERLAP=1, rounds
+        2-4's default) runs them on a side stream under the first layer's TSA gather / chain kernels instead; project()
+        then makes the consuming stream wait for the side stream's event and finish() (the encoder calls it when the layer
+        stack is done, also on an exception) joins the side stream.  NOT the default any more: on MI355X / ROCm 7.2 a gather
+        kernel of this library that shares the chip with one of its MFMA kernels running on ANOTHER hardware queue returns
+        a few wrong rows now and then (47-52 of 150 steps under an artificial load with the round-5
+        kernels, 2 of 150 with round 4's; never on one stream) — the library therefore never co-schedules its own kernels.
         The derived operands (packed weight, per-(level, camera) bias: first-use caches) are built on the MAIN stream
         before the fork, so no later main-stream reader can race their side-stream construction."""
         dev = self.mlvl_feats[0].device
-        side = self._side_streams.get(str(dev))
-        if side is None:
-            side = self._side_streams[str(dev)] = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
+        side = main
+        if overlap:
+            side = self._side_streams.get(str(dev))
+            if side is None:
+                side = self._side_streams[str(dev)] = torch.cuda.Stream(device=dev)
         gbs = [self._group_bias(vp) for vp in value_projs]
         if ext.SCA_VALUES == "f16":
             for vp, gb in zip(value_projs, gbs):
@@ -175,14 +181,16 @@ class LazyFeatures:
         if not stacked:
             for vp in value_projs:
                 ext.linear_pack_weight_bf16x3(vp.weight)
-        side.wait_stream(main)                               # the feature maps, packs and biases are ready
-        for r in self.rows:
-            r.record_stream(side)                            # read by side-stream kernels: keep them out of reuse
-        self._pending, self._side, self._scale_of = {}, side, {}
+        if overlap:
+            side.wait_stream(main)                           # the feature maps, packs and biases are ready
+            for r in self.rows:
+                r.record_stream(side)                        # read by side-stream kernels: keep them out of reuse
+        self._pending, self._side, self._scale_of = {}, (side if overlap else None), {}
         with torch.cuda.stream(side):
             scales = self._scales(value_projs, gbs)          # per-plane fp16 range scales of this call's maps
             if scales is not None:
-                scales.record_stream(main)
+                if overlap:
+                    scales.record_stream(main)
                 for l, vp in enumerate(value_projs):
                     self._scale_of[id(vp)] = scales[l:l + 1]
             if stacked:
@@ -194,9 +202,11 @@ class LazyFeatures:
                     ext.value_proj_bf16_planes(self.rows, [vp.weight for vp in value_projs], gbs, out,
                                                rows_per_group=[h * wd for h, wd in self.hw],
                                                out_group_rows=self.group_rows, out_row0=self.starts, out_scale=scales)
-                    out.record_stream(main)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
+                    ev = None
+                    if overlap:
+                        out.record_stream(main)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
                     for l, vp in enumerate(value_projs):
                         self._pending[id(vp)] = (out[l].view(self.bs * self.num_cam, self.group_rows, n), ev)
                 except ext.OccAmdError:          # e.g. the 74 KB LDS attribute refused: one launch per layer instead
@@ -205,9 +215,11 @@ class LazyFeatures:
             if not stacked:
                 for l, (vp, gb) in enumerate(zip(value_projs, gbs)):
                     out = self._launch(vp, gb, None if scales is None else scales[l:l + 1])
-                    out.record_stream(main)                  # consumed (and released) on the main stream
-                    ev = torch.cuda.Event()
-                    ev.record(side)
+                    ev = None
+                    if overlap:
+                        out.record_stream(main)              # consumed (and released) on the main stream
+                        ev = torch.cuda.Event()
+                        ev.record(side)
                     self._pending[id(vp)] = (out, ev)
 
     # fp16 value rows carry 11 significant bits and end at 65 504.  Every plane is therefore stored times a power of two
@@ -244,7 +256,7 @@ class LazyFeatures:
         """Join the side stream: projections that no layer consumed (a layer fell back to the unfused path, an
         exception unwound the encoder) must not outlive their inputs' stream ordering."""
         pending = getattr(self, '_pending', None)
-        if pending:
+        if pending and getattr(self, '_side', None) is not None:
             torch.cuda.current_stream(self.mlvl_feats[0].device).wait_stream(self._side)
         self._pending = {}
 
@@ -296,7 +308,8 @@ class LazyFeatures:
         (bs*num_cam, sum hw rounded up to even, N) fp16 in the gather's pixel-pair order (ext.sca_pair_layout)."""
         hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
         if hit is not None:
-            torch.cuda.current_stream(hit[0].device).wait_event(hit[1])
+            if hit[1] is not None:
+                torch.cuda.current_stream(hit[0].device).wait_event(hit[1])
             return hit[0]
         return self._launch(value_proj, self._group_bias(value_proj))
 

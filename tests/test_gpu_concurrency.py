@@ -1,12 +1,15 @@
 """-m gpu, always on: the DEFAULT hot path under co-scheduled load.
 
 Round 4's row-pipeline experiment produced wrong rows when kernels of different kinds overlapped on several streams, and
-the cause was not understood — which left open whether the default path (main stream + the value projection's side
-stream) is race-free or merely serialised.  This test runs the standard 4-layer step at the bench's hot-path
-configuration (full base geometry, bf16 NHWC maps) while a second stream keeps the chip busy with HBM-bound copies,
-LDS-heavy matrix-core GEMMs and a scratch-using kernel, and demands BIT-identical outputs to the solo run, 50 times.
-Every kernel of the path is deterministic (no float atomics; the gathers' statistics counters are off), so any
-difference is a hazard, not rounding."""
+the cause was not understood — which left open whether the default path is race-free or merely serialised.  Round 5 ran
+it down (tools_dev/hazard_matrix.py): a gather kernel of this library returns a few wrong rows now
+and then while one of the library's MFMA kernels runs next to it on ANOTHER hardware queue — which rounds 2-4's default did
+on purpose (the value projection on a side stream under layer 0's TSA gather: 2 of 150 steps wrong under an external load
+with round 4's kernels, 47 of 150 with this round's).  The library now issues all of its kernels on ONE stream; this test
+holds that line: the standard 4-layer step at the bench's hot-path configuration (full base geometry, bf16 NHWC maps)
+while a second stream keeps the chip busy with HBM-bound copies, LDS-heavy matrix-core GEMMs, a random gather and a
+scratch-using radix sort, BIT-identical to the solo run, 50 times.  Every kernel of the path is deterministic (no float
+atomics; the gathers' statistics counters are off), so any difference is a hazard, not rounding."""
 import pytest
 import torch
 

@@ -1,0 +1,272 @@
+// Development (round 5): minimal VICTIM kernels for the co-scheduling hazard — which hardware path hands
+// a gather kernel wrong data while the library's value-projection kernel runs next to it on another stream?
+//   lds_victim : every wave writes a known 32-byte entry per lane into its LDS slab, hands it over with wave_lds_sync()
+//                (no waitcnt: the idiom of the gather kernels) and reads its 8-lane group's entries back as broadcast
+//                ds_read_b128 — every mismatch is counted;
+//   ta_victim  : 8 lanes x 16 B per 128-byte row of a table with known contents, random row per 8-lane group, through
+//                BUFFER loads with an SGPR descriptor (the gathers' access shape) — every wrong dword is counted;
+//   gl_victim  : one dword per lane at consecutive addresses of a known table through plain global loads (the gathers'
+//                logits / offsets reads).
+// Not part of libocc_amd.so.  build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools_dev/bin/libhazard_micro.so tools_dev/hazard_micro.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../occnet_amd/csrc/common.h"
+
+namespace {
+__device__ __forceinline__ uint32_t mix(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(uint32_t* t, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) t[i] = mix((uint32_t)i * 2654435761u + 12345u);
+}
+
+__global__ __launch_bounds__(256) void lds_victim(unsigned long long* errors, int iters, int real_wait) {
+  __shared__ __attribute__((aligned(16))) occ::SampleParamB slab[4 * 8 * 9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  occ::SampleParamB* sp = slab + wave * 72;
+  const uint32_t id = (blockIdx.x * 4 + wave) * 64 + lane;
+  unsigned bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    occ::SampleParamB p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      p.w[k] = __uint_as_float(mix(id * 8 + k + it * 977u) & 0x3fffffffu);
+      p.o[k] = mix(id * 8 + 4 + k + it * 977u);
+    }
+    sp[(lane >> 3) * 9 + (lane & 7)] = p;
+    if (real_wait) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    occ::wave_lds_sync();
+    const int g = lane >> 3;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const occ::occ_u32x4 o = *reinterpret_cast<const occ::occ_u32x4*>(sp[g * 9 + s].o);
+      const float4 w = *reinterpret_cast<const float4*>(sp[g * 9 + s].w);
+      const uint32_t src = (id & ~63u) + g * 8 + s;           // the lane that wrote entry (g, s)
+      const float wf[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bad += __float_as_uint(wf[k]) != (mix(src * 8 + k + it * 977u) & 0x3fffffffu);
+        bad += o[k] != mix(src * 8 + 4 + k + it * 977u);
+      }
+    }
+    occ::wave_lds_sync();
+  }
+  if (bad) atomicAdd(errors, (unsigned long long)bad);
+}
+
+__global__ __launch_bounds__(256) void ta_victim(const uint32_t* __restrict__ table, uint32_t n_rows, unsigned long long* errors,
+                                                 int iters) {
+  const int lane = threadIdx.x & 63, c = lane & 7;
+  const uint32_t wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const __amdgpu_buffer_rsrc_t rs = occ::uniform_rsrc(table, n_rows * 128u);
+  unsigned bad = 0;
+  for (int it = 0; it < iters; it += 4) {
+    float4 v[4];
+    uint32_t row[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      row[u] = mix((wid * 8 + (lane >> 3)) * 7919u + (it + u) * 104729u) % n_rows;
+      v[u] = occ::buf_load16(rs, row[u] * 128u + c * 16u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t e0 = row[u] * 32u + c * 4u;
+      const float vf[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bad += __float_as_uint(vf[k]) != mix((e0 + k) * 2654435761u + 12345u);
+    }
+  }
+  if (bad) atomicAdd(errors, (unsigned long long)bad);
+}
+
+__global__ __launch_bounds__(256) void gl_victim(const uint32_t* __restrict__ table, uint32_t n, unsigned long long* errors, int iters) {
+  const uint32_t wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  unsigned bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t base = (mix(wid * 31u + it * 7919u) % (n / 64 - 1)) * 64;
+    const uint32_t x = table[base + lane];
+    const uint2 y = *reinterpret_cast<const uint2*>(table + ((base + 2 * lane) & ~1u));
+    bad += x != mix((base + lane) * 2654435761u + 12345u);
+    bad += y.x != mix((((base + 2 * lane) & ~1u)) * 2654435761u + 12345u);
+    bad += y.y != mix((((base + 2 * lane) & ~1u) + 1) * 2654435761u + 12345u);
+  }
+  if (bad) atomicAdd(errors, (unsigned long long)bad);
+}
+// ds_bpermute (what hipcc makes of __shfl_xor: the gathers' softmax reductions) against the same exchange by DPP quad_perm
+template <bool DPP>
+__global__ __launch_bounds__(256) void xlane_victim(unsigned long long* errors, int iters) {
+  __shared__ float pad[2304];                      // the gathers' LDS footprint (the slab), so that co-residency matches
+  const int lane = threadIdx.x & 63;
+  const uint32_t id = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x == 0) pad[0] = 0.f;
+  unsigned bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t mine = mix(id * 31u + it * 7919u);
+    uint32_t x1, x2;
+    if (DPP) {
+      x1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xb1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+      x2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x4e, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    } else {
+      x1 = (uint32_t)__shfl_xor((int)mine, 1);
+      x2 = (uint32_t)__shfl_xor((int)mine, 2);
+    }
+    bad += x1 != mix((id ^ 1u) * 31u + it * 7919u);
+    bad += x2 != mix((id ^ 2u) * 31u + it * 7919u);
+    if (!DPP) {
+      const uint32_t x4 = (uint32_t)__shfl_xor((int)mine, 4), x32 = (uint32_t)__shfl_xor((int)mine, 32);
+      bad += x4 != mix((id ^ 4u) * 31u + it * 7919u);
+      bad += x32 != mix((id ^ 32u) * 31u + it * 7919u);
+    }
+  }
+  if (bad) atomicAdd(errors, (unsigned long long)bad);
+  if (lane == 999) pad[lane] = 1.f;
+}
+// producer -> consumer across a kernel boundary of ONE stream: the producer writes table[i] = f(i, epoch) (16-byte buffer
+// stores like the chain kernels' row stores, or plain global stores), the NEXT kernel reads every word back (the gathers'
+// dword / 16-byte loads) and counts words that are not this epoch's — a stale or not-yet-visible line shows up as last
+// epoch's value
+template <bool BUF>
+__global__ __launch_bounds__(256) void produce_kernel(uint32_t* __restrict__ table, uint32_t n16, uint32_t epoch) {
+  const __amdgpu_buffer_rsrc_t rs = occ::uniform_rsrc(table, n16 * 16u);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) {
+    occ::occ_u32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = mix((i * 4 + k) * 2654435761u + epoch * 40503u);
+    if (BUF) __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(i * 16u), 0, 0);
+    else *reinterpret_cast<occ::occ_u32x4*>(table + (size_t)i * 4) = v;
+  }
+}
+template <bool BUF>
+__global__ __launch_bounds__(256) void consume_kernel(const uint32_t* __restrict__ table, uint32_t n16, uint32_t epoch,
+                                                      unsigned long long* errors) {
+  const __amdgpu_buffer_rsrc_t rs = occ::uniform_rsrc(table, n16 * 16u);
+  unsigned bad = 0, stale = 0;
+  // a different thread -> element map than the producer's (another CU / XCD reads what one wrote)
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n16; j += gridDim.x * 256) {
+    const uint32_t i = (j * 2654435761u) % n16;
+    uint32_t w[4];
+    if (BUF) {
+      const float4 v = occ::buf_load16(rs, i * 16u);
+      w[0] = __float_as_uint(v.x); w[1] = __float_as_uint(v.y); w[2] = __float_as_uint(v.z); w[3] = __float_as_uint(v.w);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w[k] = table[(size_t)i * 4 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bad += w[k] != mix((i * 4 + k) * 2654435761u + epoch * 40503u);
+      stale += w[k] == mix((i * 4 + k) * 2654435761u + (epoch - 1) * 40503u);
+    }
+  }
+  if (bad) { atomicAdd(errors, (unsigned long long)bad); atomicAdd(errors + 1, (unsigned long long)stale); }
+}
+// pure register arithmetic with results known in advance: which VALU instruction class hands a wave a wrong result while
+// another kernel's MFMAs run on the same SIMDs?  KIND 0: packed fp32 FMA (v_pk_fma_f32: what hipcc makes of the gathers'
+// float4 accumulation), 1: scalar v_fma_f32 (inline asm), 2: 32-bit integer multiply-add (address arithmetic), 3: v_exp_f32
+// / v_rcp_f32, 4: v_fma_mix_f32 (the fp16-row gather's accumulate).  Small integers in float: every result is exact.
+template <int KIND>
+__global__ __launch_bounds__(256) void valu_victim(unsigned long long* errors, int iters) {
+  const uint32_t id = blockIdx.x * 256 + threadIdx.x;
+  unsigned bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t h = mix(id * 131u + it * 7919u);
+    if (KIND == 0 || KIND == 1) {
+      float4 acc = make_float4(1.f, 2.f, 3.f, 4.f);
+      const float w = (float)(h & 7u), v = (float)((h >> 3) & 15u);
+      float4 vv = make_float4(v, v + 1.f, v + 2.f, v + 3.f);
+      asm volatile("" : "+v"(vv.x), "+v"(vv.y), "+v"(vv.z), "+v"(vv.w), "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (KIND == 0) {
+          occ::fma4(acc, w, vv);
+        } else {
+          asm volatile("v_fma_f32 %0, %4, %5, %0\n\tv_fma_f32 %1, %4, %6, %1\n\tv_fma_f32 %2, %4, %7, %2\n\tv_fma_f32 %3, %4, %8, %3"
+                       : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) : "v"(w), "v"(vv.x), "v"(vv.y), "v"(vv.z), "v"(vv.w));
+        }
+      }
+      bad += acc.x != 1.f + 16.f * w * v;
+      bad += acc.y != 2.f + 16.f * w * (v + 1.f);
+      bad += acc.z != 3.f + 16.f * w * (v + 2.f);
+      bad += acc.w != 4.f + 16.f * w * (v + 3.f);
+    } else if (KIND == 2) {
+      uint32_t a = h & 0xffffu, b = (h >> 16) | 1u, c = id;
+      asm volatile("" : "+v"(a), "+v"(b), "+v"(c));
+      uint32_t r = c;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) r = r * b + a;
+      uint32_t e = id, eb = (h >> 16) | 1u, ea = h & 0xffffu;
+      asm volatile("" : "+v"(e), "+v"(eb), "+v"(ea));  // (the reference chain runs on the same unit: two independently
+      for (int k = 0; k < 16; ++k) e = e * eb + ea;    //  scheduled evaluations are compared)
+      bad += r != e;
+    } else if (KIND == 3) {
+      float x = (float)(h & 7u);
+      asm volatile("" : "+v"(x));
+      const float e2 = __builtin_amdgcn_exp2f(x);           // exact powers of two
+      const float rc = __builtin_amdgcn_rcpf(e2);
+      bad += e2 != (float)(1u << (h & 7u));
+      bad += rc != 1.f / (float)(1u << (h & 7u));
+    } else if (KIND == 5) {
+      // IEEE fp32 division (v_div_scale / v_rcp / v_div_fmas / v_div_fixup: v_div_fmas reads VCC implicitly), the way the
+      // gathers normalise their offsets and softmax weights; a compare-and-select in front leaves a non-trivial VCC
+      float k = (float)((h & 63u) + 1u), bq = (float)(((h >> 6) & 1023u) + 1u), a2 = (float)((h >> 16) & 255u);
+      asm volatile("" : "+v"(k), "+v"(bq), "+v"(a2));
+      const float num = k * bq;                             // exact: < 2^16
+      const float sel = a2 > 100.f ? num : num + 0.f;
+      const float q1 = sel / bq;
+      const float q2 = (a2 + 1.f) / (a2 + 1.f);
+      const float q3 = (k * 3.f) / 3.f;
+      bad += q1 != k;
+      bad += q2 != 1.f;
+      bad += q3 != k;
+    } else {
+      float acc = 1.f;
+      const float w = (float)(h & 7u);
+      unsigned packed = 0x40003c00u;                        // fp16 (1.0, 2.0)
+      asm volatile("" : "+v"(packed), "+v"(acc));
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { occ::fma_mix_lo(acc, w, packed); occ::fma_mix_hi(acc, w, packed); }
+      bad += acc != 1.f + 8.f * w * 3.f;
+    }
+  }
+  if (bad) atomicAdd(errors, (unsigned long long)bad);
+}
+}  // namespace
+
+extern "C" void hz_valu_victim(unsigned long long* errors, int blocks, int iters, int kind, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(valu_victim<0>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+    case 1: hipLaunchKernelGGL(valu_victim<1>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+    case 2: hipLaunchKernelGGL(valu_victim<2>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+    case 3: hipLaunchKernelGGL(valu_victim<3>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+    case 5: hipLaunchKernelGGL(valu_victim<5>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+    default: hipLaunchKernelGGL(valu_victim<4>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+  }
+}
+extern "C" void hz_produce_consume(uint32_t* table, uint32_t n16, uint32_t epoch, unsigned long long* errors, int buf_store,
+                                   int buf_load, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (buf_store) hipLaunchKernelGGL(produce_kernel<true>, dim3(1024), dim3(256), 0, st, table, n16, epoch);
+  else hipLaunchKernelGGL(produce_kernel<false>, dim3(1024), dim3(256), 0, st, table, n16, epoch);
+  if (buf_load) hipLaunchKernelGGL(consume_kernel<true>, dim3(2048), dim3(256), 0, st, table, n16, epoch, errors);
+  else hipLaunchKernelGGL(consume_kernel<false>, dim3(2048), dim3(256), 0, st, table, n16, epoch, errors);
+}
+extern "C" void hz_xlane_victim(unsigned long long* errors, int blocks, int iters, int dpp, void* stream) {
+  if (dpp) hipLaunchKernelGGL(xlane_victim<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, errors, iters);
+  else hipLaunchKernelGGL(xlane_victim<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, errors, iters);
+}
+extern "C" void hz_fill(uint32_t* t, long n, void* stream) {
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, t, n);
+}
+extern "C" void hz_lds_victim(unsigned long long* errors, int blocks, int iters, int real_wait, void* stream) {
+  hipLaunchKernelGGL(lds_victim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, errors, iters, real_wait);
+}
+extern "C" void hz_ta_victim(const uint32_t* table, uint32_t n_rows, unsigned long long* errors, int blocks, int iters, void* stream) {
+  hipLaunchKernelGGL(ta_victim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, n_rows, errors, iters);
+}
+extern "C" void hz_gl_victim(const uint32_t* table, uint32_t n, unsigned long long* errors, int blocks, int iters, void* stream) {
+  hipLaunchKernelGGL(gl_victim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, n, errors, iters);
+}

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
 }
 
 
-// ---- tile kernel (round 5): the value rows staged through LDS --------------------------------------------------------------
+// ---- tile kernel (round 5, OPT-IN: OCC_TSA_TILE=1): the value rows staged through LDS ----------------------------------------
 // The TSA gather is LOCAL: a query samples the BEV map a few pixels around its own position (the reference initialises the
 // offsets to k * (cos, sin) steps, k = 1..4 pixels, temporal_self_attention.py:117-133), and 64 samples x 4 corners per query
 // re-read every 128-byte head row of the neighbourhood ~32 times.  The wave-per-query kernel above fetches each of those 256
@@ -271,11 +271,13 @@ extern "C" int occ_tsa_fused_forward_f32(const float* value, int64_t value_bt_st
     return OCC_E_UNSUPPORTED;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // the tile kernel (value rows staged through LDS) whenever the queries are the whole BEV map, query q at pixel
-  // (q / bev_w, q % bev_w) — `order` is a locality hint of the wave-per-query kernel and plays no role there.
-  // OCC_TSA_TILE=0 (development switch) keeps the wave-per-query kernel.
+  // OCC_TSA_TILE=1: the tile kernel (value rows staged through LDS) when the queries are the whole BEV map, query q at
+  // pixel (q / bev_w, q % bev_w) — `order` is a locality hint of the wave-per-query kernel and plays no role there.
+  // Measured (round 5, same box, hot-path step, both kernels alone on the stream): 59.5 us per launch against the
+  // wave-per-query kernel's 53-54 us (profiles/r05_c11_hot_kernel_trace_stats.txt, r05_c11_tsa_ab.txt) — correct
+  // (tests/test_gpu_msda.py), not faster: off by default.
   const char* tile_env = getenv("OCC_TSA_TILE");           // read per call: the tests switch it inside one process
-  const bool tile_on = !(tile_env && tile_env[0] == '0');
+  const bool tile_on = tile_env && tile_env[0] == '1';
   if (tile_on && (long)Nq == (long)bev_h * bev_w) {
     const int tiles_x = (bev_w + kTsaTile - 1) / kTsaTile, tiles_y = (bev_h + kTsaTile - 1) / kTsaTile;
     const int tiles = tiles_x * tiles_y, per_xcd = (tiles + 7) / 8;

@@ -93,11 +93,14 @@ def compare_digest(name, t, gold, tol):
     slab_err = float(np.abs(d['slabs'] - gold[f'{name}_slabs']).max()) / per
     assert slab_err < tol / 10, f'{name}: mean error over a slab {slab_err}'
     if f'{name}_fine' in gold:
-        # every element is covered: one element off by tol * sqrt(FULL_FINE) (0.023 at 1e-3) in an otherwise matching chunk
-        # fails; independent per-element errors of the size the fp16 value rows leave (<= 2.4e-4) sum to ~ 3e-3 at worst
+        # every element is covered: the MEAN error over any 512 contiguous elements stays below tol / 4 — one element off by
+        # 0.13 (at tol 1e-3) in an otherwise matching chunk fails, so does one wrong BEV query (every channel's chunk moves).
+        # Not tighter: the errors the fp16 value rows leave (<= 2.4e-4 per element) are CORRELATED along a chunk (neighbouring
+        # queries of one channel share their sampled rows): measured 0.035 per chunk at four layers, sqrt(512) x the
+        # per-element error would have been 0.005
         fine = np.abs(d['fine'].astype(np.float64) - gold[f'{name}_fine'].astype(np.float64))
         worst = int(fine.argmax())
-        assert float(fine.max()) < tol * FULL_FINE ** 0.5, \
+        assert float(fine.max()) < tol / 4 * FULL_FINE, \
             f'{name}: elements [{worst * FULL_FINE}, {(worst + 1) * FULL_FINE}) sum to {float(fine.max())} off the reference'
     return sub_err, slab_err
 

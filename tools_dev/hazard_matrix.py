@@ -25,7 +25,9 @@ def nhwc(f):
 
 x = [nhwc(f.to(torch.bfloat16)) for f in synthetic.make_features(g, seed=12)]
 metas = synthetic.make_img_metas(g)
-OPS = [o for o in ("linear_pair_chain", "tsa_fused_forward", "linear_ln_chain", "value_range_scale", "value_proj_bf16_planes",
+# (value_proj_bf16_planes is not compared: its buffer carries one never-written padding pixel per camera — the gathers that
+# read the planes are compared instead)
+OPS = [o for o in ("linear_pair_chain", "tsa_fused_forward", "linear_ln_chain", "value_range_scale",
                    "sca_fused_forward", "encoder_ffn_chain", "conv3d_bn_relu", "conv3d_heads_decode") if hasattr(ext, o)]
 trace = []
 real = {o: getattr(ext, o) for o in OPS}
@@ -87,7 +89,7 @@ def own_kernels():
     if "range" in kinds:
         real["value_range_scale"](map_rows, [20.0] * 4, [5.0] * 4)
     if "vproj" in kinds:
-        real["value_proj_bf16_planes"](map_rows, ws, gbs, planes, rows_per_group=hw, out_group_rows=total, out_row0=starts)
+        ext.value_proj_bf16_planes(map_rows, ws, gbs, planes, rows_per_group=hw, out_group_rows=total, out_row0=starts)
 
 
 with torch.cuda.stream(load):          # the load's own first-use costs are paid before the measured repetitions

@@ -23,7 +23,7 @@
 
 namespace occ {
 
-constexpr int kVrMaxSeg = 8, kVrMaxPlanes = 8, kVrUnroll = 8;
+constexpr int kVrMaxSeg = 8, kVrMaxPlanes = 8, kVrUnroll = 12;   // 12 x 2048 x 256 pieces = 100 MB per round: the base maps in ONE round
 struct VrSegments {
   const uint4* a[kVrMaxSeg];
   int first[kVrMaxSeg + 1];           // cumulative 16-byte pieces: segment s holds pieces [first[s], first[s + 1])

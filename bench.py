@@ -582,6 +582,21 @@ def extra_legs(args, cfg, model, geo, device):
         del st
     except Exception as e:
         out["hotpath"] = {"error": repr(e)}
+    # the same hot path with the SCA value rows kept in fp32 (OCC_SCA_VALUES=f32: the reference's @force_fp32 storage,
+    # spatial_cross_attention.py:75,387-390) — the mode that stays inside 1e-3 for ANY feature scale
+    # (tests/test_gpu_value_range.py), timed next to the default fp16 rows
+    try:
+        from occnet_amd import ext as _ext
+        rows0 = _ext.SCA_VALUES
+        _ext.SCA_VALUES = "f32"
+        try:
+            st = Stepper(model, geo, "hotpath", args.backbone_dtype, device, seed=0, hot_feat_format="backbone")
+            out["hotpath_f32_rows"] = dict(run(st, 12), workload="hot path with fp32 SCA value rows (OCC_SCA_VALUES=f32)")
+            del st
+        finally:
+            _ext.SCA_VALUES = rows0
+    except Exception as e:
+        out["hotpath_f32_rows"] = {"error": repr(e)}
     try:
         if getattr(model, "img_backbone", None) is not None:
             st = Stepper(model, geo, "e2e", args.backbone_dtype, device, seed=0, plan=args.backbone_plan, history=3)

@@ -208,6 +208,22 @@ __global__ __launch_bounds__(256) void valu_victim(unsigned long long* errors, i
       const float rc = __builtin_amdgcn_rcpf(e2);
       bad += e2 != (float)(1u << (h & 7u));
       bad += rc != 1.f / (float)(1u << (h & 7u));
+    } else if (KIND == 6) {
+      // the set-up arithmetic of the gathers as the FAILING build of tsa_tile_kernel compiled it: two IEEE divisions whose
+      // v_div_fixup results are consumed at once by PACKED fp32 ops (v_pk_add_f32 / v_pk_fma_f32) — loc = ref + o / (W, H),
+      // (h_im, w_im) = loc * (H, W) - 0.5.  Operands chosen so that every step is exact.
+      float W = (float)(128 + (h & 64u)), Hh = (float)(64 + ((h >> 7) & 64u));          // 128 or 192; 64 or 128
+      float kx = (float)((h >> 8) & 31u), ky = (float)((h >> 13) & 31u);
+      float rx = 0.25f + 0.25f * (float)((h >> 18) & 1u), ry = 0.125f * (float)(((h >> 19) & 3u) + 1u);
+      asm volatile("" : "+v"(W), "+v"(Hh), "+v"(kx), "+v"(ky), "+v"(rx), "+v"(ry));
+      const float ox = kx * W * 0.0078125f, oy = ky * Hh * 0.0078125f;     // o = k * size / 128: o / size = k / 128, exact
+      const float lx = rx + ox / W, ly = ry + oy / Hh;
+      const float w_im = lx * W - 0.5f, h_im = ly * Hh - 0.5f;
+      const float ex = (rx + kx * 0.0078125f) * W - 0.5f, ey = (ry + ky * 0.0078125f) * Hh - 0.5f;
+      float e1 = ex, e2 = ey;
+      asm volatile("" : "+v"(e1), "+v"(e2));
+      bad += w_im != e1;
+      bad += h_im != e2;
     } else if (KIND == 5) {
       // IEEE fp32 division (v_div_scale / v_rcp / v_div_fmas / v_div_fixup: v_div_fmas reads VCC implicitly), the way the
       // gathers normalise their offsets and softmax weights; a compare-and-select in front leaves a non-trivial VCC
@@ -243,6 +259,7 @@ extern "C" void hz_valu_victim(unsigned long long* errors, int blocks, int iters
     case 2: hipLaunchKernelGGL(valu_victim<2>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
     case 3: hipLaunchKernelGGL(valu_victim<3>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
     case 5: hipLaunchKernelGGL(valu_victim<5>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+    case 6: hipLaunchKernelGGL(valu_victim<6>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
     default: hipLaunchKernelGGL(valu_victim<4>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
   }
 }

@@ -76,6 +76,7 @@ valu = {
     "VALU 32-bit integer multiply-add": lambda: lib.hz_valu_victim(P(err.data_ptr()), 8192, 64, 2, st()),
     "VALU v_exp_f32 / v_rcp_f32": lambda: lib.hz_valu_victim(P(err.data_ptr()), 8192, 256, 3, st()),
     "VALU IEEE fp32 division (v_div_scale/fmas/fixup)": lambda: lib.hz_valu_victim(P(err.data_ptr()), 8192, 256, 5, st()),
+    "gather set-up: v_div_fixup -> v_pk_add_f32 -> v_pk_fma_f32": lambda: lib.hz_valu_victim(P(err.data_ptr()), 8192, 256, 6, st()),
     "VALU v_fma_mix_f32": lambda: lib.hz_valu_victim(P(err.data_ptr()), 8192, 64, 4, st()),
 }
 victims = {

@@ -83,7 +83,25 @@ ca_w2 = ((torch.rand(768, 256, generator=gl) * 2 - 1) * 0.06).cuda()
 ca_b2 = torch.zeros(768, device='cuda')
 
 
+_micro = None
+_sink = torch.zeros(4, device='cuda')
+
+
+def spin(kind, iters):
+    """synthetic aggressors of tools_dev/hazard_micro.hip (spinN in HZ_LOAD): 0 = MFMAs only, 1 = MFMAs + LDS reads,
+    2 = LDS reads only, 3 = packed-fp32 VALU only"""
+    global _micro
+    if _micro is None:
+        import ctypes
+        _micro = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libhazard_micro.so"))
+    import ctypes
+    _micro.hz_spin(ctypes.c_void_p(_sink.data_ptr()), kind, 512, iters, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
 def own_kernels():
+    for kd in range(4):
+        if f"spin{kd}" in kinds:
+            spin(kd, int(os.environ.get("HZ_SPIN_ITERS", "20000")))
     if "chainA" in kinds:          # chain program A (output_proj + LN + the SCA's query Linears) on own buffers
         real["linear_ln_chain"](ca_attn, ca_q, ca_w1, ca_b1, ca_ln, ca_w2, ca_b2)
     if "range" in kinds:

@@ -249,8 +249,64 @@ __global__ __launch_bounds__(256) void valu_victim(unsigned long long* errors, i
   }
   if (bad) atomicAdd(errors, (unsigned long long)bad);
 }
+// Synthetic AGGRESSORS (round 5): which ingredient of the library's MFMA kernels disturbs a co-resident gather wave?
+//   KIND 0: nothing but matrix-core instructions on registers (v_mfma_f32_32x32x16_bf16, 8 independent accumulators,
+//           back to back — the issue pattern of the chain / projection kernels, no memory traffic at all);
+//   KIND 1: the same + LDS fragment reads (ds_read_b128 out of a 64 KB dynamic tile) between the MFMAs;
+//   KIND 2: the LDS reads alone;  KIND 3: packed-fp32 VALU FMAs alone.
+typedef float hz_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 hz_bf16x8 __attribute__((ext_vector_type(8)));
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void spin_kernel(float* __restrict__ sink, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char tile[];
+  const int lane = threadIdx.x & 63;
+  if (KIND == 1 || KIND == 2)
+    for (int i = threadIdx.x; i < 65536 / 16; i += 256) reinterpret_cast<float4*>(tile)[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+  __syncthreads();
+  hz_f32x16 acc[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[a][k] = 0.f;
+  occ::occ_u32x4 fa = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, fb = fa;     // bf16 1.0 x 8
+  float4 v = make_float4(1.f, 1.f, 1.f, 1.f), w = make_float4(0.5f, 0.25f, 0.125f, 0.0625f);
+  for (int it = 0; it < iters; ++it) {
+    if (KIND == 1 || KIND == 2) {
+      const float4 r = *reinterpret_cast<const float4*>(tile + (((lane * 16 + it * 1040) & 65535) & ~15));
+      fa[0] ^= __float_as_uint(r.x) & 1u;
+      fa[1] ^= __float_as_uint(r.z) & 1u;
+      v.x += (r.y + r.w) * 1e-30f;
+    }
+    if (KIND == 0 || KIND == 1) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hz_bf16x8, fa), __builtin_bit_cast(hz_bf16x8, fb),
+                                                         acc[a], 0, 0, 0);
+    }
+    if (KIND == 3) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) occ::fma4(v, 0.999f, w);
+    }
+  }
+  float sum = v.x + v.y + v.z + v.w;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) sum += acc[a][0] + acc[a][7];
+  if (sum == 123.456f) sink[0] = sum;               // never true: keeps the work alive
+}
 }  // namespace
 
+extern "C" void hz_spin(float* sink, int kind, int blocks, int iters, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int lds = (kind == 1 || kind == 2) ? 65536 : 0;
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(spin_kernel<0>, dim3(blocks), dim3(256), lds, st, sink, iters); break;
+    case 1: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spin_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            hipLaunchKernelGGL(spin_kernel<1>, dim3(blocks), dim3(256), lds, st, sink, iters); break;
+    case 2: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spin_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            hipLaunchKernelGGL(spin_kernel<2>, dim3(blocks), dim3(256), lds, st, sink, iters); break;
+    default: hipLaunchKernelGGL(spin_kernel<3>, dim3(blocks), dim3(256), lds, st, sink, iters); break;
+  }
+}
 extern "C" void hz_valu_victim(unsigned long long* errors, int blocks, int iters, int kind, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   switch (kind) {

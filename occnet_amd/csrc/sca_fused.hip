@@ -93,10 +93,10 @@ __global__ __launch_bounds__(256, 3) void sca_fused_kernel(
     float sum = e;
 #pragma unroll
     for (int d = LP / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    aw[k] = e / sum;
+    aw[k] = fdiv(e, sum);                      // (fdiv, not `/`: common.h)
     const float2 o = *reinterpret_cast<const float2*>(orow + 2 * idx);
-    ox[k] = o.x / (float)lvW;
-    oy[k] = o.y / (float)lvH;
+    ox[k] = fdiv(o.x, (float)lvW);
+    oy[k] = fdiv(o.y, (float)lvH);
     pre[wave][0][k][lane] = aw[k];
     pre[wave][1][k][lane] = ox[k];
     pre[wave][2][k][lane] = oy[k];
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 3) void sca_fused_kernel(
   }
 
   const float inv = (float)(count > 0 ? count : 1);
-  float4 o4 = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
+  float4 o4 = make_float4(fdiv(acc.x, inv), fdiv(acc.y, inv), fdiv(acc.z, inv), fdiv(acc.w, inv));
   *reinterpret_cast<float4*>(slots + ((long)b * Nq + q) * row_stride + g * D + c4 * 4) = o4;
 
   if (stats) {
@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     for (int d = 4; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      aw[k] = x[k] / sum;
-      ox[k] = o[2 * k] / (float)lvW;
-      oy[k] = o[2 * k + 1] / (float)lvH;
+      aw[k] = fdiv(x[k], sum);                 // (fdiv, not `/`: common.h — the division expansion is what the hazard hits)
+      ox[k] = fdiv(o[2 * k], (float)lvW);
+      oy[k] = fdiv(o[2 * k + 1], (float)lvH);
     }
   }
 
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
   acc2.w += __shfl_xor(acc2.w, 32);
   if (half == 0) {
     float* dst = slots + ((long)b * Nq + q) * row_stride + g * D + c4 * 8;
-    *reinterpret_cast<float4*>(dst) = make_float4(acc.x / inv, acc.y / inv, acc.z / inv, acc.w / inv);
-    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc2.x / inv, acc2.y / inv, acc2.z / inv, acc2.w / inv);
+    *reinterpret_cast<float4*>(dst) = make_float4(fdiv(acc.x, inv), fdiv(acc.y, inv), fdiv(acc.z, inv), fdiv(acc.w, inv));
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(fdiv(acc2.x, inv), fdiv(acc2.y, inv), fdiv(acc2.z, inv), fdiv(acc2.w, inv));
   }
 
   if (stats) {

@@ -43,13 +43,15 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
   const float e = expf(x - mx);
   float sum = e + __shfl_xor(e, 1);
   sum += __shfl_xor(sum, 2);
-  const float aw = e / sum;
-  const float2 o = *reinterpret_cast<const float2*>(offs + ((long)b * Nq + q) * offs_stride + 2 * lane);
+  const float aw = fdiv(e, sum);                 // (fdiv, not `/`: common.h — the division expansion is what the hazard hits)
+  float2 o = *reinterpret_cast<const float2*>(offs + ((long)b * Nq + q) * offs_stride + 2 * lane);
+  o.x = fdiv(o.x, (float)bev_w);
+  o.y = fdiv(o.y, (float)bev_h);
   const float2 rf = *reinterpret_cast<const float2*>(ref_2d + (((long)b * 2 + t) * Nq + q) * 2);
   // corners outside the BEV map carry an out-of-range byte offset: the buffer load returns 0 without a request (no
   // dummy load of row 0, no 0 * Inf)
   SampleParamB p;
-  bilinear_setup_b(rf.x + o.x / (float)bev_w, rf.y + o.y / (float)bev_h, aw, bev_h, bev_w, 0,
+  bilinear_setup_b(rf.x + o.x, rf.y + o.y, aw, bev_h, bev_w, 0,
                    (unsigned)row_stride * 4u, kOobOffset, true, p);
   sp[m * NSp + (lane & 7)] = p;
   wave_lds_sync();
@@ -183,10 +185,10 @@ __global__ __launch_bounds__(256, 3) void tsa_tile_kernel(
         const float e = expf(xl - mx);
         float sum = e + __shfl_xor(e, 1);
         sum += __shfl_xor(sum, 2);
-        const float aw = e / sum;
+        const float aw = fdiv(e, sum);
         SampleParamB p;
         // offsets in PIXELS first (pix_bytes = 1), then window-relative LDS bytes or a flagged global byte offset
-        bilinear_setup_b(rf[pass].x + ofc[pass].x / (float)bev_w, rf[pass].y + ofc[pass].y / (float)bev_h, aw, bev_h, bev_w,
+        bilinear_setup_b(rf[pass].x + fdiv(ofc[pass].x, (float)bev_w), rf[pass].y + fdiv(ofc[pass].y, (float)bev_h), aw, bev_h, bev_w,
                          0, 1u, 0xffffffffu, live[pass], p);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

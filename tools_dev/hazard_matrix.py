@@ -41,6 +41,12 @@ def tensors(o):
     return []
 
 
+# HZ_SLEEP_BEFORE=<op>[,<op>]: spin the GPU for HZ_SLEEP_CYCLES (default 100 000 ~ 45 us) on the step's stream in front of
+# the named launches — does a pause between a producer kernel and its consumer change the failure rate?
+_sleep_ops = set(filter(None, os.environ.get("HZ_SLEEP_BEFORE", "").split(",")))
+_sleep_cycles = int(os.environ.get("HZ_SLEEP_CYCLES", "100000"))
+for o in _sleep_ops:
+    real[o] = (lambda fn: lambda *a, **k: (torch.cuda._sleep(_sleep_cycles), fn(*a, **k))[1])(real[o])
 for o in OPS:
     setattr(ext, o, (lambda name: lambda *a, **k: (lambda out: (trace.append((name, [t.detach() for t in tensors(out)])), out)[1])(
         real[name](*a, **k)))(o))

@@ -249,6 +249,112 @@ __global__ __launch_bounds__(256) void valu_victim(unsigned long long* errors, i
   }
   if (bad) atomicAdd(errors, (unsigned long long)bad);
 }
+// The TSA gather's inner structure with known answers: per-sample parameters (4 weights, 4 row offsets) written to the
+// per-wave LDS slab by the set-up lane, handed over with wave_lds_sync(), read back as broadcast ds_read_b128 by the 8 lanes
+// of a group, 4 buffer loads of 16 bytes per sample into registers, float4 FMAs — LDS returns and vector-memory returns
+// interleaved as densely as in the real kernel.  Table word (row, j) = small integer f(row, j), weights 0..3: every sum is
+// exact, the expected value is recomputed from the indices alone.  LDSPARAMS = false keeps the parameters in registers
+// (each lane recomputes its group's samples): the same memory traffic without the slab.
+__device__ __forceinline__ float tab_f(uint32_t row, uint32_t j) { return (float)(mix(row * 32u + j) & 15u); }
+__global__ __launch_bounds__(256) void fill_small_kernel(float* t, uint32_t n_rows) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_rows * 32u; i += gridDim.x * 256) t[i] = tab_f(i >> 5, i & 31u);
+}
+template <bool LDSPARAMS>
+__global__ __launch_bounds__(256) void gather_victim(const float* __restrict__ table, uint32_t n_rows, unsigned long long* errors,
+                                                     int iters) {
+  __shared__ __attribute__((aligned(16))) occ::SampleParamB slab[4 * 8 * 9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3, c = lane & 7;
+  occ::SampleParamB* sp = slab + wave * 72;
+  const uint32_t wid = blockIdx.x * 4 + wave;
+  const __amdgpu_buffer_rsrc_t rs = occ::uniform_rsrc(table, n_rows * 128u);
+  unsigned bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    auto param = [&](int gg, int ss, occ::SampleParamB& p) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t h = mix(((wid * 8 + gg) * 8 + ss) * 4 + k + it * 1000003u);
+        p.w[k] = (float)(h & 3u);
+        p.o[k] = ((h >> 2) % n_rows) * 128u;
+      }
+    };
+    if (LDSPARAMS) {
+      occ::SampleParamB p;
+      param(g, c, p);                       // set-up lane (g, s = c)
+      sp[g * 9 + c] = p;
+      occ::wave_lds_sync();
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), exp4 = acc;
+    for (int s0 = 0; s0 < 8; s0 += 4) {
+      float4 v[4][4];
+      float4 w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        occ::SampleParamB p;
+        if (LDSPARAMS) {
+          const occ::occ_u32x4 o = *reinterpret_cast<const occ::occ_u32x4*>(sp[g * 9 + s0 + u].o);
+          w[u] = *reinterpret_cast<const float4*>(sp[g * 9 + s0 + u].w);
+          p.o[0] = o[0]; p.o[1] = o[1]; p.o[2] = o[2]; p.o[3] = o[3];
+        } else {
+          param(g, s0 + u, p);
+          w[u] = make_float4(p.w[0], p.w[1], p.w[2], p.w[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[u][k] = occ::buf_load16(rs, p.o[k] + c * 16u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        occ::fma4(acc, w[u].x, v[u][0]); occ::fma4(acc, w[u].y, v[u][1]); occ::fma4(acc, w[u].z, v[u][2]); occ::fma4(acc, w[u].w, v[u][3]);
+      }
+    }
+    for (int ss = 0; ss < 8; ++ss) {
+      occ::SampleParamB p;
+      param(g, ss, p);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t row = p.o[k] / 128u;
+        exp4.x += p.w[k] * tab_f(row, c * 4 + 0); exp4.y += p.w[k] * tab_f(row, c * 4 + 1);
+        exp4.z += p.w[k] * tab_f(row, c * 4 + 2); exp4.w += p.w[k] * tab_f(row, c * 4 + 3);
+      }
+    }
+    bad += (acc.x != exp4.x) + (acc.y != exp4.y) + (acc.z != exp4.z) + (acc.w != exp4.w);
+    if (LDSPARAMS) occ::wave_lds_sync();
+  }
+  if (bad) atomicAdd(errors, (unsigned long long)bad);
+}
+
+// The gathers' OUTPUT side: one wave per query row, the row written as ONE 64-lane x 16-byte store after a short gather-like
+// prologue (a few buffer loads, so that the wave's timing resembles the real kernels'); a second kernel (after the first has
+// completed) reads every row back.  Rows carry (row, word, epoch): a lost store shows as LAST epoch's value.
+__global__ __launch_bounds__(256) void store_victim(const float* __restrict__ table, uint32_t n_tab_rows, uint32_t* __restrict__ out,
+                                                    uint32_t n_rows, uint32_t epoch) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const __amdgpu_buffer_rsrc_t rs = occ::uniform_rsrc(table, n_tab_rows * 128u);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const uint32_t r = mix(row * 8u + u + epoch * 977u) % n_tab_rows;
+    const float4 v = occ::buf_load16(rs, r * 128u + (lane & 7) * 16u);
+    occ::fma4(acc, 1.f, v);
+  }
+  const uint32_t salt = (acc.x + acc.y + acc.z + acc.w) < 0.f ? 1u : 0u;      // always 0 (the table is non-negative)
+  occ::occ_u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = mix((row * 256u + lane * 4u + k) * 2654435761u + epoch * 40503u) + salt;
+  *reinterpret_cast<occ::occ_u32x4*>(out + (size_t)row * 256 + lane * 4) = o;
+}
+__global__ __launch_bounds__(256) void store_check(const uint32_t* __restrict__ out, uint32_t n_rows, uint32_t epoch,
+                                                   unsigned long long* errors) {
+  unsigned bad = 0, stale = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_rows * 256u; i += gridDim.x * 256) {
+    const uint32_t w = out[i];
+    bad += w != mix(i * 2654435761u + epoch * 40503u);
+    stale += w == mix(i * 2654435761u + (epoch - 1) * 40503u);
+  }
+  if (bad) { atomicAdd(errors, (unsigned long long)bad); atomicAdd(errors + 1, (unsigned long long)stale); }
+}
+
 // Synthetic AGGRESSORS (round 5): which ingredient of the library's MFMA kernels disturbs a co-resident gather wave?
 //   KIND 0: nothing but matrix-core instructions on registers (v_mfma_f32_32x32x16_bf16, 8 independent accumulators,
 //           back to back — the issue pattern of the chain / projection kernels, no memory traffic at all);
@@ -295,6 +401,20 @@ __global__ __launch_bounds__(256, 2) void spin_kernel(float* __restrict__ sink, 
 }
 }  // namespace
 
+extern "C" void hz_fill_small(float* t, uint32_t n_rows, void* stream) {
+  hipLaunchKernelGGL(fill_small_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, t, n_rows);
+}
+extern "C" void hz_gather_victim(const float* table, uint32_t n_rows, unsigned long long* errors, int blocks, int iters,
+                                 int lds_params, void* stream) {
+  if (lds_params) hipLaunchKernelGGL(gather_victim<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, n_rows, errors, iters);
+  else hipLaunchKernelGGL(gather_victim<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, n_rows, errors, iters);
+}
+extern "C" void hz_store_victim(const float* table, uint32_t n_tab_rows, uint32_t* out, uint32_t n_rows, uint32_t epoch,
+                                unsigned long long* errors, int check, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!check) hipLaunchKernelGGL(store_victim, dim3((n_rows + 3) / 4), dim3(256), 0, st, table, n_tab_rows, out, n_rows, epoch);
+  else hipLaunchKernelGGL(store_check, dim3(2048), dim3(256), 0, st, out, n_rows, epoch, errors);
+}
 extern "C" void hz_spin(float* sink, int kind, int blocks, int iters, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int lds = (kind == 1 || kind == 2) ? 65536 : 0;

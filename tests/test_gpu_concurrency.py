@@ -1,15 +1,17 @@
 """-m gpu, always on: the DEFAULT hot path under co-scheduled load.
 
 Round 4's row-pipeline experiment produced wrong rows when kernels of different kinds overlapped on several streams, and
-the cause was not understood — which left open whether the default path is race-free or merely serialised.  Round 5 ran
-it down (tools_dev/hazard_matrix.py): a gather kernel of this library returns a few wrong rows now
-and then while one of the library's MFMA kernels runs next to it on ANOTHER hardware queue — which rounds 2-4's default did
-on purpose (the value projection on a side stream under layer 0's TSA gather: 2 of 150 steps wrong under an external load
-with round 4's kernels, 47 of 150 with this round's).  The library now issues all of its kernels on ONE stream; this test
-holds that line: the standard 4-layer step at the bench's hot-path configuration (full base geometry, bf16 NHWC maps)
-while a second stream keeps the chip busy with HBM-bound copies, LDS-heavy matrix-core GEMMs, a random gather and a
-scratch-using radix sort, BIT-identical to the solo run, 50 times.  Every kernel of the path is deterministic (no float
-atomics; the gathers' statistics counters are off), so any difference is a hazard, not rounding."""
+the cause was not understood.  Round 5 ran it down: the IEEE fp32 division expansion of hipcc
+(v_div_scale / v_rcp / v_div_fmas / v_div_fixup) in the gather kernels returns wrong quotients in lanes 48-63 now and then
+while a wave of one of this library's MFMA kernels is resident on the same SIMD — the default of rounds 2-4 (value
+projection on a side stream under layer 0's TSA gather) was exposed to it (2 of 150 steps under an external load with round
+4's kernels, 47 of 150 with this round's first cut).  Two things close it: the gathers compute their quotients without that
+expansion (occ::fdiv, csrc/common.h) and the library issues all of its kernels on ONE stream.  This test holds the line: the
+standard 4-layer step at the bench's hot-path configuration (full base geometry, bf16 NHWC maps) while a second stream keeps
+the chip busy with HBM-bound copies, LDS-heavy matrix-core GEMMs, a random gather, a scratch-using radix sort AND the two
+kernels of this library that used to trigger it (the stacked value projection and chain program A, on buffers of their own),
+BIT-identical to the solo run, 50 times.  Every kernel of the path is deterministic (no float atomics; the gathers'
+statistics counters are off), so any difference is a hazard, not rounding."""
 import pytest
 import torch
 
@@ -46,6 +48,20 @@ def test_default_hot_path_is_bit_identical_under_co_scheduled_load():
         dst = torch.empty_like(big)
         idx = torch.randint(0, 1 << 20, (1 << 22,), device='cuda')
         tab = torch.randn(1 << 20, 64, device='cuda')
+        # this library's own MFMA kernels as a FOREIGN load (buffers of their own: no data or event relation to the step)
+        from occnet_amd import ext
+        gl = torch.Generator().manual_seed(3)
+        rows = [f.permute(0, 1, 3, 4, 2).reshape(-1, f.shape[2]) for f in x]
+        hw = [f.shape[3] * f.shape[4] for f in x]
+        starts = [sum(hw[:i]) for i in range(len(hw))]
+        total = sum(hw) + (sum(hw) & 1)
+        ws = [((torch.rand(256, 256, generator=gl) * 2 - 1) * 0.1).cuda() for _ in range(4)]
+        gbs = [torch.randn(4, 6, 256, generator=gl).cuda() for _ in range(4)]
+        planes = torch.empty(4, 6 * total, 256, dtype=torch.float16, device='cuda')
+        ca = dict(attn=torch.randn(1, 40000, 256, device='cuda'), q=torch.randn(1, 40000, 256, device='cuda'),
+                  w1=((torch.rand(256, 256, generator=gl) * 2 - 1) * 0.06).cuda(), b1=torch.zeros(256, device='cuda'),
+                  ln=torch.nn.LayerNorm(256).cuda(), w2=((torch.rand(768, 256, generator=gl) * 2 - 1) * 0.06).cuda(),
+                  b2=torch.zeros(768, device='cuda'))
         bad = []
         for rep in range(50):
             with torch.cuda.stream(load):
@@ -54,6 +70,8 @@ def test_default_hot_path_is_bit_identical_under_co_scheduled_load():
                     c = a @ b                            # matrix cores + LDS
                     s = tab[idx[(rep % 4) << 20:((rep % 4) + 1) << 20]].sum(0)   # random gather (texture path)
                     st = torch.sort(c[:256].float().view(-1))[0]                 # rocPRIM radix sort: LDS + scratch
+                ext.value_proj_bf16_planes(rows, ws, gbs, planes, rows_per_group=hw, out_group_rows=total, out_row0=starts)
+                ext.linear_ln_chain(ca['attn'], ca['q'], ca['w1'], ca['b1'], ca['ln'], ca['w2'], ca['b2'])
             out = prod(x, metas)
             torch.cuda.synchronize()
             for k in keys:

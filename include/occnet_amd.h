@@ -45,6 +45,10 @@ extern "C" {
 int occ_abi_version(void);
 /* Thread-local message describing the last failure in this thread ("" if none). */
 const char* occ_last_error(void);
+/* Test hook: q[i] = the quotient a[i] / d[i] as the gather kernels compute it (reciprocal + Newton step + residual correction,
+ * csrc/common.h occ::fdiv — NOT the compiler's IEEE division expansion, whose results are unreliable on gfx950 while an
+ * MFMA-issuing wave shares the SIMD: DESIGN.md section 8d).  a, d, q: n DEVICE floats; d normal and non-zero. */
+int occ_selftest_fdiv_f32(const float* a, const float* d, float* q, int64_t n, void* stream);
 
 /* ==========================================================================================
  * PART I — THE REFERENCE INTERFACE.  The entry points a maintainer of the reference binds: one per interface the

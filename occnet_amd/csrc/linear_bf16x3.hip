@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(
       bev = *reinterpret_cast<const float4*>(ln_b + n0 + c);
     }
   }
-  const float inv_n = 1.f / (float)N;
+  const float inv_n = fdiv(1.f, (float)N);     // (no `/` on fp32 in device code: common.h)
   float* sO = reinterpret_cast<float*>(lds);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {

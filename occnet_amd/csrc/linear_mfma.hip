@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(
       bev = *reinterpret_cast<const float4*>(ln_b + n0 + c);
     }
   }
-  const float inv_n = 1.f / (float)N;
+  const float inv_n = fdiv(1.f, (float)N);     // (no `/` on fp32 in device code: common.h)
   // all 8 residual rows of this wave are requested before any is consumed (clamped, unconditional):
   // a load inside the row loop would serialise 8 dependent memory round trips
   float4 rres[8];

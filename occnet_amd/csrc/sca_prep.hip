@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void sca_prep_fwd_kernel(
     float sum = e;
 #pragma unroll
     for (int d = LP / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    arow[idx] = e / sum;
-    *reinterpret_cast<float2*>(lrow + 2 * idx) = make_float2(rxy.x + o.x / Wl, rxy.y + o.y / Hl);
+    arow[idx] = fdiv(e, sum);                  // (fdiv, not `/`: common.h — the division expansion is what the hazard hits)
+    *reinterpret_cast<float2*>(lrow + 2 * idx) = make_float2(rxy.x + fdiv(o.x, Wl), rxy.y + fdiv(o.y, Hl));
   }
 }
 
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void sca_prep_bwd_kernel(
       for (int d = LP / 2; d >= 1; d >>= 1) dot += __shfl_xor(dot, d);
       gl[k] += a * (ga - dot);
       const float2 g2 = *reinterpret_cast<const float2*>(grad_loc + (row * (M * LP) + idx) * 2);
-      gx[k] += g2.x / Wl;
-      gy[k] += g2.y / Hl;
+      gx[k] += fdiv(g2.x, Wl);
+      gy[k] += fdiv(g2.y, Hl);
     }
   }
   float* drow = dproj + ((long)b * Q + q) * proj_ld;

@@ -208,3 +208,31 @@ def test_head_parity_and_range_over_feature_scales(amp, rows, monkeypatch):
         print(f"{rows} rows, amp {amp:g} (max|v| {vmax:.3g}) {k}: lazy path vs oracle {d:.3e}, flatten path vs oracle {d2:.3e} "
               f"(bound {bound:g})")
         assert d < bound and d2 < bound
+
+
+def test_fdiv_is_faithfully_rounded():
+    """occ::fdiv (csrc/common.h): the quotient the gather kernels use INSTEAD of hipcc's IEEE division expansion — the
+    instruction sequence behind the co-scheduling hazard of DESIGN.md section 8d.  Reciprocal + one Newton step + one residual
+    correction: within 1 ulp of the correctly rounded quotient everywhere in the gathers' operand range, equal to it in
+    almost every case."""
+    import ctypes
+    from occnet_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    n = 1 << 22
+    # numerators: softmax terms in (0, 1], pixel offsets up to a few hundred, accumulated values up to 1e5 (both signs);
+    # divisors: softmax sums in [1, 32], map sizes 1 ... 4096, camera counts 1 ... 6
+    a = torch.cat([torch.rand(n // 4, generator=g), (torch.rand(n // 4, generator=g) - 0.5) * 600,
+                   torch.randn(n // 4, generator=g) * 1e3, torch.randn(n // 4, generator=g) * 1e5]).cuda()
+    d = torch.cat([1 + 31 * torch.rand(n // 4, generator=g), torch.randint(1, 4097, (n // 4,), generator=g).float(),
+                   torch.randint(1, 7, (n // 4,), generator=g).float(), 1 + 31 * torch.rand(n // 4, generator=g)]).cuda()
+    q = torch.empty_like(a)
+    rc = _lib.lib().occ_selftest_fdiv_f32(_lib.ptr(a), _lib.ptr(d), _lib.ptr(q), ctypes.c_int64(n), _lib.stream_ptr(a.device))
+    _lib.check(rc, "selftest_fdiv")
+    torch.cuda.synchronize()
+    want = (a.double() / d.double())
+    ieee = want.float()                                            # the correctly rounded quotient
+    ulp = torch.maximum(torch.abs(torch.nextafter(ieee, ieee * 2) - ieee), torch.full_like(ieee, 1e-45))
+    err = (q.double() - want).abs() / ulp.double()
+    exact = float((q == ieee).float().mean())
+    print(f"fdiv: max error {float(err.max()):.3f} ulp, equal to the correctly rounded quotient in {exact:.6%} of {n} cases")
+    assert float(err.max()) <= 1.0 and exact > 0.999

@@ -5,6 +5,9 @@ stream, on CRAFTED inputs that say what went wrong in a wrong row:
                  weights sum to one) — a deviation means wrong WEIGHTS;
   case "centre": logits = 0, offsets = 0: every sample sits on the query's own pixel, output = the query's own value row — a
                  deviation means a wrong row FETCH (address or data).
+With the library as it is now (the gathers compute their quotients with occ::fdiv) every case reports 0; the commit before
+"Gather kernels without the IEEE division expansion" reproduces the hazard (99 of 100 runs), and OCC_TSA_VARIANT there selects
+the compile-time variants of profiles/r05_c17_tsa_standalone_variants.log.
 usage: python tools_dev/hazard_tsa_standalone.py [reps]"""
 import os
 import sys

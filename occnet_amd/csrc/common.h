@@ -74,13 +74,14 @@ __device__ __forceinline__ unsigned short bf16_rne(float f) {
 }
 
 // fp32 quotient WITHOUT the IEEE division expansion.  hipcc turns `a / d` into v_div_scale_f32 (x2, one writes VCC) /
-// v_rcp_f32 / v_fma chain / v_div_fmas_f32 (reads VCC implicitly) / v_div_fixup_f32.  Round 5 found that sequence to be the
-// instruction pattern behind the co-scheduling hazard of the gather kernels: while a wave of one of
-// this library's MFMA kernels is resident on the same SIMD, the quotients of lanes 48-63 — the last 16-lane pass of the
-// wave64 instructions — come out wrong now and then (the real TSA kernel alone next to the value projection: 99 of 100
-// runs; with its three divisions written as below: 0 of 60, profiles/r05_c17_tsa_standalone_variants.log).  Reciprocal +
-// one Newton step + one residual correction: faithfully rounded (<= 1 ulp, correctly rounded in almost all cases) for
-// normal, non-zero d — every divisor in the gather kernels is a positive map size, a softmax sum >= 1 or a camera count.
+// v_rcp_f32 / v_fma chain / v_div_fmas_f32 (reads VCC implicitly) / v_div_fixup_f32: 12 instructions and a VCC round trip
+// where 5 do.  History: with their divisions written this way the gather kernels stopped showing the
+// co-scheduling hazard of round 5 (the real TSA kernel alone next to the value projection: wrong in lanes 48-63 in 99 of
+// 100 runs with `/`, 0 of 100 with fdiv) — but a self-contained copy of the kernel fails WITH fdiv as well (item 10 there):
+// the expansion is not what the hazard hits, fdiv moved the kernels out of its window.  The guarantee is the single stream.
+// Reciprocal + one Newton step + one residual correction: faithfully rounded (<= 1 ulp; equal to the correctly rounded
+// quotient in all 4 194 304 cases of tests/test_gpu_value_range.py) for normal, non-zero d — every divisor in the gather
+// kernels is a positive map size, a softmax sum >= 1 or a camera count.
 __device__ __forceinline__ float fdiv(float a, float d) {
   float r = __builtin_amdgcn_rcpf(d);
   r = fmaf(fmaf(-d, r, 1.f), r, r);

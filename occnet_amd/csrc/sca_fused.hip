@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     for (int d = 4; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      aw[k] = fdiv(x[k], sum);                 // (fdiv, not `/`: common.h — the division expansion is what the hazard hits)
+      aw[k] = fdiv(x[k], sum);                 // (fdiv, not `/`: see common.h)
       ox[k] = fdiv(o[2 * k], (float)lvW);
       oy[k] = fdiv(o[2 * k + 1], (float)lvH);
     }

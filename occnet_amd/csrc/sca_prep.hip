@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void sca_prep_fwd_kernel(
     float sum = e;
 #pragma unroll
     for (int d = LP / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    arow[idx] = fdiv(e, sum);                  // (fdiv, not `/`: common.h — the division expansion is what the hazard hits)
+    arow[idx] = fdiv(e, sum);                  // (fdiv, not `/`: see common.h)
     *reinterpret_cast<float2*>(lrow + 2 * idx) = make_float2(rxy.x + fdiv(o.x, Wl), rxy.y + fdiv(o.y, Hl));
   }
 }

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void tsa_fused_kernel(
   const float e = expf(x - mx);
   float sum = e + __shfl_xor(e, 1);
   sum += __shfl_xor(sum, 2);
-  const float aw = fdiv(e, sum);                 // (fdiv, not `/`: common.h — the division expansion is what the hazard hits)
+  const float aw = fdiv(e, sum);                 // (fdiv, not `/`: see common.h)
   float2 o = *reinterpret_cast<const float2*>(offs + ((long)b * Nq + q) * offs_stride + 2 * lane);
   o.x = fdiv(o.x, (float)bev_w);
   o.y = fdiv(o.y, (float)bev_h);

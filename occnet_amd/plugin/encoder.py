@@ -29,7 +29,7 @@ from .spatial_cross_attention import _require_device
 # the SCA value projections of ALL layers depend on the camera features only: they are launched before the first layer
 # (LazyFeatures.prefetch: ONE stacked launch).  OCC_VPROJ_OVERLAP=1 puts that launch on a side stream under the first
 # layer's TSA / Linear kernels (rounds 2-4's default: 6.764 -> 6.734 ms per sample in round 2) — off since round 5: that
-# co-residency is how the division hazard of DESIGN.md section 8d was met, and with today's kernels the side stream buys
+# co-residency is how the co-scheduling hazard of DESIGN.md section 8d was met, and with today's kernels the side stream buys
 # nothing (2.255-2.272 against 2.25 ms per hot-path step): the library runs its kernels on ONE stream
 _VPROJ_OVERLAP = os.environ.get("OCC_VPROJ_OVERLAP", "0") == "1"
 

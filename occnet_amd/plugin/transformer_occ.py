@@ -155,10 +155,10 @@ class LazyFeatures:
         2-4's default) runs them on a side stream under the first layer's TSA gather / chain kernels instead; project()
         then makes the consuming stream wait for the side stream's event and finish() (the encoder calls it when the layer
         stack is done, also on an exception) joins the side stream.  NOT the default any more: that schedule is how the
-        division hazard of DESIGN.md section 8d was met (hipcc's fp32 division expansion in a gather kernel returns wrong
-        quotients while one of the library's MFMA kernels shares the chip on another hardware queue: 47-52 of 150 steps under
-        an artificial load, 2 of 150 with round 4's kernels) — the gathers no longer contain that expansion, and the side
-        stream buys nothing (2.255-2.272 against 2.25 ms per hot-path step), so the library keeps to one stream.
+        co-scheduling hazard of DESIGN.md section 8d was met (a gather kernel's sampling set-up comes out wrong in lanes
+        48-63 while one of the library's MFMA kernels shares the chip on another hardware queue: 47-52 of 150 steps under an
+        artificial load, 2 of 150 with round 4's kernels; 0 of 150 with today's kernels, which section 8d item 10 shows to be
+        no guarantee), and the side stream buys nothing (2.255-2.272 against 2.25 ms per hot-path step): one stream.
         The derived operands (packed weight, per-(level, camera) bias: first-use caches) are built on the MAIN stream
         before the fork, so no later main-stream reader can race their side-stream construction."""
         dev = self.mlvl_feats[0].device

@@ -1,12 +1,13 @@
 """-m gpu, always on: the DEFAULT hot path under co-scheduled load.
 
 Round 4's row-pipeline experiment produced wrong rows when kernels of different kinds overlapped on several streams, and
-the cause was not understood.  Round 5 ran it down: the IEEE fp32 division expansion of hipcc
-(v_div_scale / v_rcp / v_div_fmas / v_div_fixup) in the gather kernels returns wrong quotients in lanes 48-63 now and then
-while a wave of one of this library's MFMA kernels is resident on the same SIMD — the default of rounds 2-4 (value
-projection on a side stream under layer 0's TSA gather) was exposed to it (2 of 150 steps under an external load with round
-4's kernels, 47 of 150 with this round's first cut).  Two things close it: the gathers compute their quotients without that
-expansion (occ::fdiv, csrc/common.h) and the library issues all of its kernels on ONE stream.  This test holds the line: the
+the cause was not understood.  Round 5 ran it down: the gather kernels compute a wrong sampling
+set-up in lanes 48-63 (the last 16-lane pass of their wave64 instructions) now and then while a wave of one of this
+library's MFMA kernels runs on another hardware queue — the default of rounds 2-4 (value projection on a side stream under
+layer 0's TSA gather) was exposed to it (2 of 150 steps under an external load with round 4's kernels, 47 of 150 with this
+round's first cut).  The library now issues all of its kernels on ONE stream (the guarantee), and since the gathers'
+divisions became occ::fdiv the kernels have not shown it under any foreign load either (a measurement: section 8d item 10
+— the self-contained reproducer points at the set-up's scalar lane masks, which the gathers still have).  This test holds the line: the
 standard 4-layer step at the bench's hot-path configuration (full base geometry, bf16 NHWC maps) while a second stream keeps
 the chip busy with HBM-bound copies, LDS-heavy matrix-core GEMMs, a random gather, a scratch-using radix sort AND the two
 kernels of this library that used to trigger it (the stacked value projection and chain program A, on buffers of their own),

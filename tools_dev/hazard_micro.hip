@@ -355,6 +355,89 @@ __global__ __launch_bounds__(256) void store_check(const uint32_t* __restrict__ 
   if (bad) { atomicAdd(errors, (unsigned long long)bad); atomicAdd(errors + 1, (unsigned long long)stale); }
 }
 
+// THE REPRODUCER (round 5): the TSA gather as it was BEFORE occ::fdiv — its softmax weight and its two offset normalisations
+// are plain fp32 divisions, which hipcc expands into v_div_scale / v_rcp / v_div_fmas / v_div_fixup — on a value map of ones:
+// every interior query's output must be 1 (softmax and bilinear weights sum to one), whatever the offsets and logits.  Counts
+// the output words that are off by more than 1e-3.  USE_FDIV = true is the same kernel with the three quotients computed by
+// occ::fdiv.  (next to an MFMA-issuing kernel on another stream the `/` build returns wrong weights in
+// lanes 48-63.)
+// bilinear_setup_b without lane masks in scalar registers: every condition becomes a 0 / 1 VGPR at once (v_cmp + v_cndmask,
+// VCC consumed by the very next VALU instruction), conditions are combined with VALU integer ANDs and the selects compare those
+// integers — no s_and_b64 / s_and_saveexec_b64 / branch ever reads a mask a v_cmp has just written.
+__device__ __forceinline__ void bilinear_setup_vb(float loc_x, float loc_y, float attn, int H, int W, unsigned pix_bytes,
+                                                  unsigned dead, occ::SampleParamB& sp) {
+  const float h_im = loc_y * (float)H - 0.5f, w_im = loc_x * (float)W - 0.5f;
+  auto flag = [](bool c) { int f = c ? 1 : 0; asm volatile("" : "+v"(f)); return f; };
+  const int adm = flag(h_im > -1.f) & flag(w_im > -1.f) & flag(h_im < (float)H) & flag(w_im < (float)W);
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h_low = (int)hf, w_low = (int)wf;
+  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+  const int t = flag(h_low >= 0) & adm, b = flag(h_low + 1 <= H - 1) & adm, l = flag(w_low >= 0), r = flag(w_low + 1 <= W - 1);
+  const int base = h_low * W + w_low;
+  const int c0 = t & l, c1 = t & r, c2 = b & l, c3 = b & r;
+  sp.w[0] = c0 ? hh * hw * attn : 0.f; sp.o[0] = c0 ? (unsigned)base * pix_bytes : dead;
+  sp.w[1] = c1 ? hh * lw * attn : 0.f; sp.o[1] = c1 ? (unsigned)(base + 1) * pix_bytes : dead;
+  sp.w[2] = c2 ? lh * hw * attn : 0.f; sp.o[2] = c2 ? (unsigned)(base + W) * pix_bytes : dead;
+  sp.w[3] = c3 ? lh * lw * attn : 0.f; sp.o[3] = c3 ? (unsigned)(base + W + 1) * pix_bytes : dead;
+}
+
+// VAR (ablations of the victim): 64 = bilinear_setup_vb (no scalar lane masks); 1 quotients by occ::fdiv; 2 bare v_exp_f32 instead of expf; 4 no softmax at all (weight 1/4:
+// no shuffles, no exponential, no quotient); 8 offsets forced to zero (every sample on the query's own pixel centre);
+// 16 s_nop 7 x 2 between the set-up arithmetic and the LDS hand-over; 32 the per-sample terms handed over with a real
+// s_waitcnt + block barrier instead of the wave-level fence
+template <int VAR>
+__global__ __launch_bounds__(256) void tsa_div_victim(const float* __restrict__ value, const float* __restrict__ offs,
+                                                      const float* __restrict__ logits, unsigned long long* errors, int bev_h,
+                                                      int bev_w) {
+  constexpr int M = 8, D = 32, P = 4, NS = 2 * P, NSp = NS + 1;
+  __shared__ __attribute__((aligned(16))) occ::SampleParamB smem[4 * M * NSp];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Nq = bev_h * bev_w;
+  const long q = (long)blockIdx.x * 4 + wave;
+  if (q >= Nq) return;
+  occ::SampleParamB* sp = smem + wave * M * NSp;
+  constexpr int row_stride = M * D;
+  const int m = lane >> 3;
+  const float x = logits[q * 64 + lane];
+  float mx = fmaxf(x, __shfl_xor(x, 1));
+  mx = fmaxf(mx, __shfl_xor(mx, 2));
+  constexpr bool USE_FDIV = (VAR & 1) != 0;
+  const float e = (VAR & 2) ? __builtin_amdgcn_exp2f((x - mx) * 1.44269504f) : expf(x - mx);
+  float sum = e + __shfl_xor(e, 1);
+  sum += __shfl_xor(sum, 2);
+  float aw = USE_FDIV ? occ::fdiv(e, sum) : e / sum;
+  if (VAR & 4) aw = 0.25f;
+  float2 o = *reinterpret_cast<const float2*>(offs + q * 128 + 2 * lane);
+  if (VAR & 8) o = make_float2(0.f, 0.f);
+  const int qy = (int)(q / bev_w), qx = (int)(q - (long)qy * bev_w);
+  const float2 rf = USE_FDIV ? make_float2(occ::fdiv((float)qx + 0.5f, (float)bev_w), occ::fdiv((float)qy + 0.5f, (float)bev_h))
+                             : make_float2(((float)qx + 0.5f) / (float)bev_w, ((float)qy + 0.5f) / (float)bev_h);
+  const float ox = USE_FDIV ? occ::fdiv(o.x, (float)bev_w) : o.x / (float)bev_w;
+  const float oy = USE_FDIV ? occ::fdiv(o.y, (float)bev_h) : o.y / (float)bev_h;
+  occ::SampleParamB p;
+  if (VAR & 64) bilinear_setup_vb(rf.x + ox, rf.y + oy, aw, bev_h, bev_w, (unsigned)row_stride * 4u, occ::kOobOffset, p);
+  else occ::bilinear_setup_b(rf.x + ox, rf.y + oy, aw, bev_h, bev_w, 0, (unsigned)row_stride * 4u, occ::kOobOffset, true, p);
+  if (VAR & 16) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(p.w[0]), "+v"(p.w[1]), "+v"(p.w[2]), "+v"(p.w[3]));
+  sp[m * NSp + (lane & 7)] = p;
+  if (VAR & 32) __syncthreads(); else occ::wave_lds_sync();
+  const int g = lane >> 3, c4 = lane & 7;
+  const unsigned map_bytes = (unsigned)bev_h * (unsigned)bev_w * (unsigned)row_stride * 4u;
+  const __amdgpu_buffer_rsrc_t r0 = occ::uniform_rsrc(value, map_bytes);
+  const unsigned lane_off = (unsigned)(g * D + c4 * 4) * 4u;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  a0 = occ::gather_samples_buf<4>(r0, lane_off, sp + g * NSp, P, a0);
+  a1 = occ::gather_samples_buf<4>(r0, lane_off, sp + g * NSp + P, P, a1);
+  const float4 o4 = make_float4((a0.x + a1.x) * 0.5f, (a0.y + a1.y) * 0.5f, (a0.z + a1.z) * 0.5f, (a0.w + a1.w) * 0.5f);
+  const bool interior = qy >= 16 && qy < bev_h - 16 && qx >= 16 && qx < bev_w - 16;     // offsets stay inside the map
+  unsigned bad = 0;
+  if (interior)
+    bad = (fabsf(o4.x - 1.f) > 1e-3f) + (fabsf(o4.y - 1.f) > 1e-3f) + (fabsf(o4.z - 1.f) > 1e-3f) + (fabsf(o4.w - 1.f) > 1e-3f);
+  if (bad) {
+    atomicAdd(errors, (unsigned long long)bad);
+    atomicAdd(errors + 1 + (lane >> 4), 1ull);          // which 16-lane quarter of the wave
+  }
+}
+
 // Synthetic AGGRESSORS (round 5): which ingredient of the library's MFMA kernels disturbs a co-resident gather wave?
 //   KIND 0: nothing but matrix-core instructions on registers (v_mfma_f32_32x32x16_bf16, 8 independent accumulators,
 //           back to back — the issue pattern of the chain / projection kernels, no memory traffic at all);
@@ -414,6 +497,13 @@ extern "C" void hz_store_victim(const float* table, uint32_t n_tab_rows, uint32_
   hipStream_t st = (hipStream_t)stream;
   if (!check) hipLaunchKernelGGL(store_victim, dim3((n_rows + 3) / 4), dim3(256), 0, st, table, n_tab_rows, out, n_rows, epoch);
   else hipLaunchKernelGGL(store_check, dim3(2048), dim3(256), 0, st, out, n_rows, epoch, errors);
+}
+extern "C" void hz_tsa_div_victim(const float* value, const float* offs, const float* logits, unsigned long long* errors, int bev_h,
+                                  int bev_w, int use_fdiv, void* stream) {
+  const int blocks = (bev_h * bev_w + 3) / 4;
+#define HZ_V(V) case V: hipLaunchKernelGGL(tsa_div_victim<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, value, offs, logits, errors, bev_h, bev_w); break;
+  switch (use_fdiv) { HZ_V(0) HZ_V(1) HZ_V(2) HZ_V(4) HZ_V(8) HZ_V(12) HZ_V(16) HZ_V(32) HZ_V(5) HZ_V(64) HZ_V(65) HZ_V(76) default: break; }
+#undef HZ_V
 }
 extern "C" void hz_spin(float* sink, int kind, int blocks, int iters, void* stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -7,7 +7,9 @@ stream, on CRAFTED inputs that say what went wrong in a wrong row:
                  deviation means a wrong row FETCH (address or data).
 With the library as it is now (the gathers compute their quotients with occ::fdiv) every case reports 0; the commit before
 "Gather kernels without the IEEE division expansion" reproduces the hazard (99 of 100 runs), and OCC_TSA_VARIANT there selects
-the compile-time variants of profiles/r05_c17_tsa_standalone_variants.log.
+the compile-time variants of profiles/r05_c17_tsa_standalone_variants.log.  tools_dev/hazard_repro.py is the self-contained
+successor (a copy of that kernel in hazard_micro.hip, no torch): it fails with fdiv as well and is cured by a set-up without
+scalar lane masks.
 usage: python tools_dev/hazard_tsa_standalone.py [reps]"""
 import os
 import sys

@@ -1,0 +1,3 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+( HZ_ONLY_VPROJ=1 HZ_VARIANTS=0,64 timeout 150 python tools_dev/hazard_repro.py 150 ) > gpurun_out/r05_c22_repro.log 2>&1; grep -E "REPRO|Error|error" gpurun_out/r05_c22_repro.log | cut -c1-260

@@ -544,3 +544,35 @@ def test_fp16_value_range_terms_and_aten_scale():
         assert float((back - v).abs().max()) <= float(v.abs().max()) * 2.0 ** -11
     for bad in (torch.zeros(3, 4), torch.tensor([1.0, float('inf')]), torch.tensor([float('nan'), 2.0])):
         assert float(ext.f16_range_scaled(bad)[1]) == 1.0
+
+
+def test_value_range_a_priori_bound_dominates_every_projection():
+    """csrc/value_range.hip's inequality, restated on the host: for ANY map x with max|x| = a,
+    |x . W[n] + gbias[n]| <= a * max_n sum_k |W[n][k]| * (1 + 2^-8) + max|gbias| =: bound, and with s = 2^(15 - e) for
+    bound = m * 2^e (m in [0.5, 1)) every scaled value stays <= 2^15 — half of fp16's largest finite number — also for the
+    adversarial map that attains the bound (x = a * sign(W[n*])), and the fp16 rows keep 11 significant bits relative to the
+    plane's bound.  (The kernel itself against torch: tests/test_gpu_value_range.py.)"""
+    import math
+    g = torch.Generator().manual_seed(5)
+    for amp in (1e-3, 6.0, 1.8e4, 1e7, 3e30):
+        W = ((torch.rand(64, 96, generator=g) * 2 - 1) * 0.1).double()
+        gb = (torch.randn(64, generator=g) * 3).double()
+        x = (torch.randn(200, 96, generator=g) * amp).to(torch.bfloat16)
+        nstar = int(W.abs().sum(1).argmax())
+        a = float(x.abs().max())
+        x[0] = (torch.sign(W[nstar]) * a).to(torch.bfloat16)          # attains a * rowL1(W[n*]) exactly (a is a bf16 number)
+        v = x.double() @ W.T + gb
+        l1, bm = float(W.abs().sum(1).max()), float(gb.abs().max())
+        bound = float(torch.tensor(l1, dtype=torch.float32) * torch.tensor(a, dtype=torch.float32) * 1.00390625
+                      + torch.tensor(bm, dtype=torch.float32))     # the kernel's fp32 arithmetic
+        assert float(v.abs().max()) <= bound
+        assert float(v.abs().max()) >= 0.99 * (a * l1 - bm)            # ... and the bound is tight: the adversarial row reaches it
+        m, e = math.frexp(bound)
+        k = max(-100, min(100, 15 - e))
+        s = 2.0 ** k
+        if -100 < 15 - e < 100:
+            assert 2.0 ** 14 <= bound * s <= 2.0 ** 15
+        h = (v * s).float().half()
+        assert torch.isfinite(h).all() and float(h.abs().max()) <= 2.0 ** 15
+        back = h.double() / s
+        assert float((back - v).abs().max()) <= bound * 2.0 ** -11 + 2.0 ** -24 / s   # 11 bits of the bound; subnormal floor

@@ -498,6 +498,68 @@ extern "C" void hz_store_victim(const float* table, uint32_t n_tab_rows, uint32_
   if (!check) hipLaunchKernelGGL(store_victim, dim3((n_rows + 3) / 4), dim3(256), 0, st, table, n_tab_rows, out, n_rows, epoch);
   else hipLaunchKernelGGL(store_check, dim3(2048), dim3(256), 0, st, out, n_rows, epoch, errors);
 }
+// The suspected pattern in isolation: a lane mask written by v_cmp into an SGPR pair / VCC and read
+// by the SCALAR unit in the very next instruction (s_and_b64, s_and_saveexec_b64), as hipcc compiles the gathers' admission test.
+// MODE 0: the masks are ANDed on the SALU and the result selects through v_cndmask; MODE 1: ... and gates a v_mov through
+// s_and_saveexec_b64 (the branch form); MODE 2: the same test in C (whatever hipcc makes of it).  The expected bit comes from
+// shifts and adds on the integer the operands were made from — no comparison, no mask.
+template <int MODE>
+__global__ __launch_bounds__(256) void mask_victim(unsigned long long* errors, int iters) {
+  const uint32_t id = blockIdx.x * 256 + threadIdx.x;
+  unsigned bad = 0;
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t h = mix(id * 131u + it * 7919u);
+    const uint32_t xi = h & 15u, yi = (h >> 4) & 15u;               // x = xi - 4 in -4 .. 11, y likewise
+    float x = (float)xi - 4.f, y = (float)yi - 4.f, lx = 8.f, ly = 6.f;
+    asm volatile("" : "+v"(x), "+v"(y), "+v"(lx), "+v"(ly));
+    // x > -1  <=>  xi >= 4;   x < 8  <=>  xi < 12;   y > -1  <=>  yi >= 4;   y < 6  <=>  yi < 10
+    const unsigned expect = ((xi + 12u) >> 4) & (1u - ((xi + 4u) >> 4)) & ((yi + 12u) >> 4) & (1u - ((yi + 6u) >> 4));
+    unsigned r;
+    if (MODE == 0) {
+      unsigned long long m;
+      asm volatile("v_cmp_lt_f32_e32 vcc, -1.0, %2\n\t"
+                   "v_cmp_lt_f32_e64 %0, -1.0, %3\n\t"
+                   "s_and_b64 %0, vcc, %0\n\t"
+                   "v_cmp_lt_f32_e32 vcc, %2, %4\n\t"
+                   "s_and_b64 %0, vcc, %0\n\t"
+                   "v_cmp_lt_f32_e32 vcc, %3, %5\n\t"
+                   "s_and_b64 %0, vcc, %0\n\t"
+                   "v_cndmask_b32_e64 %1, 0, 1, %0"
+                   : "=&s"(m), "=&v"(r) : "v"(x), "v"(y), "v"(lx), "v"(ly) : "vcc");
+    } else if (MODE == 1) {
+      unsigned long long m, sv;
+      asm volatile("v_cmp_lt_f32_e32 vcc, -1.0, %3\n\t"
+                   "v_cmp_lt_f32_e64 %0, -1.0, %4\n\t"
+                   "s_and_b64 %0, vcc, %0\n\t"
+                   "v_cmp_lt_f32_e32 vcc, %3, %5\n\t"
+                   "s_and_b64 %0, vcc, %0\n\t"
+                   "v_cmp_lt_f32_e32 vcc, %4, %6\n\t"
+                   "s_and_b64 %0, vcc, %0\n\t"
+                   "v_mov_b32 %2, 0\n\t"
+                   "s_and_saveexec_b64 %1, %0\n\t"
+                   "v_mov_b32 %2, 1\n\t"
+                   "s_or_b64 exec, exec, %1"
+                   : "=&s"(m), "=&s"(sv), "=&v"(r) : "v"(x), "v"(y), "v"(lx), "v"(ly) : "vcc");
+    } else {
+      r = 0;
+      if (x > -1.f && y > -1.f && x < lx && y < ly) r = 1;
+      asm volatile("" : "+v"(r));
+    }
+    bad += r ^ expect;
+  }
+  if (bad) {
+    atomicAdd(errors, (unsigned long long)bad);
+    atomicAdd(errors + 1 + ((threadIdx.x & 63) >> 4), (unsigned long long)bad);
+  }
+}
+extern "C" void hz_mask_victim(unsigned long long* errors, int blocks, int iters, int mode, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(mask_victim<0>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+    case 1: hipLaunchKernelGGL(mask_victim<1>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+    default: hipLaunchKernelGGL(mask_victim<2>, dim3(blocks), dim3(256), 0, st, errors, iters); break;
+  }
+}
 extern "C" void hz_tsa_div_victim(const float* value, const float* offs, const float* logits, unsigned long long* errors, int bev_h,
                                   int bev_w, int use_fdiv, void* stream) {
   const int blocks = (bev_h * bev_w + 3) / 4;

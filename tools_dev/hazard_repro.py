@@ -54,6 +54,26 @@ if os.environ.get("HZ_VARIANTS"):
     VARIANTS = tuple(v for v in VARIANTS if v[1] in keep)
 if os.environ.get("HZ_ONLY_VPROJ") == "1":
     loads = {k: v for k, v in loads.items() if k == "occ value projection"}
+if os.environ.get("HZ_MASK") == "1":      # the suspected instruction pattern in isolation (hazard_micro.hip::mask_victim)
+    lfn = loads["occ value projection"]
+    for mode, mname in ((0, "v_cmp -> s_and_b64 -> v_cndmask (asm)"), (1, "v_cmp -> s_and_b64 -> s_and_saveexec_b64 (asm)"),
+                        (2, "the same test in C")):
+        for neighbour in (False, True):
+            err.zero_()
+            bad_reps = 0
+            for rep in range(reps):
+                before = int(err[0].item())
+                if neighbour:
+                    with torch.cuda.stream(load):
+                        lfn()
+                for _ in range(4):
+                    lib.hz_mask_victim(P(err.data_ptr()), 4096, 512, mode, st())
+                torch.cuda.synchronize()
+                bad_reps += int(err[0].item()) > before
+            e = err.tolist()
+            print(f"REPRO neighbour = {'occ value projection' if neighbour else 'none':22s} victim = lane-mask micro-kernel, {mname:48s}: "
+                  f"{e[0]:8d} wrong bits in {bad_reps} of {reps} repetitions; lanes 0-15 / 16-31 / 32-47 / 48-63: {e[1:]}", flush=True)
+    sys.exit(0)
 for lname, lfn in loads.items():
     for vname, use_fdiv in VARIANTS:
         err.zero_()

@@ -102,10 +102,6 @@ def parse():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer (default, the BASELINE metric): forward pass; train: forward + loss + "
                          "backward + DDP/RCCL gradient all-reduce + clip + AdamW step per sample")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="infer only, experiment: samples dealt round-robin to this many HIP streams, so the backbone "
-                         "of sample i+1 can run under the hot path of sample i (throughput, not latency; default 1 = "
-                         "the metric as defined: one sample at a time)")
     ap.add_argument("--history", type=int, default=0,
                     help="BASELINE.json configs[2] (temporal self-attention with a real history): every sample = this many "
                          "history frames through BEVFormerOcc.obtain_history_bev (reference bevformer_occ.py:159-178) + "
@@ -809,7 +805,7 @@ def main():
 
     run_step = stepper
     step_graph_note = None
-    graph_ok = args.mode == "infer" and args.streams == 1 and args.input == "resident-f32" and not args.per_step
+    graph_ok = args.mode == "infer" and args.input == "resident-f32" and not args.per_step
     if args.step_graph is None:
         # multi-rank launches replay the step from a hipGraph by default: N ranks share one host, and ~150 Python-driven
         # launches per 2.3 ms hot-path step (host_enqueue_ms_per_step) are the one thing that can break replica scaling.
@@ -850,11 +846,7 @@ def main():
         for step_i in range(steps):
             if args.per_step:       # GPU-side time of every step (events on the current stream; no host sync)
                 e0 = torch.cuda.Event(enable_timing=True); e0.record()
-            if lanes is not None:
-                with torch.cuda.stream(lanes[step_i % len(lanes)]):
-                    stepper()
-            else:
-                run_step()
+            run_step()
             if args.per_step:
                 e1 = torch.cuda.Event(enable_timing=True); e1.record()
                 step_events.append((e0, e1))
@@ -871,11 +863,6 @@ def main():
             el = float(t.item())
         return el
 
-    lanes = None
-    if args.streams > 1 and args.mode == "infer" and args.input == "resident-f32":
-        lanes = [torch.cuda.Stream(device=device) for _ in range(args.streams)]
-        for s_ in lanes:
-            s_.wait_stream(torch.cuda.current_stream())
     # THE timed region: K steps; the only instrumentation inside it is one HIP event pair around every launch of the
     # roofline kernel (the SCA gather: 4 launches per frame pass)
     record = None if args.no_kernel_timing else ext.kernel_timing(True)
@@ -885,11 +872,7 @@ def main():
     for _ in range(5):
         torch.cuda.synchronize()
         t_e = time.perf_counter()
-        if lanes is not None:
-            with torch.cuda.stream(lanes[0]):
-                stepper()
-        else:
-            run_step()
+        run_step()
         enqueue_s.append(time.perf_counter() - t_e)
     torch.cuda.synchronize()
     times = ext.kernel_times_ms(record) if record is not None else {}
@@ -960,7 +943,7 @@ def main():
                              f"prev_bev; value counts SAMPLES (queues), frames/s = value x {1 + args.history}"),
                 "mode": args.mode, "scope": stepper.scope, "input": args.input if stepper.scope == "e2e" else None,
                 "samples_per_gpu": 1, "global_batch": world,
-                "parallelism": f"dp{world}", "streams": args.streams, "step_graph": bool(args.step_graph),
+                "parallelism": f"dp{world}", "step_graph": bool(args.step_graph),
                 "step_graph_note": step_graph_note,
                 "hot_path_dtype": "f32",
                 "linear_precision": ext.LINEAR_PRECISION,

@@ -33,31 +33,60 @@ struct __attribute__((aligned(16))) SampleParam {
   int o[4];
 };
 
+// A lane predicate as a 0 / 1 integer in a VGPR.  The sampling set-up of every gather / scatter kernel of this library keeps
+// its conditions in this form: v_cmp -> v_cndmask at once, conditions combined by VALU integer ANDs, selects on those
+// integers.  hipcc compiles the plain `bool` form into lane masks in SGPR pairs combined on the scalar unit (v_cmp ->
+// s_and_b64 / s_and_saveexec_b64), and a self-contained copy of the TSA gather with THAT set-up returns wrong weights in
+// lanes 48-63 in 149 of 150 runs while a wave of an MFMA kernel is resident on another hardware queue; with this form
+// 0 of 150, outputs bit-identical (tools_dev/lab/hazard/README.md; standing test tests/test_gpu_hazard_repro.py).  The empty
+// asm keeps the compiler from folding the integer back into a scalar lane mask.
+__device__ __forceinline__ int lane_flag(bool c) {
+  int f = c ? 1 : 0;
+  asm volatile("" : "+v"(f));
+  return f;
+}
+
 // Arithmetic of mmcv's ms_deformable_im2col:
 //   h_im = loc_y*H - 0.5, w_im = loc_x*W - 0.5, admitted iff -1 < h_im < H and -1 < w_im < W,
 //   corners (h_low,w_low) (h_low,w_high) (h_high,w_low) (h_high,w_high) each read only if inside.
-// row_stride = floats between two consecutive keys (= M*D).  Returns #corners inside the map.
-__device__ __forceinline__ int bilinear_setup(float loc_x, float loc_y, float attn, int H, int W,
-                                              int lvl_start, int row_stride, SampleParam& sp) {
-  sp.w[0] = sp.w[1] = sp.w[2] = sp.w[3] = 0.f;
-  sp.o[0] = sp.o[1] = sp.o[2] = sp.o[3] = 0;
+// c[k] = 1 iff the sample is admitted (and `live`) and corner k lies inside the map; lh / lw / hh / hw are the fractional
+// weights of an admitted sample and garbage (possibly NaN) otherwise: always select on adm / c[k], never multiply by them.
+struct BilinearTerms {
+  float lh, lw, hh, hw;
+  int h_low, w_low;
+  int adm;
+  int c[4];
+};
+__device__ __forceinline__ BilinearTerms bilinear_terms(float loc_x, float loc_y, int H, int W, int live) {
+  BilinearTerms t;
   const float h_im = loc_y * (float)H - 0.5f;
   const float w_im = loc_x * (float)W - 0.5f;
-  int n_in = 0;
-  if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    const int h_low = (int)hf, w_low = (int)wf;
-    const int h_high = h_low + 1, w_high = w_low + 1;
-    const float lh = h_im - hf, lw = w_im - wf;
-    const float hh = 1.f - lh, hw = 1.f - lw;
-    const bool t = h_low >= 0, b = h_high <= H - 1, l = w_low >= 0, r = w_high <= W - 1;
-    const int base = lvl_start + h_low * W + w_low;
-    if (t && l) { sp.w[0] = hh * hw * attn; sp.o[0] = base * row_stride; ++n_in; }
-    if (t && r) { sp.w[1] = hh * lw * attn; sp.o[1] = (base + 1) * row_stride; ++n_in; }
-    if (b && l) { sp.w[2] = lh * hw * attn; sp.o[2] = (base + W) * row_stride; ++n_in; }
-    if (b && r) { sp.w[3] = lh * lw * attn; sp.o[3] = (base + W + 1) * row_stride; ++n_in; }
-  }
-  return n_in;
+  t.adm = live & lane_flag(h_im > -1.f) & lane_flag(w_im > -1.f) & lane_flag(h_im < (float)H) & lane_flag(w_im < (float)W);
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  t.h_low = (int)hf;
+  t.w_low = (int)wf;
+  t.lh = h_im - hf;
+  t.lw = w_im - wf;
+  t.hh = 1.f - t.lh;
+  t.hw = 1.f - t.lw;
+  const int top = lane_flag(t.h_low >= 0) & t.adm, bot = lane_flag(t.h_low + 1 <= H - 1) & t.adm;
+  const int lft = lane_flag(t.w_low >= 0), rgt = lane_flag(t.w_low + 1 <= W - 1);
+  t.c[0] = top & lft; t.c[1] = top & rgt; t.c[2] = bot & lft; t.c[3] = bot & rgt;
+  return t;
+}
+
+// One bilinear sample resolved for the gather: weights already multiplied by the attention weight, element offsets of the
+// corner rows (row_stride = floats between two consecutive keys = M*D); 0 / 0 for corners outside the map, so the load
+// stays legal and contributes 0*v.  Returns #corners inside the map.
+__device__ __forceinline__ int bilinear_setup(float loc_x, float loc_y, float attn, int H, int W,
+                                              int lvl_start, int row_stride, int live, SampleParam& sp) {
+  const BilinearTerms t = bilinear_terms(loc_x, loc_y, H, W, live);
+  const int base = lvl_start + t.h_low * W + t.w_low;
+  sp.w[0] = t.c[0] ? t.hh * t.hw * attn : 0.f; sp.o[0] = t.c[0] ? base * row_stride : 0;
+  sp.w[1] = t.c[1] ? t.hh * t.lw * attn : 0.f; sp.o[1] = t.c[1] ? (base + 1) * row_stride : 0;
+  sp.w[2] = t.c[2] ? t.lh * t.hw * attn : 0.f; sp.o[2] = t.c[2] ? (base + W) * row_stride : 0;
+  sp.w[3] = t.c[3] ? t.lh * t.lw * attn : 0.f; sp.o[3] = t.c[3] ? (base + W + 1) * row_stride : 0;
+  return t.c[0] + t.c[1] + t.c[2] + t.c[3];
 }
 
 // f32 -> bf16, round to nearest even, two values per instruction: gfx950's v_cvt_pk_bf16_f32 (one VALU op
@@ -158,30 +187,18 @@ struct __attribute__((aligned(16))) SampleParamB {   // like SampleParam, offset
   unsigned o[4];
 };
 
-// bilinear_setup (common.h) with byte offsets: corner k of pixel (h, w) -> (lvl_pix0 + h*W + w) * pix_bytes;
-// corners outside the map (and every corner of a sample that fails the admission test, or when !live) get
-// `dead` (weight 0).  Returns the number of corners inside the map.
+// bilinear_setup with byte offsets: corner k of pixel (h, w) -> (lvl_pix0 + h*W + w) * pix_bytes; corners outside the map
+// (and every corner of a sample that fails the admission test, or when !live) get `dead` (weight 0).  Returns the number of
+// corners inside the map.
 __device__ __forceinline__ int bilinear_setup_b(float loc_x, float loc_y, float attn, int H, int W, int lvl_pix0,
-                                                unsigned pix_bytes, unsigned dead, bool live, SampleParamB& sp) {
-  sp.w[0] = sp.w[1] = sp.w[2] = sp.w[3] = 0.f;
-  sp.o[0] = sp.o[1] = sp.o[2] = sp.o[3] = dead;
-  const float h_im = loc_y * (float)H - 0.5f;
-  const float w_im = loc_x * (float)W - 0.5f;
-  int n_in = 0;
-  if (live && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-    const float hf = floorf(h_im), wf = floorf(w_im);
-    const int h_low = (int)hf, w_low = (int)wf;
-    const int h_high = h_low + 1, w_high = w_low + 1;
-    const float lh = h_im - hf, lw = w_im - wf;
-    const float hh = 1.f - lh, hw = 1.f - lw;
-    const bool t = h_low >= 0, b = h_high <= H - 1, l = w_low >= 0, r = w_high <= W - 1;
-    const int base = lvl_pix0 + h_low * W + w_low;
-    if (t && l) { sp.w[0] = hh * hw * attn; sp.o[0] = (unsigned)base * pix_bytes; ++n_in; }
-    if (t && r) { sp.w[1] = hh * lw * attn; sp.o[1] = (unsigned)(base + 1) * pix_bytes; ++n_in; }
-    if (b && l) { sp.w[2] = lh * hw * attn; sp.o[2] = (unsigned)(base + W) * pix_bytes; ++n_in; }
-    if (b && r) { sp.w[3] = lh * lw * attn; sp.o[3] = (unsigned)(base + W + 1) * pix_bytes; ++n_in; }
-  }
-  return n_in;
+                                                unsigned pix_bytes, unsigned dead, int live, SampleParamB& sp) {
+  const BilinearTerms t = bilinear_terms(loc_x, loc_y, H, W, live);
+  const int base = lvl_pix0 + t.h_low * W + t.w_low;
+  sp.w[0] = t.c[0] ? t.hh * t.hw * attn : 0.f; sp.o[0] = t.c[0] ? (unsigned)base * pix_bytes : dead;
+  sp.w[1] = t.c[1] ? t.hh * t.lw * attn : 0.f; sp.o[1] = t.c[1] ? (unsigned)(base + 1) * pix_bytes : dead;
+  sp.w[2] = t.c[2] ? t.lh * t.hw * attn : 0.f; sp.o[2] = t.c[2] ? (unsigned)(base + W) * pix_bytes : dead;
+  sp.w[3] = t.c[3] ? t.lh * t.lw * attn : 0.f; sp.o[3] = t.c[3] ? (unsigned)(base + W + 1) * pix_bytes : dead;
+  return t.c[0] + t.c[1] + t.c[2] + t.c[3];
 }
 
 typedef unsigned occ_u32x4 __attribute__((ext_vector_type(4)));

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
     for (int s0 = 0; s0 < LP; s0 += U) {
       float4 v[U][4];
       float lh_[U], lw_[U], a_[U], Hf[U], Wf[U];
-      bool ok[U][4], live[U];
+      int ok[U][4];                            // 0 / 1 lane flags in VGPRs (common.h: lane_flag)
+      bool live[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int s = s0 + u < LP ? s0 + u : LP - 1;
@@ -94,17 +95,12 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
         const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
         a_[u] = attn[si];
         Hf[u] = (float)H; Wf[u] = (float)W;
-        const float h_im = xy.y * (float)H - 0.5f;
-        const float w_im = xy.x * (float)W - 0.5f;
-        const bool in = live[u] && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const int h_low = (int)hf, w_low = (int)wf;
-        lh_[u] = in ? h_im - hf : 0.f;        // a non-finite location must give 0, not 0 * NaN
-        lw_[u] = in ? w_im - wf : 0.f;
-        const bool t_ok = h_low >= 0, b_ok = h_low + 1 <= H - 1, l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
-        ok[u][0] = in && t_ok && l_ok; ok[u][1] = in && t_ok && r_ok;
-        ok[u][2] = in && b_ok && l_ok; ok[u][3] = in && b_ok && r_ok;
-        const long base = (st + (long)h_low * W + w_low) * row_stride;
+        const BilinearTerms t = bilinear_terms(xy.x, xy.y, H, W, lane_flag(live[u]));
+        lh_[u] = t.adm ? t.lh : 0.f;          // a non-finite location must give 0, not 0 * NaN
+        lw_[u] = t.adm ? t.lw : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ok[u][k] = t.c[k];
+        const long base = (st + (long)t.h_low * W + t.w_low) * row_stride;
         v[u][0] = *reinterpret_cast<const float4*>(vb + (ok[u][0] ? base : 0));
         v[u][1] = *reinterpret_cast<const float4*>(vb + (ok[u][1] ? base + row_stride : 0));
         v[u][2] = *reinterpret_cast<const float4*>(vb + (ok[u][2] ? base + (long)W * row_stride : 0));
@@ -150,20 +146,19 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
     const long si = item * LP + s;
     const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
     const float a = attn[si];
-    const float h_im = xy.y * (float)H - 0.5f;
-    const float w_im = xy.x * (float)W - 0.5f;
     float g_attn = 0.f, g_x = 0.f, g_y = 0.f;
-    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {   // group-uniform
-      const float hf = floorf(h_im), wf = floorf(w_im);
-      const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
-      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-      const bool t_ok = h_low >= 0, b_ok = h_high <= H - 1, l_ok = w_low >= 0, r_ok = w_high <= W - 1;
-      const long base = (st + (long)h_low * W + w_low) * row_stride;
-      float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1, v3 = v1, v4 = v1;
-      if (t_ok && l_ok) v1 = *reinterpret_cast<const float4*>(vb + base);
-      if (t_ok && r_ok) v2 = *reinterpret_cast<const float4*>(vb + base + row_stride);
-      if (b_ok && l_ok) v3 = *reinterpret_cast<const float4*>(vb + base + (long)W * row_stride);
-      if (b_ok && r_ok) v4 = *reinterpret_cast<const float4*>(vb + base + (long)(W + 1) * row_stride);
+    const BilinearTerms t = bilinear_terms(xy.x, xy.y, H, W, 1);
+    if (t.adm) {   // group-uniform
+      const float lh = t.lh, lw = t.lw, hh = t.hh, hw = t.hw;
+      const long base = (st + (long)t.h_low * W + t.w_low) * row_stride;
+      const long o1 = base, o2 = base + row_stride, o3 = base + (long)W * row_stride, o4 = base + (long)(W + 1) * row_stride;
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      // unconditional loads (a corner outside the map reads row 0 of the batch entry and is replaced by 0)
+      const float4 r1 = *reinterpret_cast<const float4*>(vb + (t.c[0] ? o1 : 0));
+      const float4 r2 = *reinterpret_cast<const float4*>(vb + (t.c[1] ? o2 : 0));
+      const float4 r3 = *reinterpret_cast<const float4*>(vb + (t.c[2] ? o3 : 0));
+      const float4 r4 = *reinterpret_cast<const float4*>(vb + (t.c[3] ? o4 : 0));
+      const float4 v1 = t.c[0] ? r1 : z4, v2 = t.c[1] ? r2 : z4, v3 = t.c[2] ? r3 : z4, v4 = t.c[3] ? r4 : z4;
       const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
       const float tx[4] = {top.x, top.y, top.z, top.w};
       const float a1[4] = {v1.x, v1.y, v1.z, v1.w}, a2[4] = {v2.x, v2.y, v2.z, v2.w};
@@ -175,10 +170,10 @@ __global__ __launch_bounds__(256) void msda_bwd_d32_kernel(
         g_x += ta * (hh * (a2[k] - a1[k]) + lh * (a4[k] - a3[k]));
         g_y += ta * (hw * (a3[k] - a1[k]) + lw * (a4[k] - a2[k]));
         if (VALUE_ATOMICS) {
-          if (t_ok && l_ok) unsafeAtomicAdd(gvb + base + k, ta * w1);
-          if (t_ok && r_ok) unsafeAtomicAdd(gvb + base + row_stride + k, ta * w2);
-          if (b_ok && l_ok) unsafeAtomicAdd(gvb + base + (long)W * row_stride + k, ta * w3);
-          if (b_ok && r_ok) unsafeAtomicAdd(gvb + base + (long)(W + 1) * row_stride + k, ta * w4);
+          if (t.c[0]) unsafeAtomicAdd(gvb + o1 + k, ta * w1);
+          if (t.c[1]) unsafeAtomicAdd(gvb + o2 + k, ta * w2);
+          if (t.c[2]) unsafeAtomicAdd(gvb + o3 + k, ta * w3);
+          if (t.c[3]) unsafeAtomicAdd(gvb + o4 + k, ta * w4);
         }
       }
       g_x *= (float)W;
@@ -260,26 +255,25 @@ __global__ __launch_bounds__(256) void msda_bwd_bin_kernel(
   const unsigned char fl = nzflag[item];
   const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
   const float a = attn[si];
-  const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
-  const bool ok = in_grid && fl != 0 && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-  const float hf = floorf(h_im), wf = floorf(w_im);
-  const int h_low = (int)hf, w_low = (int)wf;
-  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-  const bool l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
-  const bool both = l_ok && r_ok;
+  const BilinearTerms t = bilinear_terms(xy.x, xy.y, H, W, lane_flag(in_grid) & lane_flag(fl != 0));
+  const int ok = t.adm;
+  const int h_low = t.h_low, w_low = t.w_low;
+  const float lh = t.lh, lw = t.lw, hh = t.hh, hw = t.hw;
+  const int l_ok = lane_flag(w_low >= 0), r_ok = lane_flag(w_low + 1 <= W - 1);
+  const int both = l_ok & r_ok;
   const int gbase = (int)((b * M + m) * (long)bins_per_bm) + binoff;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {                       // top row, bottom row (wave-uniform control flow)
     const int hy = h_low + r;
-    const bool valid = ok && hy >= 0 && hy <= H - 1;
+    const int valid = ok & lane_flag(hy >= 0) & lane_flag(hy <= H - 1);
     const float wy = (r ? lh : hh) * a;
     const float wl = l_ok ? wy * hw : 0.f, wr = r_ok ? wy * lw : 0.f;
     // left pixel (or the right one when the left is outside the map) decides the bin
     const int pl = hy * W + (l_ok ? w_low : w_low + 1);
     const int bin = valid ? pl / kBinPix : 0, in = pl - bin * kBinPix;
-    const bool split = valid && both && in == kBinPix - 1;   // the pair straddles a bin edge: two single items
-    const float i0 = l_ok ? wl : wr, i1 = (both && !split) ? wr : 0.f;
-    const int slot = bwd_agg_add<FILL>(counter, valid, gbase + bin, lane);
+    const int split = valid & both & lane_flag(in == kBinPix - 1);   // the pair straddles a bin edge: two single items
+    const float i0 = l_ok ? wl : wr, i1 = (both & (split ^ 1)) ? wr : 0.f;
+    const int slot = bwd_agg_add<FILL>(counter, valid != 0, gbase + bin, lane);
     if (FILL && valid) items[slot] = BwdItem{(q << 5) | in, i0, i1};
     if (split) {                                      // 1 in 32: plain atomics
       if (FILL) {
@@ -336,31 +330,30 @@ __global__ __launch_bounds__(kBinBlockThreads) void msda_bwd_bin_block_kernel(
   const unsigned char fl = nzflag[item];
   const float2 xy = *reinterpret_cast<const float2*>(loc + si * 2);
   const float a = attn[si];
-  const float h_im = xy.y * (float)H - 0.5f, w_im = xy.x * (float)W - 0.5f;
-  const bool ok = in_grid && fl != 0 && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-  const float hf = floorf(h_im), wf = floorf(w_im);
-  const int h_low = (int)hf, w_low = (int)wf;
-  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-  const bool l_ok = w_low >= 0, r_ok = w_low + 1 <= W - 1;
-  const bool both = l_ok && r_ok;
+  const BilinearTerms t = bilinear_terms(xy.x, xy.y, H, W, lane_flag(in_grid) & lane_flag(fl != 0));
+  const int ok = t.adm;
+  const int h_low = t.h_low, w_low = t.w_low;
+  const float lh = t.lh, lw = t.lw, hh = t.hh, hw = t.hw;
+  const int l_ok = lane_flag(w_low >= 0), r_ok = lane_flag(w_low + 1 <= W - 1);
+  const int both = l_ok & r_ok;
 
   // same row items as msda_bwd_bin_kernel: per bilinear row one item at the left pixel's bin (two single items when
   // the pair straddles a bin edge)
-  bool valid[2], split[2];
+  int valid[2], split[2];                              // 0 / 1 lane flags (common.h: lane_flag)
   int bin[2], in[2], slot[2], slot2[2];
   float i0[2], i1[2], wr_[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int hy = h_low + r;
-    valid[r] = ok && hy >= 0 && hy <= H - 1;
+    valid[r] = ok & lane_flag(hy >= 0) & lane_flag(hy <= H - 1);
     const float wy = (r ? lh : hh) * a;
     const float wl = l_ok ? wy * hw : 0.f, wr = r_ok ? wy * lw : 0.f;
     const int pl = hy * W + (l_ok ? w_low : w_low + 1);
     bin[r] = valid[r] ? pl / kBinPix : 0;
     in[r] = pl - bin[r] * kBinPix;
-    split[r] = valid[r] && both && in[r] == kBinPix - 1;
+    split[r] = valid[r] & both & lane_flag(in[r] == kBinPix - 1);
     i0[r] = l_ok ? wl : wr;
-    i1[r] = (both && !split[r]) ? wr : 0.f;
+    i1[r] = (both & (split[r] ^ 1)) ? wr : 0.f;
     wr_[r] = wr;
     slot[r] = slot2[r] = 0;
     if (valid[r]) slot[r] = atomicAdd(&hist[bin[r]], 1);            // LDS
@@ -648,22 +641,19 @@ __global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
       const long st = lstart[l];
       const long si = item * LP + s;
       const float loc_w = loc[si * 2], loc_h = loc[si * 2 + 1], a = attn[si];
-      const float h_im = loc_h * (float)H - 0.5f, w_im = loc_w * (float)W - 0.5f;
-      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
-        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-        const bool t_ok = h_low >= 0, b_ok = h_high <= H - 1, l_ok = w_low >= 0, r_ok = w_high <= W - 1;
-        const long base = voff + (st + (long)h_low * W + w_low) * row_stride;
-        float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+      const BilinearTerms t = bilinear_terms(loc_w, loc_h, H, W, 1);
+      if (t.adm) {
+        const float lh = t.lh, lw = t.lw, hh = t.hh, hw = t.hw;
+        const long base = voff + (st + (long)t.h_low * W + t.w_low) * row_stride;
+        const long o1 = base, o2 = base + row_stride, o3 = base + (long)W * row_stride, o4 = base + (long)(W + 1) * row_stride;
         const float ta = top * a;
-        if (t_ok && l_ok) { v1 = value[base]; unsafeAtomicAdd(grad_value + base, ta * hh * hw); }
-        if (t_ok && r_ok) { v2 = value[base + row_stride];
-                            unsafeAtomicAdd(grad_value + base + row_stride, ta * hh * lw); }
-        if (b_ok && l_ok) { v3 = value[base + (long)W * row_stride];
-                            unsafeAtomicAdd(grad_value + base + (long)W * row_stride, ta * lh * hw); }
-        if (b_ok && r_ok) { v4 = value[base + (long)(W + 1) * row_stride];
-                            unsafeAtomicAdd(grad_value + base + (long)(W + 1) * row_stride, ta * lh * lw); }
+        // unconditional loads (a corner outside the map reads element 0 and is replaced by 0), conditional atomics
+        const float r1 = value[t.c[0] ? o1 : 0], r2 = value[t.c[1] ? o2 : 0], r3 = value[t.c[2] ? o3 : 0], r4 = value[t.c[3] ? o4 : 0];
+        const float v1 = t.c[0] ? r1 : 0.f, v2 = t.c[1] ? r2 : 0.f, v3 = t.c[2] ? r3 : 0.f, v4 = t.c[3] ? r4 : 0.f;
+        if (t.c[0]) unsafeAtomicAdd(grad_value + o1, ta * hh * hw);
+        if (t.c[1]) unsafeAtomicAdd(grad_value + o2, ta * hh * lw);
+        if (t.c[2]) unsafeAtomicAdd(grad_value + o3, ta * lh * hw);
+        if (t.c[3]) unsafeAtomicAdd(grad_value + o4, ta * lh * lw);
         g_attn = top * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
         g_x = ta * (hh * (v2 - v1) + lh * (v4 - v3)) * (float)W;
         g_y = ta * (hw * (v3 - v1) + lw * (v4 - v2)) * (float)H;

@@ -52,13 +52,11 @@ __global__ __launch_bounds__(256) void msda_fwd_d32_kernel(
     const float a = attn[si];
     if (BUF) {
       SampleParamB p;
-      bilinear_setup_b(xy.x, xy.y, a, H, W, st, (unsigned)row_stride * 4u, kOobOffset, live, p);
+      bilinear_setup_b(xy.x, xy.y, a, H, W, st, (unsigned)row_stride * 4u, kOobOffset, lane_flag(live), p);
       spb[g * LPp + s] = p;
     } else {
       SampleParam p;
-      p.w[0] = p.w[1] = p.w[2] = p.w[3] = 0.f;
-      p.o[0] = p.o[1] = p.o[2] = p.o[3] = 0;
-      if (live) bilinear_setup(xy.x, xy.y, a, H, W, st, row_stride, p);
+      bilinear_setup(xy.x, xy.y, a, H, W, st, row_stride, lane_flag(live), p);
       sp[g * LPp + s] = p;
     }
   }
@@ -104,21 +102,15 @@ __global__ __launch_bounds__(256) void msda_fwd_scalar_kernel(
       const long si = (item * L + l) * P + p;
       const float loc_w = loc[si * 2], loc_h = loc[si * 2 + 1];
       const float weight = attn[si];
-      const float h_im = loc_h * (float)H - 0.5f;
-      const float w_im = loc_w * (float)W - 0.5f;
-      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const int h_low = (int)hf, w_low = (int)wf, h_high = h_low + 1, w_high = w_low + 1;
-        const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-        float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-        if (h_low >= 0 && w_low >= 0) v1 = vb[(st + (long)h_low * W + w_low) * row_stride];
-        if (h_low >= 0 && w_high <= W - 1) v2 = vb[(st + (long)h_low * W + w_high) * row_stride];
-        if (h_high <= H - 1 && w_low >= 0) v3 = vb[(st + (long)h_high * W + w_low) * row_stride];
-        if (h_high <= H - 1 && w_high <= W - 1)
-          v4 = vb[(st + (long)h_high * W + w_high) * row_stride];
-        const float val = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
-        col += val * weight;
-      }
+      const BilinearTerms t = bilinear_terms(loc_w, loc_h, H, W, 1);
+      // unconditional loads: a corner outside the map (or of a sample that is not admitted) reads element 0 of the batch entry
+      // and is replaced by 0 (select, not multiply: 0 * Inf)
+      const long base = (st + (long)t.h_low * W + t.w_low) * row_stride;
+      const float r1 = vb[t.c[0] ? base : 0], r2 = vb[t.c[1] ? base + row_stride : 0];
+      const float r3 = vb[t.c[2] ? base + (long)W * row_stride : 0], r4 = vb[t.c[3] ? base + (long)(W + 1) * row_stride : 0];
+      const float v1 = t.c[0] ? r1 : 0.f, v2 = t.c[1] ? r2 : 0.f, v3 = t.c[2] ? r3 : 0.f, v4 = t.c[3] ? r4 : 0.f;
+      const float val = t.hh * t.hw * v1 + t.hh * t.lw * v2 + t.lh * t.hw * v3 + t.lh * t.lw * v4;
+      col += t.adm ? val * weight : 0.f;
     }
   }
   out[idx] = col;

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 3) void sca_fused_kernel(
       SampleParamB p;
       const float aw_k = pre[wave][0][k][lane], ox_k = pre[wave][1][k][lane], oy_k = pre[wave][2][k][lane];
       n_in += bilinear_setup_b(rxy.x + ox_k, rxy.y + oy_k, aw_k, lvH, lvW, lvS,
-                               (unsigned)row_stride * 4u, kOobOffset, true, p);
+                               (unsigned)row_stride * 4u, kOobOffset, 1, p);
       sp[m * LPp + s] = p;
     }
     wave_lds_sync();
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
       SampleParamB p;
       const float aw_k = aw[k], ox_k = ox[k], oy_k = oy[k];
       n_in += bilinear_setup_b(rxy.x + ox_k, rxy.y + oy_k, aw_k, lvH, lvW, lvS,
-                               (unsigned)row_stride * EV, kOobOffset, true, p);
+                               (unsigned)row_stride * EV, kOobOffset, 1, p);
       // pixel-pair layout (file header): byte offset pix * 512 -> (pix >> 1) * 1024 + (pix & 1) * 64; the out-of-range
       // marker stays out of range
 #pragma unroll

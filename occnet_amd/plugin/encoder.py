@@ -11,7 +11,6 @@ SpatialCrossAttention layer would otherwise rebuild with nonzero(); the encoder 
 hands it (plus a cache-friendly query processing order) to all layers through kwargs.
 """
 import copy
-import os
 import warnings
 
 import numpy as np
@@ -27,11 +26,7 @@ from .spatial_cross_attention import _require_device
 
 
 # the SCA value projections of ALL layers depend on the camera features only: they are launched before the first layer
-# (LazyFeatures.prefetch: ONE stacked launch).  OCC_VPROJ_OVERLAP=1 puts that launch on a side stream under the first
-# layer's TSA / Linear kernels (rounds 2-4's default: 6.764 -> 6.734 ms per sample in round 2) — off since round 5: that
-# co-residency is how the co-scheduling hazard of DESIGN.md section 8d was met, and with today's kernels the side stream buys
-# nothing (2.255-2.272 against 2.25 ms per hot-path step): the library runs its kernels on ONE stream
-_VPROJ_OVERLAP = os.environ.get("OCC_VPROJ_OVERLAP", "0") == "1"
+# (LazyFeatures.prefetch: ONE stacked launch, on the caller's stream like everything else the library enqueues)
 
 # (Rounds 4-5 built and measured a ROW PIPELINE on top of the chain kernels — the BEV queries cut into K row bands, every
 # layer walked band by band on K streams so that the TSA gather / program A / SCA gather / program B of different bands
@@ -459,7 +454,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         if hasattr(value, 'prefetch') and not torch.is_grad_enabled():
             vps = [getattr(getattr(a, 'deformable_attention', None), 'value_proj', None)
                    for layer in self.layers for a in layer.attentions]
-            value.prefetch([vp for vp in vps if vp is not None], overlap=_VPROJ_OVERLAP)
+            value.prefetch([vp for vp in vps if vp is not None])
         # inference: the row-local Linear chains of a layer as two launches (BEVFormerLayer.forward_chain)
         # (the chain path takes none of the mask / query_pos arguments of BEVFormerLayer.forward: a caller that passes one
         # gets the unfused layer, never an unmasked result — ADVICE r4)

@@ -141,33 +141,16 @@ class LazyFeatures:
             self._flat = flat.view(self.bs, self.num_cam, flat.shape[1], flat.shape[2]).permute(1, 2, 0, 3)
         return self._flat
 
-    _side_streams = {}
-    # (Round 5 measured three LAYERED schedules — plane l + 1 projected on the side stream from the start of layer l + 1, from
-    # layer l's chain program B, or from layer l's gather on, so that it is the most recent large write when its gather
-    # starts — against this one stacked launch, same box: 2.576 / 2.588 / 2.545 ms per hot-path step against 2.49; the gather
-    # gained 3 % (0.197 against 0.202 ms), the chain kernels lost 5-12 % to the co-running projections.  Rejected;
-    # profiles/r05_c2_vproj_schedule_ab.txt.)
+    # (Round 5 measured three LAYERED schedules — plane l + 1 projected on a side stream from the start of layer l + 1, from
+    # layer l's chain program B, or from layer l's gather on — against this one stacked launch, same box: 2.576 / 2.588 /
+    # 2.545 ms per hot-path step against 2.49.  Rejected; profiles/r05_c2_vproj_schedule_ab.txt.  Rounds 2-4 ran the stacked
+    # launch on a side stream under layer 0's TSA gather (2.255-2.272 against 2.25 ms: nothing gained); that switch,
+    # OCC_VPROJ_OVERLAP, left the library in round 6: everything the library enqueues goes to the CALLER's stream.)
 
-    def prefetch(self, value_projs, overlap=False):
-        """project() for several layers' value_proj modules AHEAD of the layer stack: the projections depend on the camera
-        features only, not on the BEV queries, so all of them go in ONE stacked launch (the maps are read once).
-        Default (round 5): on the CALLER's stream, in front of the first layer.  overlap=True (OCC_VPROJ_OVERLAP=1, rounds
-        2-4's default) runs them on a side stream under the first layer's TSA gather / chain kernels instead; project()
-        then makes the consuming stream wait for the side stream's event and finish() (the encoder calls it when the layer
-        stack is done, also on an exception) joins the side stream.  NOT the default any more: that schedule is how the
-        co-scheduling hazard of DESIGN.md section 8d was met (a gather kernel's sampling set-up comes out wrong in lanes
-        48-63 while one of the library's MFMA kernels shares the chip on another hardware queue: 47-52 of 150 steps under an
-        artificial load, 2 of 150 with round 4's kernels; 0 of 150 with today's kernels, which section 8d item 10 shows to be
-        no guarantee), and the side stream buys nothing (2.255-2.272 against 2.25 ms per hot-path step): one stream.
-        The derived operands (packed weight, per-(level, camera) bias: first-use caches) are built on the MAIN stream
-        before the fork, so no later main-stream reader can race their side-stream construction."""
-        dev = self.mlvl_feats[0].device
-        main = torch.cuda.current_stream(dev)
-        side = main
-        if overlap:
-            side = self._side_streams.get(str(dev))
-            if side is None:
-                side = self._side_streams[str(dev)] = torch.cuda.Stream(device=dev)
+    def prefetch(self, value_projs):
+        """project() for several layers' value_proj modules AHEAD of the layer stack, on the caller's stream: the projections
+        depend on the camera features only, not on the BEV queries, so all of them go in ONE stacked launch (the maps are read
+        once)."""
         gbs = [self._group_bias(vp) for vp in value_projs]
         if ext.SCA_VALUES == "f16":
             for vp, gb in zip(value_projs, gbs):
@@ -176,52 +159,34 @@ class LazyFeatures:
                                                 for vp in value_projs) and value_projs[0].weight.shape[0] % 256 == 0)
         if stacked:
             try:
-                ext.value_proj_planes_prepare([vp.weight for vp in value_projs])     # stack + pack on the MAIN stream
+                ext.value_proj_planes_prepare([vp.weight for vp in value_projs])     # stack + pack
             except ext.OccAmdError:
                 stacked = False
         if not stacked:
             for vp in value_projs:
                 ext.linear_pack_weight_bf16x3(vp.weight)
-        if overlap:
-            side.wait_stream(main)                           # the feature maps, packs and biases are ready
-            for r in self.rows:
-                r.record_stream(side)                        # read by side-stream kernels: keep them out of reuse
-        self._pending, self._side, self._scale_of = {}, (side if overlap else None), {}
-        with torch.cuda.stream(side):
-            scales = self._scales(value_projs, gbs)          # per-plane fp16 range scales of this call's maps
-            if scales is not None:
-                if overlap:
-                    scales.record_stream(main)
+        self._pending, self._scale_of = {}, {}
+        scales = self._scales(value_projs, gbs)              # per-plane fp16 range scales of this call's maps
+        if scales is not None:
+            for l, vp in enumerate(value_projs):
+                self._scale_of[id(vp)] = scales[l:l + 1]
+        if stacked:
+            # ONE launch for all layers: every block projects its rows with all the layers' weights, the feature
+            # maps are read from HBM once (occ_value_proj_bf16_planes); layer l's values are plane l
+            n = value_projs[0].weight.shape[0]
+            try:
+                out = self._alloc(n, planes=len(value_projs))
+                ext.value_proj_bf16_planes(self.rows, [vp.weight for vp in value_projs], gbs, out,
+                                           rows_per_group=[h * wd for h, wd in self.hw],
+                                           out_group_rows=self.group_rows, out_row0=self.starts, out_scale=scales)
                 for l, vp in enumerate(value_projs):
-                    self._scale_of[id(vp)] = scales[l:l + 1]
-            if stacked:
-                # ONE launch for all layers: every block projects its rows with all the layers' weights, the feature
-                # maps are read from HBM once (occ_value_proj_bf16_planes); layer l's values are plane l
-                n = value_projs[0].weight.shape[0]
-                try:
-                    out = self._alloc(n, planes=len(value_projs))
-                    ext.value_proj_bf16_planes(self.rows, [vp.weight for vp in value_projs], gbs, out,
-                                               rows_per_group=[h * wd for h, wd in self.hw],
-                                               out_group_rows=self.group_rows, out_row0=self.starts, out_scale=scales)
-                    ev = None
-                    if overlap:
-                        out.record_stream(main)
-                        ev = torch.cuda.Event()
-                        ev.record(side)
-                    for l, vp in enumerate(value_projs):
-                        self._pending[id(vp)] = (out[l].view(self.bs * self.num_cam, self.group_rows, n), ev)
-                except ext.OccAmdError:          # e.g. the 74 KB LDS attribute refused: one launch per layer instead
-                    stacked = False
-                    self._pending = {}
-            if not stacked:
-                for l, (vp, gb) in enumerate(zip(value_projs, gbs)):
-                    out = self._launch(vp, gb, None if scales is None else scales[l:l + 1])
-                    ev = None
-                    if overlap:
-                        out.record_stream(main)              # consumed (and released) on the main stream
-                        ev = torch.cuda.Event()
-                        ev.record(side)
-                    self._pending[id(vp)] = (out, ev)
+                    self._pending[id(vp)] = out[l].view(self.bs * self.num_cam, self.group_rows, n)
+            except ext.OccAmdError:          # e.g. the 74 KB LDS attribute refused: one launch per layer instead
+                stacked = False
+                self._pending = {}
+        if not stacked:
+            for l, (vp, gb) in enumerate(zip(value_projs, gbs)):
+                self._pending[id(vp)] = self._launch(vp, gb, None if scales is None else scales[l:l + 1])
 
     # fp16 value rows carry 11 significant bits and end at 65 504.  Every plane is therefore stored times a power of two
     # chosen per call ON THE DEVICE from an a-priori bound of its values (ext.value_range_scale: max|x| of this call's maps
@@ -254,11 +219,7 @@ class LazyFeatures:
         return getattr(self, '_scale_of', {}).get(id(value_proj))
 
     def finish(self):
-        """Join the side stream: projections that no layer consumed (a layer fell back to the unfused path, an
-        exception unwound the encoder) must not outlive their inputs' stream ordering."""
-        pending = getattr(self, '_pending', None)
-        if pending and getattr(self, '_side', None) is not None:
-            torch.cuda.current_stream(self.mlvl_feats[0].device).wait_stream(self._side)
+        """Drop projections no layer consumed (a layer fell back to the unfused path, an exception unwound the encoder)."""
         self._pending = {}
 
     def _group_bias(self, value_proj):
@@ -309,9 +270,7 @@ class LazyFeatures:
         (bs*num_cam, sum hw rounded up to even, N) fp16 in the gather's pixel-pair order (ext.sca_pair_layout)."""
         hit = getattr(self, '_pending', {}).pop(id(value_proj), None)
         if hit is not None:
-            if hit[1] is not None:
-                torch.cuda.current_stream(hit[0].device).wait_event(hit[1])
-            return hit[0]
+            return hit
         return self._launch(value_proj, self._group_bias(value_proj))
 
 

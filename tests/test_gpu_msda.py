@@ -164,37 +164,3 @@ def test_tsa_fused_never_reads_corners_outside_the_map():
     ly = (ref.view(B, 2, Nq, 1, 1, 2)[..., 1].permute(0, 2, 3, 1, 4) + o[..., 1] / bh) * bh - 0.5
     may = ((lx > -1) & (lx < 1) & (ly > -1) & (ly < 1)).flatten(3).any(-1)
     assert not bool((touched.cpu() & ~may).any())
-
-
-@pytest.mark.parametrize("name,B,bh,bw,shared,off_px", [
-    ("base_like_shared", 1, 40, 56, True, 1.5),        # most samples inside the staged window
-    ("history", 1, 24, 20, False, 2.0),                # two different maps, staged one after the other
-    ("batch2_ragged_edges", 2, 19, 27, False, 2.5),    # tiles cut by both map edges, two batch entries
-    ("far_offsets", 1, 32, 32, True, 12.0),            # most samples beyond the halo: the global-memory fallback
-])
-def test_tsa_tile_kernel_matches_the_wave_per_query_kernel(name, B, bh, bw, shared, off_px, monkeypatch):
-    """Round 5: the TSA gather with the value rows staged through LDS per 8 x 8 query tile (tsa_tile_kernel) against the
-    wave-per-query kernel it replaces (itself checked against the oracle above and in test_gpu_modules.py): same
-    sampling arithmetic, fp32 summation order differs.  Reference points = the pixel centres of the queries
-    (encoder.py:64-77: what TemporalSelfAttention is given); offsets in pixels, the reference's init puts them at 1..4."""
-    from occnet_amd import ext
-    g = torch.Generator().manual_seed(31)
-    M, D, P = 8, 32, 4
-    Nq = bh * bw
-    value = torch.randn(B if shared else B * 2, Nq, M, D, generator=g)
-    offs = torch.randn(B, Nq, M * 2 * P * 2, generator=g) * off_px
-    logits = torch.randn(B, Nq, M * 2 * P, generator=g)
-    ys, xs = torch.meshgrid(torch.arange(bh), torch.arange(bw), indexing='ij')
-    ref = torch.stack([(xs.flatten() + 0.5) / bw, (ys.flatten() + 0.5) / bh], -1)
-    ref = ref[None, :, None, :].expand(B * 2, Nq, 1, 2).contiguous()
-    args = (offs.cuda(), logits.cuda(), ref.cuda(), bh, bw, M, P)
-    monkeypatch.setenv("OCC_TSA_TILE", "0")
-    want = ext.tsa_fused_forward(value.cuda(), *args, shared_queue=shared)
-    monkeypatch.setenv("OCC_TSA_TILE", "1")
-    got = ext.tsa_fused_forward(value.cuda(), *args, shared_queue=shared)
-    d = float((got - want).abs().max())
-    far = float((offs.abs() >= 5).float().mean())
-    print(f"tsa tile kernel {name}: max|tile - wave| = {d:.3e} (scale {float(want.abs().max()):.2f}; {far:.0%} of the offset "
-          f"components beyond the 5-pixel halo)")
-    assert d < 2e-6 * max(1.0, float(want.abs().max()))
-    assert float(want.abs().max()) > 0.1

@@ -9,16 +9,20 @@
 //     |v[n]| = |sum_k x[k] W[n][k] + gbias[n]|  <=  max|x| * max_n sum_k |W[n][k]|  +  max|gbias|  =: bound
 //     s = 2^(15 - e),  bound = m * 2^e with m in [0.5, 1)      =>      |v * s| <= 2^15 = half of the fp16 limit
 //
-// max|x| is measured here (one pass over the bf16 feature maps, 16-bit integer maxima of the sign-stripped patterns:
-// two elements per VALU op, HBM/MALL-bound); the two weight-side terms are constants of the weight state and arrive
-// from the host.  The projection multiplies its fp32 accumulators by s before the fp16 conversion, the gather divides
+// max|x| comes from the PRODUCER of the maps when it is this library's backbone plan (round 6: the FPN output
+// convolutions fold the sign-stripped bf16 patterns of what they store into 8 device words — conv3x3_nhwc_bf16.hip —
+// and occ_value_range_scale_from_amax derives the scales in one 64-thread launch), or is measured here for foreign maps
+// (one pass over the bf16 feature maps, 16-bit integer maxima of the sign-stripped patterns: two elements per VALU
+// op, HBM/MALL-bound: 52 us for the 95 MB of the base maps).  The two weight-side terms are constants of the weight
+// state and are read from DEVICE memory (round 6: no host round trip, graph-safe, follow the live weights).  The projection multiplies its fp32 accumulators by s before the fp16 conversion, the gather divides
 // its fp32 result by count * s: both are exact (power of two), so the only effect of the scale is WHERE the fp16
 // exponent window sits — fp16's relative precision is the same anywhere in its normal range (2^-14 .. 2^16), and with
 // the bound at 2^15 values down to 2^-29 of the bound are still normal numbers.  Inf / NaN in the maps give s = 1 (such
 // rows are Inf / NaN in the fp32 path as well).
 //
-// One launch, self-cleaning: the blocks fold their maxima into work[0] (atomic max), take a ticket from work[1], and
-// the last block to finish derives the scales and resets both words for the next call on the stream.
+// One kernel: the blocks fold their maxima into work[0] (atomic max), take a ticket from work[1], and the last block to
+// finish derives the scales.  The launcher zeroes both words in front of the kernel (a 8-byte memset node: a stale
+// ticket word — an aborted launch, a foreign writer — can then not leave scale_out unwritten).
 #include "common.h"
 
 namespace occ {
@@ -30,10 +34,7 @@ struct VrSegments {
   int lda8[kVrMaxSeg];
   int n;
 };
-struct VrPlanes {
-  float row_l1[kVrMaxPlanes], bias_max[kVrMaxPlanes];
-  int n;
-};
+constexpr int kVrAmaxWords = 8;       // producer-side maxima are sharded over 8 words (block id & 7): less same-address traffic
 
 typedef unsigned short vr_u16x2 __attribute__((ext_vector_type(2)));
 
@@ -55,8 +56,34 @@ __device__ __forceinline__ float vr_scale_of(float bound) {
   return ldexpf(1.f, k);
 }
 
+// scale_out[0..P) = scales, [P] = max|x|, [P+1..2P] = bounds (diagnostics)
+__device__ __forceinline__ void vr_write_scales(unsigned bits, int n_planes, const float* __restrict__ row_l1,
+                                                const float* __restrict__ bias_max, float* __restrict__ scale_out) {
+  const float amax = __uint_as_float(bits << 16);        // bf16 pattern -> f32 (Inf / NaN patterns stay what they are)
+  scale_out[n_planes] = amax;
+  for (int p = 0; p < n_planes; ++p) {
+    // 2^-8 of slack on the weight term: the kernel's hi/lo bf16 weight split and fp32 accumulation are exact to
+    // 2^-17 of |x|.|w|, far inside it (and the target leaves another factor of two below the fp16 limit)
+    const float bound = row_l1[p] * amax * 1.00390625f + bias_max[p];
+    scale_out[p] = vr_scale_of(bound);
+    scale_out[n_planes + 1 + p] = bound;
+  }
+}
+
+// the maxima arrive from the producer of the maps (8 words of sign-stripped bf16 patterns): one thread
+__global__ void value_range_from_amax_kernel(const unsigned* __restrict__ amax8, int n_planes,
+                                             const float* __restrict__ row_l1, const float* __restrict__ bias_max,
+                                             float* __restrict__ scale_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned b = 0;
+  for (int i = 0; i < kVrAmaxWords; ++i) b = amax8[i] > b ? amax8[i] : b;
+  vr_write_scales(b & 0xffffu, n_planes, row_l1, bias_max, scale_out);
+}
+
 template <bool CONTIG>
-__global__ __launch_bounds__(256) void value_range_scale_kernel(VrSegments seg, int K8, VrPlanes planes,
+__global__ __launch_bounds__(256) void value_range_scale_kernel(VrSegments seg, int K8, int n_planes,
+                                                                const float* __restrict__ row_l1,
+                                                                const float* __restrict__ bias_max,
                                                                 float* __restrict__ scale_out,
                                                                 unsigned* __restrict__ work) {
   __shared__ unsigned smax[4];
@@ -109,23 +136,17 @@ __global__ __launch_bounds__(256) void value_range_scale_kernel(VrSegments seg, 
     for (int w = 1; w < 4; ++w) b = smax[w] > b ? smax[w] : b;
     // No fences: both words are only ever touched by device-scope atomics (performed at the coherence point, not in an XCD's
     // L2), and the ticket is requested only after the maximum's RETURN value has arrived — i.e. after that atomic has been
-    // performed — through its return value.  (The first cut put a __threadfence() around the ticket: an L2 write-back +
-    // invalidate per block, 2 048 of them as the launch drains: 85-114 us for a 95 MB stream.)
-    unsigned old = atomicMax(&work[0], b);
-    asm volatile("" : "+v"(old));            // the return value is HERE: the maximum has been performed
-    const unsigned ticket = atomicAdd(&work[1], 1u);
+    // performed.  The ticket's operand is made to depend on that return value (an asm the compiler cannot see through, with a
+    // memory clobber), so neither the compiler nor the memory pipeline can put the ticket in front of the maximum.  (The
+    // first cut put a __threadfence() around the ticket: an L2 write-back + invalidate per block, 2 048 of them as the
+    // launch drains: 85-114 us for a 95 MB stream.)
+    const unsigned old = atomicMax(&work[0], b);
+    unsigned one = 1u;
+    asm volatile("" : "+v"(one) : "v"(old) : "memory");
+    const unsigned ticket = atomicAdd(&work[1], one);
     if (ticket == gridDim.x - 1) {
-      const unsigned bits = atomicExch(&work[0], 0u);        // read + reset for the next call
-      atomicExch(&work[1], 0u);
-      const float amax = __uint_as_float(bits << 16);        // bf16 pattern -> f32 (Inf / NaN patterns stay what they are)
-      scale_out[planes.n] = amax;
-      for (int p = 0; p < planes.n; ++p) {
-        // 2^-8 of slack on the weight term: the kernel's hi/lo bf16 weight split and fp32 accumulation are exact to
-        // 2^-17 of |x|.|w|, far inside it (and the target leaves another factor of two below the fp16 limit)
-        const float bound = planes.row_l1[p] * amax * 1.00390625f + planes.bias_max[p];
-        scale_out[p] = vr_scale_of(bound);
-        scale_out[planes.n + 1 + p] = bound;
-      }
+      const unsigned bits = atomicMax(&work[0], 0u);         // read at the coherence point
+      vr_write_scales(bits, n_planes, row_l1, bias_max, scale_out);
     }
   }
 }
@@ -163,25 +184,36 @@ extern "C" int occ_value_range_scale_bf16(int n_segments, const void* const* a, 
   }
   for (int i = n_segments; i <= kVrMaxSeg; ++i) seg.first[i] = (int)pieces;
   seg.n = n_segments;
-  VrPlanes pl;
-  for (int p = 0; p < kVrMaxPlanes; ++p) {
-    const int j = p < n_planes ? p : n_planes - 1;
-    OCC_CHECK_ARG(!(row_l1[j] < 0.f) && !(bias_max[j] < 0.f), "value_range_scale: negative bound term for plane %d", j);
-    pl.row_l1[p] = row_l1[j];
-    pl.bias_max[p] = bias_max[j];
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(work, 0, 2 * sizeof(uint32_t), st) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("value_range_scale: could not zero the work words");
+    return OCC_E_LAUNCH;
   }
-  pl.n = n_planes;
   // kVrUnroll 16-byte loads per thread and round; no more blocks than one round needs, at most 8 per CU
   long blocks = (pieces + kVrUnroll * 256 - 1) / (kVrUnroll * 256);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
   bool contig = true;
   for (int i = 0; i < n_segments; ++i) contig = contig && lda[i] == K;
   if (contig)
-    hipLaunchKernelGGL(value_range_scale_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), seg, K / 8, pl, scale_out, work);
+    hipLaunchKernelGGL(value_range_scale_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, seg, K / 8, n_planes,
+                       row_l1, bias_max, scale_out, work);
   else
-    hipLaunchKernelGGL(value_range_scale_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), seg, K / 8, pl, scale_out, work);
+    hipLaunchKernelGGL(value_range_scale_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, seg, K / 8, n_planes,
+                       row_l1, bias_max, scale_out, work);
   OCC_CHECK_LAUNCH("value_range_scale");
+  return OCC_OK;
+}
+
+// The same scales from maxima the PRODUCER of the maps accumulated (amax8: 8 words, each the largest sign-stripped bf16
+// pattern a shard of the producer's blocks stored — occ_conv3x3_nhwc_bf16_amax): no pass over the maps.
+extern "C" int occ_value_range_scale_from_amax(const uint32_t* amax8, int n_planes, const float* row_l1,
+                                               const float* bias_max, float* scale_out, void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(amax8 && row_l1 && bias_max && scale_out, "value_range_scale_from_amax: null pointer argument");
+  OCC_CHECK_ARG(n_planes > 0 && n_planes <= kVrMaxPlanes, "value_range_scale_from_amax: 1..%d planes", kVrMaxPlanes);
+  hipLaunchKernelGGL(value_range_from_amax_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), amax8,
+                     n_planes, row_l1, bias_max, scale_out);
+  OCC_CHECK_LAUNCH("value_range_scale_from_amax");
   return OCC_OK;
 }

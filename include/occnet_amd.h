@@ -443,14 +443,19 @@ int occ_value_proj_bf16_f16pairs(int n_segments, const void* const* a, const int
  *     |a . W_p^T + gb_p|  <=  max|a| * row_l1[p] + bias_max[p],      row_l1[p] = max_n sum_k |W_p[n][k]|,
  *     scale_out[p] = 2^(15 - e) with bound_p = m 2^e, m in [0.5, 1)   (bound_p * scale <= 2^15 = half of the fp16 limit)
  * so no finite input can saturate; a zero / Inf / NaN bound gives 1.  max|a| is measured over every segment (bf16 rows,
- * K % 8 == 0, lda % 8 == 0); row_l1 / bias_max: HOST arrays of n_planes (<= 8) floats, constants of the weight state.
+ * K % 8 == 0, lda % 8 == 0); row_l1 / bias_max: DEVICE arrays of n_planes (<= 8) floats (abi 3: no host round trip, the
+ * call is graph-safe and follows the live weights).
  * scale_out: DEVICE floats [0, n_planes) scales, [n_planes] max|a|, [n_planes + 1, 2 n_planes + 1) the bounds.
- * work: two DEVICE words, zero before the first call; the kernel leaves them zero (calls sharing `work` must be
- * stream-ordered).  Scaling by a power of two is exact both ways: results equal the unscaled fp16-row path's wherever
- * that one does not saturate. */
+ * work: two DEVICE words of scratch, zeroed by the call itself (calls sharing `work` must be stream-ordered).  Scaling by
+ * a power of two is exact both ways: results equal the unscaled fp16-row path's wherever that one does not saturate. */
 int occ_value_range_scale_bf16(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows, int K,
                                int n_planes, const float* row_l1, const float* bias_max, float* scale_out,
                                uint32_t* work, void* stream);
+/* The same scales when the PRODUCER of the maps already holds max|a|: amax8 = 8 DEVICE words, the largest sign-stripped
+ * bf16 pattern each shard of the producer's blocks stored (occ_conv3x3_nhwc_bf16_amax; the maximum over the 8 words is
+ * max|a|).  One 64-thread launch instead of a pass over the maps (52 us at the base config). */
+int occ_value_range_scale_from_amax(const uint32_t* amax8, int n_planes, const float* row_l1, const float* bias_max,
+                                    float* scale_out, void* stream);
 
 /* Several projections of the SAME rows in one launch — the four encoder layers' SCA value projections depend on the
  * camera features only (spatial_cross_attention.py:366 in each of the 4 layers): weight_packed = pack of the
@@ -510,6 +515,12 @@ int occ_conv1x1_nhwc_bf16(const void* x, const void* weight, const float* bias, 
 int occ_conv3x3_pack_weight_bf16(const float* weight, void* packed, int Cout, int Cin, void* stream);
 int occ_conv3x3_nhwc_bf16(const void* x, const void* weight_packed, const float* bias, void* out, int batch,
                           int H, int W, int Cin, int Cout, int stride, int relu, void* stream);
+/* The same convolution; additionally folds max|out| (the sign-stripped bf16 pattern of every element it stores) into the
+ * 8 DEVICE words amax8 with atomic maxima.  The words ACCUMULATE across launches: zero them once in front of the FPN's
+ * output convolutions (the maps the reference flattens at transformer_occ.py:204-222), then hand them to
+ * occ_value_range_scale_from_amax. */
+int occ_conv3x3_nhwc_bf16_amax(const void* x, const void* weight_packed, const float* bias, void* out, int batch,
+                               int H, int W, int Cin, int Cout, int stride, int relu, uint32_t* amax8, void* stream);
 
 /* MFMA B-operand packing: f32 row-major (N, K) matrix -> bf16 in v_mfma_f32_32x32x16_bf16 fragment order
  * packed[((ks * N/32 + nt) * 64 + lane) * 8 + j] = w[nt*32 + (lane & 31)][ks*16 + (lane >> 5)*8 + j], so a wave

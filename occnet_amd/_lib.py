@@ -32,7 +32,7 @@ def declared_symbols(header=HEADER_PATH):
 
 
 _lib = None
-ABI = 2     # include/occnet_amd.h: bumped whenever a signature changes (2: range scales of the fp16 value rows)
+ABI = 3     # include/occnet_amd.h: bumped whenever a signature changes (2: range scales of the fp16 value rows; 3: their weight terms in device memory)
 
 
 def lib():

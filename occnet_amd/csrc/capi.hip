@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace occ
 
-extern "C" int occ_abi_version(void) { return 2; }
+extern "C" int occ_abi_version(void) { return 3; }
 
 // q[i] = occ::fdiv(a[i], d[i]) — the gathers' quotient (common.h) exposed so that the tests can measure it against IEEE division
 namespace occ {

@@ -104,18 +104,18 @@ __device__ __forceinline__ unsigned short bf16_rne(float f) {
 
 // fp32 quotient WITHOUT the IEEE division expansion.  hipcc turns `a / d` into v_div_scale_f32 (x2, one writes VCC) /
 // v_rcp_f32 / v_fma chain / v_div_fmas_f32 (reads VCC implicitly) / v_div_fixup_f32: 12 instructions and a VCC round trip
-// where 5 do.  History: with their divisions written this way the gather kernels stopped showing the
-// co-scheduling hazard of round 5 (the real TSA kernel alone next to the value projection: wrong in lanes 48-63 in 99 of
-// 100 runs with `/`, 0 of 100 with fdiv) — but a self-contained copy of the kernel fails WITH fdiv as well (item 10 there):
-// the expansion is not what the hazard hits, fdiv moved the kernels out of its window.  The guarantee is the single stream.
-// Reciprocal + one Newton step + one residual correction: faithfully rounded (<= 1 ulp; equal to the correctly rounded
-// quotient in all 4 194 304 cases of tests/test_gpu_value_range.py) for normal, non-zero d — every divisor in the gather
-// kernels is a positive map size, a softmax sum >= 1 or a camera count.
+// where 5 do.  Reciprocal + one Newton step + one residual correction: faithfully rounded (<= 1 ulp; equal to the correctly
+// rounded quotient in all 4 194 304 cases of tests/test_gpu_value_range.py) for normal, non-zero d with |d| < 2^126 (beyond
+// it v_rcp_f32 flushes to zero) — every divisor in the gather kernels is a positive map size, a softmax sum >= 1 or a
+// camera count times a range scale <= 2^100.  A non-finite numerator (an overflowed accumulator) or an overflowing quotient
+// gives a * r — Inf / NaN like the IEEE quotient — instead of the NaN the residual step would make of Inf - Inf.
+// (History: tools_dev/lab/hazard/README.md — with `/` the gathers of round 5 met the co-scheduling hazard more often.)
 __device__ __forceinline__ float fdiv(float a, float d) {
   float r = __builtin_amdgcn_rcpf(d);
   r = fmaf(fmaf(-d, r, 1.f), r, r);
   const float q = a * r;
-  return fmaf(fmaf(-q, d, a), r, q);
+  const float c = fmaf(fmaf(-q, d, a), r, q);
+  return fabsf(q) < __builtin_huge_valf() ? c : q;
 }
 
 // Orders this wave's LDS writes before its later LDS reads (cross-lane hand-off inside ONE wave:

@@ -38,6 +38,12 @@ template <int S> struct C3Geom {
 
 __device__ __forceinline__ unsigned short c3_f32_to_bf16(float f) { return bf16_rne(f); }
 
+typedef unsigned short c3_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned c3_absmax2(unsigned m, unsigned x) {   // v_and + v_pk_max_u16
+  const c3_u16x2 a = __builtin_bit_cast(c3_u16x2, m), b = __builtin_bit_cast(c3_u16x2, x & 0x7fff7fffu);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(a, b));
+}
+
 // torch weight (Cout, Cin, 3, 3) f32 -> bf16 in MFMA B-fragment order
 // packed[chunk = ci/32][tap = ky*3+kx][ks = 0,1][Cout/32][lane][8]:  element j of lane `lane` is
 // w[co = nt*32 + (lane & 31)][ci = chunk*32 + ks*16 + (lane >> 5)*8 + j][tap]
@@ -61,7 +67,7 @@ template <int NT, int S, int PF>
 __global__ __launch_bounds__(256, 3) void conv3x3_nhwc_bf16_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ bias,
     unsigned short* __restrict__ out, int H, int W, int Ho, int Wo, int Cin, int Cout, int tiles_x,
-    int tiles_y, int relu) {
+    int tiles_y, int relu, unsigned* __restrict__ amax8) {
   using G = C3Geom<S>;
   constexpr int RT = G::RT, BN = 128 * NT, WR = 32 * NT, OLD = BN + 4;
   constexpr int kC3ROW = G::ROW, kC3TH = G::TH;
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_nhwc_bf16_kernel(
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col_live) bv = *reinterpret_cast<const float4*>(bias + n0 + c);
   float* sO = reinterpret_cast<float*>(lds);
+  unsigned amax2 = 0;                                        // two 16-bit maxima of the sign-stripped bf16 patterns stored
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     __syncthreads();
@@ -224,8 +231,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_nhwc_bf16_kernel(
         }
         const uint2 o = make_uint2(pack_bf16x2_rne(v.x, v.y), pack_bf16x2_rne(v.z, v.w));
         *reinterpret_cast<uint2*>(out + (((long)img * Ho + oy) * Wo + ox) * Cout + n0 + c) = o;
+        amax2 = c3_absmax2(c3_absmax2(amax2, o.x), o.y);
       }
     }
+  }
+  // max|out| of what this launch stored, for the consumer's fp16 range scale (value_range.hip): one atomic per wave into
+  // one of 8 words (Inf / NaN patterns order above every finite one and reach the consumer as such)
+  if (amax8 != nullptr) {
+    unsigned m16 = (amax2 & 0xffffu) > (amax2 >> 16) ? (amax2 & 0xffffu) : (amax2 >> 16);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)m16, d);
+      m16 = o > m16 ? o : m16;
+    }
+    if (lane == 0 && m16 != 0u) atomicMax(amax8 + ((blockIdx.x + wave) & 7u), m16);
   }
 }
 
@@ -248,9 +267,9 @@ extern "C" int occ_conv3x3_pack_weight_bf16(const float* weight, void* packed, i
   return OCC_OK;
 }
 
-extern "C" int occ_conv3x3_nhwc_bf16(const void* x, const void* weight_packed, const float* bias, void* out,
-                                     int batch, int H, int W, int Cin, int Cout, int stride, int relu,
-                                     void* stream) {
+static int conv3x3_nhwc_bf16_launch(const void* x, const void* weight_packed, const float* bias, void* out,
+                                    int batch, int H, int W, int Cin, int Cout, int stride, int relu,
+                                    uint32_t* amax8, void* stream) {
   using namespace occ;
   OCC_CHECK_ARG(x && weight_packed && bias && out, "conv3x3_nhwc_bf16: null pointer argument");
   OCC_CHECK_ARG(batch > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_nhwc_bf16: bad dimension");
@@ -267,10 +286,26 @@ extern "C" int occ_conv3x3_nhwc_bf16(const void* x, const void* weight_packed, c
 #define OCC_C3_LAUNCH(NTT, BNN, SS, PFF)                                                            \
   hipLaunchKernelGGL((conv3x3_nhwc_bf16_kernel<NTT, SS, PFF>), dim3(gx, (unsigned)(Cout / BNN)), dim3(256), 0, st, \
                      reinterpret_cast<const uint4*>(x), reinterpret_cast<const uint4*>(weight_packed), \
-                     bias, reinterpret_cast<unsigned short*>(out), H, W, Ho, Wo, Cin, Cout, tiles_x, tiles_y, relu)
+                     bias, reinterpret_cast<unsigned short*>(out), H, W, Ho, Wo, Cin, Cout, tiles_x, tiles_y, relu, amax8)
   // ring of 6 k-steps + 3 waves per SIMD measured faster than 12 k-steps + 2 waves on every ResNet-50 shape
   if (stride == 2) OCC_C3_LAUNCH(1, 128, 2, 6); else OCC_C3_LAUNCH(1, 128, 1, 6);
 #undef OCC_C3_LAUNCH
   OCC_CHECK_LAUNCH("conv3x3_nhwc_bf16");
   return OCC_OK;
+}
+
+extern "C" int occ_conv3x3_nhwc_bf16(const void* x, const void* weight_packed, const float* bias, void* out,
+                                     int batch, int H, int W, int Cin, int Cout, int stride, int relu,
+                                     void* stream) {
+  return conv3x3_nhwc_bf16_launch(x, weight_packed, bias, out, batch, H, W, Cin, Cout, stride, relu, nullptr, stream);
+}
+
+// The same convolution; additionally folds max|out| (sign-stripped bf16 patterns of every element it stores) into amax8[0..8)
+// with atomic maxima — the words ACCUMULATE across launches (the caller zeroes them once in front of the FPN's output
+// convolutions) and feed occ_value_range_scale_from_amax: the consumer's range pass over the maps is not needed.
+extern "C" int occ_conv3x3_nhwc_bf16_amax(const void* x, const void* weight_packed, const float* bias, void* out,
+                                          int batch, int H, int W, int Cin, int Cout, int stride, int relu,
+                                          uint32_t* amax8, void* stream) {
+  OCC_CHECK_ARG(amax8, "conv3x3_nhwc_bf16_amax: null amax8");
+  return conv3x3_nhwc_bf16_launch(x, weight_packed, bias, out, batch, H, W, Cin, Cout, stride, relu, amax8, stream);
 }

@@ -64,7 +64,7 @@ __device__ __forceinline__ void vr_write_scales(unsigned bits, int n_planes, con
   for (int p = 0; p < n_planes; ++p) {
     // 2^-8 of slack on the weight term: the kernel's hi/lo bf16 weight split and fp32 accumulation are exact to
     // 2^-17 of |x|.|w|, far inside it (and the target leaves another factor of two below the fp16 limit)
-    const float bound = row_l1[p] * amax * 1.00390625f + bias_max[p];
+    const float bound = fabsf(row_l1[p]) * amax * 1.00390625f + fabsf(bias_max[p]);     // (|.|: a negative term is a caller bug)
     scale_out[p] = vr_scale_of(bound);
     scale_out[n_planes + 1 + p] = bound;
   }

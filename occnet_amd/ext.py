@@ -55,6 +55,12 @@ class _timed:
         return False
 
 
+def _note_flops(name, flops):
+    """bench.py's backbone roofline: the FLOPs of an instrumented launch, next to its event pair."""
+    if _TIMING is not None and (_TIMING_ONLY is None or name in _TIMING_ONLY):
+        _TIMING.setdefault(name + '_flops', []).append(float(flops))
+
+
 def kernel_times_ms(record):
     """{name: [ms per launch]} from a kernel_timing() record (call after a device synchronize); entries
     that are plain numbers (e.g. 'linear_flops') pass through."""
@@ -505,40 +511,78 @@ def _check_out_scale(what, out_scale, planes, out):
         raise OccAmdError(f"{what}: out_scale must be a contiguous float32 device vector of >= {planes} entries")
 
 
-_RANGE_WORK = {}        # (device, stream) -> the two self-resetting work words of occ_value_range_scale_bf16
+def _range_terms_dev(row_l1, bias_max, dev):
+    """(P,) float32 device vectors of the two weight-side terms: device tensors pass through, host floats are uploaded."""
+    def one(v):
+        if isinstance(v, torch.Tensor):
+            t = v.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        else:
+            t = torch.tensor([float(x) for x in v], dtype=torch.float32, device=dev)
+        return t
+    r, b = one(row_l1), one(bias_max)
+    if r.numel() != b.numel() or r.numel() == 0:
+        raise OccAmdError("value_range_scale: row_l1 and bias_max must have one entry per plane")
+    return r, b
 
 
 def value_range_scale(a_list, row_l1, bias_max):
     """Per-plane power-of-two scales for fp16 storage of the projections of the bf16 feature rows `a_list` (csrc/value_range.hip):
     -> float32 device vector t of 2 P + 1 entries, t[:P] = s_p with  (max|x| * row_l1[p] * (1 + 2^-8) + bias_max[p]) * s_p <= 2^15,
     t[P] = max|x| over every map, t[P + 1 + p] = the bound of plane p (diagnostics).  row_l1[p] = max_n sum_k |W_p[n][k]|,
-    bias_max[p] = max |group bias of p| — host floats, constants of the weight state.  No host synchronisation; one launch on
-    the current stream.  Pass t[:P] as value_proj_bf16*(out_scale=) and t[p:p+1] as sca_fused_forward(value_scale=)."""
+    bias_max[p] = max |group bias of p| — (P,) float32 DEVICE tensors (round 6; host sequences are uploaded: tests).  No host
+    synchronisation; a memset node + one launch on the current stream.  Pass t[:P] as value_proj_bf16*(out_scale=) and
+    t[p:p+1] as sca_fused_forward(value_scale=)."""
     if isinstance(a_list, torch.Tensor):
         a_list = [a_list]
-    S, P = len(a_list), len(row_l1)
-    if len(bias_max) != P:
-        raise OccAmdError("value_range_scale: row_l1 and bias_max must have one entry per plane")
+    S = len(a_list)
     K = a_list[0].shape[1]
     for a in a_list:
         if not (a.is_cuda and a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1 and a.shape[1] == K):
             raise OccAmdUnsupported("value_range_scale: every a must be a (M, K) bfloat16 device matrix with unit column stride")
     dev = a_list[0].device
-    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
-    work = _RANGE_WORK.get(key)
-    if work is None:
-        if len(_RANGE_WORK) >= 16:
-            _RANGE_WORK.pop(next(iter(_RANGE_WORK)))
-        work = _RANGE_WORK[key] = torch.zeros(2, dtype=torch.int32, device=dev)
-    out = torch.empty(2 * P + 1, dtype=torch.float32, device=dev)
+    r, b = _range_terms_dev(row_l1, bias_max, dev)
+    P = r.numel()
+    # 2 P + 1 result floats + the kernel's two work words in ONE allocation of the caller's pool (the launcher zeroes the
+    # words: nothing is cached across calls, streams or graph captures)
+    buf = torch.empty(2 * P + 3, dtype=torch.float32, device=dev)
+    out, work = buf[:2 * P + 1], buf[2 * P + 1:]
     arr64 = lambda v: (ctypes.c_int64 * S)(*[int(x) for x in v])
-    arrf = lambda v: (ctypes.c_float * P)(*[float(x) for x in v])
     a_ptrs = (ctypes.c_void_p * S)(*[a.data_ptr() for a in a_list])
     with torch.cuda.device(dev), _timed('value_range'):
         rc = _lib.lib().occ_value_range_scale_bf16(
             i32(S), a_ptrs, arr64([a.stride(0) for a in a_list]), arr64([a.shape[0] for a in a_list]), i32(K), i32(P),
-            arrf(row_l1), arrf(bias_max), ptr(out), ptr(work), stream_ptr(dev))
+            ptr(r), ptr(b), ptr(out), ptr(work), stream_ptr(dev))
     _lib.check(rc, "value_range_scale")
+    return out
+
+
+def new_absmax_words(device):
+    """8 zeroed device words for conv3x3_nhwc(amax=...): the producer side of value_range_scale_from_amax."""
+    return torch.zeros(8, dtype=torch.int32, device=device)
+
+
+def feature_absmax_words(a_list):
+    """The 8 words a producer would have accumulated, for maps that did not come from this library's backbone plan (bench
+    set-up, tests): max of the sign-stripped bf16 patterns of every element, replicated."""
+    if isinstance(a_list, torch.Tensor):
+        a_list = [a_list]
+    m = torch.stack([(a.detach().contiguous().view(torch.int16).to(torch.int32) & 0x7fff).amax() for a in a_list]).amax()
+    return m.to(torch.int32).reshape(1).repeat(8)
+
+
+def value_range_scale_from_amax(amax8, row_l1, bias_max):
+    """value_range_scale when the producer of the maps accumulated max|x| itself (conv3x3_nhwc(amax=...) of the backbone plan's
+    FPN output convolutions): one 64-thread launch instead of a pass over the maps.  Same result vector."""
+    if not (isinstance(amax8, torch.Tensor) and amax8.is_cuda and amax8.dtype == torch.int32 and amax8.numel() == 8
+            and amax8.is_contiguous()):
+        raise OccAmdError("value_range_scale_from_amax: amax8 must be 8 contiguous int32 device words")
+    dev = amax8.device
+    r, b = _range_terms_dev(row_l1, bias_max, dev)
+    P = r.numel()
+    out = torch.empty(2 * P + 1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), _timed('value_range'):
+        rc = _lib.lib().occ_value_range_scale_from_amax(ptr(amax8), i32(P), ptr(r), ptr(b), ptr(out), stream_ptr(dev))
+    _lib.check(rc, "value_range_scale_from_amax")
     return out
 
 
@@ -1278,9 +1322,10 @@ def stem_conv7x7_pool(x, weight_frag, bias):
     Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
     out = torch.empty((N, 64, Hp, Wp), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _timed('bb_stem7x7_pool'):
         rc = _lib.lib().occ_stem_conv7x7_pool_f32_bf16(ptr(x), ptr(weight_frag), ptr(bias), ptr(out), i32(N),
                                                        i32(H), i32(W), stream_ptr(x.device))
+    _note_flops('bb_stem7x7_pool', 2.0 * N * Hc * Wc * 64 * 147)
     _lib.check(rc, "stem_conv7x7_pool")
     return out
 
@@ -1364,11 +1409,12 @@ def conv1x1_nhwc(x, weight_frag, bias, residual=None, relu=False, stride=1, resi
     if residual is not None and not (residual.dtype == torch.bfloat16 and tuple(residual.shape) == want and
                                      residual.is_contiguous(memory_format=torch.channels_last)):
         raise OccAmdUnsupported("conv1x1_nhwc: residual must match the output (channels_last bfloat16)")
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _timed('bb_conv1x1'):
         rc = _lib.lib().occ_conv1x1_nhwc_bf16(ptr(x), ptr(weight_frag), ptr(bias), ptr(residual), ptr(out),
                                               i32(N), i32(H), i32(W), i32(Cin), i32(Cout), i32(s),
                                               i32(1 if relu else 0), i32(1 if residual_upsample2 else 0),
                                               stream_ptr(x.device))
+    _note_flops('bb_conv1x1', 2.0 * N * Ho * Wo * Cin * Cout)
     _lib.check(rc, "conv1x1_nhwc")
     return out
 
@@ -1420,11 +1466,12 @@ def bottleneck64_nhwc(x, pack):
     if Cin != pack['cin']:
         raise OccAmdError("bottleneck64_nhwc: x has %d channels, the pack was built for %d" % (Cin, pack['cin']))
     out = torch.empty((N, 256, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _timed('bb_bottleneck64'):
         rc = _lib.lib().occ_bottleneck64_nhwc_bf16(ptr(x), ptr(pack['w1']), ptr(pack['b1']), ptr(pack['w2']),
                                                    ptr(pack['b2']), ptr(pack['w3']), ptr(pack['b3']), ptr(out),
                                                    i32(N), i32(H), i32(W), i32(Cin), i32(1 if pack['ds'] else 0),
                                                    stream_ptr(x.device))
+    _note_flops('bb_bottleneck64', 2.0 * N * H * W * (Cin * 64 + 9 * 64 * 64 + 64 * 256 + (Cin * 256 if pack['ds'] else 0)))
     _lib.check(rc, "bottleneck64_nhwc")
     return out
 
@@ -1443,10 +1490,12 @@ def conv3x3_pack_weight(weight):
     return packed
 
 
-def conv3x3_nhwc(x, w_packed, bias, cout, relu=False, stride=1):
+def conv3x3_nhwc(x, w_packed, bias, cout, relu=False, stride=1, amax=None):
     """3x3 / pad 1 / stride 1 or 2 convolution + bias (+ ReLU) on a channels_last bf16 activation, one launch.
     x (N, Cin, H, W) channels_last bf16; w_packed from conv3x3_pack_weight; bias (Cout) f32
-    -> (N, Cout, (H-1)//stride+1, (W-1)//stride+1) channels_last bf16."""
+    -> (N, Cout, (H-1)//stride+1, (W-1)//stride+1) channels_last bf16.
+    amax: 8 int32 device words (new_absmax_words) the launch folds max|out| into (atomic maxima of the sign-stripped bf16
+    patterns; they accumulate over launches) — the input of value_range_scale_from_amax."""
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)):
         raise OccAmdUnsupported("conv3x3_nhwc: x must be a channels_last bfloat16 device tensor")
@@ -1457,11 +1506,19 @@ def conv3x3_nhwc(x, w_packed, bias, cout, relu=False, stride=1):
     st = int(stride)
     if st not in (1, 2):
         raise OccAmdUnsupported("conv3x3_nhwc: stride must be 1 or 2")
+    if amax is not None and not (amax.is_cuda and amax.dtype == torch.int32 and amax.numel() == 8 and amax.is_contiguous()):
+        raise OccAmdError("conv3x3_nhwc: amax must be 8 contiguous int32 device words")
     out = torch.empty((N, cout, (H - 1) // st + 1, (W - 1) // st + 1), dtype=torch.bfloat16, device=x.device,
                       memory_format=torch.channels_last)
-    with torch.cuda.device(x.device):
-        rc = _lib.lib().occ_conv3x3_nhwc_bf16(ptr(x), ptr(w_packed), ptr(bias), ptr(out), i32(N), i32(H),
-                                              i32(W), i32(Cin), i32(cout), i32(st), i32(1 if relu else 0),
-                                              stream_ptr(x.device))
+    with torch.cuda.device(x.device), _timed('bb_conv3x3'):
+        if amax is None:
+            rc = _lib.lib().occ_conv3x3_nhwc_bf16(ptr(x), ptr(w_packed), ptr(bias), ptr(out), i32(N), i32(H),
+                                                  i32(W), i32(Cin), i32(cout), i32(st), i32(1 if relu else 0),
+                                                  stream_ptr(x.device))
+        else:
+            rc = _lib.lib().occ_conv3x3_nhwc_bf16_amax(ptr(x), ptr(w_packed), ptr(bias), ptr(out), i32(N), i32(H),
+                                                       i32(W), i32(Cin), i32(cout), i32(st), i32(1 if relu else 0),
+                                                       ptr(amax), stream_ptr(x.device))
+    _note_flops('bb_conv3x3', 2.0 * N * out.shape[2] * out.shape[3] * 9 * Cin * cout)
     _lib.check(rc, "conv3x3_nhwc")
     return out

@@ -364,8 +364,13 @@ class FusedInferenceBackbone(nn.Module):
         self._c3[idx] = c3
         return idx
 
-    def _conv(self, i, x, relu=False, add=None):
+    def _conv(self, i, x, relu=False, add=None, amax=None):
+        """amax (FPN output convolutions only): 8 device words the 3x3 kernel folds max|out| into; any other route clears
+        self._amax_ok — the maps then carry no maximum and their consumer measures it (ext.value_range_scale)."""
         w, b = getattr(self, f'w{i}'), getattr(self, f'b{i}')
+        if amax is not None and not (self._c3.get(i) and add is None and not self.fused_ops
+                                     and x.is_contiguous(memory_format=torch.channels_last)):
+            self._amax_ok = False
         s, p, d, g = self._convs[i]
         if self.fused_ops and add is not None:
             return torch.miopen_convolution_add_relu(x, w, add, 1.0, b.to(w.dtype), s, p, d, g)
@@ -378,7 +383,8 @@ class FusedInferenceBackbone(nn.Module):
                                     relu=relu or add is not None, stride=s[0])
         if self._c3.get(i) and add is None and x.is_contiguous(memory_format=torch.channels_last):
             from .. import ext
-            return ext.conv3x3_nhwc(x, getattr(self, f'p{i}'), b, w.shape[0], relu=relu, stride=s[0])
+            return ext.conv3x3_nhwc(x, getattr(self, f'p{i}'), b, w.shape[0], relu=relu, stride=s[0],
+                                    amax=amax if getattr(self, '_amax_ok', False) else None)
         if self.hip_tail and w.shape[0] % 8 == 0:
             from .. import ext
             y = F.conv2d(x, w, None, s, p, d, g)
@@ -495,10 +501,17 @@ class FusedInferenceBackbone(nn.Module):
             lat[i] = self._conv(li, xin)
             if up is not None:
                 lat[i] = lat[i] + F.interpolate(up, size=lat[i].shape[2:], **nk.upsample_cfg)
-        outs = [self._conv(self.fpn[i], lat[i]) for i in range(n)]
+        # the output convolutions fold max|out| into 8 device words while they store the maps: the fp16 range scale of the SCA
+        # value rows needs max|x| over exactly these maps (csrc/value_range.hip), and a separate pass over them costs 52 us
+        amax = None
+        self._amax_ok = bool(lat[0].is_cuda and self.dtype == torch.bfloat16)
+        if self._amax_ok:
+            from .. import ext
+            amax = ext.new_absmax_words(lat[0].device)
+        outs = [self._conv(self.fpn[i], lat[i], amax=amax) for i in range(n)]
         if nk.num_outs > n:
             if not nk.add_extra_convs:
-                for _ in range(nk.num_outs - n):
+                for _ in range(nk.num_outs - n):                    # a subset of outs[-1]: the maximum still bounds it
                     outs.append(F.max_pool2d(outs[-1], 1, stride=2))
             else:
                 if nk.add_extra_convs == 'on_input':
@@ -507,8 +520,11 @@ class FusedInferenceBackbone(nn.Module):
                     src = lat[-1]
                 else:
                     src = outs[-1]
-                outs.append(self._conv(self.fpn[n], src))
+                outs.append(self._conv(self.fpn[n], src, amax=amax))
                 for i in range(n + 1, nk.num_outs):
                     src = F.relu(outs[-1]) if nk.relu_before_extra_convs else outs[-1]
-                    outs.append(self._conv(self.fpn[i], src))
+                    outs.append(self._conv(self.fpn[i], src, amax=amax))
+        if self._amax_ok:
+            for o in outs:
+                o._occ_absmax = amax          # rides on the tensor OBJECTS: a consumer that reshapes them re-attaches it
         return tuple(outs)

@@ -152,6 +152,10 @@ class BEVFormerOcc(BaseModule):
                 out.append(f.view(int(B / len_queue), len_queue, int(BN / B), C, H, W))
             else:
                 out.append(f.view(B, int(BN / B), C, H, W))
+                # max|x| over the maps, accumulated by the plan's FPN output convolutions (backbone.py): rides on the views
+                am = getattr(f, '_occ_absmax', None)
+                if am is not None:
+                    out[-1]._occ_absmax = am
         return out
 
     def enable_fused_backbone(self, dtype=torch.bfloat16, fused_ops=False, hip_tail=True, use_graph=False,
@@ -204,6 +208,9 @@ class BEVFormerOcc(BaseModule):
         for f in feats:
             BN, C, H, W = f.size()
             out.append(f.view(B, N, C, H, W))
+            am = getattr(f, '_occ_absmax', None)
+            if am is not None:
+                out[-1]._occ_absmax = am
         return out, hw
 
     def load_checkpoint(self, path_or_state, strict=False, map_location='cpu'):

@@ -152,9 +152,6 @@ class LazyFeatures:
         depend on the camera features only, not on the BEV queries, so all of them go in ONE stacked launch (the maps are read
         once)."""
         gbs = [self._group_bias(vp) for vp in value_projs]
-        if ext.SCA_VALUES == "f16":
-            for vp, gb in zip(value_projs, gbs):
-                self._range_terms(vp, gb)                    # host-side constants (first call of a weight state: one sync)
         stacked = (len(value_projs) > 1 and all(tuple(vp.weight.shape) == tuple(value_projs[0].weight.shape)
                                                 for vp in value_projs) and value_projs[0].weight.shape[0] % 256 == 0)
         if stacked:
@@ -193,24 +190,39 @@ class LazyFeatures:
     # x the projection's largest absolute row sum + its largest bias), so that no finite feature map can saturate; the gather
     # divides the scale out again (exact).  Round 4 only warned (|v| = 1.8e4 on the benchmarked maps, 3.6x under the limit).
     def _range_terms(self, value_proj, gb):
-        """(max_n sum_k |W[n][k]|, max|group bias|) of a projection: host floats, measured once per weight state (the one
-        host synchronisation of this path, on the first call after a weight change)."""
+        """(max_n sum_k |W[n][k]|, max|group bias|) of a projection as a 2-element DEVICE tensor: computed by two small
+        reductions on the stream when the weight state changes, never read back (round 6: no host synchronisation, valid
+        inside a captured graph, follows the live weights)."""
         w = value_proj.weight
         key = (w.data_ptr(), w._version, gb.data_ptr(), gb._version, cache_epoch())
         hit = getattr(value_proj, '_occ_range_terms', None)
         if hit is None or hit[0] != key:
             with torch.no_grad():
-                t = torch.stack([w.detach().float().abs().sum(1).amax(), gb.detach().abs().amax()]).tolist()
-            hit = (key, float(t[0]), float(t[1]), w, gb)         # the sources stay referenced: the key stays unambiguous
+                t = torch.stack([w.detach().float().abs().sum(1).amax(), gb.detach().abs().amax()])
+            hit = (key, t, w, gb)                                # the sources stay referenced: the key stays unambiguous
             value_proj._occ_range_terms = hit
-        return hit[1], hit[2]
+        return hit[1]
+
+    def _absmax_words(self):
+        """The 8 device words of max|x| the producer of the maps accumulated (the backbone plan's FPN output convolutions),
+        or None: all levels must carry the SAME words object."""
+        am = getattr(self.mlvl_feats[0], '_occ_absmax', None)
+        if am is None or any(getattr(f, '_occ_absmax', None) is not am for f in self.mlvl_feats):
+            return None
+        return am
 
     def _scales(self, value_projs, gbs):
-        """The planes' range scales for THIS call's maps (one launch on the current stream), or None (fp32 rows)."""
+        """The planes' range scales for THIS call's maps, or None (fp32 rows): from the producer's maximum when the maps carry
+        one (a 64-thread launch), otherwise measured over the maps (ext.value_range_scale: one pass, 52 us at the base config)."""
         if ext.SCA_VALUES != "f16":
             return None
-        terms = [self._range_terms(vp, gb) for vp, gb in zip(value_projs, gbs)]
-        t = ext.value_range_scale(self.rows, [a for a, _ in terms], [b for _, b in terms])
+        terms = torch.stack([self._range_terms(vp, gb) for vp, gb in zip(value_projs, gbs)])      # (P, 2)
+        row_l1, bias_max = terms[:, 0].contiguous(), terms[:, 1].contiguous()
+        am = self._absmax_words()
+        if am is not None:
+            t = ext.value_range_scale_from_amax(am, row_l1, bias_max)
+        else:
+            t = ext.value_range_scale(self.rows, row_l1, bias_max)
         self.range_report_ = t                                   # 2 P + 1 device floats: scales, max|x|, bounds
         return t[:len(value_projs)]
 

@@ -14,7 +14,7 @@ def test_library_exports_declared_symbols():
     assert 'occ_ms_deform_attn_forward_f32' in declared and 'occ_sca_fused_forward_f32' in declared
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
-    assert lib.occ_abi_version() == _lib.ABI == 2
+    assert lib.occ_abi_version() == _lib.ABI == 3
 
 
 def test_argument_validation_without_gpu():
@@ -77,13 +77,15 @@ def test_backbone_and_projection_entry_points_validate_without_gpu():
     assert b'plane_cols' in lib.occ_last_error()
     # range scales of the fp16 value rows (round 5): argument checks
     f4 = (ctypes.c_float * 4)(1.0, 1.0, 1.0, 1.0)
-    neg = (ctypes.c_float * 4)(1.0, -1.0, 1.0, 1.0)
     rargs = lambda n, lda, K, planes, l1=f4: (n, ptrs, lda, one, K, planes, l1, f4, p, p, null)
     assert lib.occ_value_range_scale_bf16(*rargs(0, one, 64, 4)) == -1                            # no segments
     assert lib.occ_value_range_scale_bf16(*rargs(1, one, 64, 9)) == -1                            # > 8 planes
     assert lib.occ_value_range_scale_bf16(*rargs(1, one, 60, 4)) == -3                            # K % 8
     assert lib.occ_value_range_scale_bf16(*rargs(1, (ctypes.c_int64 * 1)(32), 64, 4)) == -1       # lda < K
-    assert lib.occ_value_range_scale_bf16(*rargs(1, one, 64, 4, neg)) == -1 and b'negative' in lib.occ_last_error()
+    # (round 6, abi 3: row_l1 / bias_max are DEVICE arrays — their sign cannot be checked on the host; the kernel takes |.|)
+    assert lib.occ_value_range_scale_from_amax(null, 4, f4, f4, p, null) == -1                      # no maxima
+    assert lib.occ_value_range_scale_from_amax(p, 9, f4, f4, p, null) == -1                         # > 8 planes
+    assert lib.occ_conv3x3_nhwc_bf16_amax(p, p, p, p, 1, 4, 4, 32, 128, 1, 1, null, null) == -1     # null amax8
     assert lib.occ_value_range_scale_bf16(1, ptrs, one, one, 64, 4, f4, f4, null, p, null) == -1  # no output
     # fused second convolution + heads + decode (round 3)
     lib.occ_conv3d_heads_pack_bytes.restype = ctypes.c_int64

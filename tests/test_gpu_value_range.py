@@ -236,3 +236,107 @@ def test_fdiv_is_faithfully_rounded():
     exact = float((q == ieee).float().mean())
     print(f"fdiv: max error {float(err.max()):.3f} ulp, equal to the correctly rounded quotient in {exact:.6%} of {n} cases")
     assert float(err.max()) <= 1.0 and exact > 0.999
+    # non-finite numerators and overflowing quotients behave like the IEEE quotient: Inf stays Inf with the
+    # quotient's sign, NaN stays NaN — the residual step alone would turn Inf into NaN (Inf - Inf)
+    inf, nan = float('inf'), float('nan')
+    a2 = torch.tensor([inf, -inf, inf, nan, 3.0e38, -3.0e38, 0.0, 1.0], device='cuda')
+    d2 = torch.tensor([2.0, 3.0, -4.0, 2.0, 0.25, 0.125, 5.0, 3.0], device='cuda')
+    q2 = torch.empty_like(a2)
+    rc = _lib.lib().occ_selftest_fdiv_f32(_lib.ptr(a2), _lib.ptr(d2), _lib.ptr(q2), ctypes.c_int64(8), _lib.stream_ptr(a2.device))
+    _lib.check(rc, "selftest_fdiv")
+    want2 = a2 / d2
+    assert torch.equal(torch.isnan(q2), torch.isnan(want2))
+    assert torch.equal(q2[~torch.isnan(q2)], want2[~torch.isnan(want2)])
+
+
+# ---- round 6: max|x| from the PRODUCER of the maps (no pass over them) ---------------------------------------------------------
+def _pattern_max(*tensors):
+    return max(int((t.contiguous().view(torch.int16).to(torch.int32) & 0x7fff).max()) for t in tensors)
+
+
+@pytest.mark.parametrize("N,C,Cout,H,W,relu,stride", [(2, 128, 128, 9, 21, True, 1), (1, 256, 256, 29, 50, False, 1),
+                                                       (1, 256, 256, 29, 50, True, 2), (6, 256, 256, 58, 100, False, 1)])
+def test_conv3x3_epilogue_accumulates_the_absolute_maximum(N, C, Cout, H, W, relu, stride):
+    """occ_conv3x3_nhwc_bf16_amax: the 8 words hold the largest sign-stripped bf16 pattern of what the launch STORED (ragged
+    tiles: nothing from outside the image), they ACCUMULATE over launches, and the output equals the plain launch's."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(C + H * W + stride)
+    x = (torch.randn(N, C, H, W, generator=g) * 3).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    wp = ext.conv3x3_pack_weight(w)
+    plain = ext.conv3x3_nhwc(x, wp, b, Cout, relu=relu, stride=stride)
+    words = ext.new_absmax_words(x.device)
+    got = ext.conv3x3_nhwc(x, wp, b, Cout, relu=relu, stride=stride, amax=words)
+    assert torch.equal(got, plain)
+    assert int(words.max()) == _pattern_max(got) and int(words.min()) >= 0
+    # a second launch with smaller outputs leaves the maximum, one with larger outputs raises it
+    small = ext.conv3x3_nhwc(x, wp, b * 0, Cout, relu=True, stride=stride, amax=words)
+    assert int(words.max()) == max(_pattern_max(got), _pattern_max(small))
+    big = ext.conv3x3_nhwc(x, wp, b + 1000.0, Cout, relu=relu, stride=stride, amax=words)
+    assert int(words.max()) == _pattern_max(big) > _pattern_max(got)
+    # the derived scales equal the measuring kernel's on the same maps
+    rows = [t.permute(0, 2, 3, 1).reshape(-1, Cout) for t in (got, small, big)]
+    t_meas = ext.value_range_scale(rows, [7.0, 0.3], [2.0, 0.0]).cpu()
+    t_prod = ext.value_range_scale_from_amax(words, [7.0, 0.3], [2.0, 0.0]).cpu()
+    assert torch.equal(t_meas, t_prod)
+    assert torch.equal(ext.value_range_scale_from_amax(ext.feature_absmax_words(rows), [7.0, 0.3], [2.0, 0.0]).cpu(), t_meas)
+
+
+@pytest.mark.parametrize("poison", [float('inf'), float('nan')])
+def test_conv3x3_epilogue_maximum_carries_inf_and_nan(poison):
+    from occnet_amd import ext
+    x = torch.randn(1, 128, 9, 12).cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x[0, 5, 4, 4] = poison
+    w = (torch.randn(128, 128, 3, 3) / 34).cuda()
+    words = ext.new_absmax_words(x.device)
+    out = ext.conv3x3_nhwc(x, ext.conv3x3_pack_weight(w), torch.zeros(128, device='cuda'), 128, amax=words)
+    assert not bool(torch.isfinite(out.float()).all())
+    assert int(words.max()) >= 0x7f80                                    # an Inf / NaN pattern reached the words
+    t = ext.value_range_scale_from_amax(words, [10.0], [3.0]).cpu()
+    assert float(t[0]) == 1.0                                            # ... and the scale of such maps is 1
+
+
+def test_backbone_plan_hands_its_maximum_to_the_value_projection(monkeypatch):
+    """The inference plan's FPN output convolutions accumulate max|x|; the detector's reshaped views carry the words; the
+    head's LazyFeatures derives the range scales from them (value_range_scale_from_amax) instead of measuring the maps —
+    same scales, same outputs, bit for bit, and the measuring kernel is not launched."""
+    import os
+    from occnet_amd import ext
+    from occnet_amd.plugin import Config, build_model, import_plugin
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs', 'occ_base_200x200x16.py'))
+    cfg.merge_from_dict({'model.pts_bbox_head.bev_h': 40, 'model.pts_bbox_head.bev_w': 40,
+                         'model.pts_bbox_head.positional_encoding.row_num_embed': 40,
+                         'model.pts_bbox_head.positional_encoding.col_num_embed': 40,
+                         'model.pts_bbox_head.transformer.rotate_center': [20, 20]})
+    import_plugin(cfg)
+    torch.manual_seed(0)
+    model = build_model(cfg.model)
+    model.init_weights()
+    model = model.cuda().eval()
+    model.enable_fused_backbone(dtype=torch.bfloat16)
+    g = dict(synthetic.BASE, img_h=256, img_w=416)
+    img = (torch.randn(1, 6, 3, 256, 416, generator=torch.Generator().manual_seed(4)) * 57).cuda()
+    metas = synthetic.make_img_metas(g)
+    calls = dict(meas=0, prod=0)
+    real_m, real_p = ext.value_range_scale, ext.value_range_scale_from_amax
+    monkeypatch.setattr(ext, 'value_range_scale', lambda *a, **k: (calls.__setitem__('meas', calls['meas'] + 1), real_m(*a, **k))[1])
+    monkeypatch.setattr(ext, 'value_range_scale_from_amax',
+                        lambda *a, **k: (calls.__setitem__('prod', calls['prod'] + 1), real_p(*a, **k))[1])
+    with torch.no_grad():
+        feats = model.extract_feat(img=img)
+        words = getattr(feats[0], '_occ_absmax', None)
+        assert words is not None and all(getattr(f, '_occ_absmax', None) is words for f in feats)
+        assert int(words.max()) == _pattern_max(*feats)
+        out = model.pts_bbox_head(feats, metas)
+        rep = model.pts_bbox_head.transformer.value_range_report.clone()
+        assert calls == dict(meas=0, prod=1)
+        for f in feats:                                # the same maps without the side band: measured
+            del f._occ_absmax
+        out2 = model.pts_bbox_head(feats, metas)
+        rep2 = model.pts_bbox_head.transformer.value_range_report
+        assert calls == dict(meas=1, prod=1)
+    assert torch.equal(rep, rep2)
+    for k in ('bev_embed', 'occ', 'flow'):
+        assert torch.equal(out[k], out2[k]), k

@@ -517,8 +517,8 @@ def test_x3linear_on_host_is_a_plain_linear():
 
 def test_fp16_value_range_terms_and_aten_scale():
     """Range-safe fp16 SCA value rows.  LazyFeatures._range_terms: the weight-side constants of the
-    a-priori bound (largest absolute row sum of W, largest |group bias|) are measured once per weight state and follow
-    in-place updates; ext.f16_range_scaled (the ATen counterpart for fp32-projected rows): a power-of-two scale that puts
+    a-priori bound (largest absolute row sum of W, largest |group bias|) are derived once per weight state, stay on the
+    device, and follow in-place updates; ext.f16_range_scaled (the ATen counterpart for fp32-projected rows): a power-of-two scale that puts
     max|v| into [2^14, 2^15], exact to undo, 1 for all-zero / non-finite rows."""
     from occnet_amd import ext
     from occnet_amd.plugin.transformer_occ import LazyFeatures
@@ -527,12 +527,13 @@ def test_fp16_value_range_terms_and_aten_scale():
     with torch.no_grad():
         vp.weight.copy_(torch.arange(32.).view(4, 8) - 10.0)
     gb = torch.tensor([[[0.5, -7.25, 1.0, 2.0]]])
-    l1, bm = lf._range_terms(vp, gb)
+    t = lf._range_terms(vp, gb)                                # a 2-element tensor on the weights' device: never read back
+    l1, bm = float(t[0]), float(t[1])
     assert l1 == float(vp.weight.abs().sum(1).max()) and bm == 7.25
-    assert lf._range_terms(vp, gb) == (l1, bm) and vp._occ_range_terms[0][1] == vp.weight._version
+    assert lf._range_terms(vp, gb) is t and vp._occ_range_terms[0][1] == vp.weight._version
     with torch.no_grad():
         vp.weight.mul_(3.0)                                    # in-place update: new weight state, measured again
-    assert lf._range_terms(vp, gb)[0] == 3.0 * l1
+    assert float(lf._range_terms(vp, gb)[0]) == 3.0 * l1
     for amp in (1e-6, 0.37, 6.0, 1.8e4, 1e5, 1e7, 3e30):
         v = torch.randn(5, 7, 16) * amp
         h, s = ext.f16_range_scaled(v)

@@ -216,8 +216,15 @@ class LazyFeatures:
         one (a 64-thread launch), otherwise measured over the maps (ext.value_range_scale: one pass, 52 us at the base config)."""
         if ext.SCA_VALUES != "f16":
             return None
-        terms = torch.stack([self._range_terms(vp, gb) for vp, gb in zip(value_projs, gbs)])      # (P, 2)
-        row_l1, bias_max = terms[:, 0].contiguous(), terms[:, 1].contiguous()
+        terms = [self._range_terms(vp, gb) for vp, gb in zip(value_projs, gbs)]
+        # the stacked (2, P) term vectors are a constant of the weight state too: cached on the first projection (the entry
+        # holds the per-projection tensors, so their identity keys it) — no small stack / copy kernels per step
+        hit = getattr(value_projs[0], '_occ_range_terms_stacked', None)
+        if hit is None or len(hit[0]) != len(terms) or any(a is not b for a, b in zip(hit[0], terms)):
+            st = torch.stack(terms).t().contiguous()                                             # (2, P)
+            hit = (terms, st)
+            value_projs[0]._occ_range_terms_stacked = hit
+        row_l1, bias_max = hit[1][0], hit[1][1]
         am = self._absmax_words()
         if am is not None:
             t = ext.value_range_scale_from_amax(am, row_l1, bias_max)

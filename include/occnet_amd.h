@@ -181,6 +181,25 @@ int occ_sca_fused_forward_f16v(const void* value_f16, const int64_t* spatial_sha
                                int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq,
                                const float* value_scale, void* stream);
 
+/* The same gather over q16 VALUE maps (round 6): the fp16 maps' geometry, pair layout and byte count, but BLOCK FLOATING
+ * POINT — every 16-byte piece (8 channels of one head of one pixel) holds 8 two's-complement int16 mantissas q_j under one
+ * 4-bit exponent E:  value_j * s = q_j * 2^(E - 15), E = the binary exponent of the piece's largest |value * s| (0 .. 15),
+ * stored in the two low bits of elements 0 and 1 (E & 3, E >> 2; those two are rounded to the nearest value with these
+ * low bits, i.e. to 14 bits).  The reference keeps these rows in fp32 (spatial_cross_attention.py:75,387-390); fp16 rows
+ * round every element to 2^-12 relative, q16 rounds the elements that dominate the gather's sums to 2^-16 relative —
+ * measured against the CPU oracle: DESIGN.md section 2.  Written by occ_value_proj_bf16_planes(out_f16 = 2),
+ * occ_value_proj_bf16_q16pairs or occ_sca_rows_encode_q16.  value_scale: the plane's range scale s (or NULL = 1). */
+int occ_sca_fused_forward_q16v(const void* value_q16, const int64_t* spatial_shapes,
+                               const int64_t* level_start_index, const float* offs, int64_t offs_stride,
+                               const float* logits, int64_t logits_stride, const float* ref_cam,
+                               const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats,
+                               int B, int NC, int S, int M, int D, int L, int P, int Z, int Nq,
+                               const float* value_scale, void* stream);
+/* fp32 value rows -> q16 pixel pairs.  v (groups, S, C) f32 contiguous, C % 32 == 0; out (groups, S + (S & 1), C) int16 in
+ * the pair order (the pad row of an odd S is not written); scale: NULL or one DEVICE float s, a power of two with
+ * max|v| * s <= 2^15. */
+int occ_sca_rows_encode_q16(const float* v, void* out, const float* scale, int64_t groups, int S, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused temporal self-attention gather over the 2-deep BEV queue (single level):
  *   out[b,q,:] = 0.5 * sum_{t in {0,1}} MSDA( value[b*2+t], softmax_p(logits[b,q,m,t,:]),
@@ -436,6 +455,13 @@ int occ_value_proj_bf16_f16pairs(int n_segments, const void* const* a, const int
                             const float* const* group_bias, int bias_groups, const void* weight_packed,
                             void* out, int64_t ldo, int K, int N, int64_t out_group_rows, const float* out_scale,
                             void* stream);
+/* same with q16 pixel pairs (occ_sca_fused_forward_q16v); exists on the activation-resident kernel only (K == 256,
+ * N % 256 == 0, rows_per_group >= 128): OCC_E_UNSUPPORTED otherwise — project to f32 and use occ_sca_rows_encode_q16. */
+int occ_value_proj_bf16_q16pairs(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
+                            const int64_t* rows_per_group, const int64_t* out_row0,
+                            const float* const* group_bias, int bias_groups, const void* weight_packed,
+                            void* out, int64_t ldo, int K, int N, int64_t out_group_rows, const float* out_scale,
+                            void* stream);
 
 /* Range-safe fp16 value rows (csrc/value_range.hip).  The reference keeps the SCA value rows in fp32
  * (spatial_cross_attention.py:75,387-390, @force_fp32); stored as fp16 a plane whose values pass 65 504 would be clamped.
@@ -463,7 +489,8 @@ int occ_value_range_scale_from_amax(const uint32_t* amax8, int n_planes, const f
  * plane p of `out` (planes plane_stride elements apart, rows of ldo elements, plane_cols columns; fp16 when out_f16) just
  * as the single-projection calls above would.  The column blocks of a row block are dealt to one XCD back to back: the
  * feature maps are read from HBM once instead of once per layer.  plane_cols % 256 == 0, otherwise OCC_E_UNSUPPORTED.
- * out_scale: NULL, or n_planes DEVICE floats: plane p is multiplied by out_scale[p] before it is stored (abi 2). */
+ * out_scale: NULL, or n_planes DEVICE floats: plane p is multiplied by out_scale[p] before it is stored (abi 2).
+ * out_f16: 0 = f32 rows, 1 = fp16 pixel pairs, 2 = q16 pixel pairs (abi 3). */
 int occ_value_proj_bf16_planes(int n_segments, const void* const* a, const int64_t* lda, const int64_t* rows,
                                const int64_t* rows_per_group, const int64_t* out_row0,
                                const float* const* group_bias, int bias_groups, const void* weight_packed, void* out,

@@ -278,12 +278,70 @@ __device__ __forceinline__ void fma8h(float4& acc, float4& acc2, float w, const 
   fma_mix_lo(acc2.x, w, h[2]); fma_mix_hi(acc2.y, w, h[2]); fma_mix_lo(acc2.z, w, h[3]); fma_mix_hi(acc2.w, w, h[3]);
 }
 
-// Gather over fp16 value rows: a lane's 16 bytes are 8 channels (4 lanes per 64-byte head row).  ROLLING window over NS
+// ---- q16 value rows (round 6): block floating point, 16 bits per element like the fp16 rows ---------------------------------
+// A 16-byte piece = 8 channels of one head of one pixel = 8 two's-complement int16 mantissas q_j sharing ONE 4-bit exponent E:
+//     value_j * s = q_j * 2^(E - 15)          (s = the plane's power-of-two range scale, |value * s| <= 2^15: value_range.hip)
+// E is the binary exponent of the piece's largest |value * s| (clamped to 0 .. 15), so the largest element uses all 15
+// magnitude bits: its rounding error is 2^-16 relative against fp16's 2^-12 — and EVERY element of the piece is rounded to that
+// same absolute step, which is what the weighted sums downstream see (their error is set by the large terms).  E lives in
+// the two low bits of elements 0 and 1 (E & 3, E >> 2): those two carry 14-bit mantissas, chosen by the encoder as the
+// nearest value with the forced low bits, so the decoder uses all eight int16 as they are.  Decode cost per 16-byte load:
+// 3 VALU for E, one v_ldexp for w * 2^E, 8 v_cvt_f32_i32 (SDWA word select, sign-extending) and 4 v_pk_fma_f32 — against
+// 8 v_fma_mix for fp16 rows.  The gather's result carries the factor 2^15 * s, divided out with the camera count.
+__device__ __forceinline__ void fma8q(float4& acc, float4& acc2, float w, const float4& raw) {
+  typedef float occ_f32x2 __attribute__((ext_vector_type(2)));
+  const occ_u32x4 h = __builtin_bit_cast(occ_u32x4, raw);
+  const unsigned e = (h[0] & 3u) | ((h[0] >> 14) & 12u);
+  const float ws = ldexpf(w, (int)e);
+  const occ_f32x2 ww = {ws, ws};
+  occ_f32x2 a0 = {acc.x, acc.y}, a1 = {acc.z, acc.w}, a2 = {acc2.x, acc2.y}, a3 = {acc2.z, acc2.w};
+  const occ_f32x2 v0 = {(float)(short)(h[0] & 0xffffu), (float)((int)h[0] >> 16)};
+  const occ_f32x2 v1 = {(float)(short)(h[1] & 0xffffu), (float)((int)h[1] >> 16)};
+  const occ_f32x2 v2 = {(float)(short)(h[2] & 0xffffu), (float)((int)h[2] >> 16)};
+  const occ_f32x2 v3 = {(float)(short)(h[3] & 0xffffu), (float)((int)h[3] >> 16)};
+  a0 = __builtin_elementwise_fma(v0, ww, a0);
+  a1 = __builtin_elementwise_fma(v1, ww, a1);
+  a2 = __builtin_elementwise_fma(v2, ww, a2);
+  a3 = __builtin_elementwise_fma(v3, ww, a3);
+  acc = make_float4(a0[0], a0[1], a1[0], a1[1]);
+  acc2 = make_float4(a2[0], a2[1], a3[0], a3[1]);
+}
+
+// q16 ENCODER pieces (the value projection's epilogue and occ_sca_rows_encode_q16 share them; restated in numpy by
+// tests/q16_ref.py).  u = value * s clamped to [-2^15, 2^15] (a NaN becomes 0), m = the piece's max |u|.
+__device__ __forceinline__ float q16_clamp(float u) {
+  u = u == u ? u : 0.f;
+  return fminf(fmaxf(u, -32768.f), 32768.f);
+}
+__device__ __forceinline__ int q16_exponent(float m) {           // E in 0 .. 15: m < 2^E (m = 2^15 itself: E = 15)
+  const int x = m > 0.f ? __builtin_amdgcn_frexp_expf(m) : 0;    // m = f 2^x, f in [0.5, 1)
+  return x < 0 ? 0 : x > 15 ? 15 : x;
+}
+__device__ __forceinline__ int q16_quant(float u, int E) {       // elements 2 .. 7: round to nearest even, |q| <= 32767
+  const int q = (int)rintf(ldexpf(u, 15 - E));
+  return q > 32767 ? 32767 : q < -32767 ? -32767 : q;
+}
+__device__ __forceinline__ int q16_quant_tagged(float u, int E, int r) {   // elements 0, 1: the nearest integer = r (mod 4)
+  const float y = ldexpf(u, 15 - E);
+  const int qf = (int)rintf(y);
+  const int d = (qf - r) & 3;
+  int q = d == 0 ? qf : d == 1 ? qf - 1 : d == 3 ? qf + 1 : (y >= (float)qf ? qf + 2 : qf - 2);
+  q = q > 32767 ? q - 4 : q < -32768 ? q + 4 : q;
+  return q;
+}
+__device__ __forceinline__ unsigned q16_pack2(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+
+template <bool Q>
+__device__ __forceinline__ void fma8x(float4& acc, float4& acc2, float w, const float4& raw) {
+  if (Q) fma8q(acc, acc2, w, raw); else fma8h(acc, acc2, w, raw);
+}
+
+// Gather over 16-bit value rows (fp16, or q16 when Q): a lane's 16 bytes are 8 channels (4 lanes per 64-byte head row).  ROLLING window over NS
 // (compile-time) samples: the 4 corner loads of sample j + DEPTH are requested right after sample j is consumed, so
 // DEPTH * 4 loads stay in flight instead of batches that drain to zero.  The window loop is NOT unrolled (fully unrolled,
 // hipcc hoists the parameter reads of later samples and spills); the weights are read when the sample is consumed (their
 // LDS latency hides under the wait for the rows; held from issue to consumption they cost 16 more live registers).
-template <int NS, int DEPTH_ = 4>
+template <int NS, int DEPTH_ = 4, bool Q = false>
 __device__ __forceinline__ void gather_samples_buf_h(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_off,
                                                      const SampleParamB* sp, float4& acc, float4& acc2) {
   constexpr int DEPTH = NS < DEPTH_ ? NS : DEPTH_;
@@ -301,8 +359,8 @@ __device__ __forceinline__ void gather_samples_buf_h(__amdgpu_buffer_rsrc_t rsrc
     for (int u = 0; u < DEPTH; ++u) {
       const float4 w = *reinterpret_cast<const float4*>(sp[j0 + u].w);
       const occ_u32x4 o = *reinterpret_cast<const occ_u32x4*>(sp[j0 + DEPTH + u].o);
-      fma8h(acc, acc2, w.x, v[u][0]); fma8h(acc, acc2, w.y, v[u][1]);
-      fma8h(acc, acc2, w.z, v[u][2]); fma8h(acc, acc2, w.w, v[u][3]);
+      fma8x<Q>(acc, acc2, w.x, v[u][0]); fma8x<Q>(acc, acc2, w.y, v[u][1]);
+      fma8x<Q>(acc, acc2, w.z, v[u][2]); fma8x<Q>(acc, acc2, w.w, v[u][3]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[u][k] = buf_load16(rsrc, o[k] + lane_off);
     }
@@ -310,8 +368,8 @@ __device__ __forceinline__ void gather_samples_buf_h(__amdgpu_buffer_rsrc_t rsrc
 #pragma unroll
   for (int u = 0; u < DEPTH; ++u) {
     const float4 w = *reinterpret_cast<const float4*>(sp[NS - DEPTH + u].w);
-    fma8h(acc, acc2, w.x, v[u][0]); fma8h(acc, acc2, w.y, v[u][1]);
-    fma8h(acc, acc2, w.z, v[u][2]); fma8h(acc, acc2, w.w, v[u][3]);
+    fma8x<Q>(acc, acc2, w.x, v[u][0]); fma8x<Q>(acc, acc2, w.y, v[u][1]);
+    fma8x<Q>(acc, acc2, w.z, v[u][2]); fma8x<Q>(acc, acc2, w.w, v[u][3]);
   }
 }
 

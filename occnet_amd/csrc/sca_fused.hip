@@ -161,7 +161,7 @@ static int launch_sca(const float* value, const int64_t* shapes, const int64_t* 
 }
 
 // fp16 value rows (see the file header): 4 lanes x 16 B per head row, two sample halves per head, rolling load window
-template <int L, int P, int WPS, int DEPTH>
+template <int L, int P, int WPS, int DEPTH, bool Q>
 __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     const void* __restrict__ value_, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lstart, const float* __restrict__ offs, long offs_stride,
@@ -277,14 +277,15 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     // (round 1 issued a dummy load of row 0 for them: 9 % of the rows through the texture path, and 0 * Inf)
     const __amdgpu_buffer_rsrc_t rsrc =
         uniform_rsrc(value + ((long)b * NC + c) * S * row_stride * EV, (unsigned)S * row_stride * EV);
-    gather_samples_buf_h<LP / 2, DEPTH>(rsrc, (unsigned)(g * 128 + c4 * 16), sp + g * LPp + half * (LP / 2), acc, acc2);
+    gather_samples_buf_h<LP / 2, DEPTH, Q>(rsrc, (unsigned)(g * 128 + c4 * 16), sp + g * LPp + half * (LP / 2), acc, acc2);
     wave_lds_sync();  // WAR: next camera rewrites the LDS slab
     ++n_rows;
   }
 
   // value_scale: the power-of-two range scale s the projection stored the fp16 rows with (value_range.hip); dividing by
   // count * s undoes it exactly
-  const float inv = (float)(count > 0 ? count : 1) * (value_scale != nullptr ? *value_scale : 1.f);
+  // (q16 rows: the mantissas additionally carry 2^15, common.h fma8q)
+  const float inv = (float)(count > 0 ? count : 1) * (value_scale != nullptr ? *value_scale : 1.f) * (Q ? 32768.f : 1.f);
   // the two sample halves of a head sit 32 lanes apart
   acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32);
   acc.w += __shfl_xor(acc.w, 32);
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
   }
 }
 
-template <int L, int P, int WPS = 4, int DEPTH = 2>
+template <int L, int P, bool Q, int WPS = 4, int DEPTH = 2>
 static int launch_sca_h(const void* value, const int64_t* shapes, const int64_t* lstart,
                         const float* offs, long offs_stride, const float* logits, long logits_stride,
                         const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
@@ -314,17 +315,17 @@ static int launch_sca_h(const void* value, const int64_t* shapes, const int64_t*
                         hipStream_t st, const float* value_scale) {
   const long waves = (long)B * Nq;
   const long blocks = (waves + kScaWaves - 1) / kScaWaves;
-  hipLaunchKernelGGL((sca_fused_h_kernel<L, P, WPS, DEPTH>), dim3((unsigned)blocks), dim3(256), 0, st, value,
+  hipLaunchKernelGGL((sca_fused_h_kernel<L, P, WPS, DEPTH, Q>), dim3((unsigned)blocks), dim3(256), 0, st, value,
                      shapes, lstart, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits,
                      order, slots, reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq, value_scale);
-  OCC_CHECK_LAUNCH("sca_fused_forward_f16v");
+  OCC_CHECK_LAUNCH(Q ? "sca_fused_forward_q16v" : "sca_fused_forward_f16v");
   return OCC_OK;
 }
 
 }  // namespace occ
 
 namespace occ {
-static int sca_dispatch(const void* value, bool halfv, const int64_t* spatial_shapes,
+static int sca_dispatch(const void* value, int rowfmt /* 0 f32, 1 f16, 2 q16 */, const int64_t* spatial_shapes,
                         const int64_t* level_start_index, const float* offs, int64_t offs_stride,
                         const float* logits, int64_t logits_stride, const float* ref_cam,
                         const uint32_t* vis_bits, const int32_t* order, float* slots, uint64_t* stats, int B,
@@ -337,7 +338,8 @@ static int sca_dispatch(const void* value, bool halfv, const int64_t* spatial_sh
                 "sca_fused_forward: bad dimension (B=%d NC=%d S=%d Nq=%d Z=%d L=%d P=%d)", B, NC, S,
                 Nq, Z, L, P);
   OCC_CHECK_ARG(P % Z == 0, "sca_fused_forward: num_points(%d) must be a multiple of Z(%d)", P, Z);
-  OCC_CHECK_ARG(!halfv || S % 2 == 0, "sca_fused_forward: fp16 value maps are stored in pixel pairs: S(%d) must be even", S);
+  const bool halfv = rowfmt != 0;
+  OCC_CHECK_ARG(!halfv || S % 2 == 0, "sca_fused_forward: 16-bit value maps are stored in pixel pairs: S(%d) must be even", S);
   OCC_CHECK_ARG(offs_stride >= (int64_t)M * L * P * 2 && logits_stride >= (int64_t)M * L * P,
                 "sca_fused_forward: row strides smaller than a row");
   OCC_CHECK_ARG((long)S * M * D * 4 < (long)kOobOffset, "sca_fused_forward: value batch entry too large");
@@ -350,10 +352,14 @@ static int sca_dispatch(const void* value, bool halfv, const int64_t* spatial_sh
   // through a development switch, since removed: profiles/r03_sca_probe_fp16_rows.txt)
 #define OCC_SCA_CASE(LL, PP)                                                                       \
   if (L == LL && P == PP) {                                                                        \
-    if (halfv)                                                                                     \
-      return launch_sca_h<LL, PP>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits,     \
-                                  (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
-                                  value_scale);                                                                  \
+    if (rowfmt == 2)                                                                               \
+      return launch_sca_h<LL, PP, true>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
+                                        (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
+                                        value_scale);                                                            \
+    if (rowfmt == 1)                                                                               \
+      return launch_sca_h<LL, PP, false>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
+                                         (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
+                                         value_scale);                                                           \
     return launch_sca<LL, PP>(reinterpret_cast<const float*>(value), spatial_shapes, level_start_index, offs,    \
                               (long)offs_stride, logits, (long)logits_stride, ref_cam, vis_bits, order, slots,   \
                               stats, B, NC, S, Z, Nq, st);                                                       \
@@ -375,7 +381,7 @@ extern "C" int occ_sca_fused_forward_f32(const float* value, const int64_t* spat
                                          const uint32_t* vis_bits, const int32_t* order,
                                          float* slots, uint64_t* stats, int B, int NC, int S, int M,
                                          int D, int L, int P, int Z, int Nq, void* stream) {
-  return occ::sca_dispatch(value, false, spatial_shapes, level_start_index, offs, offs_stride, logits, logits_stride,
+  return occ::sca_dispatch(value, 0, spatial_shapes, level_start_index, offs, offs_stride, logits, logits_stride,
                            ref_cam, vis_bits, order, slots, stats, B, NC, S, M, D, L, P, Z, Nq, stream);
 }
 
@@ -387,7 +393,22 @@ extern "C" int occ_sca_fused_forward_f16v(const void* value_f16, const int64_t* 
                                           float* slots, uint64_t* stats, int B, int NC, int S, int M,
                                           int D, int L, int P, int Z, int Nq, const float* value_scale,
                                           void* stream) {
-  return occ::sca_dispatch(value_f16, true, spatial_shapes, level_start_index, offs, offs_stride, logits,
+  return occ::sca_dispatch(value_f16, 1, spatial_shapes, level_start_index, offs, offs_stride, logits,
+                           logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, M, D, L, P, Z, Nq, stream,
+                           value_scale);
+}
+
+// q16 value rows (block floating point, common.h fma8q): same layout, geometry and arguments as the fp16-row entry; value_q16 as
+// written by occ_value_proj_bf16_planes(out_format = 2) / occ_sca_rows_encode_q16, value_scale the plane's range scale.
+extern "C" int occ_sca_fused_forward_q16v(const void* value_q16, const int64_t* spatial_shapes,
+                                          const int64_t* level_start_index, const float* offs,
+                                          int64_t offs_stride, const float* logits,
+                                          int64_t logits_stride, const float* ref_cam,
+                                          const uint32_t* vis_bits, const int32_t* order,
+                                          float* slots, uint64_t* stats, int B, int NC, int S, int M,
+                                          int D, int L, int P, int Z, int Nq, const float* value_scale,
+                                          void* stream) {
+  return occ::sca_dispatch(value_q16, 2, spatial_shapes, level_start_index, offs, offs_stride, logits,
                            logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, M, D, L, P, Z, Nq, stream,
                            value_scale);
 }

@@ -240,7 +240,9 @@ constexpr int kVprTileBytes = kVprRows * kVprK * 2;
 constexpr int kVprLdsBytes = kVprTileBytes + 4 * kVprScratch;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <bool OUTH>
+// OFMT: 0 = fp32 rows, 1 = fp16 pixel pairs, 2 = q16 pixel pairs (block floating point, common.h: 16 bits per element, one
+// 4-bit exponent per 16-byte piece of 8 channels)
+template <int OFMT>
 __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
     VpSegments seg, const uint4* __restrict__ wp, int bias_groups, void* __restrict__ out_, long ldo, int N,
     long out_group_rows, int plane_cols, long plane_stride, const float* __restrict__ out_scale) {
@@ -372,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
     }
 
     // ---- epilogue of the pass: CPR columns of a 32-row tile at a time through the wave's scratch (row pitch 80 B) ------
+    constexpr bool OUTH = OFMT != 0;
     constexpr int EB = OUTH ? 2 : 4, CPR = OUTH ? 32 : 16;      // bytes / element, columns per round (64-byte row segments)
     int elane = lane;                               // opaque per pass: the store offsets are recomputed here instead of
     asm volatile("" : "+v"(elane));                 // living (spilled) across the k loop
@@ -386,7 +389,22 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
       for (int t = 0; t < 2; ++t) {
 #pragma unroll
         for (int rd = 0; rd < 32 / CPR; ++rd) {
-          if (OUTH) {
+          if (OFMT == 2) {
+            // q16: the 8 channels of a 16-byte piece are this lane's 4 (kb = 0: elements 0-3) and lane + 32's 4 (elements 4-7);
+            // they agree on the piece's exponent through one cross-lane maximum; elements 0 and 1 carry it in their low bits
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float u0 = q16_clamp(acc[rt][t][4 * q + 0] * osc), u1 = q16_clamp(acc[rt][t][4 * q + 1] * osc);
+              const float u2 = q16_clamp(acc[rt][t][4 * q + 2] * osc), u3 = q16_clamp(acc[rt][t][4 * q + 3] * osc);
+              float m = fmaxf(fmaxf(fabsf(u0), fabsf(u1)), fmaxf(fabsf(u2), fabsf(u3)));
+              m = fmaxf(m, __shfl_xor(m, 32));
+              const int E = q16_exponent(m);
+              const int q0 = kb == 0 ? q16_quant_tagged(u0, E, E & 3) : q16_quant(u0, E);
+              const int q1 = kb == 0 ? q16_quant_tagged(u1, E, E >> 2) : q16_quant(u1, E);
+              *reinterpret_cast<uint2*>(scratch + vi * kVprPitch + 16 * q + 8 * kb) =
+                  make_uint2(q16_pack2(q0, q1), q16_pack2(q16_quant(u2, E), q16_quant(u3, E)));
+            }
+          } else if (OUTH) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               *reinterpret_cast<uint2*>(scratch + vi * kVprPitch + 16 * q + 8 * kb) =
@@ -437,8 +455,10 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
                                   const int64_t* rows, const int64_t* rows_per_group,
                                   const int64_t* out_row0, const float* const* group_bias,
                                   int bias_groups, const void* weight_packed, void* out, int64_t ldo,
-                                  int K, int N, int64_t out_group_rows, bool out_f16, void* stream,
-                                  int plane_cols = 0, int64_t plane_stride = 0, const float* out_scale = nullptr) {
+                                  int K, int N, int64_t out_group_rows, int out_fmt /* 0 f32, 1 f16 pairs, 2 q16 pairs */,
+                                  void* stream, int plane_cols = 0, int64_t plane_stride = 0,
+                                  const float* out_scale = nullptr) {
+  const bool out_f16 = out_fmt != 0;        // 16-bit elements in the pixel-pair layout
   using namespace occ;
   OCC_CHECK_ARG(a && lda && rows && rows_per_group && out_row0 && weight_packed && out,
                 "value_proj_bf16: null pointer argument");
@@ -501,13 +521,19 @@ static int value_proj_bf16_launch(int n_segments, const void* const* a, const in
                            (long)out_group_rows, plane_cols, (long)plane_stride, out_scale);
       return e;
     };
-    const hipError_t e = out_f16 ? launch(value_proj_resident_kernel<true>) : launch(value_proj_resident_kernel<false>);
+    const hipError_t e = out_fmt == 2 ? launch(value_proj_resident_kernel<2>)
+                         : out_fmt == 1 ? launch(value_proj_resident_kernel<1>) : launch(value_proj_resident_kernel<0>);
     if (e != hipSuccess) {
       set_error("value_proj_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return OCC_E_LAUNCH;
     }
     OCC_CHECK_LAUNCH("value_proj_bf16");
     return OCC_OK;
+  }
+  if (out_fmt == 2) {
+    set_error("value_proj_bf16: q16 output exists on the activation-resident kernel only (K = 256, N %% 256 == 0, groups of >= "
+              "128 rows): project to fp32 and encode with occ_sca_rows_encode_q16");
+    return OCC_E_UNSUPPORTED;
   }
   // stacked projections (planes): the column blocks of a row block are dealt to one XCD (see the kernel)
   const bool walk = plane_stride != 0 && plane_cols % 256 == 0;
@@ -535,7 +561,7 @@ extern "C" int occ_value_proj_bf16_f32(int n_segments, const void* const* a, con
                                        int bias_groups, const void* weight_packed, float* out, int64_t ldo,
                                        int K, int N, int64_t out_group_rows, void* stream) {
   return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
-                                weight_packed, out, ldo, K, N, out_group_rows, false, stream);
+                                weight_packed, out, ldo, K, N, out_group_rows, 0, stream);
 }
 
 // same, output written as fp16 IN THE PIXEL-PAIR ORDER of occ_sca_fused_forward_f16v (ldo in fp16 elements); the symbol was
@@ -547,7 +573,18 @@ extern "C" int occ_value_proj_bf16_f16pairs(int n_segments, const void* const* a
                                        int bias_groups, const void* weight_packed, void* out, int64_t ldo,
                                        int K, int N, int64_t out_group_rows, const float* out_scale, void* stream) {
   return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
-                                weight_packed, out, ldo, K, N, out_group_rows, true, stream, 0, 0, out_scale);
+                                weight_packed, out, ldo, K, N, out_group_rows, 1, stream, 0, 0, out_scale);
+}
+
+// same, output as q16 pixel pairs (block floating point: common.h); OCC_E_UNSUPPORTED where only the tiled kernel applies
+// (the caller projects to fp32 and encodes with occ_sca_rows_encode_q16)
+extern "C" int occ_value_proj_bf16_q16pairs(int n_segments, const void* const* a, const int64_t* lda,
+                                       const int64_t* rows, const int64_t* rows_per_group,
+                                       const int64_t* out_row0, const float* const* group_bias,
+                                       int bias_groups, const void* weight_packed, void* out, int64_t ldo,
+                                       int K, int N, int64_t out_group_rows, const float* out_scale, void* stream) {
+  return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
+                                weight_packed, out, ldo, K, N, out_group_rows, 2, stream, 0, 0, out_scale);
 }
 
 // Several projections of the SAME rows in one launch (the four encoder layers' SCA value projections depend on the
@@ -568,6 +605,62 @@ extern "C" int occ_value_proj_bf16_planes(int n_segments, const void* const* a, 
     return OCC_E_UNSUPPORTED;
   }
   return value_proj_bf16_launch(n_segments, a, lda, rows, rows_per_group, out_row0, group_bias, bias_groups,
-                                weight_packed, out, ldo, K, n_planes * plane_cols, out_group_rows, out_f16 != 0, stream,
-                                plane_cols, plane_stride, out_scale);
+                                weight_packed, out, ldo, K, n_planes * plane_cols, out_group_rows,
+                                out_f16 == 2 ? 2 : out_f16 != 0 ? 1 : 0, stream, plane_cols, plane_stride, out_scale);
+}
+
+// fp32 value rows -> q16 pixel pairs (block floating point: common.h fma8q / q16_*), the operand of occ_sca_fused_forward_q16v,
+// for value maps that were projected in fp32 (feature inputs other than the backbone's bf16 NHWC maps; shapes the resident
+// projection does not cover).  v: (groups, S, C) fp32 contiguous, C = heads * 32; out: (groups, S + (S & 1), C) int16 in the
+// pair order [group][pix >> 1][head][pix & 1][32] (the pad row of an odd S is not written); scale: one DEVICE float s (a power
+// of two with max|v| * s <= 2^15 — ext.f16_range_scaled's rule), NULL = 1.
+namespace occ {
+__global__ __launch_bounds__(256) void sca_rows_encode_q16_kernel(const float* __restrict__ v, uint4* __restrict__ out,
+                                                                  const float* __restrict__ scale, long groups, int S,
+                                                                  int C) {
+  const int pieces = C / 8;
+  const long n = groups * S * pieces;
+  const float s = scale != nullptr ? *scale : 1.f;
+  const int Sp = S + (S & 1);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int pc = (int)(i % pieces);
+    const long row = i / pieces;
+    const int pix = (int)(row % S);
+    const long g = row / S;
+    const float4 a = *reinterpret_cast<const float4*>(v + row * C + pc * 8);
+    const float4 b = *reinterpret_cast<const float4*>(v + row * C + pc * 8 + 4);
+    const float u[8] = {q16_clamp(a.x * s), q16_clamp(a.y * s), q16_clamp(a.z * s), q16_clamp(a.w * s),
+                        q16_clamp(b.x * s), q16_clamp(b.y * s), q16_clamp(b.z * s), q16_clamp(b.w * s)};
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(u[j]));
+    const int E = q16_exponent(m);
+    uint4 o;
+    o.x = q16_pack2(q16_quant_tagged(u[0], E, E & 3), q16_quant_tagged(u[1], E, E >> 2));
+    o.y = q16_pack2(q16_quant(u[2], E), q16_quant(u[3], E));
+    o.z = q16_pack2(q16_quant(u[4], E), q16_quant(u[5], E));
+    o.w = q16_pack2(q16_quant(u[6], E), q16_quant(u[7], E));
+    const int head = pc >> 2, piece = pc & 3;
+    // 16-byte units: a pixel pair holds C / 32 heads x 8 units (2 pixels x 4 pieces)
+    out[((g * (Sp / 2) + (pix >> 1)) * (C / 32) + head) * 8 + (pix & 1) * 4 + piece] = o;
+  }
+}
+}  // namespace occ
+
+extern "C" int occ_sca_rows_encode_q16(const float* v, void* out, const float* scale, int64_t groups, int S, int C,
+                                       void* stream) {
+  using namespace occ;
+  OCC_CHECK_ARG(v && out, "sca_rows_encode_q16: null pointer argument");
+  OCC_CHECK_ARG(groups > 0 && S > 0 && C > 0, "sca_rows_encode_q16: bad dimension");
+  if (C % 32) {
+    set_error("sca_rows_encode_q16: C=%d is not a multiple of 32 (whole heads)", C);
+    return OCC_E_UNSUPPORTED;
+  }
+  const long n = groups * S * (C / 8);
+  long blocks = (n + 255) / 256;
+  blocks = blocks > 8192 ? 8192 : blocks;
+  hipLaunchKernelGGL(sca_rows_encode_q16_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), v,
+                     reinterpret_cast<uint4*>(out), scale, (long)groups, S, C);
+  OCC_CHECK_LAUNCH("sca_rows_encode_q16");
+  return OCC_OK;
 }

@@ -168,18 +168,32 @@ def point_sampling(ref_3d, lidar2img, ego2lidar, pc_range, img_h, img_w):
 
 # Storage type of the projected value maps the fused SCA gather reads: 'f16' (default for the fused inference path: one
 # head row of a pixel = 64 bytes = 4 lanes x 16 bytes, so a wave load fetches 16 rows instead of 8 — csrc/sca_fused.hip)
-# or 'f32' (OCC_SCA_VALUES=f32: the round-1/2 kernel, 8 lanes per 128-byte row).  Sampling arithmetic, attention weights
-# and accumulation are fp32 in both.
+# or 'f32' (OCC_SCA_VALUES=f32: the round-1/2 kernel, 8 lanes per 128-byte row), or 'q16' (round 6: block floating point —
+# the fp16 rows' geometry and byte count, int16 mantissas sharing one 4-bit exponent per 16-byte piece of 8 channels: the
+# largest element of a piece is rounded to 2^-16 relative instead of fp16's 2^-12; csrc/common.h fma8q).  Sampling arithmetic,
+# attention weights and accumulation are fp32 in all three.
 SCA_VALUES = os.environ.get("OCC_SCA_VALUES", "f16")
+if SCA_VALUES not in ("f16", "f32", "q16"):
+    raise OccAmdError(f"OCC_SCA_VALUES={SCA_VALUES!r}: expected f16, f32 or q16")
+
+
+def sca_rows_16bit():
+    """True when the fused gather's value maps are 16-bit rows in the pixel-pair layout with a range scale (f16, q16)."""
+    return SCA_VALUES in ("f16", "q16")
+
+
+def sca_rows_dtype():
+    return {"f16": torch.float16, "q16": torch.int16, "f32": torch.float32}[SCA_VALUES]
 
 
 def sca_variant_name():
-    return ("sca_fused_h_kernel<4,8> (query-major, fp16 value rows)" if SCA_VALUES == "f16"
-            else "sca_fused_kernel<4,8> (query-major, fp32 value rows)")
+    return {"f16": "sca_fused_h_kernel<4,8> (query-major, fp16 value rows)",
+            "q16": "sca_fused_h_kernel<4,8,Q> (query-major, q16 block-floating-point value rows)",
+            "f32": "sca_fused_kernel<4,8> (query-major, fp32 value rows)"}[SCA_VALUES]
 
 
 def sca_value_bytes():
-    return 2 if SCA_VALUES == "f16" else 4
+    return 2 if sca_rows_16bit() else 4
 
 
 def sca_pair_layout(value):
@@ -211,10 +225,13 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
     fp16 tensor first (a copy: tests and the fp32-projection path only).
     value_scale (fp16 maps only): 1-element float32 device tensor s, a power of two — the maps hold s * value
     (value_range_scale / f16_range_scaled), the kernel divides its fp32 sums by count * s: the same result, whatever s."""
-    half = value.dtype == torch.float16
+    q16 = value.dtype == torch.int16
+    half = value.dtype == torch.float16 or q16
+    if q16 and value_layout != "pairs":
+        raise OccAmdError("sca_fused_forward: q16 value maps exist in the pixel-pair layout only (sca_rows_encode_q16)")
     if value_scale is not None:
         if not half:
-            raise OccAmdError("sca_fused_forward: value_scale goes with fp16 value maps")
+            raise OccAmdError("sca_fused_forward: value_scale goes with 16-bit value maps")
         if not (value_scale.is_cuda and value_scale.dtype == torch.float32 and value_scale.numel() == 1
                 and value_scale.device == value.device):
             raise OccAmdError("sca_fused_forward: value_scale must be a 1-element float32 tensor on the value's device")
@@ -248,7 +265,8 @@ def sca_fused_forward(value, spatial_shapes, level_start_index, offs, logits, re
     if order is not None and (order.dtype != torch.int32 or order.numel() != Nq):
         raise OccAmdError("sca_fused_forward: order must be int32 (Nq)")
     slots = torch.empty((B, Nq, M * D), dtype=torch.float32, device=value.device)
-    fn = _lib.lib().occ_sca_fused_forward_f16v if half else _lib.lib().occ_sca_fused_forward_f32
+    fn = (_lib.lib().occ_sca_fused_forward_q16v if q16 else _lib.lib().occ_sca_fused_forward_f16v if half
+          else _lib.lib().occ_sca_fused_forward_f32)
     tail = (ptr(value_scale), stream_ptr(value.device)) if half else (stream_ptr(value.device),)
     with torch.cuda.device(value.device), _timed('sca_fused_forward'):
         rc = fn(ptr(value), ptr(spatial_shapes), ptr(level_start_index), ptr(offs), i64(offs.stride(1)), ptr(logits),
@@ -597,6 +615,32 @@ def f16_range_scaled(v):
     return (v * s).clamp(-65504.0, 65504.0).half(), s.reshape(1)
 
 
+def sca_rows_encode_q16(v, scale=None):
+    """fp32 value rows (BN, S, C) [or (BN, S, M, D)], C = heads * 32 -> q16 pixel pairs: int16 (BN, S + (S & 1), C) in the fused
+    gather's pair order, each 16-byte piece of 8 channels holding int16 mantissas of scale * v under one 4-bit exponent
+    (csrc/common.h; numpy restatement: tests/q16_ref.py).  scale: 1-element float32 device tensor, a power of two with
+    max|v| * scale <= 2^15 (q16_range_scaled derives it), None = 1."""
+    _need_cuda_f32("v", v)
+    BN, S = v.shape[0], v.shape[1]
+    C = v.numel() // (BN * S)
+    out = torch.empty((BN, S + (S & 1), C), dtype=torch.int16, device=v.device)
+    if S & 1:
+        out[:, S:].zero_()                       # the pad row: never sampled, kept defined
+    with torch.cuda.device(v.device):
+        rc = _lib.lib().occ_sca_rows_encode_q16(ptr(v), ptr(out), ptr(scale), i64(BN), i32(S), i32(C), stream_ptr(v.device))
+    _lib.check(rc, "sca_rows_encode_q16")
+    return out
+
+
+def q16_range_scaled(v):
+    """fp32 value rows -> (q16 pixel pairs, s): the q16 counterpart of f16_range_scaled (same power-of-two rule for s)."""
+    amax = v.detach().abs().amax().float()
+    _, e = torch.frexp(amax)
+    ok = torch.isfinite(amax) & (amax > 0)
+    s = torch.where(ok, torch.ldexp(torch.ones_like(amax), (15 - e).clamp(-100, 100)), torch.ones_like(amax)).reshape(1)
+    return sca_rows_encode_q16(v.contiguous(), s), s
+
+
 def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_rows, out_row0, out_scale=None):
     """For every segment s (FPN level) and row m = g*rows_per_group[s] + i of a_list[s]:
         out[g*out_group_rows + out_row0[s] + i] = a_list[s][m] @ weight.T + group_bias[s][g % G]   (fp32 out),
@@ -611,7 +655,8 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
         if group_bias is not None:
             group_bias = group_bias.unsqueeze(0)
     S = len(a_list)
-    out_half = out.dtype == torch.float16
+    out_q16 = out.dtype == torch.int16
+    out_half = out.dtype == torch.float16 or out_q16
     if not out_half:
         _need_cuda_f32("out", out)
     if not out.is_cuda or out.dim() != 2 or out.stride(1) != 1:
@@ -642,7 +687,8 @@ def value_proj_bf16(a_list, weight, group_bias, out, rows_per_group, out_group_r
     packed = linear_pack_weight_bf16x3(weight)
     arr64 = lambda v: (ctypes.c_int64 * S)(*[int(x) for x in v])
     a_ptrs = (ctypes.c_void_p * S)(*[a.data_ptr() for a in a_list])
-    fn = _lib.lib().occ_value_proj_bf16_f16pairs if out_half else _lib.lib().occ_value_proj_bf16_f32
+    fn = (_lib.lib().occ_value_proj_bf16_q16pairs if out_q16 else _lib.lib().occ_value_proj_bf16_f16pairs if out_half
+          else _lib.lib().occ_value_proj_bf16_f32)
     tail = (ptr(out_scale), stream_ptr(out.device)) if out_half else (stream_ptr(out.device),)
     with torch.cuda.device(out.device), _timed('value_proj'):
         rc = fn(
@@ -682,10 +728,11 @@ def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, o
     N, K = weights[0].shape
     if any(tuple(w.shape) != (N, K) for w in weights) or N % 256:
         raise OccAmdUnsupported("value_proj_bf16_planes: equal (N, K) weights with N % 256 == 0 needed")
-    out_half = out.dtype == torch.float16
+    out_q16 = out.dtype == torch.int16
+    out_half = out.dtype == torch.float16 or out_q16
     if not (out.is_cuda and out.dim() == 3 and out.shape[0] == P and out.shape[2] == N and out.is_contiguous()
             and (out_half or out.dtype == torch.float32)):
-        raise OccAmdError("value_proj_bf16_planes: out must be a contiguous (P, rows, N) fp32 / fp16 device tensor")
+        raise OccAmdError("value_proj_bf16_planes: out must be a contiguous (P, rows, N) fp32 / fp16 / int16 (q16) device tensor")
     for a, rpg, r0 in zip(a_list, rows_per_group, out_row0):
         if not (a.is_cuda and a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1 and a.shape[1] == K):
             raise OccAmdUnsupported("value_proj_bf16_planes: every a must be a (M, K) bfloat16 device matrix with unit "
@@ -713,7 +760,8 @@ def value_proj_bf16_planes(a_list, weights, group_biases, out, rows_per_group, o
     with torch.cuda.device(out.device), _timed('value_proj'):
         rc = _lib.lib().occ_value_proj_bf16_planes(
             i32(S), a_ptrs, arr64([a.stride(0) for a in a_list]), arr64([a.shape[0] for a in a_list]),
-            arr64(rows_per_group), arr64(out_row0), gb_ptrs, i32(G), ptr(hit[1]), ptr(out), i32(1 if out_half else 0),
+            arr64(rows_per_group), arr64(out_row0), gb_ptrs, i32(G), ptr(hit[1]), ptr(out),
+            i32(2 if out_q16 else 1 if out_half else 0),
             i64(N), i32(K), i32(P), i32(N), i64(out.stride(0)), i64(out_group_rows), ptr(out_scale),
             stream_ptr(out.device))
     _lib.check(rc, "value_proj_bf16_planes")

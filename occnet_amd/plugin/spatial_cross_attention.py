@@ -258,13 +258,16 @@ class SpatialCrossAttention(BaseModule):
             bs = value.bs
             v = value.project(da.value_proj)
             vscale = value.value_scale(da.value_proj)                   # fp16 rows: the plane's range scale (exact)
-            layout = "pairs" if v.dtype == torch.float16 else "rows"    # the projection's fp16 epilogue writes pairs
+            layout = "pairs" if v.dtype in (torch.float16, torch.int16) else "rows"    # the 16-bit epilogues write pairs
         else:
             num_cams, l, bs, _ = value.shape
             v = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
             v = ext.linear(v, da.value_proj.weight, da.value_proj.bias)
             if ext.SCA_VALUES == "f16":
                 v, vscale = ext.f16_range_scaled(v)                     # power-of-two scale: no fp16 saturation
+            elif ext.SCA_VALUES == "q16":
+                v, vscale = ext.q16_range_scaled(v)                     # block floating point, pixel-pair order
+                layout = "pairs"
         v = v.view(bs * self.num_cams, v.shape[1], da.num_heads, -1)
         n_off = da.sampling_offsets.out_features
         if vis_bits is None:

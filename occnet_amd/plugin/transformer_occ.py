@@ -214,7 +214,7 @@ class LazyFeatures:
     def _scales(self, value_projs, gbs):
         """The planes' range scales for THIS call's maps, or None (fp32 rows): from the producer's maximum when the maps carry
         one (a 64-thread launch), otherwise measured over the maps (ext.value_range_scale: one pass, 52 us at the base config)."""
-        if ext.SCA_VALUES != "f16":
+        if not ext.sca_rows_16bit():
             return None
         terms = [self._range_terms(vp, gb) for vp, gb in zip(value_projs, gbs)]
         # the stacked (2, P) term vectors are a constant of the weight state too: cached on the first projection (the entry
@@ -262,12 +262,12 @@ class LazyFeatures:
     def group_rows(self):
         """rows of one camera's block in the projected maps: fp16 maps are stored in pixel PAIRS (ext.sca_pair_layout),
         so an odd pixel count is padded by one (never written, never read: no sampling corner maps to it)"""
-        return self.total + (self.total & 1) if ext.SCA_VALUES == "f16" else self.total
+        return self.total + (self.total & 1) if ext.sca_rows_16bit() else self.total
 
     def _alloc(self, n, planes=None):
         rows = self.bs * self.num_cam * self.group_rows
         return torch.empty((rows, n) if planes is None else (planes, rows, n), device=self.rows[0].device,
-                           dtype=torch.float16 if ext.SCA_VALUES == "f16" else torch.float32)
+                           dtype=ext.sca_rows_dtype())
 
     def _launch(self, value_proj, gb, scale="measure"):
         """One projection on the current stream.  scale: its range scale (1-element device tensor), None (fp32 rows), or
@@ -280,8 +280,16 @@ class LazyFeatures:
                 self._scale_of = {}
             self._scale_of[id(value_proj)] = scale
         out = self._alloc(n)
-        ext.value_proj_bf16(self.rows, w, gb, out, rows_per_group=[h * wd for h, wd in self.hw],
-                            out_group_rows=self.group_rows, out_row0=self.starts, out_scale=scale)
+        kw = dict(rows_per_group=[h * wd for h, wd in self.hw], out_row0=self.starts)
+        try:
+            ext.value_proj_bf16(self.rows, w, gb, out, out_group_rows=self.group_rows, out_scale=scale, **kw)
+        except ext.OccAmdUnsupported:
+            if out.dtype != torch.int16:
+                raise
+            # q16 rows exist on the activation-resident projection only: other shapes project to fp32 rows and encode
+            tmp = torch.empty((self.bs * self.num_cam * self.total, n), dtype=torch.float32, device=out.device)
+            ext.value_proj_bf16(self.rows, w, gb, tmp, out_group_rows=self.total, **kw)
+            out = ext.sca_rows_encode_q16(tmp.view(self.bs * self.num_cam, self.total, n), scale).view(-1, n)
         return out.view(self.bs * self.num_cam, self.group_rows, n)
 
     def project(self, value_proj):

@@ -222,9 +222,9 @@ _SCA_SHAPES = {
 
 
 @pytest.mark.parametrize("shape", sorted(_SCA_SHAPES))
-@pytest.mark.parametrize("values", ["f32", "f16"])
+@pytest.mark.parametrize("values", ["f32", "f16", "q16"])
 def test_sca_gather_kernels_match_oracle(values, shape, monkeypatch):
-    """Both SCA gather kernels (fp32 value rows: sca_fused_kernel; fp16 value rows, the default: sca_fused_h_kernel)
+    """The SCA gather kernels (fp32 value rows: sca_fused_kernel; fp16 rows and q16 block-floating-point rows: sca_fused_h_kernel)
     on every (levels, points, z-anchors) combination with a fused kernel, batch 2 (the reference takes the camera
     lists of batch element 0 for every element, spatial_cross_attention.py:138-140), ragged tail (Nq = 1 444 is not
     a multiple of the 4 queries of a block), vs the oracle head."""
@@ -241,7 +241,8 @@ def test_sca_gather_kernels_match_oracle(values, shape, monkeypatch):
     with torch.no_grad():
         out_o = ora(feats, metas, only_bev=True)
         out_p = prod([f.cuda() for f in feats], metas, only_bev=True)
-    assert calls and all(c == (torch.float16 if values == "f16" else torch.float32) for c in calls), calls
+    want_dtype = {"f16": torch.float16, "q16": torch.int16, "f32": torch.float32}[values]
+    assert calls and all(c == want_dtype for c in calls), calls
     d = maxdiff(out_p, out_o)
     print(f"kernel {kernel} {shape}: bev max|hip - oracle| = {d:.3e}")
     assert d < TOL
@@ -302,11 +303,15 @@ def test_sca_fp16_values_vs_fp32_values(feat_format, monkeypatch):
         exact = prod([dev(f) for f in feats], metas)
         monkeypatch.setattr(ext, "SCA_VALUES", "f16")
         half = prod([dev(f) for f in feats], metas)
+        monkeypatch.setattr(ext, "SCA_VALUES", "q16")
+        q16 = prod([dev(f) for f in feats], metas)
     for k in ('bev_embed', 'occ', 'flow'):
-        d_exact, d_half = maxdiff(exact[k], out_o[k]), maxdiff(half[k], out_o[k])
-        print(f"{feat_format} {k}: fp32 values {d_exact:.3e}, fp16 values {d_half:.3e} vs oracle")
-        assert d_exact < TOL and d_half < TOL
-        assert maxdiff(half[k], exact[k]) > 0.0            # two different kernels really ran
+        d_exact, d_half, d_q = maxdiff(exact[k], out_o[k]), maxdiff(half[k], out_o[k]), maxdiff(q16[k], out_o[k])
+        print(f"{feat_format} {k}: fp32 values {d_exact:.3e}, fp16 values {d_half:.3e}, q16 values {d_q:.3e} vs oracle; "
+              f"q16 vs fp32 rows {maxdiff(q16[k], exact[k]):.3e}, fp16 vs fp32 rows {maxdiff(half[k], exact[k]):.3e}")
+        assert d_exact < TOL and d_half < TOL and d_q < TOL
+        assert maxdiff(half[k], exact[k]) > 0.0            # different kernels really ran
+        assert maxdiff(q16[k], exact[k]) > 0.0 and maxdiff(q16[k], exact[k]) < maxdiff(half[k], exact[k])
 
 
 def test_fp16_value_kernels_in_isolation():

@@ -148,7 +148,7 @@ def test_gather_under_the_range_scale_is_exact(k):
 F16_ROWS_ENVELOPE = 2e-3
 
 
-@pytest.mark.parametrize("rows", ["f16", "f32"])
+@pytest.mark.parametrize("rows", ["f16", "f32", "q16"])
 @pytest.mark.parametrize("amp", [1.0, 1e3, 1e5, 1e7])
 def test_head_parity_and_range_over_feature_scales(amp, rows, monkeypatch):
     """bf16 NHWC maps scaled by amp (projected |v| ~ 6 amp: past the fp16 limit from 1e5 on) through
@@ -196,13 +196,16 @@ def test_head_parity_and_range_over_feature_scales(amp, rows, monkeypatch):
                     vmax = max(vmax, top / float(s[p]))
             if amp >= 1e5:
                 assert vmax > 65504                    # these planes would not have fitted fp16 unscaled
+        elif rows == "q16":
+            assert all(o.dtype == torch.int16 and s is not None for o, s in seen)
         else:
             assert all(o.dtype == torch.float32 and s is None for o, s in seen)
         del seen[:]
         prod.transformer.use_lazy_features = False
         out_f = prod([nhwc(f) for f in feats], metas, prev_bev=None)          # flatten path (fp16: ext.f16_range_scaled)
     assert not seen
-    bound = TOL if (rows == "f32" or amp == 1.0) else F16_ROWS_ENVELOPE
+    # q16 rows (round 6): inside the path's 1e-3 bound at EVERY feature scale, with margin
+    bound = TOL if (rows == "f32" or amp == 1.0) else 6e-4 if rows == "q16" else F16_ROWS_ENVELOPE
     for k in ('bev_embed', 'occ', 'flow'):
         d, d2 = maxdiff(out_p[k], out_o[k]), maxdiff(out_f[k], out_o[k])
         print(f"{rows} rows, amp {amp:g} (max|v| {vmax:.3g}) {k}: lazy path vs oracle {d:.3e}, flatten path vs oracle {d2:.3e} "

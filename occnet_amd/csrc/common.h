@@ -283,11 +283,12 @@ __device__ __forceinline__ void fma8h(float4& acc, float4& acc2, float w, const 
 //     value_j * s = q_j * 2^(E - 15)          (s = the plane's power-of-two range scale, |value * s| <= 2^15: value_range.hip)
 // E is the binary exponent of the piece's largest |value * s| (clamped to 0 .. 15), so the largest element uses all 15
 // magnitude bits: its rounding error is 2^-16 relative against fp16's 2^-12 — and EVERY element of the piece is rounded to that
-// same absolute step, which is what the weighted sums downstream see (their error is set by the large terms).  E lives in
+// same absolute step, which is what the weighted sums downstream see (their error is set by the large terms).  (The stored
+// rows carry s / 2, not s: a binade of headroom for the encoder, see below.)  E lives in
 // the two low bits of elements 0 and 1 (E & 3, E >> 2): those two carry 14-bit mantissas, chosen by the encoder as the
 // nearest value with the forced low bits, so the decoder uses all eight int16 as they are.  Decode cost per 16-byte load:
 // 3 VALU for E, one v_ldexp for w * 2^E, 8 v_cvt_f32_i32 (SDWA word select, sign-extending) and 4 v_pk_fma_f32 — against
-// 8 v_fma_mix for fp16 rows.  The gather's result carries the factor 2^15 * s, divided out with the camera count.
+// 8 v_fma_mix for fp16 rows.  The gather's result carries the factor 2^15 * s / 2, divided out with the camera count.
 __device__ __forceinline__ void fma8q(float4& acc, float4& acc2, float w, const float4& raw) {
   typedef float occ_f32x2 __attribute__((ext_vector_type(2)));
   const occ_u32x4 h = __builtin_bit_cast(occ_u32x4, raw);
@@ -307,29 +308,33 @@ __device__ __forceinline__ void fma8q(float4& acc, float4& acc2, float w, const 
   acc2 = make_float4(a2[0], a2[1], a3[0], a3[1]);
 }
 
-// q16 ENCODER pieces (the value projection's epilogue and occ_sca_rows_encode_q16 share them; restated in numpy by
-// tests/q16_ref.py).  u = value * s clamped to [-2^15, 2^15] (a NaN becomes 0), m = the piece's max |u|.
-__device__ __forceinline__ float q16_clamp(float u) {
-  u = u == u ? u : 0.f;
-  return fminf(fmaxf(u, -32768.f), 32768.f);
+// q16 ENCODER (the value projection's epilogue and occ_sca_rows_encode_q16; restated in numpy by tests/q16_ref.py).  The rows
+// are stored under s' = s / 2 (s = the plane's range scale, |value * s| <= 2^15: one binade of headroom, so no mantissa can
+// reach +-2^15 and the encoder needs no clamp); eosc = log2(s').  For a GROUP of channels sharing one exponent (a 16-byte
+// piece of 8, or a whole 64-byte head row of 32: a coarser group is a valid, slightly less precise encoding — the decoder
+// reads E per piece either way) with largest magnitude m:
+//     E = clip(frexp_exp(m * (1 + 2^-12)) + eosc, 0, 15)   (m = 0: E = 0),        f = 2^(eosc + 15 - E),
+//     elements 2 .. 7 of a piece:  q = rne(v * f);      elements 0, 1:  q = 4 * rne(v * f / 4 - r / 4) + r,  r = E & 3, E >> 2
+// rne by the magic-number add (x + 1.5 * 2^23 leaves rne(x) in the low mantissa bits: the low 16 bits ARE the two's
+// complement mantissa); the 2^-12 margin keeps |v * f| <= 32 760, so the tagged elements stay inside int16 as well.
+// Non-finite inputs have no q16 image: they encode to unspecified FINITE mantissas (the fp16 rows clamp them).
+constexpr float kQ16Magic = 12582912.f;
+__device__ __forceinline__ int q16_group_exponent(float m, int eosc) {
+  const int x = __builtin_amdgcn_frexp_expf(m * 1.000244140625f) + eosc;
+  const int E = x < 0 ? 0 : x > 15 ? 15 : x;
+  return m > 0.f ? E : 0;
 }
-__device__ __forceinline__ int q16_exponent(float m) {           // E in 0 .. 15: m < 2^E (m = 2^15 itself: E = 15)
-  const int x = m > 0.f ? __builtin_amdgcn_frexp_expf(m) : 0;    // m = f 2^x, f in [0.5, 1)
-  return x < 0 ? 0 : x > 15 ? 15 : x;
+__device__ __forceinline__ unsigned q16_rne_bits(float y) { return __float_as_uint(y + kQ16Magic); }
+// the mantissa words of one piece's elements (j, j + 1): regular, or tagged with (r0, r1) when sh == 2 (sh == 0: r = 0, fS = f)
+__device__ __forceinline__ unsigned q16_pack_lo16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }
+__device__ __forceinline__ unsigned q16_pair(float v0, float v1, float f) {
+  return q16_pack_lo16(q16_rne_bits(v0 * f), q16_rne_bits(v1 * f));
 }
-__device__ __forceinline__ int q16_quant(float u, int E) {       // elements 2 .. 7: round to nearest even, |q| <= 32767
-  const int q = (int)rintf(ldexpf(u, 15 - E));
-  return q > 32767 ? 32767 : q < -32767 ? -32767 : q;
+__device__ __forceinline__ unsigned q16_pair_tagged(float v0, float v1, float fS, float c0, float c1, int r0, int r1, int sh) {
+  const unsigned q0 = (q16_rne_bits(fmaf(v0, fS, c0)) << sh) + (unsigned)r0;
+  const unsigned q1 = (q16_rne_bits(fmaf(v1, fS, c1)) << sh) + (unsigned)r1;
+  return q16_pack_lo16(q0, q1);
 }
-__device__ __forceinline__ int q16_quant_tagged(float u, int E, int r) {   // elements 0, 1: the nearest integer = r (mod 4)
-  const float y = ldexpf(u, 15 - E);
-  const int qf = (int)rintf(y);
-  const int d = (qf - r) & 3;
-  int q = d == 0 ? qf : d == 1 ? qf - 1 : d == 3 ? qf + 1 : (y >= (float)qf ? qf + 2 : qf - 2);
-  q = q > 32767 ? q - 4 : q < -32768 ? q + 4 : q;
-  return q;
-}
-__device__ __forceinline__ unsigned q16_pack2(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
 
 template <bool Q>
 __device__ __forceinline__ void fma8x(float4& acc, float4& acc2, float w, const float4& raw) {

@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
 
   // value_scale: the power-of-two range scale s the projection stored the fp16 rows with (value_range.hip); dividing by
   // count * s undoes it exactly
-  // (q16 rows: the mantissas additionally carry 2^15, common.h fma8q)
-  const float inv = (float)(count > 0 ? count : 1) * (value_scale != nullptr ? *value_scale : 1.f) * (Q ? 32768.f : 1.f);
+  // (q16 rows: the mantissas additionally carry 2^15 / 2 — stored under s / 2 —, common.h fma8q)
+  const float inv = (float)(count > 0 ? count : 1) * (value_scale != nullptr ? *value_scale : 1.f) * (Q ? 16384.f : 1.f);
   // the two sample halves of a head sit 32 lanes apart
   acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32);
   acc.w += __shfl_xor(acc.w, 32);

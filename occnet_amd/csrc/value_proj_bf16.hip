@@ -381,6 +381,10 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
     const int plane = nw / plane_cols, pcol = nw - plane * plane_cols;     // the wave's 64 columns lie in one plane
     // the plane's power-of-two range scale (value_range.hip; exact): the fp16 rows of a plane cannot saturate
     const float osc = out_scale != nullptr ? out_scale[plane] : 1.f;
+    // q16: rows are stored under s / 2 (common.h); lanes kb = 0 hold a piece's elements 0-3 (0, 1 tagged with the exponent)
+    const int q_eosc = OFMT == 2 ? __builtin_amdgcn_frexp_expf(osc) - 2 : 0;
+    const int q_km = kb == 0 ? 3 : 0, q_sh = kb == 0 ? 2 : 0;
+    const float q_mulS = kb == 0 ? 0.25f : 1.f;
     char* const obase = reinterpret_cast<char*>(out_) + ((long)plane * plane_stride + pcol) * EB;
     char* const pbase = reinterpret_cast<char*>(out_) + (long)plane * plane_stride * EB;     // plane base (pair layout)
 #pragma unroll
@@ -390,19 +394,26 @@ __global__ __launch_bounds__(256, 2) void value_proj_resident_kernel(
 #pragma unroll
         for (int rd = 0; rd < 32 / CPR; ++rd) {
           if (OFMT == 2) {
-            // q16: the 8 channels of a 16-byte piece are this lane's 4 (kb = 0: elements 0-3) and lane + 32's 4 (elements 4-7);
-            // they agree on the piece's exponent through one cross-lane maximum; elements 0 and 1 carry it in their low bits
+            // q16 (common.h): ONE exponent for the whole 64-byte head row (32 channels = this lane's 16 + lane ^ 32's 16) —
+            // a coarser group than the format's 16-byte piece, a valid encoding; per-piece exponents cost 44 more VALU
+            // instructions per tile here.  A 16-byte piece = this lane's 4 channels (kb = 0: elements 0-3, the first two
+            // carry the exponent) and lane + 32's 4 (elements 4-7).
+            float m = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) m = fmaxf(m, fmaxf(fabsf(acc[rt][t][r]), fabsf(acc[rt][t][r + 1])));
+            {
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+              m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const int E = q16_group_exponent(m, q_eosc);
+            const float f = ldexpf(1.f, q_eosc + 15 - E);
+            const int r0 = E & q_km, r1 = (E >> 2) & q_km;
+            const float fS = f * q_mulS, c0 = -0.25f * (float)r0, c1 = -0.25f * (float)r1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const float u0 = q16_clamp(acc[rt][t][4 * q + 0] * osc), u1 = q16_clamp(acc[rt][t][4 * q + 1] * osc);
-              const float u2 = q16_clamp(acc[rt][t][4 * q + 2] * osc), u3 = q16_clamp(acc[rt][t][4 * q + 3] * osc);
-              float m = fmaxf(fmaxf(fabsf(u0), fabsf(u1)), fmaxf(fabsf(u2), fabsf(u3)));
-              m = fmaxf(m, __shfl_xor(m, 32));
-              const int E = q16_exponent(m);
-              const int q0 = kb == 0 ? q16_quant_tagged(u0, E, E & 3) : q16_quant(u0, E);
-              const int q1 = kb == 0 ? q16_quant_tagged(u1, E, E >> 2) : q16_quant(u1, E);
               *reinterpret_cast<uint2*>(scratch + vi * kVprPitch + 16 * q + 8 * kb) =
-                  make_uint2(q16_pack2(q0, q1), q16_pack2(q16_quant(u2, E), q16_quant(u3, E)));
+                  make_uint2(q16_pair_tagged(acc[rt][t][4 * q + 0], acc[rt][t][4 * q + 1], fS, c0, c1, r0, r1, q_sh),
+                             q16_pair(acc[rt][t][4 * q + 2], acc[rt][t][4 * q + 3], f));
             }
           } else if (OUTH) {
 #pragma unroll
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(256) void sca_rows_encode_q16_kernel(const float* _
                                                                   int C) {
   const int pieces = C / 8;
   const long n = groups * S * pieces;
-  const float s = scale != nullptr ? *scale : 1.f;
+  const int eosc = __builtin_amdgcn_frexp_expf(scale != nullptr ? *scale : 1.f) - 2;      // log2(s / 2)
   const int Sp = S + (S & 1);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int pc = (int)(i % pieces);
@@ -629,17 +640,18 @@ __global__ __launch_bounds__(256) void sca_rows_encode_q16_kernel(const float* _
     const long g = row / S;
     const float4 a = *reinterpret_cast<const float4*>(v + row * C + pc * 8);
     const float4 b = *reinterpret_cast<const float4*>(v + row * C + pc * 8 + 4);
-    const float u[8] = {q16_clamp(a.x * s), q16_clamp(a.y * s), q16_clamp(a.z * s), q16_clamp(a.w * s),
-                        q16_clamp(b.x * s), q16_clamp(b.y * s), q16_clamp(b.z * s), q16_clamp(b.w * s)};
+    const float u[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     float m = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(u[j]));
-    const int E = q16_exponent(m);
+    const int E = q16_group_exponent(m, eosc);
+    const float f = ldexpf(1.f, eosc + 15 - E);
+    const int r0 = E & 3, r1 = E >> 2;
     uint4 o;
-    o.x = q16_pack2(q16_quant_tagged(u[0], E, E & 3), q16_quant_tagged(u[1], E, E >> 2));
-    o.y = q16_pack2(q16_quant(u[2], E), q16_quant(u[3], E));
-    o.z = q16_pack2(q16_quant(u[4], E), q16_quant(u[5], E));
-    o.w = q16_pack2(q16_quant(u[6], E), q16_quant(u[7], E));
+    o.x = q16_pair_tagged(u[0], u[1], f * 0.25f, -0.25f * (float)r0, -0.25f * (float)r1, r0, r1, 2);
+    o.y = q16_pair(u[2], u[3], f);
+    o.z = q16_pair(u[4], u[5], f);
+    o.w = q16_pair(u[6], u[7], f);
     const int head = pc >> 2, piece = pc & 3;
     // 16-byte units: a pixel pair holds C / 32 heads x 8 units (2 pixels x 4 pieces)
     out[((g * (Sp / 2) + (pix >> 1)) * (C / 32) + head) * 8 + (pix & 1) * 4 + piece] = o;

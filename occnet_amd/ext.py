@@ -624,8 +624,8 @@ def sca_rows_encode_q16(v, scale=None):
     BN, S = v.shape[0], v.shape[1]
     C = v.numel() // (BN * S)
     out = torch.empty((BN, S + (S & 1), C), dtype=torch.int16, device=v.device)
-    if S & 1:
-        out[:, S:].zero_()                       # the pad row: never sampled, kept defined
+    if S & 1:                                    # the pad pixel (second slot of the last pair, every head): never sampled, kept defined
+        out.view(BN, (S + 1) // 2, C // 32, 2, 32)[:, -1, :, 1, :].zero_()
     with torch.cuda.device(v.device):
         rc = _lib.lib().occ_sca_rows_encode_q16(ptr(v), ptr(out), ptr(scale), i64(BN), i32(S), i32(C), stream_ptr(v.device))
     _lib.check(rc, "sca_rows_encode_q16")

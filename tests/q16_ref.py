@@ -1,40 +1,49 @@
-"""Test infrastructure: numpy restatement of the q16 value-row format (csrc/common.h: q16_clamp / q16_exponent / q16_quant /
-q16_quant_tagged / fma8q) — block floating point, 8 int16 mantissas per 16-byte piece under one 4-bit exponent kept in the two
-low bits of elements 0 and 1.  The HIP encoders (the value projection's epilogue, occ_sca_rows_encode_q16) must agree with
-`encode` bit for bit; `decode` is what the gather's fma8q computes per element."""
+"""Test infrastructure: numpy restatement of the q16 value-row format (csrc/common.h: q16_group_exponent / q16_pair /
+q16_pair_tagged / fma8q) — block floating point, 8 int16 mantissas per 16-byte piece under one 4-bit exponent kept in the two
+low bits of elements 0 and 1.  The HIP encoders (occ_sca_rows_encode_q16: one exponent per piece, group = 8; the value
+projection's epilogue: one exponent per 64-byte head row, group = 32) must agree with `encode` bit for bit on finite inputs;
+`decode` is what the gather's fma8q computes per element."""
 import numpy as np
 
+MAGIC = np.float32(12582912.0)           # 1.5 * 2^23
 
-def encode(v, scale=1.0):
-    """v (..., 8k) float32 -> int16 of the same shape (row order, NOT the pixel-pair layout), pieces of 8 along the last axis."""
+
+def _rne_low16(y32):
+    """low 16 bits of rne(y) as the device takes them: the mantissa bits of y + 1.5 * 2^23 (float32 add)."""
+    t = (y32.astype(np.float32) + MAGIC).astype(np.float32)
+    return t.view(np.uint32) & np.uint32(0xffff)
+
+
+def encode(v, scale=1.0, group=8):
+    """v (..., C) float32, C % group == 0, group in (8, 32) -> int16 of the same shape (row order, NOT the pixel-pair layout).
+    scale: the plane's range scale s (a power of two, max|v| * s <= 2^15); the rows are stored under s / 2."""
     v = np.asarray(v, dtype=np.float32)
     shp = v.shape
-    u = (v * np.float32(scale)).astype(np.float32).reshape(-1, 8)
-    u = np.where(np.isnan(u), np.float32(0), u)
-    u = np.clip(u, np.float32(-32768), np.float32(32768))
-    m = np.abs(u).max(axis=1)
-    _, x = np.frexp(m)                                   # m = f 2^x, f in [0.5, 1); frexp(0) = (0, 0)
-    E = np.clip(np.where(m > 0, x, 0), 0, 15).astype(np.int32)
-    y = np.ldexp(u, (15 - E)[:, None]).astype(np.float32)          # exact: a power-of-two multiple
-    qf = np.rint(y).astype(np.int32)                     # round half to even, like v_rndne_f32
-    q = np.clip(qf, -32767, 32767)
-    for j, r in ((0, E & 3), (1, E >> 2)):               # elements 0, 1: the nearest integer = r (mod 4)
-        d = (qf[:, j] - r) & 3
-        up = y[:, j] >= qf[:, j].astype(np.float32)
-        t = np.where(d == 0, qf[:, j], np.where(d == 1, qf[:, j] - 1, np.where(d == 3, qf[:, j] + 1,
-                                                                                 np.where(up, qf[:, j] + 2, qf[:, j] - 2))))
-        t = np.where(t > 32767, t - 4, np.where(t < -32768, t + 4, t))
-        q[:, j] = t
-    return q.astype(np.int16).reshape(shp)
+    eosc = int(np.frexp(np.float32(scale))[1]) - 2                       # log2(s / 2)
+    g = v.reshape(-1, group)
+    m = np.abs(g).max(axis=1).astype(np.float32)
+    mp = (m * np.float32(1.000244140625)).astype(np.float32)
+    x = np.frexp(mp)[1].astype(np.int64) + eosc
+    E = np.where(m > 0, np.clip(x, 0, 15), 0).astype(np.int64)
+    f = np.ldexp(np.float32(1.0), (eosc + 15 - E)).astype(np.float32)    # per group
+    E8 = np.repeat(E, group // 8)
+    f8 = np.repeat(f, group // 8)
+    p = v.reshape(-1, 8)
+    out = np.empty(p.shape, np.uint32)
+    out[:, 2:] = _rne_low16((p[:, 2:] * f8[:, None]).astype(np.float32))          # v * f is exact (a power of two)
+    for j, r in ((0, E8 & 3), (1, E8 >> 2)):
+        z = (p[:, j].astype(np.float64) * (f8.astype(np.float64) * 0.25) - 0.25 * r).astype(np.float32)   # one rounding = fmaf
+        out[:, j] = ((_rne_low16(z).astype(np.uint32) << np.uint32(2)) + r.astype(np.uint32)) & np.uint32(0xffff)
+    return out.astype(np.uint16).view(np.int16).reshape(shp)
 
 
 def decode(q, scale=1.0):
-    """int16 (..., 8k) -> float64 values: q_j 2^(E - 15) / scale with E read from the low bits of elements 0 and 1."""
+    """int16 (..., 8k) -> float64 values: q_j 2^(E - 15) / (scale / 2) with E read from the low bits of elements 0 and 1."""
     q = np.asarray(q, dtype=np.int16)
     shp = q.shape
     p = q.reshape(-1, 8).astype(np.int64)
     E = (p[:, 0] & 3) | ((p[:, 1] & 3) << 2)
-    return (p.astype(np.float64) * np.ldexp(1.0, E - 15)[:, None] / float(scale)).reshape(shp)
+    return (p.astype(np.float64) * np.ldexp(1.0, E - 15)[:, None] / (float(scale) * 0.5)).reshape(shp)
 
 
 def pair_layout(rows):

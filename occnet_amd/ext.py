@@ -166,13 +166,18 @@ def point_sampling(ref_3d, lidar2img, ego2lidar, pc_range, img_h, img_w):
     return ref_cam, mask.view(torch.bool), vis
 
 
-# Storage type of the projected value maps the fused SCA gather reads: 'f16' (default for the fused inference path: one
-# head row of a pixel = 64 bytes = 4 lanes x 16 bytes, so a wave load fetches 16 rows instead of 8 — csrc/sca_fused.hip)
-# or 'f32' (OCC_SCA_VALUES=f32: the round-1/2 kernel, 8 lanes per 128-byte row), or 'q16' (round 6: block floating point —
-# the fp16 rows' geometry and byte count, int16 mantissas sharing one 4-bit exponent per 16-byte piece of 8 channels: the
-# largest element of a piece is rounded to 2^-16 relative instead of fp16's 2^-12; csrc/common.h fma8q).  Sampling arithmetic,
-# attention weights and accumulation are fp32 in all three.
-SCA_VALUES = os.environ.get("OCC_SCA_VALUES", "f16")
+# Storage type of the projected value maps the fused SCA gather reads (the reference keeps them in fp32:
+# spatial_cross_attention.py:75,387-390).  All three keep sampling arithmetic, attention weights and accumulation in fp32.
+#   'q16' (default since round 6): block floating point, 16 bits per element — one head row of a pixel = 64 bytes = 4 lanes x
+#         16 bytes, so a wave load fetches 16 rows instead of 8 (csrc/sca_fused.hip); every 16-byte piece of 8 channels holds
+#         int16 mantissas under one shared 4-bit exponent (csrc/common.h fma8q): the elements that dominate the gather's sums
+#         are rounded to 2^-16 relative.  Against the CPU oracle: 7e-5 at the synthetic feature scale, < 6e-4 at ANY scale
+#         (tests/test_gpu_value_range.py);
+#   'f16' (OCC_SCA_VALUES=f16, the default of rounds 3-5): fp16 rows of the same geometry, 2^-12 relative on every element:
+#         2.2e-4 at the synthetic scale, up to 1.4e-3 when the camera term dominates the residual; 2 % faster per step
+#         (the q16 decode costs 17 VALU instructions per 16-byte load against 9, its encode 10 us per projection launch);
+#   'f32' (OCC_SCA_VALUES=f32): the reference's storage, 8 lanes per 128-byte row (round-1/2 kernel): 3e-5, +15 % per step.
+SCA_VALUES = os.environ.get("OCC_SCA_VALUES", "q16")
 if SCA_VALUES not in ("f16", "f32", "q16"):
     raise OccAmdError(f"OCC_SCA_VALUES={SCA_VALUES!r}: expected f16, f32 or q16")
 

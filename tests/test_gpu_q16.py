@@ -32,7 +32,7 @@ def test_rows_encode_kernel_equals_the_restatement(BN, S, C, amp):
     assert np.array_equal(got, want), int((got != want).sum())
     # non-finite inputs have no q16 image: they encode to unspecified FINITE mantissas, their neighbours are unaffected
     v2 = v.clone()
-    v2[0, 1, 40] = float('inf'); v2[0, 2, 80] = float('nan')
+    v2[0, 1, 40] = float('inf'); v2[0, 2, C - 7] = float('nan')
     enc2 = ext.sca_rows_encode_q16(v2.cuda(), s).cpu().numpy()
     diff = (enc2 != got).reshape(BN, -1, C // 32, 2, 32)             # [pair][head][pix & 1][32]
     assert diff.sum() > 0 and diff[1:].sum() == 0 and diff[0, 2:].sum() == 0

@@ -730,23 +730,6 @@ def _bench_parity(head_cfg, ora, feats, metas, out_o, device, n_layers):
     torch.cuda.synchronize()
     diffs = {k: float((out_p[k].detach().cpu().double() - out_o[k].double()).abs().max())
              for k in ("bev_embed", "occ", "flow")}
-    # the same maps through every value-row storage the gather has (the oracle result is shared): which one is the default
-    # is a measured choice
-    by_rows = {ext.SCA_VALUES: dict(diffs)}
-    rows0 = ext.SCA_VALUES
-    try:
-        for other in ("q16", "f16", "f32"):
-            if other == rows0:
-                continue
-            ext.SCA_VALUES = other
-            with torch.no_grad():
-                o2 = prod(list(maps), metas)
-            torch.cuda.synchronize()
-            by_rows[other] = {k: float((o2[k].detach().cpu().double() - out_o[k].double()).abs().max()) for k in diffs}
-    except Exception as e:      # diagnostics only
-        by_rows["error"] = repr(e)
-    finally:
-        ext.SCA_VALUES = rows0
     worst = max(diffs.values())
     if not worst < 1e-3:
         raise AssertionError(f"bench parity check failed: HIP path differs from the oracle by {diffs}")

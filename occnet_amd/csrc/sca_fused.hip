@@ -34,7 +34,11 @@
 // L2 round trip) and the TD 96 % busy.  With pairs the left / right corners of a sample hit the same line half the
 // time: L1 -> L2 requests 31.3 M -> 21.3 M per launch, 0.178 -> 0.156 ms (profiles/r03_sca_pair_layout.txt).  The
 // value projection's fp16 epilogue writes this layout (csrc/value_proj_bf16.hip); S must be even (padded).
-#include <cstdlib>
+// Round 6, what bounds it now (profiles/r06_c6_sca_fine_levels_only.txt): with the COARSE half of the samples (levels 2-3, half of
+// every head's 32) not gathered at all the launch drops from 206 to 166 us — so the lead of serving those levels from an
+// LDS-resident copy (a camera / head-major pass) is capped at ~40 us minus what the LDS pass itself costs; the other ~165 us are
+// the fine-level gather (~60), the 164 MB stream of query-Linear outputs and results (~42), the prologue and the per-camera
+// set-up.  Not pursued: the restructuring needs per-camera query lists, a partial-sum side buffer and 8 waves per CU.
 #include "common.h"
 
 namespace occ {
@@ -162,7 +166,7 @@ static int launch_sca(const float* value, const int64_t* shapes, const int64_t* 
 }
 
 // fp16 value rows (see the file header): 4 lanes x 16 B per head row, two sample halves per head, rolling load window
-template <int L, int P, int WPS, int DEPTH, bool Q, int XP = 0>
+template <int L, int P, int WPS, int DEPTH, bool Q>
 __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
     const void* __restrict__ value_, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lstart, const float* __restrict__ offs, long offs_stride,
@@ -271,16 +275,14 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
       for (int kk = 0; kk < 4; ++kk) p.o[kk] = (p.o[kk] & ~1023u) | ((p.o[kk] >> 3) & 64u);
       // slot k * 8 + sK, not s: the 8 lanes of a head write consecutive 32-byte entries (conflict-free); the gather
       // sums a head's LP entries, so their order in the slab is free
-      if (XP) sp[m * LPp + (sK >> 2) * 16 + k * 4 + (sK & 3)] = p;      // DEVELOPMENT: fine levels in the first half of the slab
-      else sp[m * LPp + k * 8 + sK] = p;
+      sp[m * LPp + k * 8 + sK] = p;
     }
     wave_lds_sync();
     // corners outside their map carry an out-of-range byte offset: the buffer load returns 0 without a request
     // (round 1 issued a dummy load of row 0 for them: 9 % of the rows through the texture path, and 0 * Inf)
     const __amdgpu_buffer_rsrc_t rsrc =
         uniform_rsrc(value + ((long)b * NC + c) * S * row_stride * EV, (unsigned)S * row_stride * EV);
-    if (XP == 0 || half == 0)       // DEVELOPMENT (XP = 1): the coarse half of the samples is not gathered at all (timing only)
-      gather_samples_buf_h<LP / 2, DEPTH, Q>(rsrc, (unsigned)(g * 128 + c4 * 16), sp + g * LPp + half * (LP / 2), acc, acc2);
+    gather_samples_buf_h<LP / 2, DEPTH, Q>(rsrc, (unsigned)(g * 128 + c4 * 16), sp + g * LPp + half * (LP / 2), acc, acc2);
     wave_lds_sync();  // WAR: next camera rewrites the LDS slab
     ++n_rows;
   }
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
   }
 }
 
-template <int L, int P, bool Q, int WPS = 4, int DEPTH = 2, int XP = 0>
+template <int L, int P, bool Q, int WPS = 4, int DEPTH = 2>
 static int launch_sca_h(const void* value, const int64_t* shapes, const int64_t* lstart,
                         const float* offs, long offs_stride, const float* logits, long logits_stride,
                         const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
@@ -318,7 +320,7 @@ static int launch_sca_h(const void* value, const int64_t* shapes, const int64_t*
                         hipStream_t st, const float* value_scale) {
   const long waves = (long)B * Nq;
   const long blocks = (waves + kScaWaves - 1) / kScaWaves;
-  hipLaunchKernelGGL((sca_fused_h_kernel<L, P, WPS, DEPTH, Q, XP>), dim3((unsigned)blocks), dim3(256), 0, st, value,
+  hipLaunchKernelGGL((sca_fused_h_kernel<L, P, WPS, DEPTH, Q>), dim3((unsigned)blocks), dim3(256), 0, st, value,
                      shapes, lstart, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits,
                      order, slots, reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq, value_scale);
   OCC_CHECK_LAUNCH(Q ? "sca_fused_forward_q16v" : "sca_fused_forward_f16v");
@@ -366,13 +368,6 @@ static int sca_dispatch(const void* value, int rowfmt /* 0 f32, 1 f16, 2 q16 */,
     return launch_sca<LL, PP>(reinterpret_cast<const float*>(value), spatial_shapes, level_start_index, offs,    \
                               (long)offs_stride, logits, (long)logits_stride, ref_cam, vis_bits, order, slots,   \
                               stats, B, NC, S, Z, Nq, st);                                                       \
-  }
-  {   // DEVELOPMENT (round 6 timing experiment): OCC_SCA_EXPERIMENT=1 gathers the fine levels only — wrong results
-    static const bool xp = [] { const char* e = getenv("OCC_SCA_EXPERIMENT"); return e && e[0] == '1'; }();
-    if (xp && L == 4 && P == 8 && rowfmt == 1)
-      return launch_sca_h<4, 8, false, 4, 2, 1>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits,
-                                                (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st,
-                                                value_scale);
   }
   OCC_SCA_CASE(4, 8)
   OCC_SCA_CASE(4, 4)

@@ -76,8 +76,8 @@ def test_head_forward_matches_oracle(batch):
     assert agree > 0.999
 
 
-@pytest.mark.parametrize("batch", [1, 2])
-def test_bf16_nhwc_features_take_the_direct_value_projection(batch, monkeypatch):
+@pytest.mark.parametrize("batch,rows", [(1, "f16"), (2, "f16"), (1, "q16")])
+def test_bf16_nhwc_features_take_the_direct_value_projection(batch, rows, monkeypatch):
     """Backbone-format input (bf16 NHWC maps): the SCA value projection runs straight off the maps
     (ext.value_proj_bf16_planes: ONE launch for all layers and levels; ext.value_proj_bf16 per layer when the
     layers' projections do not stack; embeddings folded into a per-(level, camera) bias) — same result as the oracle
@@ -85,6 +85,9 @@ def test_bf16_nhwc_features_take_the_direct_value_projection(batch, monkeypatch)
     from occnet_amd import ext
     g = small_cfg()
     prod, ora = build_pair(g, seed=3)
+    # (the launch count is asserted for fp16 rows; q16 rows at this small geometry take the tiled projection to fp32 +
+    # ext.sca_rows_encode_q16 — more launches, same contract: parity only)
+    monkeypatch.setattr(ext, "SCA_VALUES", rows)
     feats = [f.to(torch.bfloat16).float() for f in synthetic.make_features(g, batch=batch, seed=3)]
     metas = _metas(g, batch=batch)
     calls = []
@@ -105,7 +108,9 @@ def test_bf16_nhwc_features_take_the_direct_value_projection(batch, monkeypatch)
         prod.transformer.use_lazy_features = False
         out_f = prod([nhwc(f) for f in feats], metas, prev_bev=None)      # flatten path on the same maps
     # every layer's projection came off the maps, in one stacked launch or one launch per layer; none on the flatten path
-    assert n_layers_projected == g['num_layers'] and n_direct in (1, g['num_layers']) and len(calls) == n_direct
+    assert len(calls) == n_direct
+    if rows == "f16":
+        assert n_layers_projected == g['num_layers'] and n_direct in (1, g['num_layers'])
     for k in ('bev_embed', 'occ', 'flow'):
         d, d2 = maxdiff(out_p[k], out_o[k]), maxdiff(out_p[k], out_f[k].cpu())
         print(f"bs={batch} {k}: direct vs oracle {d:.3e}, direct vs flatten path {d2:.3e}")

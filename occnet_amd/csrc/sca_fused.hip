@@ -39,6 +39,7 @@
 // LDS-resident copy (a camera / head-major pass) is capped at ~40 us minus what the LDS pass itself costs; the other ~165 us are
 // the fine-level gather (~60), the 164 MB stream of query-Linear outputs and results (~42), the prologue and the per-camera
 // set-up.  Not pursued: the restructuring needs per-camera query lists, a partial-sum side buffer and 8 waves per CU.
+#include <cstdlib>
 #include "common.h"
 
 namespace occ {
@@ -312,6 +313,166 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
   }
 }
 
+// ---- head-major variant (round 6) --------------------------------------------------------------------------------------------
+// One wave = 8 consecutive BEV queries (of the tile order) x ONE head; the head is blockIdx & 7, i.e. the XCD the block is
+// dispatched to (block b runs on XCD b % 8): every CU — and every XCD's L2 — sees the value rows of a single head, and the 8
+// neighbouring queries of a wave sample neighbouring pixels of the same plane, so their corner rows share L1 lines (at the
+// coarse FPN levels almost all of them).  The query-major kernel above gives a wave 8 heads = 8 disjoint planes: no line is
+// shared inside a wave.  Same arithmetic per sample, same slab / window machinery; what changes is who holds what:
+//   prologue / set-up lane = (query slot j = lane >> 3, sample group sK = lane & 7) — the K consecutive samples of head m;
+//   gather lane = (query slot g = (lane >> 2) & 7, 16-byte piece c4 = lane & 3, sample half = lane >> 5);
+//   cameras: the loop runs over the UNION of the 8 queries' visible cameras, a query that does not see the camera resolves
+//   dead samples (weight 0, out-of-range offsets: no memory request).
+template <int L, int P, int WPS, int DEPTH, bool Q>
+__global__ __launch_bounds__(256, WPS) void sca_fused_hm_kernel(
+    const void* __restrict__ value_, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lstart, const float* __restrict__ offs, long offs_stride,
+    const float* __restrict__ logits, long logits_stride, const float* __restrict__ ref_cam,
+    const uint32_t* __restrict__ vis_bits, const int32_t* __restrict__ order,
+    float* __restrict__ slots, unsigned long long* __restrict__ stats, int B, int NC, int S, int Z,
+    int Nq, int tiles_per_b, const float* __restrict__ value_scale) {
+  constexpr int M = 8, D = 32, LP = L * P;
+  constexpr int K = M * LP / 64;  // samples resolved per lane
+  static_assert(LP >= 8 && LP <= 32 && (LP & (LP - 1)) == 0, "L*P must be a power of two in [8,32]");
+  static_assert(P % K == 0 && K * 8 == LP, "a lane's K samples share one level");
+  constexpr int LPp = LP + 1;
+  __shared__ __attribute__((aligned(16))) SampleParamB smem[kScaWaves * 8 * LPp];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int m = (int)(blockIdx.x & 7u);                    // the block's head = its XCD
+  const int t = (int)(blockIdx.x >> 3);
+  const int b = t / tiles_per_b;
+  const int r0 = ((t - b * tiles_per_b) * kScaWaves + wave) * 8;     // the wave's first query (position in `order`)
+  if (r0 >= Nq) return;
+  SampleParamB* sp = smem + wave * 8 * LPp;
+
+  constexpr int row_stride = M * D;
+  constexpr unsigned EV = 2u;                              // bytes per value element (fp16 / q16)
+  const char* value = reinterpret_cast<const char*>(value_);
+
+  // ---- set-up mapping: lane = (query slot j, sample group sK) -----------------------------------------------------------
+  const int j = lane >> 3, sK = lane & 7;
+  const bool jvalid = r0 + j < Nq;
+  const int rj = jvalid ? r0 + j : Nq - 1;
+  const int q = order ? order[rj] : rj;
+  const uint32_t vis = jvalid ? vis_bits[q] : 0u;          // batch 0's mask picks the cameras (the reference's quirk)
+  uint32_t uni = vis;                                      // the union over the wave's 8 queries: the camera loop's trip list
+  uni |= (uint32_t)__shfl_xor((int)uni, 8);
+  uni |= (uint32_t)__shfl_xor((int)uni, 16);
+  uni |= (uint32_t)__shfl_xor((int)uni, 32);
+  uni = __builtin_amdgcn_readfirstlane(uni);
+
+  float aw[K], ox[K], oy[K];
+  const int lane_l = (sK * K) / P;
+  const int lvH = (int)shapes[2 * lane_l], lvW = (int)shapes[2 * lane_l + 1], lvS = (int)lstart[lane_l];
+  {
+    const float* lp = logits + ((long)b * Nq + q) * logits_stride + m * LP + sK * K;
+    const float* op = offs + ((long)b * Nq + q) * offs_stride + 2 * (m * LP + sK * K);
+    float x[K], o[2 * K];
+    if constexpr (K == 4) {
+      const float4 tt = *reinterpret_cast<const float4*>(lp);
+      x[0] = tt.x; x[1] = tt.y; x[2] = tt.z; x[3] = tt.w;
+      const float4 u0 = *reinterpret_cast<const float4*>(op), u1 = *reinterpret_cast<const float4*>(op + 4);
+      o[0] = u0.x; o[1] = u0.y; o[2] = u0.z; o[3] = u0.w; o[4] = u1.x; o[5] = u1.y; o[6] = u1.z; o[7] = u1.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        x[k] = lp[k];
+        const float2 tt = *reinterpret_cast<const float2*>(op + 2 * k);
+        o[2 * k] = tt.x; o[2 * k + 1] = tt.y;
+      }
+    }
+    float mx = x[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
+#pragma unroll
+    for (int d = 4; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); sum += x[k]; }
+#pragma unroll
+    for (int d = 4; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      aw[k] = fdiv(x[k], sum);
+      ox[k] = fdiv(o[2 * k], (float)lvW);
+      oy[k] = fdiv(o[2 * k + 1], (float)lvH);
+    }
+  }
+
+  // ---- gather mapping: lane = (query slot g, 16-byte piece c4, sample half) ------------------------------------------------
+  const int g = (lane >> 2) & 7, c4 = lane & 3, half = lane >> 5;
+  const bool gvalid = r0 + g < Nq;
+  const int qg = order ? order[gvalid ? r0 + g : Nq - 1] : (gvalid ? r0 + g : Nq - 1);
+  const int count = __builtin_popcount(vis_bits[(long)b * Nq + qg]);   // this batch's mask gives the divisor
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
+  unsigned n_in = 0, n_rows = 0;
+
+  for (int c = 0; c < NC; ++c) {
+    if (!((uni >> c) & 1u)) continue;  // wave-uniform
+    const int live = (int)((vis >> c) & 1u);
+    const float* rp = ref_cam + (((long)c * B + b) * Nq + q) * Z * 2;
+    float2 rxy_k[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int z = ((sK * K + k) % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
+      rxy_k[k] = *reinterpret_cast<const float2*>(rp + 2 * z);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      SampleParamB p;
+      n_in += bilinear_setup_b(rxy_k[k].x + ox[k], rxy_k[k].y + oy[k], aw[k], lvH, lvW, lvS,
+                               (unsigned)row_stride * EV, kOobOffset, live, p);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) p.o[kk] = (p.o[kk] & ~1023u) | ((p.o[kk] >> 3) & 64u);     // pixel-pair layout
+      sp[j * LPp + k * 8 + sK] = p;
+    }
+    wave_lds_sync();
+    const __amdgpu_buffer_rsrc_t rsrc =
+        uniform_rsrc(value + ((long)b * NC + c) * S * row_stride * EV, (unsigned)S * row_stride * EV);
+    gather_samples_buf_h<LP / 2, DEPTH, Q>(rsrc, (unsigned)(m * 128 + c4 * 16), sp + g * LPp + half * (LP / 2), acc, acc2);
+    wave_lds_sync();  // WAR: next camera rewrites the LDS slab
+    n_rows += (unsigned)(live & (sK == 0) & (m == 0));
+  }
+
+  const float inv = (float)(count > 0 ? count : 1) * (value_scale != nullptr ? *value_scale : 1.f) * (Q ? 16384.f : 1.f);
+  acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32);
+  acc.w += __shfl_xor(acc.w, 32);
+  acc2.x += __shfl_xor(acc2.x, 32); acc2.y += __shfl_xor(acc2.y, 32); acc2.z += __shfl_xor(acc2.z, 32);
+  acc2.w += __shfl_xor(acc2.w, 32);
+  if (half == 0 && gvalid) {
+    float* dst = slots + ((long)b * Nq + qg) * row_stride + m * D + c4 * 8;
+    *reinterpret_cast<float4*>(dst) = make_float4(fdiv(acc.x, inv), fdiv(acc.y, inv), fdiv(acc.z, inv), fdiv(acc.w, inv));
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(fdiv(acc2.x, inv), fdiv(acc2.y, inv), fdiv(acc2.z, inv), fdiv(acc2.w, inv));
+  }
+
+  if (stats) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { n_in += __shfl_xor(n_in, d); n_rows += __shfl_xor(n_rows, d); }
+    if (lane == 0) {
+      if (n_rows) atomicAdd(&stats[0], (unsigned long long)n_rows);
+      atomicAdd(&stats[1], (unsigned long long)n_in);
+    }
+  }
+}
+
+template <int L, int P, bool Q, int WPS = 4, int DEPTH = 2>
+static int launch_sca_hm(const void* value, const int64_t* shapes, const int64_t* lstart,
+                         const float* offs, long offs_stride, const float* logits, long logits_stride,
+                         const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
+                         float* slots, uint64_t* stats, int B, int NC, int S, int Z, int Nq,
+                         hipStream_t st, const float* value_scale) {
+  const int tiles_per_b = (Nq + kScaWaves * 8 - 1) / (kScaWaves * 8);
+  const long blocks = (long)B * tiles_per_b * 8;
+  hipLaunchKernelGGL((sca_fused_hm_kernel<L, P, WPS, DEPTH, Q>), dim3((unsigned)blocks), dim3(256), 0, st, value,
+                     shapes, lstart, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits,
+                     order, slots, reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq, tiles_per_b, value_scale);
+  OCC_CHECK_LAUNCH(Q ? "sca_fused_forward_q16v (head-major)" : "sca_fused_forward_f16v (head-major)");
+  return OCC_OK;
+}
+
 template <int L, int P, bool Q, int WPS = 4, int DEPTH = 2>
 static int launch_sca_h(const void* value, const int64_t* shapes, const int64_t* lstart,
                         const float* offs, long offs_stride, const float* logits, long logits_stride,
@@ -355,8 +516,19 @@ static int sca_dispatch(const void* value, int rowfmt /* 0 f32, 1 f16, 2 q16 */,
   }
   // (fp16 rows: 4 waves per SIMD with a 2-sample rolling window is the default; 3/2, 6/1, 5/2, 3/4 and 8/1 were measured
   // through a development switch, since removed: profiles/r03_sca_probe_fp16_rows.txt)
+  // OCC_SCA_HEAD_MAJOR=1 (read per call: tests switch it inside one process): the 16-bit-row gathers on the head-major kernel
+  const char* hm_env = getenv("OCC_SCA_HEAD_MAJOR");
+  const bool head_major = hm_env != nullptr && hm_env[0] == '1';
 #define OCC_SCA_CASE(LL, PP)                                                                       \
   if (L == LL && P == PP) {                                                                        \
+    if (rowfmt == 2 && head_major)                                                                 \
+      return launch_sca_hm<LL, PP, true>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
+                                         (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
+                                         value_scale);                                                           \
+    if (rowfmt == 1 && head_major)                                                                 \
+      return launch_sca_hm<LL, PP, false>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
+                                          (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
+                                          value_scale);                                                          \
     if (rowfmt == 2)                                                                               \
       return launch_sca_h<LL, PP, true>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
                                         (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \

@@ -182,6 +182,12 @@ if SCA_VALUES not in ("f16", "f32", "q16"):
     raise OccAmdError(f"OCC_SCA_VALUES={SCA_VALUES!r}: expected f16, f32 or q16")
 
 
+def sca_head_major():
+    """OCC_SCA_HEAD_MAJOR=1: the 16-bit-row SCA gather on the head-major kernel (one wave = 8 queries x one head, heads dealt to
+    the XCDs; csrc/sca_fused.hip).  Read per call, like the library does."""
+    return os.environ.get("OCC_SCA_HEAD_MAJOR", "0") == "1"
+
+
 def sca_rows_16bit():
     """True when the fused gather's value maps are 16-bit rows in the pixel-pair layout with a range scale (f16, q16)."""
     return SCA_VALUES in ("f16", "q16")

@@ -213,7 +213,7 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                                              spatial_shapes=spatial_shapes,
                                              level_start_index=level_start_index,
                                              vis_bits=kwargs.get('vis_bits'),
-                                             bev_order=kwargs.get('bev_order'),
+                                             bev_order=kwargs.get('sca_bev_order', kwargs.get('bev_order')),
                                              gather_stats=kwargs.get('gather_stats'),
                                              post_norm=post_norm)
                 if out is not None:
@@ -265,7 +265,7 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
         wq, bq = sca.query_linear_operands()
         x1, lin = ext.linear_ln_chain(attn, q, tsa.output_proj.weight, tsa.output_proj.bias, self.norms[0], wq, bq)
         slots = sca.fused_gather(lin, value, reference_points_cam, kwargs.get('bev_mask'), spatial_shapes,
-                                 level_start_index, kwargs.get('vis_bits'), kwargs.get('bev_order'),
+                                 level_start_index, kwargs.get('vis_bits'), kwargs.get('sca_bev_order', kwargs.get('bev_order')),
                                  kwargs.get('gather_stats'))
         tail = None
         if next_tsa is not None and prev_bev is None and bs == 1 and bev_pos is not None:
@@ -416,12 +416,13 @@ class BEVFormerEncoder(TransformerLayerSequence):
             self._pos_key, self._pos_src, self._pos_qm = key, bev_pos, bev_pos.permute(1, 0, 2).contiguous()
         return self._pos_qm
 
-    def _bev_order(self, bev_h, bev_w, device):
+    def _bev_order(self, bev_h, bev_w, device, flat=False):
         """Query processing order of the gather kernels: 8x8 BEV tiles, the tile list dealt over the 8 XCDs in
-        4-query blocks (one wave per query, four waves per block)."""
-        key = (bev_h, bev_w, str(device))
+        4-query blocks (one wave per query, four waves per block).  flat: the plain tile walk — the head-major SCA gather deals
+        HEADS to the XCDs, every XCD walks all queries."""
+        key = (bev_h, bev_w, str(device), bool(flat))
         if key not in self._order_cache:
-            self._order_cache[key] = torch.from_numpy(bev_tile_order(bev_h, bev_w, n_xcd=8)).to(device)
+            self._order_cache[key] = torch.from_numpy(bev_tile_order(bev_h, bev_w, n_xcd=1 if flat else 8)).to(device)
         return self._order_cache[key]
 
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
@@ -449,6 +450,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         else:
             hybird_ref_2d = hybrid_same
         extra = dict(vis_bits=vis_bits, bev_order=self._bev_order(bev_h, bev_w, bev_query.device),
+                     sca_bev_order=self._bev_order(bev_h, bev_w, bev_query.device, flat=ext.sca_head_major()),
                      tsa_spatial_shapes=tsa_shapes, tsa_level_start_index=tsa_start)
         output = bev_query
         if hasattr(value, 'prefetch') and not torch.is_grad_enabled():

@@ -433,7 +433,7 @@ class SpatialCrossAttention(BaseModule):
                 slots = self._fused_slots(query, value, reference_points_cam, bev_mask,
                                           spatial_shapes, level_start_index,
                                           vis_bits=kwargs.get('vis_bits'),
-                                          order=kwargs.get('bev_order'),
+                                          order=kwargs.get('sca_bev_order', kwargs.get('bev_order')),
                                           stats=kwargs.get('gather_stats'))
             except OccAmdUnsupported:
                 slots = None

@@ -227,7 +227,7 @@ _SCA_SHAPES = {
 
 
 @pytest.mark.parametrize("shape", sorted(_SCA_SHAPES))
-@pytest.mark.parametrize("values", ["f32", "f16", "q16"])
+@pytest.mark.parametrize("values", ["f32", "f16", "q16", "f16-hm", "q16-hm"])
 def test_sca_gather_kernels_match_oracle(values, shape, monkeypatch):
     """The SCA gather kernels (fp32 value rows: sca_fused_kernel; fp16 rows and q16 block-floating-point rows: sca_fused_h_kernel)
     on every (levels, points, z-anchors) combination with a fused kernel, batch 2 (the reference takes the camera
@@ -235,6 +235,9 @@ def test_sca_gather_kernels_match_oracle(values, shape, monkeypatch):
     a multiple of the 4 queries of a block), vs the oracle head."""
     from occnet_amd import ext
     kernel = values
+    # "-hm": the head-major kernel (one wave = 8 queries x one head, heads dealt to the XCDs) instead of the query-major one
+    monkeypatch.setenv("OCC_SCA_HEAD_MAJOR", "1" if values.endswith("-hm") else "0")
+    values = values.split("-")[0]
     monkeypatch.setattr(ext, "SCA_VALUES", values)
     g = small_cfg(bev=(38, 38), num_layers=1, **_SCA_SHAPES[shape])
     prod, ora = build_pair(g, seed=31)

@@ -41,7 +41,7 @@ res = {
     "vmem_read_wave_instructions_per_launch": m('SQ_INSTS_VMEM_RD'),
     "wave_cycles_waiting_frac": None if not m('SQ_WAVE_CYCLES') else m('SQ_WAIT_ANY') / m('SQ_WAVE_CYCLES'),
     "wave_cycles_issue_stalled_frac": None if not m('SQ_WAVE_CYCLES') else m('SQ_WAIT_INST_ANY') / m('SQ_WAVE_CYCLES'),
-    "launches_averaged": acc['FETCH_SIZE'][0], "source": note, "round": 5,
+    "launches_averaged": acc['FETCH_SIZE'][0], "source": note, "round": 6,
 }
 with open(out, 'w') as f:
     json.dump(res, f, indent=1)

@@ -323,8 +323,8 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_h_kernel(
 //   gather lane = (query slot g = (lane >> 2) & 7, 16-byte piece c4 = lane & 3, sample half = lane >> 5);
 //   cameras: the loop runs over the UNION of the 8 queries' visible cameras, a query that does not see the camera resolves
 //   dead samples (weight 0, out-of-range offsets: no memory request).
-template <int L, int P, int WPS, int DEPTH, bool Q>
-__global__ __launch_bounds__(256, WPS) void sca_fused_hm_kernel(
+template <int L, int P, int WPS, int DEPTH, bool Q, int WB = kScaWaves>
+__global__ __launch_bounds__(64 * WB, WPS * 4 / WB) void sca_fused_hm_kernel(
     const void* __restrict__ value_, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lstart, const float* __restrict__ offs, long offs_stride,
     const float* __restrict__ logits, long logits_stride, const float* __restrict__ ref_cam,
@@ -336,14 +336,14 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_hm_kernel(
   static_assert(LP >= 8 && LP <= 32 && (LP & (LP - 1)) == 0, "L*P must be a power of two in [8,32]");
   static_assert(P % K == 0 && K * 8 == LP, "a lane's K samples share one level");
   constexpr int LPp = LP + 1;
-  __shared__ __attribute__((aligned(16))) SampleParamB smem[kScaWaves * 8 * LPp];
+  __shared__ __attribute__((aligned(16))) SampleParamB smem[WB * 8 * LPp];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int m = (int)(blockIdx.x & 7u);                    // the block's head = its XCD
   const int t = (int)(blockIdx.x >> 3);
   const int b = t / tiles_per_b;
-  const int r0 = ((t - b * tiles_per_b) * kScaWaves + wave) * 8;     // the wave's first query (position in `order`)
+  const int r0 = ((t - b * tiles_per_b) * WB + wave) * 8;     // the wave's first query (position in `order`)
   if (r0 >= Nq) return;
   SampleParamB* sp = smem + wave * 8 * LPp;
 
@@ -458,15 +458,15 @@ __global__ __launch_bounds__(256, WPS) void sca_fused_hm_kernel(
   }
 }
 
-template <int L, int P, bool Q, int WPS = 4, int DEPTH = 2>
+template <int L, int P, bool Q, int WPS = 4, int DEPTH = 2, int WB = kScaWaves>
 static int launch_sca_hm(const void* value, const int64_t* shapes, const int64_t* lstart,
                          const float* offs, long offs_stride, const float* logits, long logits_stride,
                          const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
                          float* slots, uint64_t* stats, int B, int NC, int S, int Z, int Nq,
                          hipStream_t st, const float* value_scale) {
-  const int tiles_per_b = (Nq + kScaWaves * 8 - 1) / (kScaWaves * 8);
+  const int tiles_per_b = (Nq + WB * 8 - 1) / (WB * 8);
   const long blocks = (long)B * tiles_per_b * 8;
-  hipLaunchKernelGGL((sca_fused_hm_kernel<L, P, WPS, DEPTH, Q>), dim3((unsigned)blocks), dim3(256), 0, st, value,
+  hipLaunchKernelGGL((sca_fused_hm_kernel<L, P, WPS, DEPTH, Q, WB>), dim3((unsigned)blocks), dim3(64 * WB), 0, st, value,
                      shapes, lstart, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits,
                      order, slots, reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq, tiles_per_b, value_scale);
   OCC_CHECK_LAUNCH(Q ? "sca_fused_forward_q16v (head-major)" : "sca_fused_forward_f16v (head-major)");
@@ -516,9 +516,12 @@ static int sca_dispatch(const void* value, int rowfmt /* 0 f32, 1 f16, 2 q16 */,
   }
   // (fp16 rows: 4 waves per SIMD with a 2-sample rolling window is the default; 3/2, 6/1, 5/2, 3/4 and 8/1 were measured
   // through a development switch, since removed: profiles/r03_sca_probe_fp16_rows.txt)
-  // OCC_SCA_HEAD_MAJOR=1 (read per call: tests switch it inside one process): the 16-bit-row gathers on the head-major kernel
+  // The 16-bit-row gathers run on the head-major kernel (default since round 6: 0.196 against 0.218 ms per launch, same box,
+  // profiles/r06_c9_sca_head_major_sweep.txt); OCC_SCA_HEAD_MAJOR=0 selects the query-major kernel (read per call: tests
+  // switch it inside one process).  (waves / SIMD, window, waves / block) = (4, 2, 4) measured best of (3, 4, 4) 0.2047,
+  // (4, 2, 8) 0.2051, (4, 1, 4) 0.2044 ms.
   const char* hm_env = getenv("OCC_SCA_HEAD_MAJOR");
-  const bool head_major = hm_env != nullptr && hm_env[0] == '1';
+  const bool head_major = !(hm_env != nullptr && hm_env[0] == '0');
 #define OCC_SCA_CASE(LL, PP)                                                                       \
   if (L == LL && P == PP) {                                                                        \
     if (rowfmt == 2 && head_major)                                                                 \

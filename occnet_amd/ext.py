@@ -183,9 +183,10 @@ if SCA_VALUES not in ("f16", "f32", "q16"):
 
 
 def sca_head_major():
-    """OCC_SCA_HEAD_MAJOR=1: the 16-bit-row SCA gather on the head-major kernel (one wave = 8 queries x one head, heads dealt to
-    the XCDs; csrc/sca_fused.hip).  Read per call, like the library does."""
-    return os.environ.get("OCC_SCA_HEAD_MAJOR", "0") == "1"
+    """The 16-bit-row SCA gather runs on the head-major kernel (one wave = 8 queries x one head, heads dealt to the XCDs;
+    csrc/sca_fused.hip — the default since round 6); OCC_SCA_HEAD_MAJOR=0 selects the query-major kernel.  Read per call, like
+    the library does.  (fp32 rows always take the query-major fp32 kernel.)"""
+    return os.environ.get("OCC_SCA_HEAD_MAJOR", "1") != "0" and sca_rows_16bit()
 
 
 def sca_rows_16bit():
@@ -198,8 +199,10 @@ def sca_rows_dtype():
 
 
 def sca_variant_name():
-    return {"f16": "sca_fused_h_kernel<4,8> (query-major, fp16 value rows)",
-            "q16": "sca_fused_h_kernel<4,8,Q> (query-major, q16 block-floating-point value rows)",
+    hm = sca_head_major()
+    return {"f16": "sca_fused_hm_kernel<4,8> (head-major, fp16 value rows)" if hm else "sca_fused_h_kernel<4,8> (query-major, fp16 value rows)",
+            "q16": ("sca_fused_hm_kernel<4,8,Q> (head-major, q16 block-floating-point value rows)" if hm
+                    else "sca_fused_h_kernel<4,8,Q> (query-major, q16 block-floating-point value rows)"),
             "f32": "sca_fused_kernel<4,8> (query-major, fp32 value rows)"}[SCA_VALUES]
 
 

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void point_sampling_kernel(
         s = fmaf(A[i * 4 + 3], ego2lidar[3 * 4 + j], s);
         T[i][j] = s;
       }
-    bool any = false;
+    int any = 0;                                     // lane predicates as 0 / 1 VGPR integers (common.h: lane_flag)
     for (int z = 0; z < Z; ++z) {
       const float* p = ref_3d + (((long)b * Z + z) * Nq + q) * 3;
       const float X = __fadd_rn(__fmul_rn(p[0], rx), x0);
@@ -52,19 +52,19 @@ __global__ __launch_bounds__(256) void point_sampling_kernel(
         cam[i] = s;
       }
       const float eps = 1e-5f;
-      bool m = cam[2] > eps;
+      int m = lane_flag(cam[2] > eps);
       const float den = fmaxf(cam[2], eps);
       float u = cam[0] / den, v = cam[1] / den;
       u = u / img_w;
       v = v / img_h;
-      m = m && (v > 0.0f) && (v < 1.0f) && (u < 1.0f) && (u > 0.0f);
+      m = m & lane_flag(v > 0.0f) & lane_flag(v < 1.0f) & lane_flag(u < 1.0f) & lane_flag(u > 0.0f);
       const long o = (((long)c * B + b) * Nq + q) * Z + z;
       ref_cam[o * 2 + 0] = u;
       ref_cam[o * 2 + 1] = v;
-      bev_mask[o] = m ? 1 : 0;
-      any = any || m;
+      bev_mask[o] = (uint8_t)m;
+      any |= m;
     }
-    if (any) bits |= (1u << c);
+    bits |= (uint32_t)any << c;
   }
   if (vis_bits) vis_bits[idx] = bits;
 }

@@ -211,7 +211,7 @@ class Stepper:
                 # 64-thread launch per step instead of a 52-us pass over the maps (round 6)
                 words = ext.feature_absmax_words([f.flatten(0, 1).permute(0, 2, 3, 1).reshape(-1, f.shape[2]) for f in self.feats])
                 for f in self.feats:
-                    f._occ_absmax = words
+                    ext.attach_absmax(f, words)
             if self.history:    # per level (bs, len_queue, N, C, h, w): what extract_feat(len_queue=H) returns
                 hf = [synthetic.make_features(geo, batch=1, seed=seed + 1 + i, device=device) for i in range(self.history)]
                 if hot_feat_format == "backbone":

@@ -593,6 +593,22 @@ def new_absmax_words(device):
     return torch.zeros(8, dtype=torch.int32, device=device)
 
 
+def attach_absmax(t, words):
+    """Hang the producer's max|x| words on a feature-map tensor (or a view of one) together with the tensor's version counter:
+    an in-place write to the map afterwards invalidates the side band (absmax_of returns None, the consumer measures)."""
+    t._occ_absmax = words
+    t._occ_absmax_version = t._version
+    return t
+
+
+def absmax_of(t):
+    """The words attach_absmax hung on `t`, or None (none attached, or the map was written in place since)."""
+    w = getattr(t, '_occ_absmax', None)
+    if w is None or getattr(t, '_occ_absmax_version', None) != t._version:
+        return None
+    return w
+
+
 def feature_absmax_words(a_list):
     """The 8 words a producer would have accumulated, for maps that did not come from this library's backbone plan (bench
     set-up, tests): max of the sign-stripped bf16 patterns of every element, replicated."""

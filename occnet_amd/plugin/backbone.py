@@ -525,6 +525,7 @@ class FusedInferenceBackbone(nn.Module):
                     src = F.relu(outs[-1]) if nk.relu_before_extra_convs else outs[-1]
                     outs.append(self._conv(self.fpn[i], src, amax=amax))
         if self._amax_ok:
+            from .. import ext
             for o in outs:
-                o._occ_absmax = amax          # rides on the tensor OBJECTS: a consumer that reshapes them re-attaches it
+                ext.attach_absmax(o, amax)    # rides on the tensor OBJECTS (with their version counter): a consumer that reshapes them re-attaches it
         return tuple(outs)

@@ -8,7 +8,7 @@ train_cfg / test_cfg is injected into the head's config.
 """
 import torch
 
-from .. import cache_epoch
+from .. import cache_epoch, ext
 from .bricks import BaseModule
 from .grid_mask import GridMask
 from .registry import DETECTORS, build_backbone, build_head, build_neck
@@ -153,9 +153,9 @@ class BEVFormerOcc(BaseModule):
             else:
                 out.append(f.view(B, int(BN / B), C, H, W))
                 # max|x| over the maps, accumulated by the plan's FPN output convolutions (backbone.py): rides on the views
-                am = getattr(f, '_occ_absmax', None)
+                am = ext.absmax_of(f)
                 if am is not None:
-                    out[-1]._occ_absmax = am
+                    ext.attach_absmax(out[-1], am)
         return out
 
     def enable_fused_backbone(self, dtype=torch.bfloat16, fused_ops=False, hip_tail=True, use_graph=False,
@@ -208,9 +208,9 @@ class BEVFormerOcc(BaseModule):
         for f in feats:
             BN, C, H, W = f.size()
             out.append(f.view(B, N, C, H, W))
-            am = getattr(f, '_occ_absmax', None)
+            am = ext.absmax_of(f)
             if am is not None:
-                out[-1]._occ_absmax = am
+                ext.attach_absmax(out[-1], am)
         return out, hw
 
     def load_checkpoint(self, path_or_state, strict=False, map_location='cpu'):

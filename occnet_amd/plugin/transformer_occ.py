@@ -205,9 +205,9 @@ class LazyFeatures:
 
     def _absmax_words(self):
         """The 8 device words of max|x| the producer of the maps accumulated (the backbone plan's FPN output convolutions),
-        or None: all levels must carry the SAME words object."""
-        am = getattr(self.mlvl_feats[0], '_occ_absmax', None)
-        if am is None or any(getattr(f, '_occ_absmax', None) is not am for f in self.mlvl_feats):
+        or None: all levels must carry the SAME words object, and none may have been written in place since (ext.absmax_of)."""
+        am = ext.absmax_of(self.mlvl_feats[0])
+        if am is None or any(ext.absmax_of(f) is not am for f in self.mlvl_feats):
             return None
         return am
 

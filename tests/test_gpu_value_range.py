@@ -331,14 +331,14 @@ def test_backbone_plan_hands_its_maximum_to_the_value_projection(monkeypatch):
                         lambda *a, **k: (calls.__setitem__('prod', calls['prod'] + 1), real_p(*a, **k))[1])
     with torch.no_grad():
         feats = model.extract_feat(img=img)
-        words = getattr(feats[0], '_occ_absmax', None)
-        assert words is not None and all(getattr(f, '_occ_absmax', None) is words for f in feats)
+        words = ext.absmax_of(feats[0])
+        assert words is not None and all(ext.absmax_of(f) is words for f in feats)
         assert int(words.max()) == _pattern_max(*feats)
         out = model.pts_bbox_head(feats, metas)
         rep = model.pts_bbox_head.transformer.value_range_report.clone()
         assert calls == dict(meas=0, prod=1)
-        for f in feats:                                # the same maps without the side band: measured
-            del f._occ_absmax
+        feats[1].mul_(1.0)                             # an in-place write (even a no-op) invalidates the side band: measured
+        assert ext.absmax_of(feats[1]) is None
         out2 = model.pts_bbox_head(feats, metas)
         rep2 = model.pts_bbox_head.transformer.value_range_report
         assert calls == dict(meas=1, prod=1)

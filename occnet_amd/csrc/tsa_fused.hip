@@ -10,6 +10,9 @@
 // its head's 8 samples (32 x 16-byte loads per lane) from the two queue entries' value maps and
 // writes the mean.  When there is no history BEV the reference stacks the current BEV twice:
 // pass value_bt_stride = 0 and the two entries alias one projected buffer.
+// (Round 6 measured what 16-bit value rows would buy here — a 4-lanes-per-row variant of this kernel on garbage data, timing only:
+// 53.4 -> 41.3 us per launch with the q16 decode, profiles/r06_c12_tsa_16bit_rows_timing.txt — against the q16 encoder it would need
+// in the chain kernels' tail epilogues (program B sits at 256 VGPRs): not built.)
 #include "common.h"
 
 namespace occ {

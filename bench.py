@@ -1034,13 +1034,14 @@ def main():
                         and tj.get("kernel_variant") == ext.sca_variant_name()):
                     traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
             out["roofline"] = {
-                "kernel": f"{ext.sca_variant_name()} (fused SCA deformable gather, {'f32' if ev == 4 else 'f16'} values)",
+                "kernel": f"{ext.sca_variant_name()} (fused SCA deformable gather, {ext.SCA_VALUES} value rows)",
                 # rocprofv3 PMC (profiles/): texture addresser busy most of the launch, L2 hit ~0.8, HBM-side
                 # traffic a fraction of peak -> the binding resource is the L1/TA row-gather path, not HBM
-                "bound": ("l1/ta row-gather path, not hbm: frac_alg > 1 because SURVEY.md 8(d)'s algorithmic bytes are LOGICAL "
-                          "gather bytes — every fp16 value row is re-used ~28x per launch out of L2 / the 256 MiB Infinity "
-                          "Cache (a layer's maps are 95 MB), so HBM moves `traffic`, a fraction of them; `frac` is the "
-                          "physical HBM figure"),
+                "bound": ("hbm is the roofline SURVEY.md 8(d) prices this kernel against; what binds it is the l1/ta row-gather "
+                          "path (3.6 M wave loads of 1 KB at ~21 clocks each = two thirds of the launch, DESIGN.md section 4).  "
+                          "frac_alg > 1 because 8(d)'s algorithmic bytes are LOGICAL gather bytes — every 64-byte value row is "
+                          "re-used ~28x per launch out of L1 / L2 (a layer's maps are 95 MB), so HBM moves `traffic`, a fraction "
+                          "of them (1.07 x the compulsory bytes with the head-major kernel); `frac` is the physical HBM figure"),
                 "achieved": (traffic / sec / 1e9) if traffic else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": (traffic / sec / HBM_PEAK) if traffic else None,
                 # SURVEY.md 8(d) under its own name: B_alg / t_kernel / 8.0e12 (B_alg = N_in*d*e_v + R*S*12 + R*256*4)

@@ -92,9 +92,10 @@ def make_images(cfg=BASE, batch=1, seed=0, device="cpu"):
     return x.to(device)
 
 
-def bev_tile_order(bev_h, bev_w, tile_h=8, tile_w=8, n_xcd=8, waves_per_block=4):
+def bev_tile_order(bev_h, bev_w, tile_h=8, tile_w=8, n_xcd=8, waves_per_block=4, patch=None):
     """Processing order of the BEV queries for the gather kernels (a permutation of arange(H*W)).
 
+    patch = (ph, pw): inside a full tile the queries are emitted patch by patch (ph * pw consecutive entries = one patch).
     Queries are visited in tile_h x tile_w tiles (neighbouring pillars project to neighbouring
     pixels, so a tile's samples share cache lines).  The hardware dispatches block b to XCD b % 8,
     each XCD with a private L2: the tile sequence is dealt so that every XCD walks one contiguous
@@ -107,7 +108,12 @@ def bev_tile_order(bev_h, bev_w, tile_h=8, tile_w=8, n_xcd=8, waves_per_block=4)
         if (y0 // tile_h) % 2:
             xs = reversed(list(xs))        # boustrophedon: consecutive tiles stay adjacent
         for x0 in xs:
-            tiles.append(q[y0:y0 + tile_h, x0:x0 + tile_w].reshape(-1))
+            tile = q[y0:y0 + tile_h, x0:x0 + tile_w]
+            if patch is not None and tile.shape == (tile_h, tile_w):
+                # the tile as (ph x pw) patches of 8 queries: a patch is what ONE wave of the head-major SCA gather owns
+                ph, pw = patch
+                tile = tile.reshape(tile_h // ph, ph, tile_w // pw, pw).transpose(0, 2, 1, 3)
+            tiles.append(tile.reshape(-1))
     flat = np.concatenate(tiles)
     n = flat.size
     nblk = (n + waves_per_block - 1) // waves_per_block

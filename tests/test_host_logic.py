@@ -22,6 +22,20 @@ def test_bev_tile_order_is_a_permutation(hw):
     assert o.dtype == np.int32 and np.array_equal(np.sort(o), np.arange(hw[0] * hw[1]))
 
 
+@pytest.mark.parametrize("hw,patch", [((200, 200), (2, 4)), ((38, 38), (2, 4)), ((50, 50), (4, 2)), ((16, 24), (1, 8))])
+def test_bev_tile_order_with_query_patches_is_a_permutation(hw, patch):
+    """The head-major SCA gather's order (plain tile walk, a wave's 8 consecutive entries = one ph x pw BEV patch inside full 8 x 8
+    tiles; ragged edge tiles keep row order): still a permutation, and full tiles really come out in patches."""
+    import numpy as np
+    o = synthetic.bev_tile_order(*hw, n_xcd=1, patch=patch)
+    assert sorted(o.tolist()) == list(range(hw[0] * hw[1]))
+    ph, pw = patch
+    first = o[:8]                                             # tile (0, 0) is a full tile for all cases here
+    ys, xs = first // hw[1], first % hw[1]
+    assert ys.max() - ys.min() == ph - 1 and xs.max() - xs.min() == pw - 1
+    assert len(np.unique(first)) == 8
+
+
 def test_bev_tile_order_xcd_contiguity():
     """Hardware block b runs on XCD b % 8: the queries an XCD processes form one contiguous 1/8 of the
     tile sequence, i.e. a compact band of the BEV plane."""

@@ -364,8 +364,16 @@ __global__ __launch_bounds__(64 * WB, WPS * 4 / WB) void sca_fused_hm_kernel(
   uni = __builtin_amdgcn_readfirstlane(uni);
 
   float aw[K], ox[K], oy[K];
+  // the lane's level: the L map shapes arrive as scalar loads (wave-uniform addresses) and are selected per lane — indexed by
+  // the lane's level they were three vector loads per wave, and the texture path charges a wave instruction ~21 clocks whatever
+  // its lanes fetch (round 6, second half: the non-gather loads were 15 % of the launch's wave loads)
   const int lane_l = (sK * K) / P;
-  const int lvH = (int)shapes[2 * lane_l], lvW = (int)shapes[2 * lane_l + 1], lvS = (int)lstart[lane_l];
+  int lvH = (int)shapes[0], lvW = (int)shapes[1], lvS = (int)lstart[0];
+#pragma unroll
+  for (int l = 1; l < L; ++l) {
+    const int hl = (int)shapes[2 * l], wl = (int)shapes[2 * l + 1], sl = (int)lstart[l];
+    lvH = lane_l == l ? hl : lvH; lvW = lane_l == l ? wl : lvW; lvS = lane_l == l ? sl : lvS;
+  }
   {
     const float* lp = logits + ((long)b * Nq + q) * logits_stride + m * LP + sK * K;
     const float* op = offs + ((long)b * Nq + q) * offs_stride + 2 * (m * LP + sK * K);
@@ -404,8 +412,10 @@ __global__ __launch_bounds__(64 * WB, WPS * 4 / WB) void sca_fused_hm_kernel(
   // ---- gather mapping: lane = (query slot g, 16-byte piece c4, sample half) ------------------------------------------------
   const int g = (lane >> 2) & 7, c4 = lane & 3, half = lane >> 5;
   const bool gvalid = r0 + g < Nq;
-  const int qg = order ? order[gvalid ? r0 + g : Nq - 1] : (gvalid ? r0 + g : Nq - 1);
-  const int count = __builtin_popcount(vis_bits[(long)b * Nq + qg]);   // this batch's mask gives the divisor
+  const int qg = __shfl(q, g * 8);                                     // slot g's query: held by the set-up lanes g * 8 ..
+  // this batch's mask gives the divisor (batch 0: the word the set-up lanes already hold)
+  const uint32_t own = b == 0 ? (uint32_t)__shfl((int)vis, g * 8) : (gvalid ? vis_bits[(long)b * Nq + qg] : 0u);
+  const int count = __builtin_popcount(own);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
   unsigned n_in = 0, n_rows = 0;
 
@@ -414,10 +424,18 @@ __global__ __launch_bounds__(64 * WB, WPS * 4 / WB) void sca_fused_hm_kernel(
     const int live = (int)((vis >> c) & 1u);
     const float* rp = ref_cam + (((long)c * B + b) * Nq + q) * Z * 2;
     float2 rxy_k[K];
+    if (K == 4 && P % 4 == 0 && Z % 4 == 0) {
+      // the lane's four anchors are consecutive (z0 .. z0 + 3, z0 a multiple of 4): two 16-byte loads instead of four 8-byte ones
+      const int z0 = ((sK * K) % P) % Z;
+      const float4 t0 = *reinterpret_cast<const float4*>(rp + 2 * z0), t1 = *reinterpret_cast<const float4*>(rp + 2 * z0 + 4);
+      rxy_k[0] = make_float2(t0.x, t0.y); rxy_k[1] = make_float2(t0.z, t0.w);
+      rxy_k[2 % K] = make_float2(t1.x, t1.y); rxy_k[3 % K] = make_float2(t1.z, t1.w);
+    } else {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int z = ((sK * K + k) % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
-      rxy_k[k] = *reinterpret_cast<const float2*>(rp + 2 * z);
+      for (int k = 0; k < K; ++k) {
+        const int z = ((sK * K + k) % P) % Z;  // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
+        rxy_k[k] = *reinterpret_cast<const float2*>(rp + 2 * z);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -456,278 +474,6 @@ __global__ __launch_bounds__(64 * WB, WPS * 4 / WB) void sca_fused_hm_kernel(
       atomicAdd(&stats[1], (unsigned long long)n_in);
     }
   }
-}
-
-// ---- persistent head-major variant (round 6, second half) ---------------------------------------------------------------------
-// Same roles, arithmetic and summation order as sca_fused_hm_kernel (results bit-identical); what changes is WHEN a wave asks
-// for its inputs.  A wave of the kernel above lives through a chain of dependent round trips before its first gather load
-// (order -> visibility word -> Linear outputs | anchor points of the camera -> set-up), ~5 us of its ~19 us on the chip with the
-// texture path idle for it, and again ~2 us per further camera; 16 waves per CU in random phases cover that only partly
-// (TA busy 0.66).  Here a wave stays resident and walks a strided list of 8-query items; in the MIDDLE of every gather pass
-// it requests what the NEXT pass needs — the next camera's anchor points, or, on an item's last pass, the first camera of the
-// next item — and on an item's first pass the next item's Linear outputs, the visibility words of the item after it and the
-// query indices of the one after that (a three-deep chain order -> visibility -> anchors, every link one pass ahead of its
-// use).  All through buffer loads on SGPR resources with 32-bit offsets: a slot that does not exist carries an out-of-range
-// offset and reads 0 (visibility 0 = no camera, dead samples).  An item that no camera sees runs one dead pass of camera 0.
-template <int L, int P, int WPS, int DEPTH_, bool Q, bool STATS, int WB = kScaWaves>
-__global__ __launch_bounds__(64 * WB, WPS * 4 / WB) void sca_fused_hmp_kernel(
-    const void* __restrict__ value_, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lstart, const float* __restrict__ offs, long offs_stride,
-    const float* __restrict__ logits, long logits_stride, const float* __restrict__ ref_cam,
-    const uint32_t* __restrict__ vis_bits, const int32_t* __restrict__ order,
-    float* __restrict__ slots, unsigned long long* __restrict__ stats, int B, int NC, int S, int Z,
-    int Nq, int G, const float* __restrict__ value_scale) {
-  constexpr int M = 8, D = 32, LP = L * P;
-  constexpr int K = M * LP / 64;  // samples resolved per lane
-  static_assert(LP >= 8 && LP <= 32 && (LP & (LP - 1)) == 0, "L*P must be a power of two in [8,32]");
-  static_assert(P % K == 0 && K * 8 == LP, "a lane's K samples share one level");
-  constexpr int LPp = LP + 1;
-  constexpr int NS = LP / 2;                                // samples per gather lane and pass
-  constexpr int DEPTH = NS < DEPTH_ ? NS : DEPTH_;
-  static_assert(NS % DEPTH == 0, "sample count must be a multiple of the window");
-  constexpr int PF = ((NS - DEPTH) / 2 / DEPTH) * DEPTH;    // the prefetch requests leave after this many samples of a pass
-  constexpr unsigned kDead = 0xfffffff0u;                   // beyond every resource below: the load returns 0
-  __shared__ __attribute__((aligned(16))) SampleParamB smem[WB * 8 * LPp];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int m = (int)(blockIdx.x & 7u);                    // the block's head = its XCD
-  const int stride = (int)(gridDim.x >> 3) * WB;           // waves per head (and batch entry)
-  const int total = G;                                     // 8-query items per head and batch entry
-  const int b = (int)blockIdx.y;
-  int itA = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * WB + wave);
-  if (itA >= total) return;
-  SampleParamB* sp = smem + wave * 8 * LPp;
-
-  constexpr int row_stride = M * D;
-  constexpr unsigned EV = 2u;                              // bytes per value element (fp16 / q16)
-  const char* value = reinterpret_cast<const char*>(value_);
-
-  const int j = lane >> 3, sK = lane & 7;                  // set-up lane = (query slot, sample group)
-  const int g = (lane >> 2) & 7, c4 = lane & 3, half = lane >> 5;   // gather lane = (query slot, 16-byte piece, sample half)
-  const int lane_l = (sK * K) / P;
-  const int lvH = (int)shapes[2 * lane_l], lvW = (int)shapes[2 * lane_l + 1], lvS = (int)lstart[lane_l];
-
-  const unsigned nbq = (unsigned)B * (unsigned)Nq;
-  const __amdgpu_buffer_rsrc_t rs_ord = uniform_rsrc(order, order ? (unsigned)Nq * 4u : 0u);
-  const __amdgpu_buffer_rsrc_t rs_vis = uniform_rsrc(vis_bits, nbq * 4u);
-  const __amdgpu_buffer_rsrc_t rs_log = uniform_rsrc(logits, ((nbq - 1u) * (unsigned)logits_stride + (unsigned)(M * LP)) * 4u);
-  const __amdgpu_buffer_rsrc_t rs_off = uniform_rsrc(offs, ((nbq - 1u) * (unsigned)offs_stride + (unsigned)(2 * M * LP)) * 4u);
-  const __amdgpu_buffer_rsrc_t rs_ref = uniform_rsrc(ref_cam, (unsigned)NC * nbq * (unsigned)Z * 8u);
-
-  // the slot's BEV query of item `it` (0 for a slot that does not exist; its visibility is forced to 0 below)
-  auto load_q = [&](int it) -> int {
-    const bool ok = it * 8 + j < Nq;
-    if (order == nullptr) return ok ? it * 8 + j : 0;
-    return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_ord, ok ? (unsigned)(it * 8 + j) * 4u : kDead, 0, 0);
-  };
-  auto load_vis = [&](int it, int q) -> uint32_t {          // batch 0's mask picks the cameras (the reference's quirk)
-    return __builtin_amdgcn_raw_buffer_load_b32(rs_vis, it * 8 + j < Nq ? (unsigned)q * 4u : kDead, 0, 0);
-  };
-  auto union8 = [&](uint32_t v) -> uint32_t {               // over the wave's 8 slots; never empty (camera 0, dead, otherwise)
-    v |= (uint32_t)__shfl_xor((int)v, 8);
-    v |= (uint32_t)__shfl_xor((int)v, 16);
-    v |= (uint32_t)__shfl_xor((int)v, 32);
-    v = __builtin_amdgcn_readfirstlane(v);
-    return v ? v : 1u;
-  };
-
-  // pipeline registers: item A = the next to start, B / C = the two after it
-  float lgA[K], ofA[2 * K];                                 // A's logits / offsets of this lane's K samples
-  uint32_t ownA = 0;                                        // A's own-batch visibility word of gather slot g
-  float2 rxy[K];                                            // anchor points of the NEXT pass (camera-normalised)
-  auto load_z = [&](int it, int q) {
-    const bool live = it < total;
-    const unsigned row = (unsigned)b * (unsigned)Nq + (unsigned)q;
-    const unsigned lo = live ? (row * (unsigned)logits_stride + (unsigned)(m * LP + sK * K)) * 4u : kDead;
-    const unsigned oo = live ? (row * (unsigned)offs_stride + (unsigned)(2 * (m * LP + sK * K))) * 4u : kDead;
-    if constexpr (K == 4) {
-      const float4 t = buf_load16(rs_log, lo);
-      lgA[0] = t.x; lgA[1] = t.y; lgA[2] = t.z; lgA[3] = t.w;
-      const float4 u0 = buf_load16(rs_off, oo), u1 = buf_load16(rs_off, live ? oo + 16u : kDead);
-      ofA[0] = u0.x; ofA[1] = u0.y; ofA[2] = u0.z; ofA[3] = u0.w; ofA[4] = u1.x; ofA[5] = u1.y; ofA[6] = u1.z; ofA[7] = u1.w;
-    } else {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        lgA[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_log, live ? lo + 4u * k : kDead, 0, 0));
-        typedef unsigned occ_u32x2 __attribute__((ext_vector_type(2)));
-        const occ_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_off, live ? oo + 8u * k : kDead, 0, 0);
-        ofA[2 * k] = __uint_as_float(t[0]); ofA[2 * k + 1] = __uint_as_float(t[1]);
-      }
-    }
-    const int qg = __shfl(q, g * 8);
-    ownA = __builtin_amdgcn_raw_buffer_load_b32(rs_vis, it * 8 + g < Nq ? (row - (unsigned)q + (unsigned)qg) * 4u : kDead, 0, 0);
-  };
-  auto load_ref = [&](int c, int q, bool live) {
-    const unsigned base = ((((unsigned)c * (unsigned)B + (unsigned)b) * (unsigned)Nq + (unsigned)q) * (unsigned)Z) * 8u;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      typedef unsigned occ_u32x2 __attribute__((ext_vector_type(2)));
-      const int z = ((sK * K + k) % P) % Z;                 // point p pairs with z-anchor p % Z (view(.., P//Z, Z, 2))
-      const occ_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs_ref, live ? base + (unsigned)z * 8u : kDead, 0, 0);
-      rxy[k] = make_float2(__uint_as_float(t[0]), __uint_as_float(t[1]));
-    }
-  };
-
-  // ---- fill the pipeline ---------------------------------------------------------------------------------------------------
-  int qA = load_q(itA), qB = load_q(itA + stride), qC = load_q(itA + 2 * stride);
-  uint32_t visA = load_vis(itA, qA), visB = load_vis(itA + stride, qB);
-  load_z(itA, qA);
-  uint32_t uniA = union8(visA);
-  load_ref(__builtin_ctz(uniA), qA, true);
-
-  unsigned n_in = 0, n_rows = 0;
-  const float vscale = (value_scale != nullptr ? *value_scale : 1.f) * (Q ? 16384.f : 1.f);
-  const unsigned lane_off = (unsigned)(m * 128 + c4 * 16);
-
-  for (;;) {
-    // ---- item A becomes the current item: softmax(logits), offsets / (W_l, H_l) -------------------------------------------
-    const int q = qA, r0 = itA * 8;
-    const uint32_t vis = visA;
-    uint32_t pending = uniA;
-    float aw[K], ox[K], oy[K];
-    {
-      float x[K];
-      float mx = lgA[0];
-#pragma unroll
-      for (int k = 1; k < K; ++k) mx = fmaxf(mx, lgA[k]);
-#pragma unroll
-      for (int d = 4; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-      float sum = 0.f;
-#pragma unroll
-      for (int k = 0; k < K; ++k) { x[k] = expf(lgA[k] - mx); sum += x[k]; }
-#pragma unroll
-      for (int d = 4; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        aw[k] = fdiv(x[k], sum);
-        ox[k] = fdiv(ofA[2 * k], (float)lvW);
-        oy[k] = fdiv(ofA[2 * k + 1], (float)lvH);
-      }
-    }
-    const int qg = __shfl(q, g * 8);
-    const bool gvalid = r0 + g < Nq;
-    const int count = __builtin_popcount(ownA);
-    // the pipeline moves up: A <- B <- C
-    itA += stride;
-    qA = qB; qB = qC; visA = visB;
-    uniA = union8(visA);
-    const bool moreA = itA < total;
-    bool first = true;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
-
-    do {
-      const int c = __builtin_ctz(pending);
-      pending &= pending - 1u;
-      const int live = (int)((vis >> c) & 1u);
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        SampleParamB p;
-        const int nc = bilinear_setup_b(rxy[k].x + ox[k], rxy[k].y + oy[k], aw[k], lvH, lvW, lvS,
-                                 (unsigned)row_stride * EV, kOobOffset, live, p);
-        if constexpr (STATS) n_in += nc;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) p.o[kk] = (p.o[kk] & ~1023u) | ((p.o[kk] >> 3) & 64u);     // pixel-pair layout
-        sp[j * LPp + k * 8 + sK] = p;
-      }
-      if constexpr (STATS) n_rows += (unsigned)(live & (sK == 0) & (m == 0));
-      wave_lds_sync();
-      const __amdgpu_buffer_rsrc_t rsrc =
-          uniform_rsrc(value + ((long)b * NC + c) * S * row_stride * EV, (unsigned)S * row_stride * EV);
-
-      // ---- gather: rolling window of DEPTH samples, the prefetch requests in the middle -----------------------------------
-      const SampleParamB* spg = sp + g * LPp + half * NS;
-      float4 v[DEPTH][4];
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {
-        const occ_u32x4 o = *reinterpret_cast<const occ_u32x4*>(spg[u].o);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[u][k] = buf_load16(rsrc, o[k] + lane_off);
-      }
-      auto window = [&](int j0) {
-#pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-          const float4 w = *reinterpret_cast<const float4*>(spg[j0 + u].w);
-          const occ_u32x4 o = *reinterpret_cast<const occ_u32x4*>(spg[j0 + DEPTH + u].o);
-          fma8x<Q>(acc, acc2, w.x, v[u][0]); fma8x<Q>(acc, acc2, w.y, v[u][1]);
-          fma8x<Q>(acc, acc2, w.z, v[u][2]); fma8x<Q>(acc, acc2, w.w, v[u][3]);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[u][k] = buf_load16(rsrc, o[k] + lane_off);
-        }
-      };
-#pragma unroll 1
-      for (int j0 = 0; j0 < PF; j0 += DEPTH) window(j0);
-      // what the next pass needs (its set-up already consumed rxy); on an item's first pass also the links further down
-      if (pending) load_ref(__builtin_ctz(pending), q, true);
-      else load_ref(__builtin_ctz(uniA), qA, moreA);
-      if (first) {
-        load_z(itA, qA);
-        visB = load_vis(itA + stride, qB);
-        qC = load_q(itA + 2 * stride);
-        first = false;
-      }
-#pragma unroll 1
-      for (int j0 = PF; j0 + DEPTH < NS; j0 += DEPTH) window(j0);
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {
-        const float4 w = *reinterpret_cast<const float4*>(spg[NS - DEPTH + u].w);
-        fma8x<Q>(acc, acc2, w.x, v[u][0]); fma8x<Q>(acc, acc2, w.y, v[u][1]);
-        fma8x<Q>(acc, acc2, w.z, v[u][2]); fma8x<Q>(acc, acc2, w.w, v[u][3]);
-      }
-      wave_lds_sync();  // WAR: the next pass rewrites the LDS slab
-    } while (pending);
-
-    const float inv = (float)(count > 0 ? count : 1) * vscale;
-    acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32);
-    acc.w += __shfl_xor(acc.w, 32);
-    acc2.x += __shfl_xor(acc2.x, 32); acc2.y += __shfl_xor(acc2.y, 32); acc2.z += __shfl_xor(acc2.z, 32);
-    acc2.w += __shfl_xor(acc2.w, 32);
-    if (half == 0 && gvalid) {
-      float* dst = slots + ((long)b * Nq + qg) * row_stride + m * D + c4 * 8;
-      *reinterpret_cast<float4*>(dst) = make_float4(fdiv(acc.x, inv), fdiv(acc.y, inv), fdiv(acc.z, inv), fdiv(acc.w, inv));
-      *reinterpret_cast<float4*>(dst + 4) = make_float4(fdiv(acc2.x, inv), fdiv(acc2.y, inv), fdiv(acc2.z, inv), fdiv(acc2.w, inv));
-    }
-    if (!moreA) break;
-  }
-
-  if constexpr (STATS) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { n_in += __shfl_xor(n_in, d); n_rows += __shfl_xor(n_rows, d); }
-    if (lane == 0) {
-      if (n_rows) atomicAdd(&stats[0], (unsigned long long)n_rows);
-      atomicAdd(&stats[1], (unsigned long long)n_in);
-    }
-  }
-}
-
-// persistent grid: one head per XCD as above, WPS waves per SIMD on every CU — or fewer blocks when there are fewer items
-template <int L, int P, bool Q, int WPS = 4, int DEPTH = 2, int WB = kScaWaves>
-static int launch_sca_hmp(const void* value, const int64_t* shapes, const int64_t* lstart,
-                          const float* offs, long offs_stride, const float* logits, long logits_stride,
-                          const float* ref_cam, const uint32_t* vis_bits, const int32_t* order,
-                          float* slots, uint64_t* stats, int B, int NC, int S, int Z, int Nq,
-                          hipStream_t st, const float* value_scale) {
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n;
-  }();
-  const int G = (Nq + 7) / 8;
-  const long items = G;
-  long per_head = (long)(cus / 8) * (WPS * 4 / WB);         // resident blocks of one XCD
-  const long need = (items + WB - 1) / WB;
-  if (per_head > need) per_head = need;
-  if (per_head < 1) per_head = 1;
-  if (stats)
-    hipLaunchKernelGGL((sca_fused_hmp_kernel<L, P, WPS, DEPTH, Q, true, WB>), dim3((unsigned)(per_head * 8), (unsigned)B), dim3(64 * WB),
-                       0, st, value, shapes, lstart, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits, order, slots,
-                       reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq, G, value_scale);
-  else
-    hipLaunchKernelGGL((sca_fused_hmp_kernel<L, P, WPS, DEPTH, Q, false, WB>), dim3((unsigned)(per_head * 8), (unsigned)B), dim3(64 * WB),
-                       0, st, value, shapes, lstart, offs, offs_stride, logits, logits_stride, ref_cam, vis_bits, order, slots,
-                       reinterpret_cast<unsigned long long*>(stats), B, NC, S, Z, Nq, G, value_scale);
-  OCC_CHECK_LAUNCH(Q ? "sca_fused_forward_q16v (head-major, persistent)" : "sca_fused_forward_f16v (head-major, persistent)");
-  return OCC_OK;
 }
 
 template <int L, int P, bool Q, int WPS = 4, int DEPTH = 2, int WB = kScaWaves>
@@ -794,33 +540,8 @@ static int sca_dispatch(const void* value, int rowfmt /* 0 f32, 1 f16, 2 q16 */,
   // (4, 2, 8) 0.2051, (4, 1, 4) 0.2044 ms.
   const char* hm_env = getenv("OCC_SCA_HEAD_MAJOR");
   const bool head_major = !(hm_env != nullptr && hm_env[0] == '0');
-  // the persistent form of the head-major kernel (prefetching waves); OCC_SCA_PERSIST=0 selects the one-item-per-wave form.
-  // Its row reads go through buffer resources with 32-bit byte offsets: larger inputs take the non-persistent kernel.
-  const char* ps_env = getenv("OCC_SCA_PERSIST");
-  const unsigned long long nbq = (unsigned long long)B * (unsigned long long)Nq;
-  const bool persist = !(ps_env != nullptr && ps_env[0] == '0') &&
-                       nbq * (unsigned long long)offs_stride * 4ull < (1ull << 31) &&
-                       nbq * (unsigned long long)logits_stride * 4ull < (1ull << 31) &&
-                       (unsigned long long)NC * nbq * (unsigned long long)Z * 8ull < (1ull << 31);
-  static const int hmp_variant = [] { const char* e = getenv("OCC_SCA_HMP_VARIANT"); return e ? atoi(e) : 0; }();   // development
 #define OCC_SCA_CASE(LL, PP)                                                                       \
   if (L == LL && P == PP) {                                                                        \
-    if (rowfmt == 2 && head_major && persist && hmp_variant == 1)                                  \
-      return launch_sca_hmp<LL, PP, true, 3, 2>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
-                                          (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
-                                          value_scale);                                                          \
-    if (rowfmt == 2 && head_major && persist && hmp_variant == 2)                                  \
-      return launch_sca_hmp<LL, PP, true, 3, 4>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
-                                          (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
-                                          value_scale);                                                          \
-    if (rowfmt == 2 && head_major && persist)                                                      \
-      return launch_sca_hmp<LL, PP, true>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
-                                          (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
-                                          value_scale);                                                          \
-    if (rowfmt == 1 && head_major && persist)                                                      \
-      return launch_sca_hmp<LL, PP, false>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
-                                           (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \
-                                           value_scale);                                                         \
     if (rowfmt == 2 && head_major)                                                                 \
       return launch_sca_hm<LL, PP, true>(value, spatial_shapes, level_start_index, offs, (long)offs_stride, logits, \
                                          (long)logits_stride, ref_cam, vis_bits, order, slots, stats, B, NC, S, Z, Nq, st, \

@@ -227,7 +227,7 @@ _SCA_SHAPES = {
 
 
 @pytest.mark.parametrize("shape", sorted(_SCA_SHAPES))
-@pytest.mark.parametrize("values", ["f32", "f16", "q16", "f16-hm", "q16-hm", "f16-hmp", "q16-hmp"])
+@pytest.mark.parametrize("values", ["f32", "f16", "q16", "f16-hm", "q16-hm"])
 def test_sca_gather_kernels_match_oracle(values, shape, monkeypatch):
     """The SCA gather kernels (fp32 value rows: sca_fused_kernel; fp16 rows and q16 block-floating-point rows: sca_fused_h_kernel)
     on every (levels, points, z-anchors) combination with a fused kernel, batch 2 (the reference takes the camera
@@ -236,9 +236,7 @@ def test_sca_gather_kernels_match_oracle(values, shape, monkeypatch):
     from occnet_amd import ext
     kernel = values
     # "-hm": the head-major kernel (one wave = 8 queries x one head, heads dealt to the XCDs) instead of the query-major one
-    # "-hmp": its persistent form (resident waves that prefetch the next pass's inputs; the default)
-    monkeypatch.setenv("OCC_SCA_HEAD_MAJOR", "0" if "-" not in values else "1")
-    monkeypatch.setenv("OCC_SCA_PERSIST", "1" if values.endswith("-hmp") else "0")
+    monkeypatch.setenv("OCC_SCA_HEAD_MAJOR", "1" if values.endswith("-hm") else "0")
     values = values.split("-")[0]
     monkeypatch.setattr(ext, "SCA_VALUES", values)
     g = small_cfg(bev=(38, 38), num_layers=1, **_SCA_SHAPES[shape])
@@ -256,57 +254,6 @@ def test_sca_gather_kernels_match_oracle(values, shape, monkeypatch):
     d = maxdiff(out_p, out_o)
     print(f"kernel {kernel} {shape}: bev max|hip - oracle| = {d:.3e}")
     assert d < TOL
-
-
-@pytest.mark.parametrize("rows", ["f16", "q16"])
-@pytest.mark.parametrize("case", ["ragged_b2_order", "one_item", "dense_3cams"])
-def test_sca_persistent_kernel_is_bit_identical_to_the_one_item_kernel(rows, case, monkeypatch):
-    """The persistent head-major gather (sca_fused_hmp_kernel: resident waves walking a strided item list, the next pass's
-    anchor points / Linear outputs / visibility words / query indices requested one to three passes ahead) does the arithmetic
-    of sca_fused_hm_kernel in the same order: outputs and the N_in / row counters must be bit-identical — with a ragged tail
-    (Nq % 8 != 0), batch 2 (cameras from batch 0's mask, divisor from the own batch's), a permuted `order`, queries and whole
-    8-query items that no camera sees, up to three cameras per query, and fewer items than resident waves."""
-    from occnet_amd import ext
-    B, Nq = {"ragged_b2_order": (2, 1444 + 3), "one_item": (1, 5), "dense_3cams": (1, 4096)}[case]
-    NC, M, D, L, P, Z = 6, 8, 32, 4, 8, 8
-    shapes = torch.tensor([[20, 34], [10, 17], [5, 9], [3, 5]])
-    S = int(shapes.prod(1).sum())
-    S += S & 1
-    start = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
-    gen = torch.Generator().manual_seed(7)
-    value = torch.randn(B * NC, S, M, D, generator=gen)
-    offs = torch.randn(B, Nq, M * L * P * 2, generator=gen) * 2
-    logits = torch.randn(B, Nq, M * L * P, generator=gen)
-    ref_cam = torch.rand(NC, B, Nq, Z, 2, generator=gen) * 1.2 - 0.1
-    ncam = torch.randint(0, 4 if case == "dense_3cams" else 3, (B, Nq), generator=gen)
-    vis = torch.zeros(B, Nq, dtype=torch.int32)
-    for k in range(3):
-        cam = torch.randint(0, NC, (B, Nq), generator=gen)
-        vis |= torch.where(ncam > k, torch.ones_like(cam) << cam, torch.zeros_like(cam)).to(torch.int32)
-    vis[:, 16:32] = 0                    # two whole items without a camera (one dead pass each in the persistent kernel)
-    order = torch.randperm(Nq, generator=gen).to(torch.int32).cuda() if case == "ragged_b2_order" else None
-    if rows == "q16":
-        v16, scale = ext.q16_range_scaled(value.cuda())
-        v16 = v16.view(B * NC, -1, M, D)
-    else:
-        scale = torch.tensor([4.0], device='cuda')
-        v16 = ext.sca_pair_layout((value * 4.0).half().cuda())
-    args = (shapes.cuda(), start.cuda(), offs.cuda(), logits.cuda(), ref_cam.cuda(), vis.cuda(), M, L, P)
-    outs = {}
-    for persist in ("0", "1"):
-        monkeypatch.setenv("OCC_SCA_HEAD_MAJOR", "1")
-        monkeypatch.setenv("OCC_SCA_PERSIST", persist)
-        stats = torch.zeros(2, dtype=torch.int64, device='cuda')
-        o_stats = ext.sca_fused_forward(v16, *args, order=order, stats=stats, value_layout="pairs", value_scale=scale)
-        o_plain = ext.sca_fused_forward(v16, *args, order=order, value_layout="pairs", value_scale=scale)
-        torch.cuda.synchronize()
-        assert torch.equal(o_stats, o_plain)
-        outs[persist] = (o_plain, stats.cpu().tolist())
-    assert outs["0"][1] == outs["1"][1]
-    assert outs["0"][1][0] == B * sum(bin(int(x) & 0x3f).count("1") for x in vis[0].tolist())      # batch 0's mask, every batch entry
-    assert torch.isfinite(outs["0"][0]).all()
-    assert float(outs["0"][0].abs().max()) > 0
-    assert torch.equal(outs["0"][0], outs["1"][0])
 
 
 def test_sca_gather_ignores_non_finite_values_outside_the_maps():

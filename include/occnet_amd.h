@@ -430,6 +430,31 @@ int occ_conv3d_wgrad_bf16x3_f32(const float* dy_pad, const float* x_pad, float* 
 int occ_bias_act_nhwc_bf16(void* x, const float* bias, const void* residual, int64_t rows, int C, int relu,
                            void* stream);
 
+/* Backward of that tail for the training step's autocast backbone (the reference trains its ResNet with eval-mode
+ * BatchNorm, bevformer_base_occ.py:55; conv -> + bias (+ residual) -> ReLU is one autograd node in plugin/backbone.py):
+ *   g = relu ? (y > 0 ? grad_y : 0) : grad_y   (bf16 NHWC; relu == 0: g is not written and may be NULL, y is not read)
+ *   bias_grad[c] = sum over rows of g[., c]     (fp32, deterministic: per-block partial sums added in a fixed order)
+ * in one pass over the activation.  partial: occ_bias_act_bwd_partial_floats(rows, C) floats of scratch (0 = unsupported C:
+ * C % 8 != 0 or C > 2048). */
+int64_t occ_bias_act_bwd_partial_floats(int64_t rows, int C);
+int occ_bias_act_bwd_nhwc_bf16(const void* grad_y, const void* y, void* g, float* partial, float* bias_grad,
+                               int64_t rows, int C, int relu, void* stream);
+
+/* Weight side of the same training nodes: eval-mode BatchNorm folded into a convolution weight, and the fold's chain rule,
+ * one launch each (conv_bn_folded's arithmetic, plugin/backbone.py; rstd = 1 / sqrt(running_var + eps), mean_rstd =
+ * running_mean * rstd are constants of the frozen statistics).  weight / w_folded / grad_weight: (Cout, Cin, KH, KW) fp32
+ * contiguous; w_folded_bf16_nhwc: the same values as bf16 in channels_last order [Cout][KH][KW][Cin]; bias[o] = beta[o] -
+ * gamma[o] * mean_rstd[o].  Backward: grad_w_bf16 = the convolution's bf16 weight gradient with the given ELEMENT strides;
+ * grad_weight = grad_w * gamma * rstd; grad_gamma[o] = rstd[o] * sum(grad_w[o] * weight[o]) - mean_rstd[o] * grad_bias[o]
+ * (grad_beta = grad_bias). */
+int occ_conv_bn_fold_fwd_f32(const float* weight, const float* gamma, const float* beta, const float* rstd,
+                             const float* mean_rstd, float* w_folded, void* w_folded_bf16_nhwc, float* bias, int Cout,
+                             int Cin, int KH, int KW, void* stream);
+int occ_conv_bn_fold_bwd_f32(const void* grad_w_bf16, int64_t stride_o, int64_t stride_i, int64_t stride_h, int64_t stride_w,
+                             const float* weight, const float* gamma, const float* rstd, const float* mean_rstd,
+                             const float* grad_bias, float* grad_weight, float* grad_gamma, int Cout, int Cin, int KH, int KW,
+                             void* stream);
+
 /* SCA value projection straight off the backbone's bf16 feature maps (rows A3/A8: replaces the reference's
  * fp32 feature flatten + embedding adds, transformer_occ.py:204-222, AND MSDeformableAttention3D.value_proj,
  * spatial_cross_attention.py:366), all FPN levels in one launch.  For segment (= level) s, row m = g*rpg_s + i:

@@ -1376,6 +1376,66 @@ def bias_act_nhwc_(x, bias, residual=None, relu=True):
     return x
 
 
+def bias_act_bwd_nhwc(grad_y, y=None, relu=True):
+    """Backward of bias_act_nhwc_ in one pass: -> (g, bias_grad) with g = grad_y * (y > 0) (grad_y itself when not relu) and
+    bias_grad (C) float32 = sum of g over N, H, W.  grad_y / y: channels_last bfloat16 (N, C, H, W) device tensors."""
+    ok = lambda t: (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4
+                    and t.is_contiguous(memory_format=torch.channels_last))
+    if not ok(grad_y) or (relu and not (y is not None and ok(y) and y.shape == grad_y.shape)):
+        raise OccAmdUnsupported("bias_act_bwd_nhwc: grad_y / y must be matching channels_last bfloat16 device tensors")
+    N, C, H, W = grad_y.shape
+    rows = N * H * W
+    lib = _lib.lib()
+    lib.occ_bias_act_bwd_partial_floats.restype = ctypes.c_int64
+    nfl = int(lib.occ_bias_act_bwd_partial_floats(i64(rows), i32(C)))
+    if nfl <= 0:
+        raise OccAmdUnsupported(f"bias_act_bwd_nhwc: no kernel for C={C}")
+    partial = torch.empty(nfl, dtype=torch.float32, device=grad_y.device)
+    bias_grad = torch.empty(C, dtype=torch.float32, device=grad_y.device)
+    g = torch.empty_like(grad_y) if relu else grad_y
+    with torch.cuda.device(grad_y.device):
+        rc = _lib.lib().occ_bias_act_bwd_nhwc_bf16(ptr(grad_y), ptr(y) if relu else ptr(None), ptr(g) if relu else ptr(None),
+                                                   ptr(partial), ptr(bias_grad), i64(rows), i32(C), i32(1 if relu else 0),
+                                                   stream_ptr(grad_y.device))
+    _lib.check(rc, "bias_act_bwd_nhwc")
+    return g, bias_grad
+
+
+def conv_bn_fold_fwd(weight, gamma, beta, rstd, mean_rstd):
+    """Eval-mode BatchNorm folded into a convolution weight, one launch: -> (w_folded fp32 (O, I, kh, kw) contiguous,
+    w16 = the same as bfloat16 channels_last, bias (O) fp32)."""
+    for n, t in (("weight", weight), ("gamma", gamma), ("beta", beta), ("rstd", rstd), ("mean_rstd", mean_rstd)):
+        _need_cuda_f32(n, t)
+    O, I, KH, KW = weight.shape
+    wf = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    w16 = torch.empty((O, I, KH, KW), dtype=torch.bfloat16, device=weight.device, memory_format=torch.channels_last)
+    b = torch.empty(O, dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = _lib.lib().occ_conv_bn_fold_fwd_f32(ptr(weight), ptr(gamma), ptr(beta), ptr(rstd), ptr(mean_rstd), ptr(wf), ptr(w16),
+                                                 ptr(b), i32(O), i32(I), i32(KH), i32(KW), stream_ptr(weight.device))
+    _lib.check(rc, "conv_bn_fold_fwd")
+    return wf, w16, b
+
+
+def conv_bn_fold_bwd(grad_w16, weight, gamma, rstd, mean_rstd, grad_bias):
+    """Chain rule of conv_bn_fold_fwd, one launch: grad_w16 (O, I, kh, kw) bfloat16 (any strides) -> (grad_weight fp32,
+    grad_gamma fp32); grad_beta is grad_bias."""
+    if not (grad_w16.is_cuda and grad_w16.dtype == torch.bfloat16 and grad_w16.shape == weight.shape):
+        raise OccAmdUnsupported("conv_bn_fold_bwd: grad_w16 must be a bfloat16 device tensor of the weight's shape")
+    for n, t in (("weight", weight), ("gamma", gamma), ("rstd", rstd), ("mean_rstd", mean_rstd), ("grad_bias", grad_bias)):
+        _need_cuda_f32(n, t)
+    O, I, KH, KW = weight.shape
+    dW = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    dgamma = torch.empty(O, dtype=torch.float32, device=weight.device)
+    so, si, sh, sw = grad_w16.stride()
+    with torch.cuda.device(weight.device):
+        rc = _lib.lib().occ_conv_bn_fold_bwd_f32(ptr(grad_w16), i64(so), i64(si), i64(sh), i64(sw), ptr(weight), ptr(gamma),
+                                                 ptr(rstd), ptr(mean_rstd), ptr(grad_bias), ptr(dW), ptr(dgamma), i32(O), i32(I),
+                                                 i32(KH), i32(KW), stream_ptr(weight.device))
+    _lib.check(rc, "conv_bn_fold_bwd")
+    return dW, dgamma
+
+
 def stem_pack_weight(weight):
     """(64, 3, 7, 7) stem weight (BatchNorm folded) -> the fragment-ordered (64, 224) operand of stem_conv7x7_pool:
     column ky*32 + kx*4 + c holds weight[:, c, ky, kx]; the pad columns (kx = 7, c = 3) are zero."""

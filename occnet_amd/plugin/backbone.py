@@ -42,9 +42,141 @@ def conv_bn_folded(x, conv, bn):
     return F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+def _bn_fold_constants(bn):
+    """(1 / sqrt(var + eps), mean / sqrt(var + eps)) of an eval-mode BatchNorm, cached until a buffer is written."""
+    key = (bn.running_mean._version, bn.running_var._version, bn.running_var.data_ptr(), cache_epoch())
+    cached = getattr(bn, '_occ_fold', None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            rstd = torch.rsqrt(bn.running_var + bn.eps)
+            cached = (key, rstd, bn.running_mean * rstd)
+        object.__setattr__(bn, '_occ_fold', cached)
+    return cached[1], cached[2]
+
+
+class ConvBNActFunction(torch.autograd.Function):
+    """conv -> eval-mode BatchNorm -> (+ residual) -> (ReLU) as ONE autograd node on bf16 channels_last activations: the
+    training step's form of the inference plan's fused convolutions (the reference trains its ResNet with `norm_eval=True`,
+    projects/configs/bevformer/bevformer_base_occ.py:55, under DDP: P/bevformer/apis/mmdet_train.py:71-79).
+    Forward: the BatchNorm is folded into the weights (conv_bn_folded's arithmetic) and the convolution runs on this
+    repository's 1x1 / 3x3 NHWC kernels with bias, residual and ReLU in their epilogues (other shapes: MIOpen + ONE fused
+    tail launch) — under torch.autocast the same chain costs a convolution, a bias add, a residual add and a clamp, three
+    more passes over the activation.  Backward: ONE pass makes the ReLU-masked gradient and the bias gradient
+    (ext.bias_act_bwd_nhwc; ATen: threshold_backward + a bf16 column reduction + an add at the residual join), MIOpen's data /
+    weight gradients follow, and the fold's chain rule gives the gradients of W, gamma and beta.  Same function and the same
+    gradients as conv_bn_folded up to bf16 rounding (the tail adds in fp32 and rounds once instead of three times)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, rstd, mean_rstd, conv_bias, residual, stride, padding, relu):
+        from .. import ext
+        O, I, kh, kw = weight.shape
+        cl = torch.channels_last
+        w16 = None
+        one_launch = (gamma is not None and conv_bias is None and weight.dtype == torch.float32 and weight.is_contiguous()
+                      and all(t.dtype == torch.float32 and t.is_contiguous() for t in (gamma, beta, rstd, mean_rstd)))
+        if one_launch:
+            wf, w16, b = ext.conv_bn_fold_fwd(weight, gamma, beta, rstd, mean_rstd)      # the whole fold: one launch
+        elif gamma is not None:
+            s = gamma * rstd
+            wf = weight * s.view(-1, 1, 1, 1)
+            b = torch.addcmul(beta, gamma, mean_rstd, value=-1.0)
+            if conv_bias is not None:
+                b = b + conv_bias * s
+        else:
+            wf = weight
+            b = conv_bias if conv_bias is not None else weight.new_zeros(O)
+        wf, b = wf.float(), b.float().contiguous()
+        x16 = x if (x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=cl)) else \
+            x.to(torch.bfloat16).contiguous(memory_format=cl)
+        r16 = None
+        if residual is not None:
+            r16 = residual if (residual.dtype == torch.bfloat16 and residual.is_contiguous(memory_format=cl)) else \
+                residual.to(torch.bfloat16).contiguous(memory_format=cl)
+        if w16 is None:
+            w16 = wf.to(torch.bfloat16).contiguous(memory_format=cl)
+        stride, padding = tuple(stride), tuple(padding)
+        y = None
+        if (kh, kw) == (1, 1) and padding == (0, 0) and stride[0] == stride[1] and I % 32 == 0 and O % 32 == 0:
+            y = ext.conv1x1_nhwc(x16, ext.conv1x1_pack_weight(wf.reshape(O, I)), b, residual=r16, relu=relu, stride=stride[0])
+        elif ((kh, kw) == (3, 3) and padding == (1, 1) and stride in ((1, 1), (2, 2)) and I % 32 == 0 and O % 128 == 0
+              and r16 is None):
+            y = ext.conv3x3_nhwc(x16, ext.conv3x3_pack_weight(wf.contiguous()), b, O, relu=relu, stride=stride[0])
+        if y is None:
+            y = torch.ops.aten.convolution(x16, w16, None, stride, padding, (1, 1), False, (0, 0), 1)
+            if not y.is_contiguous(memory_format=cl):
+                y = y.contiguous(memory_format=cl)
+            y = ext.bias_act_nhwc_(y, b, residual=r16, relu=relu)
+        ctx.conv = (stride, padding, bool(relu), residual is not None and residual.dtype, one_launch)
+        ctx.save_for_backward(x16, w16, y if relu else None, weight, gamma, rstd, mean_rstd, conv_bias)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        from .. import ext
+        x16, w16, y, weight, gamma, rstd, mean_rstd, conv_bias = ctx.saved_tensors
+        stride, padding, relu, res_dtype, one_launch = ctx.conv
+        s = None if (gamma is None or one_launch) else gamma * rstd
+        cl = torch.channels_last
+        if not (gy.dtype == torch.bfloat16 and gy.is_contiguous(memory_format=cl)):
+            gy = gy.to(torch.bfloat16).contiguous(memory_format=cl)
+        g, gb = ext.bias_act_bwd_nhwc(gy, y, relu=relu)
+        need = ctx.needs_input_grad
+        gx, gw, _ = torch.ops.aten.convolution_backward(g, x16, w16, None, stride, padding, (1, 1), False, (0, 0), 1,
+                                                        (bool(need[0]), bool(need[1] or need[2]), False))
+        dW = dgamma = dbeta = dcb = None
+        if gw is not None and one_launch and need[1] and need[2]:
+            dW, dgamma = ext.conv_bn_fold_bwd(gw, weight, gamma, rstd, mean_rstd, gb)    # the fold's chain rule: one launch
+        elif gw is not None:
+            gwf = gw.float()
+            if s is not None:
+                if need[1]:
+                    dW = gwf * s.view(-1, 1, 1, 1)
+                if need[2]:
+                    dot = (gwf * weight).sum((1, 2, 3))
+                    dgamma = rstd * dot - mean_rstd * gb
+                    if conv_bias is not None:
+                        dgamma = dgamma + rstd * conv_bias * gb
+            elif need[1]:
+                dW = gwf
+        if gamma is not None:
+            if need[3]:
+                dbeta = gb
+            if conv_bias is not None and need[6]:
+                dcb = s * gb
+        elif conv_bias is not None and need[6]:
+            dcb = gb
+        dres = None
+        if need[7]:
+            dres = g if res_dtype == torch.bfloat16 else g.to(res_dtype)
+        return gx, dW, dgamma, dbeta, None, None, dcb, dres, None, None, None
+
+
+def _fused_train_ok(x):
+    """The fused training nodes serve the bf16-autocast backbone of the training step (device tensors only)."""
+    return (Bottleneck.fused_train_nodes and torch.is_grad_enabled() and x.is_cuda and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype('cuda') == torch.bfloat16)
+
+
+def conv_bn_act(x, conv, bn, relu=False, residual=None):
+    """ConvBNActFunction on a Conv2d (+ eval-mode BatchNorm2d or None)."""
+    if bn is not None:
+        rstd, mean_rstd = _bn_fold_constants(bn)
+        return ConvBNActFunction.apply(x, conv.weight, bn.weight, bn.bias, rstd, mean_rstd, conv.bias, residual,
+                                       conv.stride, conv.padding, relu)
+    return ConvBNActFunction.apply(x, conv.weight, None, None, None, None, conv.bias, residual, conv.stride, conv.padding,
+                                   relu)
+
+
+def _plain_conv(conv):
+    return (tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and isinstance(conv.padding, tuple) and conv.weight.shape[0] % 8 == 0 and conv.weight.shape[0] <= 2048)
+
+
 class Bottleneck(nn.Module):
     expansion = 4
     fold_eval_bn = True     # class-wide switch (OCC_TRAIN_FOLD_BN=0 clears it)
+    fused_train_nodes = os.environ.get("OCC_TRAIN_FUSED_CONV", "1") != "0"    # ConvBNActFunction under bf16 autocast
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
@@ -61,6 +193,12 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         if (self.fold_eval_bn and torch.is_grad_enabled() and not self.bn1.training and x.is_cuda
                 and self.bn1.affine and self.bn1.track_running_stats):
+            if _fused_train_ok(x) and all(_plain_conv(c) for c in (self.conv1, self.conv2, self.conv3)) and \
+                    (self.downsample is None or _plain_conv(self.downsample[0])):
+                identity = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1])
+                out = conv_bn_act(x, self.conv1, self.bn1, relu=True)
+                out = conv_bn_act(out, self.conv2, self.bn2, relu=True)
+                return conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=identity)
             identity = x if self.downsample is None else conv_bn_folded(x, self.downsample[0], self.downsample[1])
             out = self.relu(conv_bn_folded(x, self.conv1, self.bn1))
             out = self.relu(conv_bn_folded(out, self.conv2, self.bn2))
@@ -222,14 +360,23 @@ class FPN(BaseModule):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
+    @staticmethod
+    def _run(cm, x):
+        """A bias-only ConvModule of the neck: under the training step's bf16 autocast one fused autograd node
+        (ConvBNActFunction: bias in the convolution's epilogue, bias gradient in one pass), otherwise the module itself."""
+        if (_fused_train_ok(x) and not getattr(cm, 'with_norm', False) and not getattr(cm, 'with_activation', False)
+                and isinstance(getattr(cm, 'conv', None), nn.Conv2d) and _plain_conv(cm.conv)):
+            return conv_bn_act(x, cm.conv, None)
+        return cm(x)
+
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+        laterals = [self._run(conv, inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
         n = len(laterals)
         for i in range(n - 1, 0, -1):
             laterals[i - 1] = laterals[i - 1] + F.interpolate(
                 laterals[i], size=laterals[i - 1].shape[2:], **self.upsample_cfg)
-        outs = [self.fpn_convs[i](laterals[i]) for i in range(n)]
+        outs = [self._run(self.fpn_convs[i], laterals[i]) for i in range(n)]
         if self.num_outs > len(outs):
             if not self.add_extra_convs:
                 for _ in range(self.num_outs - n):
@@ -241,10 +388,10 @@ class FPN(BaseModule):
                     src = laterals[-1]
                 else:
                     src = outs[-1]
-                outs.append(self.fpn_convs[n](src))
+                outs.append(self._run(self.fpn_convs[n], src))
                 for i in range(n + 1, self.num_outs):
                     src = F.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]
-                    outs.append(self.fpn_convs[i](src))
+                    outs.append(self._run(self.fpn_convs[i], src))
         return tuple(outs)
 
 

@@ -360,3 +360,137 @@ def test_training_backbone_frozen_prefix_runs_on_the_plan_kernels():
         assert rel < 0.06
     gr = float((res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max())
     assert gr < 0.1
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 7, 9), (1, 256, 5, 3), (3, 8, 1, 1), (2, 192, 6, 5), (1, 2048, 3, 4), (6, 512, 29, 50)])
+def test_bias_act_bwd_nhwc_matches_torch(N, C, H, W):
+    """g = grad_y * (y > 0) bit for bit; the bias gradient = fp32 column sums of g (a fixed summation order: two runs agree
+    bit for bit; vs torch's fp64 sum to fp32 accumulation noise)."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(C + H)
+    cl = lambda t: t.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = cl(torch.randn(N, C, H, W, generator=g))
+    yf = torch.randn(N, C, H, W, generator=g).relu()
+    yf.view(-1)[::7] = -0.0           # a negative zero is not > 0
+    y = cl(yf)
+    for relu in (True, False):
+        got_g, got_b = ext.bias_act_bwd_nhwc(gy, y if relu else None, relu=relu)
+        again_g, again_b = ext.bias_act_bwd_nhwc(gy, y if relu else None, relu=relu)
+        want_g = torch.where(y.float() > 0, gy, torch.zeros_like(gy)) if relu else gy
+        assert torch.equal(got_g, want_g) and torch.equal(got_b, again_b)
+        want_b = want_g.double().sum((0, 2, 3))
+        assert float((got_b.double() - want_b).abs().max()) <= 1e-5 * max(1.0, float(want_b.abs().max())) * (N * H * W) ** 0.5
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,bn,res,relu", [
+    (256, 128, 1, 1, True, False, True),      # bottleneck conv1: own 1x1 kernel
+    (128, 128, 3, 2, True, False, True),      # conv2, stride 2: own 3x3 kernel
+    (128, 512, 1, 1, True, True, True),       # conv3 + identity + ReLU: own 1x1 kernel with residual
+    (256, 512, 1, 2, True, False, False),     # downsample projection
+    (64, 64, 3, 1, True, False, True),        # a shape without an own kernel: MIOpen + the fused tail
+    (512, 256, 1, 1, False, False, False),    # FPN lateral: bias, no norm
+    (256, 256, 3, 1, False, False, False)])   # FPN output convolution
+def test_conv_bn_act_function_matches_the_autocast_chain(cin, cout, k, stride, bn, res, relu):
+    """ConvBNActFunction (one autograd node: fold + own / MIOpen convolution with fused tail; backward = one masked-gradient +
+    bias-gradient pass, MIOpen's data / weight gradients, the fold's chain rule) against the chain it replaces under
+    torch.autocast(bf16): conv_bn_folded (or the biased convolution) -> + residual -> ReLU.  Outputs and every gradient agree to
+    bf16 rounding (both sides round the activations to bf16; the fused node rounds once where the chain rounds three times)."""
+    from occnet_amd.plugin.backbone import conv_bn_act, conv_bn_folded
+    g = torch.Generator().manual_seed(cin + cout + k)
+    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=not bn).cuda()
+    norm = None
+    if bn:
+        norm = torch.nn.BatchNorm2d(cout).cuda().eval()
+        with torch.no_grad():
+            norm.running_mean.copy_(torch.randn(cout, generator=g).cuda() * 0.1)
+            norm.running_var.copy_(torch.rand(cout, generator=g).cuda() * 0.5 + 0.75)
+            norm.weight.copy_(torch.rand(cout, generator=g).cuda() * 0.5 + 0.75)
+            norm.bias.copy_(torch.randn(cout, generator=g).cuda() * 0.1)
+    cl = lambda t: t.cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    N, H, W = 2, 12, 20
+    x0 = cl(torch.randn(N, cin, H, W, generator=g))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r0 = cl(torch.randn(N, cout, Ho, Wo, generator=g)) if res else None
+    gy = cl(torch.randn(N, cout, Ho, Wo, generator=g))
+    params = [conv.weight] + ([conv.bias] if conv.bias is not None else []) + ([norm.weight, norm.bias] if bn else [])
+    out = {}
+    for mode in ("fused", "chain", "fp32"):
+        x = (x0.float() if mode == "fp32" else x0.clone(memory_format=torch.channels_last)).requires_grad_(True)
+        r = None if r0 is None else (r0.float() if mode == "fp32" else r0.clone(memory_format=torch.channels_last)).requires_grad_(True)
+        for p in params:
+            p.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=mode != "fp32"):
+            if mode == "fused":
+                y = conv_bn_act(x, conv, norm, relu=relu, residual=r)
+            else:
+                y = conv_bn_folded(x, conv, norm) if bn else conv(x)
+                if r is not None:
+                    y = y + r
+                if relu:
+                    y = torch.relu(y)
+        assert y.dtype == (torch.float32 if mode == "fp32" else torch.bfloat16)
+        y.backward(gy.float() if mode == "fp32" else gy)
+        out[mode] = [y.detach().float(), x.grad.float()] + ([] if r is None else [r.grad.float()]) + [p.grad.float().clone() for p in params]
+    # the yardstick is the fp32 chain on the same (bf16-valued) inputs: where y lands within a bf16 rounding of zero the ReLU
+    # mask of a bf16 path may flip and move whole terms of the gradients, so the two bf16 paths differ from EACH OTHER by
+    # several per cent in L2 — but the fused node (fp32 tail, one rounding) must sit as close to fp32 as the chain it replaces
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-12))
+    for i, (f, c, ref) in enumerate(zip(out["fused"], out["chain"], out["fp32"])):
+        ef, ec = rel(f, ref), rel(c, ref)
+        assert f.shape == ref.shape and ef <= max(1.5 * ec, 1e-2), (i, tuple(ref.shape), ef, ec)
+        assert ef < 8e-2, (i, ef)
+
+
+def test_training_backbone_fused_nodes_match_the_autocast_modules():
+    """ResNet-50 + FPN under bf16 autocast, training mode (norm_eval, frozen_stages=1): with the fused autograd nodes
+    (ConvBNActFunction, default) against the module graph they replace (OCC_TRAIN_FUSED_CONV=0's path) — the four FPN maps and
+    the parameter gradients agree to bf16 noise, every trainable parameter receives a gradient on both sides."""
+    from occnet_amd.plugin.backbone import FPN, Bottleneck
+    bb, g = _train_backbone()
+    neck = FPN(in_channels=[512, 1024, 2048], out_channels=256, start_level=0, add_extra_convs='on_output', num_outs=4,
+               relu_before_extra_convs=True).cuda().train()
+    x = (torch.randn(2, 3, 96, 160, generator=g) * 50.0).cuda()
+    res = {}
+    for fused in (True, False):
+        Bottleneck.fused_train_nodes = fused
+        try:
+            bb.zero_grad(set_to_none=True)
+            neck.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                outs = neck(bb(x))
+            assert len(outs) == 4
+            sum((o.float() ** 2).mean() for o in outs).backward()
+            grads = {n: p.grad.detach().float().clone() for m, pre in ((bb, 'bb.'), (neck, 'neck.'))
+                     for n, p in ((pre + k, v) for k, v in m.named_parameters()) if p.grad is not None}
+            res[fused] = ([o.detach().float() for o in outs], grads)
+        finally:
+            Bottleneck.fused_train_nodes = True
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) > 120
+    for a, b in zip(res[True][0], res[False][0]):
+        assert float((a - b).abs().max() / b.abs().max()) < 0.06
+    rel = sorted(float((res[True][1][n] - gb).abs().max() / (gb.abs().max() + 1e-12)) for n, gb in res[False][1].items())
+    print(f"fused training nodes: relative gradient difference worst {rel[-1]:.2e}, median {rel[len(rel) // 2]:.2e}")
+    assert rel[len(rel) // 2] < 0.05 and rel[-1] < 0.5
+
+
+@pytest.mark.parametrize("O,I,k", [(128, 256, 1), (128, 128, 3), (2048, 512, 1), (64, 3, 7)])
+def test_conv_bn_fold_kernels_match_torch(O, I, k):
+    """The one-launch fold and its chain rule against the ATen expressions of conv_bn_folded: w_folded bit for bit (one fp32
+    product), its bf16 channels_last copy = RNE of it, the bias one fma; grad_weight bit for bit, grad_gamma a fixed-order sum."""
+    from occnet_amd import ext
+    g = torch.Generator().manual_seed(O + I + k)
+    W = torch.randn(O, I, k, k, generator=g).cuda()
+    gamma, beta = (torch.rand(O, generator=g) + 0.5).cuda(), torch.randn(O, generator=g).cuda()
+    rstd, mean_rstd = (torch.rand(O, generator=g) + 0.5).cuda(), torch.randn(O, generator=g).cuda()
+    wf, w16, b = ext.conv_bn_fold_fwd(W, gamma, beta, rstd, mean_rstd)
+    s = gamma * rstd
+    assert torch.equal(wf, W * s.view(-1, 1, 1, 1))
+    assert w16.is_contiguous(memory_format=torch.channels_last) and torch.equal(w16, wf.to(torch.bfloat16))
+    assert float((b - (beta - gamma * mean_rstd)).abs().max()) <= 1e-6 * float(b.abs().max() + 1)
+    gb = torch.randn(O, generator=g).cuda()
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        gw = torch.randn(O, I, k, k, generator=g).cuda().to(torch.bfloat16).contiguous(memory_format=fmt)
+        dW, dgamma = ext.conv_bn_fold_bwd(gw, W, gamma, rstd, mean_rstd, gb)
+        assert torch.equal(dW, gw.float() * s.view(-1, 1, 1, 1))
+        want = rstd.double() * (gw.double() * W.double()).sum((1, 2, 3)) - mean_rstd.double() * gb.double()
+        assert float((dgamma.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())

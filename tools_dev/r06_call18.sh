@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 6 call 18: training step kernel trace (summary + time-ordered dump of the last step)
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+T=r06_c18
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_tr -o r -- python $GRAFT_REPO_ROOT/bench.py --mode train --steps 6 --warmup 3 --passes 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/${T}_trace.log 2>&1)
+grep '^{' gpurun_out/${T}_trace.log | cut -c1-200
+DB=$(find /tmp/prof_tr -name "*.db" | head -1)
+python tools_dev/rocpd_summary.py $DB 220 --last-ms 300 > gpurun_out/${T}_train_kernel_trace_stats.txt 2>&1
+python tools_dev/train_step_dump.py $DB > gpurun_out/${T}_train_step_dump.txt 2>&1
+head -5 gpurun_out/${T}_train_step_dump.txt; tail -2 gpurun_out/${T}_train_step_dump.txt
+python tools_dev/train_trace_categories.py gpurun_out/${T}_train_kernel_trace_stats.txt 6 | head -14

@@ -26,14 +26,7 @@ def conv_bn_folded(x, conv, bn):
     (batch_norm_backward_reduce + elementwise: 19 ms of the 137 ms training step on MI355X)."""
     # the statistics are frozen (eval mode): 1/sqrt(var + eps) and mean/sqrt(var + eps) are constants, cached per
     # BatchNorm until a buffer is written (three small launches per convolution instead of six, fewer in backward)
-    key = (bn.running_mean._version, bn.running_var._version, bn.running_var.data_ptr(), cache_epoch())
-    cached = getattr(bn, '_occ_fold', None)
-    if cached is None or cached[0] != key:
-        with torch.no_grad():
-            rstd = torch.rsqrt(bn.running_var + bn.eps)
-            cached = (key, rstd, bn.running_mean * rstd)
-        object.__setattr__(bn, '_occ_fold', cached)
-    _, rstd, mean_rstd = cached
+    rstd, mean_rstd = _bn_fold_constants(bn)
     s = bn.weight * rstd
     w = conv.weight * s.view(-1, 1, 1, 1)
     b = torch.addcmul(bn.bias, bn.weight, mean_rstd, value=-1.0)

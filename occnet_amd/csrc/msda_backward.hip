@@ -388,45 +388,60 @@ constexpr int kReplayCap = 2048;
 
 __global__ __launch_bounds__(1024) void msda_bwd_scan_kernel(int* __restrict__ counts, int* __restrict__ cursor,
                                                              int n, int4* __restrict__ work,
-                                                             int* __restrict__ work_count, int cap) {
-  // cap = kReplayCap, or INT_MAX in the deterministic mode (bins are never split: one block owns a bin)
+                                                             int* __restrict__ work_count, int cap,
+                                                             int* __restrict__ split_meta) {
+  // a third running count numbers the SPLIT bins (more than one work entry): entry.w = slot + 1 (0: the entry's block is the
+  // bin's only writer); the deterministic replay meets the pieces of split bin `slot` in its own scratch tile and needs their
+  // number: split_meta[2 slot + 1] (split_meta == NULL: default mode, only the flag is used); work_count[2] = split bins
   __shared__ int part[1024];
   __shared__ int wpart[1024];
+  __shared__ int spart[1024];
   const int tid = threadIdx.x;
   const int per = (n + 1023) / 1024;
   const int lo = tid * per, hi = min(lo + per, n);
-  int sum = 0, wsum = 0;
+  int sum = 0, wsum = 0, ssum = 0;
   for (int i = lo; i < hi; ++i) {
     const int c = counts[i];
     sum += c;
     wsum += c > 0 ? (c - 1) / cap + 1 : 0;
+    ssum += c > cap ? 1 : 0;
   }
   part[tid] = sum;
   wpart[tid] = wsum;
+  spart[tid] = ssum;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {                // Hillis-Steele inclusive scan of the partials
     const int v = tid >= d ? part[tid - d] : 0;
     const int wv = tid >= d ? wpart[tid - d] : 0;
+    const int sv = tid >= d ? spart[tid - d] : 0;
     __syncthreads();
     part[tid] += v;
     wpart[tid] += wv;
+    spart[tid] += sv;
     __syncthreads();
   }
   int run = tid ? part[tid - 1] : 0;
   int wrun = tid ? wpart[tid - 1] : 0;
+  int srun = tid ? spart[tid - 1] : 0;
   for (int i = lo; i < hi; ++i) {
     const int c = counts[i];
     counts[i] = run;
     cursor[i] = run;
     const int nw = c > 0 ? (c - 1) / cap + 1 : 0;
+    const int tag = nw > 1 ? srun + 1 : 0;
     for (int k = 0; k < nw; ++k)
-      work[wrun + k] = make_int4(i, run + k * cap, k + 1 < nw ? run + (k + 1) * cap : run + c, nw > 1);
+      work[wrun + k] = make_int4(i, run + k * cap, k + 1 < nw ? run + (k + 1) * cap : run + c, tag);
+    if (nw > 1) {
+      if (split_meta != nullptr) split_meta[2 * srun + 1] = nw;
+      ++srun;
+    }
     wrun += nw;
     run += c;
   }
   if (tid == 1023) {
     counts[n] = part[1023];
     work_count[0] = wpart[1023];
+    work_count[2] = spart[1023];
   }
 }
 
@@ -549,26 +564,45 @@ __global__ void msda_bwd_maxabs_kernel(const float* __restrict__ x, long n, unsi
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bits
 }
 
+// scratch of the split bins: slot s owns kDetSlotWords 64-bit words = 32 x 32 sums + 32 "non-finite" flags (low halves)
+constexpr int kDetSlotWords = kBinPix * 32 + kBinPix;
+
+// zeroes the scratch tiles and arrival counters of the split bins that exist (the grid is the upper bound of their number)
+__global__ __launch_bounds__(256) void msda_bwd_det_zero_kernel(const int* __restrict__ work_count, int* __restrict__ split_meta,
+                                                                unsigned long long* __restrict__ tiles) {
+  const int slot = (int)blockIdx.x;
+  if (slot >= work_count[2]) return;
+  if (threadIdx.x == 0) split_meta[2 * slot] = 0;
+  for (int i = threadIdx.x; i < kDetSlotWords; i += 256) tiles[(long)slot * kDetSlotWords + i] = 0ull;
+}
+
+// Round 6: the loop of the default replay (item records two steps, gradient rows one step ahead) with 64-bit fixed-point sums:
+// ONE tile per block in LDS, accumulated with LDS integer atomics (ds_add_u64: fire and forget, any number of half-waves on
+// one pixel), and hot bins SPLIT like the default mode's — the pieces of split bin `slot` add their tiles into the slot's
+// scratch with 64-bit global atomics (integer addition commutes: no order reaches the result) and the piece that arrives
+// last converts the total.  (The first version of this mode replayed a hot coarse-level bin in one block, one dependent
+// load pair per item: 78.8 against 50.1 ms per training step.)
 __global__ __launch_bounds__(256) void msda_bwd_replay_det_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lstart, const int4* __restrict__ work,
     const int* __restrict__ work_count, const BwdItem* __restrict__ items, const float* __restrict__ grad_out,
-    float* __restrict__ grad_value, int S, int M, int L, int Lq, int bins_per_bm) {
+    float* __restrict__ grad_value, int S, int M, int L, int Lq, int bins_per_bm, int* __restrict__ split_meta,
+    unsigned long long* __restrict__ tiles) {
   constexpr int D = 32;
-  extern __shared__ long long acc_d[];                 // [8 half-waves][(kBinPix + 1) * D]
+  __shared__ unsigned long long acc_d[(kBinPix + 1) * D];
   // a non-finite contribution (Inf / NaN in grad_output) has no fixed-point image: the pixels it touches are written as
   // NaN, like the float path would leave them, instead of the finite garbage of a saturated conversion
   __shared__ int bad_px[kBinPix + 1];
+  __shared__ int last_piece;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, ch = lane & 31;
   if ((int)blockIdx.x >= work_count[0]) return;
-  if (tid <= kBinPix) bad_px[tid] = 0;
-  __syncthreads();
   const int4 wk = work[blockIdx.x];
   const long bin_g = wk.x;
   const int beg = wk.y, end = wk.z;
+  const int slot = wk.w - 1;                           // >= 0: one piece of a split bin
   const int hw = wave * 2 + half;
-  long long* acc = acc_d + hw * (kBinPix + 1) * D;
-#pragma unroll
-  for (int i = 0; i <= kBinPix; ++i) acc[i * D + ch] = 0;
+  for (int i = tid; i < (kBinPix + 1) * D; i += 256) acc_d[i] = 0ull;
+  if (tid <= kBinPix) bad_px[tid] = 0;
+  __syncthreads();
   const long bm = bin_g / bins_per_bm;
   int bl = (int)(bin_g - bm * bins_per_bm);
   const int m = (int)(bm % M);
@@ -584,28 +618,77 @@ __global__ __launch_bounds__(256) void msda_bwd_replay_det_kernel(
   const float mx = __uint_as_float((unsigned)work_count[1]);           // max |grad_output| of the launch
   int e = 0;
   if (mx > 0.f) (void)frexpf(mx, &e);                                  // mx < 2^e
-  const double scale = ldexp(1.0, 40 - e), inv = ldexp(1.0, e - 40);
-  const float* go = grad_out + (b * Lq * (long)M + m) * D + ch;
-  for (int idx = beg + hw; idx < end; idx += 8) {
-    const BwdItem it = items[idx];
-    const float g = go[(long)(it.qpl >> 5) * M * D];
-    const int pl = it.qpl & 31;
-    const float c0 = g * it.w0, c1 = g * it.w1;
-    if (!(fabsf(c0) < 3.0e38f)) bad_px[pl] = 1;
-    else acc[pl * D + ch] += __double2ll_rn((double)c0 * scale);
-    if (!(fabsf(c1) < 3.0e38f)) bad_px[pl + 1] = 1;
-    else acc[(pl + 1) * D + ch] += __double2ll_rn((double)c1 * scale);
+  const int sh = 40 - e;                                               // products scaled by 2^sh: |.| < 2^40, exact in fp32
+  const double inv = ldexp(1.0, e - 40);
+  const float* go = grad_out + (b * Lq * (long)M + m) * D + ch;        // + q * M * D
+  int qA[8], qB[8], qC[8];
+  float w0A[8], w1A[8], w0B[8], w1B[8], w0C[8], w1C[8], gA[8], gB[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i0 = beg + hw + 8 * u, i1 = i0 + 64;
+    const BwdItem a = items[i0 < end ? i0 : beg];
+    const BwdItem c = items[i1 < end ? i1 : beg];
+    qA[u] = i0 < end ? a.qpl : -1; w0A[u] = a.w0; w1A[u] = a.w1;
+    qB[u] = i1 < end ? c.qpl : -1; w0B[u] = c.w0; w1B[u] = c.w1;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) gA[u] = go[(long)(qA[u] < 0 ? 0 : qA[u] >> 5) * M * D];
+  for (int base = beg; base < end; base += 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {                      // item records two steps ahead
+      const int idx = base + 128 + hw + 8 * u;
+      const BwdItem it = items[idx < end ? idx : beg];
+      qC[u] = idx < end ? it.qpl : -1; w0C[u] = it.w0; w1C[u] = it.w1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) gB[u] = go[(long)(qB[u] < 0 ? 0 : qB[u] >> 5) * M * D];   // rows one step ahead
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (qA[u] >= 0) {
+        const int pl = qA[u] & 31;
+        const float c0 = gA[u] * w0A[u], c1 = gA[u] * w1A[u];
+        if (!(fabsf(c0) < 3.0e38f)) bad_px[pl] = 1;
+        else atomicAdd(&acc_d[pl * D + ch], (unsigned long long)__float2ll_rn(ldexpf(c0, sh)));
+        if (!(fabsf(c1) < 3.0e38f)) bad_px[pl + 1] = 1;
+        else atomicAdd(&acc_d[(pl + 1) * D + ch], (unsigned long long)__float2ll_rn(ldexpf(c1, sh)));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      qA[u] = qB[u]; w0A[u] = w0B[u]; w1A[u] = w1B[u]; gA[u] = gB[u];
+      qB[u] = qC[u]; w0B[u] = w0C[u]; w1B[u] = w1C[u];
+    }
   }
   __syncthreads();
   const int p0 = bl * kBinPix, np = min(kBinPix, HW - p0);
   const long st = lstart[l];
+  if (slot < 0) {                                      // the bin's only writer
+    for (int i = tid; i < np * D; i += 256) {
+      const int px = i >> 5, c = i & 31;
+      float* dst = grad_value + ((b * S + st + p0 + px) * M + m) * D + c;
+      if (bad_px[px]) *dst = __builtin_nanf("");
+      else *dst += (float)((double)(long long)acc_d[px * D + c] * inv);
+    }
+    return;
+  }
+  unsigned long long* tile = tiles + (long)slot * kDetSlotWords;
   for (int i = tid; i < np * D; i += 256) {
+    const unsigned long long v = acc_d[i];
+    if (v != 0ull) atomicAdd(&tile[i], v);
+  }
+  if (tid < np && bad_px[tid]) atomicAdd(&tile[kBinPix * D + tid], 1ull);
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) last_piece = atomicAdd(&split_meta[2 * slot], 1) == split_meta[2 * slot + 1] - 1;
+  __syncthreads();
+  if (!last_piece) return;
+  __threadfence();
+  for (int i = tid; i < np * D; i += 256) {            // the totals, read where the atomics were executed
     const int px = i >> 5, c = i & 31;
-    long long sum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) sum += acc_d[k * (kBinPix + 1) * D + px * D + c];
-    float* dst = grad_value + ((b * S + st + p0 + px) * M + m) * D + c;                      // the bin's only writer
-    if (bad_px[px]) *dst = __builtin_nanf("");
+    const unsigned long long bad = atomicAdd(&tile[kBinPix * D + px], 0ull);
+    const long long sum = (long long)atomicAdd(&tile[i], 0ull);
+    float* dst = grad_value + ((b * S + st + p0 + px) * M + m) * D + c;
+    if (bad) *dst = __builtin_nanf("");
     else *dst += (float)((double)sum * inv);
   }
 }
@@ -682,7 +765,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic_kernel(
 }  // namespace occ
 
 namespace occ {
-struct BwdWsLayout { size_t off_cnt, off_cur, off_work, off_items, bytes; long n_bins, n_samples, max_items, work_cap; int bins_per_bm; bool ok; };
+struct BwdWsLayout { size_t off_cnt, off_cur, off_work, off_items, off_meta, off_tiles, bytes; long n_bins, n_samples, max_items, work_cap, max_split; int bins_per_bm; bool ok; };
 static BwdWsLayout bwd_ws_layout(int B, int S, int M, int L, int Lq, int P) {
   BwdWsLayout w;
   const long n_items = (long)B * Lq * M;
@@ -695,7 +778,12 @@ static BwdWsLayout bwd_ws_layout(int B, int S, int M, int L, int Lq, int P) {
   w.off_work = w.off_cur + (((size_t)(w.n_bins + 1) * 4 + 255) & ~(size_t)255);
   w.work_cap = w.n_bins + w.max_items / kReplayCap + 1;               // >= sum_bins ceil(count / kReplayCap)
   w.off_items = w.off_work + (((size_t)(w.work_cap + 1) * 16 + 255) & ~(size_t)255);   // [0] = entry count
-  w.bytes = w.off_items + (size_t)w.max_items * sizeof(BwdItem);
+  // deterministic mode: a split bin holds more than kReplayCap items, so there are at most max_items / kReplayCap of them;
+  // per slot an arrival counter + piece count and a tile of kDetSlotWords 64-bit sums
+  w.max_split = w.max_items / kReplayCap + 1;
+  w.off_meta = (w.off_items + (size_t)w.max_items * sizeof(BwdItem) + 255) & ~(size_t)255;
+  w.off_tiles = (w.off_meta + (size_t)w.max_split * 8 + 255) & ~(size_t)255;
+  w.bytes = w.off_tiles + (size_t)w.max_split * kDetSlotWords * 8;
   w.ok = Lq < (1 << 26) && w.n_bins < (1L << 30) && w.max_items < (1L << 31) && w.work_cap < (1L << 31);
   return w;
 }
@@ -788,8 +876,10 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
         hipLaunchKernelGGL(msda_bwd_bin_kernel<false>, grid_s, dim3(256), 0, st, spatial_shapes, sampling_loc,
                            attn_weight, flags, counts, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
       }
+      int* split_meta = reinterpret_cast<int*>(ws + w.off_meta);
+      unsigned long long* tiles = reinterpret_cast<unsigned long long*>(ws + w.off_tiles);
       hipLaunchKernelGGL(msda_bwd_scan_kernel, dim3(1), dim3(1024), 0, st, counts, cursor, (int)w.n_bins, work,
-                         work_count, deterministic ? 0x7fffffff : kReplayCap);
+                         work_count, kReplayCap, deterministic ? split_meta : nullptr);
       if (block_bins) {
         hipLaunchKernelGGL(msda_bwd_bin_block_kernel<true>, dim3((unsigned)grid_b), dim3(kBinBlockThreads), lds_b,
                            st, spatial_shapes, sampling_loc, attn_weight, flags, cursor, items, M, L, Lq, P,
@@ -799,10 +889,7 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
                            attn_weight, flags, cursor, items, M, L, Lq, P, w.bins_per_bm, w.n_samples);
       }
       if (deterministic) {
-        const size_t lds_d = (size_t)8 * (kBinPix + 1) * 32 * sizeof(long long);
-        hipError_t ed = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_replay_det_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
-        if (ed == hipSuccess) ed = hipMemsetAsync(work_count + 1, 0, sizeof(int), st);
+        const hipError_t ed = hipMemsetAsync(work_count + 1, 0, sizeof(int), st);
         if (ed != hipSuccess) {
           if (own) (void)hipFreeAsync(ws, st);
           set_error("ms_deform_attn_backward: deterministic mode set-up failed: %s", hipGetErrorString(ed));
@@ -810,9 +897,11 @@ extern "C" int occ_ms_deform_attn_backward_ws_f32(
         }
         hipLaunchKernelGGL(msda_bwd_maxabs_kernel, dim3(1024), dim3(256), 0, st, grad_output, n_items * 32,
                            reinterpret_cast<unsigned*>(work_count + 1));
-        hipLaunchKernelGGL(msda_bwd_replay_det_kernel, dim3((unsigned)w.work_cap), dim3(256), lds_d, st,
+        hipLaunchKernelGGL(msda_bwd_det_zero_kernel, dim3((unsigned)w.max_split), dim3(256), 0, st, work_count, split_meta,
+                           tiles);
+        hipLaunchKernelGGL(msda_bwd_replay_det_kernel, dim3((unsigned)w.work_cap), dim3(256), 0, st,
                            spatial_shapes, level_start_index, work, work_count, items, grad_output, grad_value, S, M,
-                           L, Lq, w.bins_per_bm);
+                           L, Lq, w.bins_per_bm, split_meta, tiles);
       } else {
         hipLaunchKernelGGL(msda_bwd_replay_kernel, dim3((unsigned)w.work_cap), dim3(256), 0, st,
                            spatial_shapes, level_start_index, work, work_count, items, grad_output, grad_value, S, M,

@@ -93,7 +93,7 @@ int occ_ms_deform_attn_backward_f32(const float* value, const int64_t* spatial_s
                                     float* grad_attn_weight, int B, int S, int M, int D, int L,
                                     int Lq, int P, int im2col_step, void* stream);
 /* The same with CALLER-PROVIDED scratch for the atomic-free grad_value path (D == 32): `workspace` of at least
- * occ_ms_deform_attn_backward_workspace_bytes(...) bytes, 256-byte aligned, uninitialised (0.7-0.9 GB per SCA call
+ * occ_ms_deform_attn_backward_workspace_bytes(...) bytes, 256-byte aligned, uninitialised (1.0-1.2 GB per SCA call
  * at the base config: the Python operator module takes it from torch's caching allocator).  workspace == NULL: the
  * library uses hipMallocAsync and, if that fails, falls back to float atomics with ONE warning on stderr.
  * ..._workspace_bytes returns 0 when the path does not apply (D != 32 / index ranges): workspace is then ignored. */

@@ -800,7 +800,7 @@ extern "C" int64_t occ_ms_deform_attn_backward_workspace_bytes(int B, int S, int
 
 // ms_deform_attn_backward with CALLER-PROVIDED scratch (`workspace`, at least ..._workspace_bytes() bytes, 256-byte
 // aligned, need not be initialised): the Python operator module passes a tensor from torch's caching allocator, so
-// the ~0.7-0.9 GB per SCA call at the base config neither bypass nor compete with that pool.  workspace == NULL:
+// the ~1.0-1.2 GB per SCA call at the base config neither bypass nor compete with that pool.  workspace == NULL:
 // the library allocates with hipMallocAsync; if that fails it falls back to the float-atomic kernel (~4x slower) and
 // says so ONCE on stderr.  grad_value's summation order inside a 32-pixel bin follows integer-atomic slot order:
 // the last bits of grad_value are not reproducible run to run (as with mmcv's atomicAdd) — unless

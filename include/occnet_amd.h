@@ -455,6 +455,25 @@ int occ_conv_bn_fold_bwd_f32(const void* grad_w_bf16, int64_t stride_o, int64_t 
                              const float* grad_bias, float* grad_weight, float* grad_gamma, int Cout, int Cin, int KH, int KW,
                              void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-step glue of a BEVFormerLayer (reference: encoder.py:377-404 with the module tails
+ * spatial_cross_attention.py:173-175, temporal_self_attention.py:270-272 and mmcv's FFN): y = LayerNorm(dropout(x) +
+ * residual) and its backward, one launch each, C = 256 (OCC_E_UNSUPPORTED otherwise).
+ *   forward : z = x * keep / (1 - p) + residual ; y = (z - mean) * rstd * gamma + beta ; stats[r] = (mean, rstd)
+ *   backward: grad_residual = LayerNorm's input gradient ; grad_x = grad_residual * keep / (1 - p) (p == 0: not written, may
+ *             be NULL — it IS grad_residual) ; grad_gamma_beta = (sum_rows gy * zhat | sum_rows gy), 2 C floats, by a fixed-order
+ *             two-stage sum (partial: occ_dropout_add_ln_bwd_partial_floats(rows, C) floats of scratch).
+ * keep = occ_ln_dropout_hash(element index, seed_lo, seed_hi) >= (uint32)(p * 2^32): the mask is a pure function of (seed,
+ * index) and is never stored; the caller draws `seed` per call and hands the same one to the backward. */
+unsigned occ_ln_dropout_hash(unsigned index, unsigned seed_lo, unsigned seed_hi);
+int64_t occ_dropout_add_ln_bwd_partial_floats(int64_t rows, int C);
+int occ_dropout_add_ln_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float eps,
+                               float p_drop, uint64_t seed, float* z, float* y, float* stats, int64_t rows, int C,
+                               void* stream);
+int occ_dropout_add_ln_bwd_f32(const float* grad_y, const float* z, const float* stats, const float* gamma, float p_drop,
+                               uint64_t seed, float* grad_x, float* grad_residual, float* partial, float* grad_gamma_beta,
+                               int64_t rows, int C, void* stream);
+
 /* SCA value projection straight off the backbone's bf16 feature maps (rows A3/A8: replaces the reference's
  * fp32 feature flatten + embedding adds, transformer_occ.py:204-222, AND MSDeformableAttention3D.value_proj,
  * spatial_cross_attention.py:366), all FPN levels in one launch.  For segment (= level) s, row m = g*rpg_s + i:

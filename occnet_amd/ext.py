@@ -1306,6 +1306,68 @@ TRAIN_LINEAR = os.environ.get("OCC_TRAIN_LINEAR", "x3")      # 'x3' (own kernels
 TRAIN_WGRAD_ONLY = os.environ.get("OCC_TRAIN_WGRAD_ONLY", "1") != "0"   # LinearWgradFunction for the other shapes
 
 
+class DropoutAddLayerNormFunction(torch.autograd.Function):
+    """y = LayerNorm(dropout(x, p) + residual) as ONE autograd node (csrc/ln_dropout_train.hip): the tail of every attention /
+    FFN block of a BEVFormerLayer in training (reference: encoder.py:377-404, spatial_cross_attention.py:173-175,
+    temporal_self_attention.py:270-272, mmcv FFN).  One launch forward, one (+ a small fixed-order reduce) backward instead
+    of ATen's dropout + add + LayerNorm and masked scale + two LayerNorm kernels + the residual fork's add.  The keep mask is
+    a counter-based hash of (seed, element index): never stored, regenerated in backward; the seed comes from torch's CPU
+    generator (reproducible under torch.manual_seed, no device sync)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps, p):
+        shape = x.shape
+        C = shape[-1]
+        x2, r2 = x.reshape(-1, C).contiguous(), residual.reshape(-1, C).contiguous()
+        rows = x2.shape[0]
+        z, y = torch.empty_like(x2), torch.empty_like(x2)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if p > 0 else 0
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().occ_dropout_add_ln_fwd_f32(ptr(x2), ptr(r2), ptr(weight), ptr(bias), f32(eps), f32(p),
+                                                       ctypes.c_uint64(seed), ptr(z), ptr(y), ptr(stats), i64(rows), i32(C),
+                                                       stream_ptr(x.device))
+        _lib.check(rc, "dropout_add_ln_fwd")
+        ctx.save_for_backward(z, stats, weight)
+        ctx.cfg = (float(p), seed, tuple(shape), tuple(residual.shape))
+        return y.view(shape)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        z, stats, weight = ctx.saved_tensors
+        p, seed, shape, rshape = ctx.cfg
+        rows, C = z.shape
+        gy2 = gy.reshape(rows, C).contiguous()
+        lib = _lib.lib()
+        lib.occ_dropout_add_ln_bwd_partial_floats.restype = ctypes.c_int64
+        partial = torch.empty(int(lib.occ_dropout_add_ln_bwd_partial_floats(i64(rows), i32(C))), dtype=torch.float32,
+                              device=z.device)
+        gres = torch.empty_like(z)
+        gx = torch.empty_like(z) if p > 0 else gres
+        ggb = torch.empty(2 * C, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            rc = lib.occ_dropout_add_ln_bwd_f32(ptr(gy2), ptr(z), ptr(stats), ptr(weight), f32(p), ctypes.c_uint64(seed),
+                                                ptr(gx) if p > 0 else ptr(None), ptr(gres), ptr(partial), ptr(ggb), i64(rows),
+                                                i32(C), stream_ptr(z.device))
+        _lib.check(rc, "dropout_add_ln_bwd")
+        return gx.view(shape), gres.view(rshape), ggb[:C], ggb[C:], None, None
+
+
+def dropout_add_layernorm_ok(x, residual, norm):
+    """True when DropoutAddLayerNormFunction covers this site (fp32 device rows of 256 columns, an affine LayerNorm over them)."""
+    return (isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None
+            and tuple(norm.normalized_shape) == (256,) and x.is_cuda and x.dtype == torch.float32
+            and residual.dtype == torch.float32 and x.shape == residual.shape and x.shape[-1] == 256
+            and x.numel() < (1 << 32) and norm.weight.dtype == torch.float32)
+
+
+def dropout_add_layernorm(x, residual, norm, p, training):
+    """LayerNorm(dropout(x) + residual) on the fused training node."""
+    return DropoutAddLayerNormFunction.apply(x, residual, norm.weight, norm.bias, float(norm.eps),
+                                             float(p) if training else 0.0)
+
+
 def linear_autograd(x, weight, bias=None, act=None):
     """F.linear(+ReLU) that is differentiable: on a float32 device tensor with supported shapes the forward and the
     backward run on the bf16x3 kernels; shapes the forward kernel does not cover keep the library forward and take

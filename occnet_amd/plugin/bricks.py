@@ -147,14 +147,27 @@ class FFN(BaseModule):
         except OccAmdUnsupported:
             return None
 
-    def forward(self, x, identity=None):
+    def forward(self, x, identity=None, post_norm_train=None):
+        """post_norm_train (a LayerNorm): the caller's following norm; -> (output, norm_applied) in that case."""
         if (self.num_fcs == 2 and isinstance(self.layers[0][1], nn.ReLU) and x.is_cuda
                 and torch.is_grad_enabled()):
             # training: Linear + ReLU as one kernel (the mask for the backward is the output itself)
             h = self.layers[0][2](self.layers[0][0](x, act='relu'))
-            out = self.layers[2](self.layers[1](h))
+            out = self.layers[1](h)
+            if post_norm_train is not None and self.add_identity and isinstance(self.dropout_layer, nn.Identity):
+                from .. import ext
+                res = x if identity is None else identity
+                if ext.dropout_add_layernorm_ok(out, res, post_norm_train):
+                    # the FFN's last Dropout + identity + the layer's following LayerNorm as one autograd node
+                    drop = self.layers[2]
+                    return ext.dropout_add_layernorm(out, res, post_norm_train, drop.p, drop.training), True
+            out = self.layers[2](out)
         else:
             out = self.layers(x)
+        if post_norm_train is not None:
+            if not self.add_identity:
+                return self.dropout_layer(out), False
+            return (x if identity is None else identity) + self.dropout_layer(out), False
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:

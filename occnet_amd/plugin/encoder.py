@@ -11,6 +11,7 @@ SpatialCrossAttention layer would otherwise rebuild with nonzero(); the encoder 
 hands it (plus a cache-friendly query processing order) to all layers through kwargs.
 """
 import copy
+import os
 import warnings
 
 import numpy as np
@@ -19,7 +20,7 @@ import torch.nn as nn
 
 from .. import cache_epoch, ext
 from ..synthetic import bev_tile_order
-from .bricks import BaseModule, ModuleList, build_norm_layer
+from .bricks import FFN, BaseModule, ModuleList, build_norm_layer
 from .registry import (TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_attention,
                        build_feedforward_network, build_transformer_layer)
 from .spatial_cross_attention import _require_device
@@ -145,6 +146,8 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                          norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
         self.fp16_enabled = False
         self.use_fused = True     # flip to force the op-by-op (reference-shaped) execution
+        # training: dropout + residual + LayerNorm after each block as one autograd node (OCC_TRAIN_FUSED_LN=0: ATen ops)
+        self.fused_train_tail = os.environ.get("OCC_TRAIN_FUSED_LN", "1") != "0"
         assert len(operation_order) == 6
         assert set(operation_order) == set(['self_attn', 'norm', 'cross_attn', 'ffn'])
 
@@ -169,6 +172,10 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                 and key_padding_mask is None and all(m is None for m in attn_masks)
                 and not (torch.is_grad_enabled() and (query.requires_grad or any(
                     p.requires_grad for p in self.parameters()))))
+        # training (autograd): dropout + residual + the LayerNorm that follows an attention / FFN block as ONE node
+        # (ext.DropoutAddLayerNormFunction); the block reports whether it applied the norm
+        fuse_train = (self.fused_train_tail and not fuse and not self.pre_norm and query.is_cuda
+                      and query.dtype == torch.float32 and torch.is_grad_enabled())
         ops = self.operation_order
         i = 0
         while i < len(ops):
@@ -177,6 +184,9 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
             if fuse and i + 1 < len(ops) and ops[i + 1] == 'norm' \
                     and isinstance(self.norms[norm_index], nn.LayerNorm):
                 post_norm = self.norms[norm_index]
+            tail = {}
+            if fuse_train and i + 1 < len(ops) and ops[i + 1] == 'norm' and isinstance(self.norms[norm_index], nn.LayerNorm):
+                tail = dict(post_norm_train=self.norms[norm_index])
             if layer == 'self_attn':   # temporal self attention: BEV plane is its own single level
                 attn = self.attentions[attn_index]
                 out = None
@@ -197,7 +207,12 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                         query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_index],
                         key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
                         spatial_shapes=tsa_shapes, level_start_index=tsa_start, bev_h=bev_h,
-                        bev_w=bev_w, **kwargs)
+                        bev_w=bev_w, **(tail if getattr(attn, 'supports_post_norm_train', False) else {}), **kwargs)
+                    if tail and getattr(attn, 'supports_post_norm_train', False):
+                        query, normed = query
+                        if normed:
+                            norm_index += 1
+                            i += 1
                 attn_index += 1
                 identity = query
             elif layer == 'norm':
@@ -228,7 +243,13 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                         key_pos=key_pos, reference_points=ref_3d,
                         reference_points_cam=reference_points_cam, mask=mask,
                         attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
-                        spatial_shapes=spatial_shapes, level_start_index=level_start_index, **kwargs)
+                        spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                        **(tail if getattr(attn, 'supports_post_norm_train', False) else {}), **kwargs)
+                    if tail and getattr(attn, 'supports_post_norm_train', False):
+                        query, normed = query
+                        if normed:
+                            norm_index += 1
+                            i += 1
                 attn_index += 1
                 identity = query
             elif layer == 'ffn':
@@ -240,6 +261,11 @@ class BEVFormerLayer(MyCustomBaseTransformerLayer):
                     query = out
                     norm_index += 1
                     i += 1
+                elif tail and isinstance(ffn, FFN):
+                    query, normed = ffn(query, identity if self.pre_norm else None, **tail)
+                    if normed:
+                        norm_index += 1
+                        i += 1
                 else:
                     query = ffn(query, identity if self.pre_norm else None)
                 ffn_index += 1

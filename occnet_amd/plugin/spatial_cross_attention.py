@@ -196,6 +196,8 @@ class SpatialCrossAttention(BaseModule):
     """Each BEV query attends, through MSDeformableAttention3D, to the cameras its pillar projects
     into; the per-camera results are averaged over the visible cameras (reference :31-175)."""
 
+    supports_post_norm_train = True     # forward(post_norm_train=LayerNorm) -> (output, norm applied?) (encoder.py)
+
     def __init__(self, embed_dims=256, num_cams=6, pc_range=None, dropout=0.1, init_cfg=None,
                  batch_first=False,
                  deformable_attention=dict(type='MSDeformableAttention3D', embed_dims=256,
@@ -441,4 +443,9 @@ class SpatialCrossAttention(BaseModule):
             slots = self._unfused_slots(query, key, value, reference_points_cam, bev_mask,
                                         spatial_shapes, level_start_index)
         slots = self.output_proj(slots)
-        return self.dropout(slots) + inp_residual
+        norm = kwargs.get('post_norm_train')
+        if norm is not None and ext.dropout_add_layernorm_ok(slots, inp_residual, norm):
+            # training: dropout + residual + the layer's following LayerNorm as one autograd node (the layer skips its norm)
+            return ext.dropout_add_layernorm(slots, inp_residual, norm, self.dropout.p, self.training), True
+        out = self.dropout(slots) + inp_residual
+        return (out, False) if norm is not None else out

@@ -30,6 +30,8 @@ from .spatial_cross_attention import _CatLinearCache, _require_device
 @ATTENTION.register_module()
 class TemporalSelfAttention(BaseModule):
 
+    supports_post_norm_train = True     # forward(post_norm_train=LayerNorm) -> (output, norm applied?) (encoder.py)
+
     def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, num_bev_queue=2,
                  im2col_step=64, dropout=0.1, batch_first=True, norm_cfg=None, init_cfg=None):
         super().__init__(init_cfg)
@@ -219,7 +221,12 @@ class TemporalSelfAttention(BaseModule):
         output = self.output_proj(output)
         if not self.batch_first:
             output = output.permute(1, 0, 2)
-        return self.dropout(output) + identity
+        norm = kwargs.get('post_norm_train')
+        if norm is not None and ext.dropout_add_layernorm_ok(output, identity, norm):
+            # training: dropout + residual + the layer's following LayerNorm as one autograd node (the layer skips its norm)
+            return ext.dropout_add_layernorm(output, identity, norm, self.dropout.p, self.training), True
+        out = self.dropout(output) + identity
+        return (out, False) if norm is not None else out
 
     def _unfused(self, query, value, key_padding_mask, reference_points, spatial_shapes,
                  level_start_index):

@@ -183,10 +183,13 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.occ_sca_prep_forward_f32(p, i64(768), 768, ip, p, ip, p, p, 1, i64(4), 8, 4, 8, 3, null) == -1   # P % Z
     assert lib.occ_sca_prep_forward_f32(p, i64(512), 512, ip, p, ip, p, p, 1, i64(4), 8, 4, 8, 4, null) == -1   # short rows
     assert lib.occ_sca_prep_backward_f32(p, p, p, ip, 2, ip, p, 768, 1, i64(4), i64(2), 8, 2, 8, null) == -3
-    # backward scratch: flags + counters + work list + 4 * samples row items of 12 bytes; 0 for other head sizes
+    # backward scratch: flags + counters + work list + 4 * samples row items of 12 bytes + (deterministic mode) one tile of
+    # 32 x 32 + 32 64-bit words per possible split bin (more than 2 048 items); 0 for other head sizes
     B, S, M, D, L, Lq, P = 6, 30825, 8, 32, 4, 9900, 8
     need = lib.occ_ms_deform_attn_backward_workspace_bytes(B, S, M, D, L, Lq, P)
-    assert need > 4 * (B * Lq * M * L * P) * 12 and need < 1.1 * 4 * (B * Lq * M * L * P) * 12 + (64 << 20)
+    items = 4 * (B * Lq * M * L * P)
+    tiles = (items // 2048 + 1) * (32 * 32 + 32) * 8
+    assert need > items * 12 + tiles and need < 1.1 * items * 12 + tiles + (64 << 20)
     assert lib.occ_ms_deform_attn_backward_workspace_bytes(B, S, M, 64, L, Lq, P) == 0
     rc = lib.occ_ms_deform_attn_backward_ws_f32(p, p, p, p, p, p, p, p, p, 1, 4, 8, 32, 1, 4, 4, 64, p, i64(16), null)
     assert rc == -1 and b'workspace too small' in lib.occ_last_error()

@@ -387,3 +387,95 @@ def test_data_copy_before_eval_is_caught_by_the_content_fingerprint():
     n0.data.fill_(0.75), n1.data.fill_(1.25)                # the two tensors swap contents: same multiset of norms
     model.eval()
     assert occnet_amd.cache_epoch() > e3
+
+
+def _keep_mask(n, seed, p):
+    """numpy restatement of csrc/ln_dropout_train.hip's keep decision for elements 0 .. n-1."""
+    import numpy as np
+    i = np.arange(n, dtype=np.uint32)
+    s0, s1 = np.uint32(seed & 0xffffffff), np.uint32(seed >> 32)
+    with np.errstate(over='ignore'):
+        h = i ^ s0
+        h ^= h >> np.uint32(16); h *= np.uint32(0x85ebca6b); h ^= h >> np.uint32(13); h *= np.uint32(0xc2b2ae35); h ^= h >> np.uint32(16)
+        h += s1
+        h ^= h >> np.uint32(15); h *= np.uint32(0x2c1b3c6d); h ^= h >> np.uint32(12)
+    return h >= np.uint32(int(p * 4294967296.0))
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("rows", [5, 4003])
+def test_dropout_add_layernorm_node_matches_torch(rows, p, monkeypatch):
+    """ext.DropoutAddLayerNormFunction (one launch forward, one + a fixed-order reduce backward) against torch ops with the SAME
+    keep mask (restated on the host from the kernel's counter-based hash): y, the gradients of x, residual, gamma and beta; the
+    library's host copy of the hash equals the restatement; the keep rate is 1 - p."""
+    import ctypes
+    import numpy as np
+    from occnet_amd import _lib, ext
+    g = torch.Generator().manual_seed(rows)
+    C = 256
+    x0 = torch.randn(2, rows, C, generator=g).cuda()
+    r0 = torch.randn(2, rows, C, generator=g).cuda()
+    gy = torch.randn(2, rows, C, generator=g).cuda()
+    ln = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(C, generator=g).cuda() + 0.5)
+        ln.bias.copy_(torch.randn(C, generator=g).cuda() * 0.1)
+    seeds = []
+    real = torch.randint
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: (lambda t: (seeds.append(int(t.item())), t)[1])(real(*a, **k)))
+    x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+    assert ext.dropout_add_layernorm_ok(x, r, ln)
+    y = ext.dropout_add_layernorm(x, r, ln, p, True)
+    monkeypatch.undo()
+    y.backward(gy)
+    got = [y.detach(), x.grad.clone(), r.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()]
+    ln.weight.grad = ln.bias.grad = None
+    n = x0.numel()
+    if p > 0:
+        assert len(seeds) == 1
+        keep = _keep_mask(n, seeds[0], p)
+        lib = _lib.lib()
+        lib.occ_ln_dropout_hash.restype = ctypes.c_uint32
+        thr = int(p * 4294967296.0)
+        for i in (0, 1, 255, 256, n - 1):
+            assert (lib.occ_ln_dropout_hash(ctypes.c_uint32(i), ctypes.c_uint32(seeds[0] & 0xffffffff),
+                                            ctypes.c_uint32(seeds[0] >> 32)) >= thr) == bool(keep[i])
+        assert abs(float(keep.mean()) - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4
+        mask = torch.from_numpy(keep.astype(np.float32)).cuda().view_as(x0) / (1 - p)
+    else:
+        assert not seeds
+        mask = torch.ones_like(x0)
+    x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+    yr = ln(x * mask + r)
+    yr.backward(gy)
+    want = [yr.detach(), x.grad, r.grad, ln.weight.grad, ln.bias.grad]
+    for a, b, name in zip(got, want, ("y", "gx", "gres", "dgamma", "dbeta")):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-12))
+        assert err < 2e-5, (name, err)
+
+
+def test_layer_with_the_fused_tail_matches_the_aten_tail(monkeypatch):
+    """A BEVFormerLayer under autograd, dropout inactive (eval mode): the fused dropout + residual + LayerNorm nodes (default)
+    against the ATen tail (fused_train_tail = False) — same output, same parameter gradients."""
+    from occnet_amd.plugin.encoder import BEVFormerLayer
+    g = small_cfg(bev=(20, 20), num_layers=1)
+    prod, _ = build_pair(g, seed=5)
+    prod = prod.eval()
+    feats = [f.cuda() for f in synthetic.make_features(g, seed=5)]
+    metas = synthetic.make_img_metas(g)
+    layers = [m for m in prod.modules() if isinstance(m, BEVFormerLayer)]
+    assert layers
+    res = {}
+    for fused in (True, False):
+        for m in layers:
+            m.fused_train_tail = fused
+        prod.zero_grad(set_to_none=True)
+        out = prod(feats, metas)
+        (out['occ'].float().square().mean() + out['flow'].float().square().mean()).backward()
+        res[fused] = (out['bev_embed'].detach().clone(),
+                      {n: p.grad.detach().clone() for n, p in prod.named_parameters() if p.grad is not None})
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) > 40
+    assert float((res[True][0] - res[False][0]).abs().max()) < 2e-5
+    for n, gb in res[False][1].items():
+        err = float((res[True][1][n] - gb).abs().max() / (gb.abs().max() + 1e-12))
+        assert err < 2e-4, (n, err)

@@ -193,3 +193,51 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.occ_ms_deform_attn_backward_workspace_bytes(B, S, M, 64, L, Lq, P) == 0
     rc = lib.occ_ms_deform_attn_backward_ws_f32(p, p, p, p, p, p, p, p, p, 1, 4, 8, 32, 1, 4, 4, 64, p, i64(16), null)
     assert rc == -1 and b'workspace too small' in lib.occ_last_error()
+
+
+def test_round6_training_nodes_validate_without_gpu():
+    """Round-6 training entry points (masked gradient + bias gradient pass, BatchNorm fold, dropout + residual + LayerNorm
+    node): scratch sizing, argument checks before any launch, and the keep-mask hash — a HOST function of the library — against
+    its numpy restatement (the restatement the GPU test derives its reference mask from)."""
+    import numpy as np
+    lib = _lib.lib()
+    null = ctypes.c_void_p(0)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    i64, f32 = ctypes.c_int64, ctypes.c_float
+    lib.occ_bias_act_bwd_partial_floats.restype = ctypes.c_int64
+    lib.occ_dropout_add_ln_bwd_partial_floats.restype = ctypes.c_int64
+    lib.occ_ln_dropout_hash.restype = ctypes.c_uint32
+    # bias_act backward: <= 512 blocks of 256 / (C / 8) rows each, one row of C partial sums per block; C % 8 == 0, C <= 2048
+    assert lib.occ_bias_act_bwd_partial_floats(i64(6 * 116 * 200), 512) == 512 * 512
+    assert lib.occ_bias_act_bwd_partial_floats(i64(7), 64) == 1 * 64
+    assert lib.occ_bias_act_bwd_partial_floats(i64(100), 12) == 0 and lib.occ_bias_act_bwd_partial_floats(i64(100), 4096) == 0
+    assert lib.occ_bias_act_bwd_nhwc_bf16(null, p, p, p, p, i64(8), 64, 1, null) == -1
+    assert lib.occ_bias_act_bwd_nhwc_bf16(p, null, null, p, p, i64(8), 64, 1, null) == -1        # relu needs y and g
+    assert lib.occ_bias_act_bwd_nhwc_bf16(p, null, null, p, p, i64(8), 12, 0, null) == -3        # C % 8
+    assert lib.occ_conv_bn_fold_fwd_f32(null, p, p, p, p, p, p, p, 8, 8, 1, 1, null) == -1
+    assert lib.occ_conv_bn_fold_bwd_f32(p, i64(8), i64(1), i64(1), i64(1), p, p, p, p, p, p, p, 0, 8, 1, 1, null) == -1
+    # dropout + residual + LayerNorm: C = 256 only; <= 1024 blocks of 4 rows, 2 C partial sums per block
+    assert lib.occ_dropout_add_ln_bwd_partial_floats(i64(40000), 256) == 1024 * 512
+    assert lib.occ_dropout_add_ln_bwd_partial_floats(i64(5), 256) == 2 * 512
+    assert lib.occ_dropout_add_ln_bwd_partial_floats(i64(5), 128) == 0
+    u64 = ctypes.c_uint64
+    assert lib.occ_dropout_add_ln_fwd_f32(null, p, p, p, f32(1e-5), f32(0.1), u64(1), p, p, p, i64(4), 256, null) == -1
+    assert lib.occ_dropout_add_ln_fwd_f32(p, p, p, p, f32(1e-5), f32(1.0), u64(1), p, p, p, i64(4), 256, null) == -1      # p < 1
+    assert lib.occ_dropout_add_ln_fwd_f32(p, p, p, p, f32(1e-5), f32(0.1), u64(1), p, p, p, i64(4), 128, null) == -3
+    assert b'C = 256' in lib.occ_last_error()
+    assert lib.occ_dropout_add_ln_bwd_f32(p, p, p, p, f32(0.1), u64(1), null, p, p, p, i64(4), 256, null) == -1            # p > 0 needs grad_x
+    # the keep-mask hash
+    seed = 0x1234567_89abcdef
+    idx = np.concatenate([np.arange(4096, dtype=np.uint32), np.array([2 ** 31, 2 ** 32 - 1], dtype=np.uint32)])
+    s0, s1 = np.uint32(seed & 0xffffffff), np.uint32(seed >> 32)
+    with np.errstate(over='ignore'):
+        h = idx ^ s0
+        h ^= h >> np.uint32(16); h *= np.uint32(0x85ebca6b); h ^= h >> np.uint32(13); h *= np.uint32(0xc2b2ae35); h ^= h >> np.uint32(16)
+        h += s1
+        h ^= h >> np.uint32(15); h *= np.uint32(0x2c1b3c6d); h ^= h >> np.uint32(12)
+    got = np.array([lib.occ_ln_dropout_hash(ctypes.c_uint32(int(i)), ctypes.c_uint32(int(s0)), ctypes.c_uint32(int(s1))) for i in idx],
+                   dtype=np.uint32)
+    assert np.array_equal(got, h)
+    keep = (h[:4096] >= np.uint32(int(0.1 * 4294967296.0))).mean()
+    assert abs(keep - 0.9) < 0.03
